@@ -1,0 +1,167 @@
+/*
+ * mmg.h -- C-ABI of the MI355X-native REINFORCE exchange path (libmmg.so).
+ *
+ * The reference (nyu-dl/MultimodalGame) has no FFI: its hot path is reached through the
+ * Python objects of model.py.  This header is the boundary a maintainer would bind (ctypes,
+ * see INTEGRATION.md) to replace exactly these reference call sites:
+ *
+ *   mmg_exchange_forward   <- exchange()                    model.py:725-876  (called at 1240, 640)
+ *                             + output selection / NLL      model.py:879-904, 1264-1275
+ *   mmg_loss_stats         <- mask derivation + the batch statistics of
+ *                             multistep_loss_binary/_bas    model.py:1248-1262, 907-988
+ *   mmg_backward           <- the four loss.backward()      model.py:1309, 1316, 1322, 1328
+ *   mmg_clip_step          <- clip_grad_norm + optimizer    model.py:1310-1311, 1317-1318, 1323-1324, 1329-1330
+ *   mmg_train_step         <- the whole per-minibatch block model.py:1240-1339 (single GPU)
+ *   mmg_sender_forward     <- Sender.forward                model.py:144-238 (non-attention, sender_mix=sum)
+ *   mmg_receiver_forward   <- Receiver.forward              model.py:303-477 (non-desc_attn)
+ *   mmg_baseline_forward   <- Baseline.forward              model.py:496-516
+ *
+ * Conventions
+ *   - plain pointers and sizes; every pointer named d_* is DEVICE memory owned by the caller
+ *     (torch tensors' data_ptr()).  The library never allocates device memory: the caller hands
+ *     it one workspace of mmg_workspace_bytes() bytes at mmg_create().
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void*, 0 = null stream) and is
+ *     asynchronous w.r.t. the host; no host synchronisation happens inside any call.
+ *   - return value: 0 = ok, negative = error (message via mmg_last_error()); nothing throws
+ *     across the ABI.  One handle per device per process; not thread-safe (the reference is
+ *     single-threaded).
+ *   - all floating-point data is fp32, row-major, PyTorch [out,in] weight layout; masks are
+ *     uint8; targets int64 (as the reference's LongTensor).
+ */
+#ifndef MMG_H_
+#define MMG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMG_VERSION 1
+
+enum { MMG_OPT_RMSPROP = 0, MMG_OPT_ADAM = 1, MMG_OPT_SGD = 2 };          /* model.py:1725 */
+enum { MMG_AGENT_RECEIVER = 0, MMG_AGENT_SENDER = 1, MMG_AGENT_BASELINE_REC = 2, MMG_AGENT_BASELINE_SEN = 3 };
+
+/* Frozen copy of the gflags the hot path reads (model.py:1639-1741). */
+typedef struct mmg_config {
+    int32_t batch;            /* B: samples handled by THIS process (-batch_size / world_size)      */
+    int32_t global_batch;     /* samples of the whole minibatch over all ranks (== batch if 1 GPU)   */
+    int32_t batch_offset;     /* index of this rank's first sample inside the global minibatch       */
+    int32_t n_classes;        /* D: rows of the description matrix                                   */
+    int32_t feat_dim;         /* F: -img_feat_dim                                                    */
+    int32_t h_dim;            /* H: -img_h_dim                                                       */
+    int32_t w_dim;            /* W: -rec_w_dim == -sender_out_dim (model.py:1756)                    */
+    int32_t rec_hidden;       /* R: -rec_hidden                                                      */
+    int32_t wv_dim;           /* V: -wv_dim                                                          */
+    int32_t bas_hidden;       /* K: -baseline_hid_dim                                                */
+    int32_t max_exchange;     /* T: -max_exchange                                                    */
+    int32_t use_binary;       /* -use_binary                                                         */
+    int32_t fixed_exchange;   /* -fixed_exchange                                                     */
+    int32_t s_prob_prod;      /* -s_prob_prod (eval-mode stop bit, model.py:423-427)                 */
+    int32_t has_entropy_s, has_entropy_sen, has_entropy_rec;   /* flag is not None (model.py:925)    */
+    float   entropy_s, entropy_sen, entropy_rec;               /* model.py:1730-1732                 */
+    float   first_rec;        /* -first_rec (model.py:786)                                           */
+    int32_t optim_type;       /* MMG_OPT_*                                                           */
+    float   learning_rate;    /* -learning_rate                                                      */
+    int32_t top_k;            /* -top_k_train                                                        */
+} mmg_config;
+
+/* One parameter tensor inside the flat parameter / gradient / optimizer-state buffers. */
+typedef struct mmg_param_entry {
+    char    name[48];         /* state_dict key, e.g. "rnn.weight_ih" (SURVEY.md §8 b)               */
+    int32_t agent;            /* MMG_AGENT_*                                                         */
+    int32_t rows, cols;       /* cols == 0 for 1-D tensors                                           */
+    int64_t offset;           /* in floats from the start of the flat buffer (16-byte aligned)       */
+} mmg_param_entry;
+
+/* One named array inside the workspace ("tape"): everything exchange() returns plus what the
+ * backward pass re-reads. */
+typedef struct mmg_tape_entry {
+    char    name[32];
+    int32_t dtype;            /* 0 = f32, 1 = u8, 2 = i32, 3 = f64                                   */
+    int32_t ndim;
+    int64_t dims[4];
+    int64_t offset;           /* bytes from the start of the workspace                               */
+} mmg_tape_entry;
+
+typedef struct mmg_handle mmg_handle;
+
+const char* mmg_last_error(void);
+int     mmg_version(void);
+
+/* Layout queries (host only, no GPU needed). */
+int64_t mmg_param_count(const mmg_config* cfg);                                   /* floats incl. padding */
+int     mmg_param_table(const mmg_config* cfg, mmg_param_entry* out, int max_entries);   /* returns count */
+int64_t mmg_workspace_bytes(const mmg_config* cfg);
+int     mmg_tape_table(const mmg_config* cfg, mmg_tape_entry* out, int max_entries);     /* returns count */
+
+/* d_params / d_grads: flat fp32 buffers of mmg_param_count() floats.  d_opt_state: 2x that
+ * (RMSprop square_avg | unused; Adam exp_avg | exp_avg_sq; SGD unused), zero-initialised by the
+ * caller.  d_workspace: mmg_workspace_bytes() bytes, 256-byte aligned. */
+mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int64_t workspace_bytes,
+                       float* d_params, float* d_grads, float* d_opt_state);
+void    mmg_destroy(mmg_handle* h);
+
+/* Runs the T-step conversation of one minibatch (model.py:725-876) and the output selection /
+ * log-softmax / NLL reward (model.py:879-904, 1264-1275).
+ *   d_x [B,F] f32, d_target [B] i64 (may be NULL when train==0 and no accuracy is wanted),
+ *   d_desc [D,V] f32.
+ *   Sampling (train==1): if d_u_z/d_u_s/d_u_w ([T,B,W],[T,B],[T,B,W] f32 uniforms, the reference's
+ *   np.random.rand draws in its call order) are non-NULL they are consumed; otherwise the in-kernel
+ *   Philox4x32-10 generator keyed by (seed, the handle's device-side minibatch counter) is used.
+ *   train==0: messages are round(p), stop bit round(prod p_s) (model.py:229, 423-427, 462).
+ *   run_all_steps==1: every sample runs all T steps (what exchange() returns to Python);
+ *   ==0: a sample stops computing once its own conversation has ended (its later steps are masked
+ *   out of every loss, so training results are identical).
+ * Results land in the workspace arrays listed by mmg_tape_table(). */
+int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
+                         const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed,
+                         int train, int run_all_steps, void* stream);
+
+/* Per-rank partial sums of every batch statistic the losses need (counts, sums and squared sums
+ * of reward-minus-baseline per stream and step, ...) into the f64 tape array "stats".  With more
+ * than one rank the caller all-reduces (sum) that array between this call and mmg_backward. */
+int mmg_loss_stats(mmg_handle* h, void* stream);
+
+/* Gradient of the four losses (model.py:1296-1305) w.r.t. all parameters into d_grads (the whole
+ * flat buffer is overwritten).  Also writes the six loss scalars into the tape array "losses". */
+int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, void* stream);
+
+/* Per-agent clip_grad_norm(max_norm=1) + optimizer update on the flat buffers.  In continuous mode
+ * (use_binary==0) only the receiver is updated (model.py:1313). */
+int mmg_clip_step(mmg_handle* h, void* stream);
+
+/* forward(train) + stats + backward + clip_step for a single-GPU minibatch. */
+int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
+                   const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed, void* stream);
+
+/* Agent-level entry points (forward only; one exchange step), mirroring the reference modules.
+ *   sender:   x[B,F], w[B,W] (ignored when t==0), t -> message[B,W], probs[B,W] (NULL if continuous),
+ *             h_x[B,H]                                                   model.py:193-238
+ *   receiver: z[B,W], desc[D,V], h_z[B,R] in/out (zeros for a fresh conversation), s_prob_prod[B]
+ *             in/out (eval; `first` != 0 restarts the product) -> s[B], s_prob[B], w[B,W],
+ *             w_probs[B,W], y[B,D], h_w[B,R]                             model.py:333-342, 411-477
+ *   baseline: which = MMG_AGENT_BASELINE_REC/SEN; x[B,x_dim] or NULL, binary[B,W], inp[B,R] or NULL
+ *             -> score[B]                                                model.py:496-516
+ * Uniform pointers as in mmg_exchange_forward (NULL + train==1 -> Philox with `seed`, step t). */
+int mmg_sender_forward(mmg_handle* h, const float* d_x, const float* d_w, int t, int train,
+                       const float* d_u_z, uint64_t seed,
+                       float* d_message, float* d_probs, float* d_h_x, void* stream);
+int mmg_receiver_forward(mmg_handle* h, const float* d_z, const float* d_desc, float* d_h_z,
+                         float* d_s_prob_prod, int first, int t, int train,
+                         const float* d_u_s, const float* d_u_w, uint64_t seed,
+                         float* d_s, float* d_s_prob, float* d_w, float* d_w_probs, float* d_y,
+                         float* d_h_w, void* stream);
+int mmg_baseline_forward(mmg_handle* h, int which, const float* d_x, const float* d_binary,
+                         const float* d_inp, int rows, float* d_score, void* stream);
+
+/* Test/bench hooks: per-kernel timing of the most recent mmg_train_step measured with HIP events on
+ * the launch stream (enable before the step; read after a stream sync). */
+int mmg_set_profiling(mmg_handle* h, int enabled);
+int mmg_get_kernel_times(mmg_handle* h, char* names, int names_bytes, float* ms, int max_kernels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMG_H_ */

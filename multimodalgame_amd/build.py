@@ -1,0 +1,24 @@
+"""Builds libmmg.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "mmg.hip")
+OUT = os.path.join(HERE, "libmmg.so")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("mmg.hip", "layout.h", "device_utils.h", "kernels_fwd.h", "kernels_bwd.h")]
+DEPS.append(os.path.join(os.path.dirname(HERE), "include", "mmg.h"))
+
+
+def build_library(force=False, verbose=True):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build_library(force=True)

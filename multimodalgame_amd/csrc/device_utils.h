@@ -1,0 +1,148 @@
+// device_utils.h -- wave64 helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MMG_BLOCK 256          // 4 wave64 per workgroup everywhere
+#define MMG_EPS 1e-8f          // the reference's log(p + 1e-8)   model.py:908
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// wave-level sum over aligned groups of G lanes (G power of two, <= 64)
+__device__ __forceinline__ float group_sum(float v, int G) {
+    for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum(v, 64); }
+__device__ __forceinline__ float wave_max(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-wide reductions through a small LDS scratch (>= 8 floats); every thread gets the result.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-major GEMV, lanes along K:  for n < N:  epi(n, sum_k W[n*ld + k] * v[k])
+// W is the PyTorch [out,in] weight in global memory (L2-resident), v lives in LDS (16-byte
+// aligned).  G = lanes per row (power of two covering K/4 float4 items), 64/G rows per wave pass,
+// so each wave-wide load instruction covers contiguous rows.  The epilogue runs on one lane per
+// row.  Falls back to scalar loads when the row stride / base are not 16-byte aligned.
+// No barrier inside; callers __syncthreads() before consuming what the epilogue stored.
+// ---------------------------------------------------------------------------------------------
+template <class Epi>
+__device__ __forceinline__ void gemv_rows(const float* __restrict__ Wm, int ld, int N, int K,
+                                          const float* v, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const bool vec = ((ld & 3) == 0) && ((K & 3) == 0) && ((((uintptr_t)Wm) & 15) == 0);
+    const int items = vec ? (K >> 2) : K;
+    int G = 1;
+    while (G < 64 && G < items) G <<= 1;
+    const int rpw = 64 / G, sub = lane / G, gl = lane - sub * G;
+    for (int n0 = wave * rpw; n0 < N; n0 += nw * rpw) {
+        const int n = n0 + sub;
+        float acc = 0.f;
+        if (n < N) {
+            const float* row = Wm + (size_t)n * ld;
+            if (vec) {
+                const float4* r4 = reinterpret_cast<const float4*>(row);
+                const float4* v4 = reinterpret_cast<const float4*>(v);
+                for (int k = gl; k < items; k += G) {
+                    const float4 a = r4[k], b = v4[k];
+                    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+                    acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                }
+            } else {
+                for (int k = gl; k < items; k += G) acc = fmaf(row[k], v[k], acc);
+            }
+        }
+        acc = group_sum(acc, G);
+        if (gl == 0 && n < N) epi(n, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposed GEMV, lanes along the output:  out[k] (+)= sum_n W[n*ld + k] * d[n],  k < K.
+// d and out in LDS; `scratch` >= blockDim.x floats.  Ends with a barrier (out is ready).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gemv_t(const float* __restrict__ Wm, int ld, int N, int K,
+                                       const float* d, float* out, float* scratch, bool accumulate) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (K >= nt) {
+        for (int k = tid; k < K; k += nt) {
+            float acc = 0.f;
+            for (int n = 0; n < N; ++n) acc = fmaf(Wm[(size_t)n * ld + k], d[n], acc);
+            out[k] = accumulate ? out[k] + acc : acc;
+        }
+        __syncthreads();
+        return;
+    }
+    const int parts = nt / K;
+    const int part = tid / K, k = tid - part * K;
+    if (part < parts) {
+        float acc = 0.f;
+        for (int n = part; n < N; n += parts) acc = fmaf(Wm[(size_t)n * ld + k], d[n], acc);
+        scratch[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < K) {
+        float sacc = 0.f;
+        for (int p = 0; p < parts; ++p) sacc += scratch[p * K + tid];
+        out[tid] = accumulate ? out[tid] + sacc : sacc;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), one call per Bernoulli draw: counter = (element index,
+// minibatch counter, stream id, 0), key = 64-bit seed.  Returns a uniform in [0,1) with 24 bits.
+// tests/philox_ref.py holds the numpy restatement used to feed the oracle the same numbers.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+        const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1;
+        const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (float)(x0 >> 8) * (1.0f / 16777216.0f);
+}
+
+// one 16x16x4 fp32 MFMA step:  D += A(16x4) * B(4x16);  lane l holds A[l&15][l>>4], B[l>>4][l&15],
+// D[(l>>4)*4 + reg][l&15]   (cdna_hip_programming.md §3)
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+}  // namespace mmg

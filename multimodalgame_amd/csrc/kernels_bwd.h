@@ -1,0 +1,525 @@
+// kernels_bwd.h -- loss statistics, hand-written backward and the optimizer of the exchange path.
+//   k_stats     per-rank partial sums of every batch statistic (one workgroup)
+//   k_bwd_conv  one workgroup per sample: REINFORCE / entropy / NLL / MSE gradient seeds
+//                and reverse-time propagation through the receiver GRU;
+//               writes every pre-activation gradient to the tape
+//   k_dC        reduction over samples of the class-side gradient of the y head
+//   k_wgrad     all weight gradients as grouped fp32-MFMA  dW = delta^T . input  tiles plus
+//               bias gradients as column sums -- deterministic (no float atomics)
+//   k_gradnorm / k_opt   per-agent clip_grad_norm(1.0) + RMSprop / Adam / SGD on the flat buffers
+#pragma once
+#include "device_utils.h"
+#include "layout.h"
+
+namespace mmg {
+
+// ---------------------------------------------------------------------------------------------
+// k_stats.  Active sets (model.py:1256-1262) expressed through t*(b), the step whose logits are
+// the sample's output: m_t[b] == 1  <=>  t <= t*(b);  m_{t+1}[b] == 1 (after the forced final zero,
+// model.py:870)  <=>  t < t*(b).  Fixed exchange has t* = T-1 for every sample, which reproduces the
+// unmasked sums over T (T-1 for the receiver messages, rec_feats[:-1] at model.py:1286).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMG_BLOCK) void k_stats(Dims dm, Tape tp) {
+    const int T = dm.T, B = dm.B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int npairs = 5 * T + 2;
+    for (int p = wave; p < npairs; p += nw) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        if (p >= 5 * T) {                       // sum of rewards (-> NLL) and top-k hits
+            const int which = p - 5 * T;
+            for (int b = lane; b < B; b += 64) a0 += which == 0 ? (double)tp.logs[b] : (double)tp.hit[b];
+            a0 = wave_sum_d(a0);
+            if (lane == 0) tp.stats[stat_glob(T, which)] = a0;
+            continue;
+        }
+        const int kind = p / T, t = p - kind * T;
+        const bool enabled = dm.use_binary && !(kind == 0 && dm.fixed);
+        if (enabled) {
+            for (int b = lane; b < B; b += 64) {
+                const int ts = tp.tstar[b];
+                const bool act = (kind == 1) ? (t < ts) : (t <= ts);
+                if (!act) continue;
+                const size_t row = (size_t)t * B + b;
+                const float L = tp.logs[b];
+                if (kind < 3) {
+                    const float beta = (kind == 2) ? tp.bs[row] : tp.br[row];
+                    const float lp = (kind == 0) ? tp.lp_s[row] : (kind == 1) ? tp.lp_w[row] : tp.lp_z[row];
+                    const float ne = (kind == 0) ? tp.ne_s[row] : (kind == 1) ? tp.ne_w[row] : tp.ne_z[row];
+                    const double wv = (double)(L - beta);          // model.py:912
+                    a0 += 1.0; a1 += wv; a2 += wv * wv; a3 += wv * (double)lp; a4 += (double)ne;
+                } else {
+                    const float beta = (kind == 3) ? tp.br[row] : tp.bs[row];
+                    const double dv = (double)(beta - L);          // model.py:972
+                    a0 += dv * dv;
+                }
+            }
+        }
+        a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2); a3 = wave_sum_d(a3); a4 = wave_sum_d(a4);
+        if (lane == 0) {
+            if (kind < 3) {
+                double* st = tp.stats + stat_stream(T, kind, t, 0);
+                st[0] = a0; st[1] = a1; st[2] = a2; st[3] = a3; st[4] = a4;
+            } else {
+                tp.stats[stat_bas(T, kind - 3, t)] = a0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coefficients of the multistep losses from the (globally reduced) statistics.
+//   cw[k][t] = c_t / n_t / max(1, std_t)   multiplies -(L - beta) * dlogp     (model.py:912-916)
+//   ce[k][t] = c_t / n_t * lambda_k        multiplies d negent                (model.py:919-926)
+//   cb[t]    = c_t / n_t * 2               multiplies (beta - L)              (model.py:972)
+// with c_t = n_t / sum_t n_t (Adaptive, model.py:960-961) or 1 / len(list) (Fixed, model.py:967).
+// ---------------------------------------------------------------------------------------------
+struct LossCoef { float* cw; float* ce; float* cb; };   // LDS: cw[3*T], ce[3*T], cb[T]
+
+__device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* st, LossCoef lc, float* losses_out) {
+    const int T = dm.T;
+    if (threadIdx.x == 0) {
+        double loss[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k) {
+            double nsum = 0;
+            for (int t = 0; t < T; ++t) nsum += st[stat_stream(T, k, t, 0)];
+            const int len = (k == 1) ? T - 1 : T;
+            const float lam = (k == 0) ? dm.es : (k == 1) ? dm.erec : dm.esen;
+            const bool has = (k == 0) ? dm.has_es : (k == 1) ? dm.has_erec : dm.has_esen;
+            for (int t = 0; t < T; ++t) {
+                const double* s5 = st + stat_stream(T, k, t, 0);
+                const double n = s5[0];
+                float cw = 0.f, ce = 0.f;
+                if (n > 0 && nsum > 0) {
+                    const double c_over_n = dm.fixed ? 1.0 / ((double)len * n) : 1.0 / nsum;
+                    double denom = 1.0;
+                    if (n > 1) {                                        // model.py:914-915
+                        const double mean = s5[1] / n;
+                        double var = (s5[2] - n * mean * mean) / (n - 1.0);
+                        if (var < 0) var = 0;
+                        const double sd = sqrt(var);
+                        denom = sd > 1.0 ? sd : 1.0;
+                    }
+                    cw = (float)(c_over_n / denom);
+                    ce = has ? (float)(c_over_n * (double)lam) : 0.f;
+                    loss[k] += -(double)cw * s5[3] + (double)ce * s5[4];
+                }
+                lc.cw[k * T + t] = cw; lc.ce[k * T + t] = ce;
+            }
+        }
+        double lb[2] = {0, 0};
+        {
+            double nsum = 0;
+            for (int t = 0; t < T; ++t) nsum += st[stat_stream(T, 2, t, 0)];
+            for (int t = 0; t < T; ++t) {
+                const double n = st[stat_stream(T, 2, t, 0)];
+                float cb = 0.f;
+                if (n > 0 && nsum > 0) {
+                    const double c_over_n = dm.fixed ? 1.0 / ((double)T * n) : 1.0 / nsum;
+                    cb = (float)(2.0 * c_over_n);
+                    lb[0] += c_over_n * st[stat_bas(T, 0, t)];
+                    lb[1] += c_over_n * st[stat_bas(T, 1, t)];
+                }
+                lc.cb[t] = cb;
+            }
+        }
+        if (losses_out) {
+            int nsteps = 0;
+            for (int t = 0; t < T; ++t) nsteps += (st[stat_stream(T, 2, t, 0)] > 0) ? 1 : 0;
+            if (!dm.use_binary) nsteps = T;
+            losses_out[0] = (float)(-st[stat_glob(T, 0)] / (double)dm.Bg);   // NLL (model.py:1271)
+            losses_out[1] = (float)loss[0];                                  // loss_binary_s
+            losses_out[2] = (float)loss[1];                                  // loss_binary_rec
+            losses_out[3] = (float)loss[2];                                  // loss_binary_sen
+            losses_out[4] = (float)lb[0];                                    // loss_bas_rec
+            losses_out[5] = (float)lb[1];                                    // loss_bas_sen
+            losses_out[6] = (float)nsteps;                                   // exchange steps the reference executes
+            losses_out[7] = (float)st[stat_glob(T, 1)];                      // top-k hits
+        }
+    }
+    __syncthreads();
+}
+
+// d loss / d logit of one Bernoulli unit: REINFORCE term + entropy term (Appendix A.4)
+__device__ __forceinline__ float bit_seed(float q, float p, float wh, float ce) {
+    const float pe = p + MMG_EPS, qe = 1.f - p + MMG_EPS;
+    float dLdp = -wh * (q / pe - (1.f - q) / qe);
+    if (ce != 0.f) dLdp += ce * (logf(pe) + p / pe - logf(qe) - (1.f - p) / qe);
+    return dLdp * p * (1.f - p);
+}
+
+__host__ __device__ inline int bwd_smem_floats(const Dims& d) {
+    auto p4 = [](int n) { return (n + 3) & ~3; };
+    return 7 * d.T + 3 * p4(d.H) + 3 * p4(d.W) + 6 * p4(d.R) + 2 * p4(3 * d.R) + p4(d.D) + MMG_BLOCK + 32;
+}
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T, K = dm.K;
+    auto p4 = [](int n) { return (n + 3) & ~3; };
+    float* p = smem;
+    LossCoef lc; lc.cw = p; p += 3 * T; lc.ce = p; p += 3 * T; lc.cb = p; p += T;
+    p = smem + ((7 * T + 3) & ~3);
+    float* s_dhx = p; p += p4(H);   float* s_da = p; p += p4(H);   float* s_dpre = p; p += p4(H);
+    float* s_dlz = p; p += p4(W);   float* s_dlw = p; p += p4(W);  float* s_dc0 = p; p += p4(W);
+    float* s_dh = p; p += p4(R);    float* s_dhn = p; p += p4(R);  float* s_dg = p; p += p4(R);
+    float* s_A = p; p += p4(R);     float* s_dA = p; p += p4(R);   float* s_hs = p; p += p4(R);
+    float* s_dgi = p; p += p4(3 * R); float* s_dgh = p; p += p4(3 * R);
+    float* s_dy = p; p += p4(D);
+    float* s_red = p; p += MMG_BLOCK;
+    float* s_misc = p;
+
+    loss_coefficients(dm, tp.stats, lc, b == 0 ? tp.losses : nullptr);
+
+    const bool binary = dm.use_binary != 0;
+    const int tstar = tp.tstar[b];
+    const float L = tp.logs[b];
+    const float* cw_s = lc.cw, *cw_r = lc.cw + T, *cw_z = lc.cw + 2 * T;
+    const float* ce_s = lc.ce, *ce_r = lc.ce + T, *ce_z = lc.ce + 2 * T;
+
+    for (int i = tid; i < R; i += nt) s_dh[i] = 0.f;
+    for (int i = tid; i < H; i += nt) s_dhx[i] = 0.f;
+    __syncthreads();
+
+    // ---------------- zero the gradient tapes of steps this sample never took ----------------
+    for (int t = tstar + 1; t < T; ++t) {
+        const size_t row = (size_t)t * B + b;
+        for (int i = tid; i < W; i += nt) { tp.dlz[row * W + i] = 0.f; tp.dlw[row * W + i] = 0.f; }
+        for (int i = tid; i < H; i += nt) tp.dpre[row * H + i] = 0.f;
+        for (int i = tid; i < R; i += nt) tp.dgpre[row * R + i] = 0.f;
+        for (int i = tid; i < 3 * R; i += nt) { tp.dgi[row * 3 * R + i] = 0.f; tp.dgh[row * 3 * R + i] = 0.f; }
+        for (int i = tid; i < K; i += nt) { tp.dhid_s[row * K + i] = 0.f; tp.dhid_r[row * K + i] = 0.f; }
+        if (tid == 0) { tp.dls[row] = 0.f; tp.dbs[row] = 0.f; tp.dbr[row] = 0.f; }
+    }
+
+    // ---------------- reverse time ----------------
+    for (int t = tstar; t >= 0; --t) {
+        const size_t row = (size_t)t * B + b;
+        const float* hn = tp.h + ((size_t)(t + 1) * B + b) * R;    // h after step t
+        const float* hp = tp.h + ((size_t)t * B + b) * R;          // h before step t
+
+        // ---- receiver message head (stream 1: active while m_{t+1} == 1) ----
+        const bool act_next = binary && (t < tstar);
+        if (act_next) {
+            const float wh = (L - tp.br[row]) * cw_r[t];
+            for (int j = tid; j < W; j += nt) {
+                const float v = bit_seed(tp.w[row * W + j], tp.pw[row * W + j], wh, ce_r[t]);
+                s_dlw[j] = v; tp.dlw[row * W + j] = v;
+            }
+            __syncthreads();
+            gemv_t(P.p[R_W_W], R, W, R, s_dlw, s_dg, s_red, false);            // dg = W_w^T dlw
+            for (int i = tid; i < R; i += nt) {
+                const float g = tp.g[row * R + i];
+                const float v = s_dg[i] * (1.f - g * g);
+                s_dg[i] = v; tp.dgpre[row * R + i] = v;
+            }
+            __syncthreads();
+            gemv_t(P.p[R_WH_W], R, R, R, s_dg, s_dh, s_red, true);             // dh += W_h^T dgpre
+        } else {
+            for (int j = tid; j < W; j += nt) tp.dlw[row * W + j] = 0.f;
+            for (int i = tid; i < R; i += nt) tp.dgpre[row * R + i] = 0.f;
+        }
+        // ---- stop head (stream 0, Adaptive only) ----
+        if (binary && !dm.fixed) {
+            const float wh = (L - tp.br[row]) * cw_s[t];
+            const float dls = bit_seed(tp.s[row], tp.ps[row], wh, ce_s[t]);
+            if (tid == 0) tp.dls[row] = dls;
+            const float* ws = P.p[R_S_W];
+            for (int i = tid; i < R; i += nt) s_dh[i] += ws[i] * dls;
+        } else if (tid == 0) {
+            tp.dls[row] = 0.f;
+        }
+        __syncthreads();
+        // ---- class logits at the output step (NLL, model.py:1271) ----
+        if (t == tstar) {
+            const int tgt = (int)target[b];
+            float dsum = 0.f;
+            for (int d = tid; d < D; d += nt) {
+                const float v = (tp.sm[(size_t)b * D + d] - (d == tgt ? 1.f : 0.f)) / (float)dm.Bg;
+                s_dy[d] = v; tp.dy[(size_t)b * D + d] = v; dsum += v;
+            }
+            dsum = block_sum(dsum, s_misc);
+            if (tid == 0) tp.dysum[b] = dsum;
+            for (int i = tid; i < R; i += nt) { const float v = hn[i]; s_hs[i] = v; tp.hstar[(size_t)b * R + i] = v; }
+            __syncthreads();
+            gemv_rows(P.p[R_Y1_W], R + V, R, R, s_hs, [&](int n, float acc) { s_A[n] = acc; });
+            __syncthreads();
+            const float* w2 = P.p[R_Y2_W];
+            for (int i = tid; i < R; i += nt) {
+                const float a = s_A[i];
+                float acc = 0.f;
+                for (int d = 0; d < D; ++d) acc += (a + tp.Cd[(size_t)d * R + i] > 0.f) ? s_dy[d] : 0.f;
+                const float v = acc * w2[i];
+                s_dA[i] = v; tp.dA[(size_t)b * R + i] = v; tp.Astar[(size_t)b * R + i] = a;
+            }
+            __syncthreads();
+            gemv_t(P.p[R_Y1_W], R + V, R, R, s_dA, s_dh, s_red, true);         // dh += W_y1h^T dA
+        }
+        // ---- GRU cell backward ----
+        {
+            const float* gr = tp.gru + row * 4 * R;
+            for (int i = tid; i < R; i += nt) {
+                const float rr = gr[i], uu = gr[R + i], nn = gr[2 * R + i], ghn = gr[3 * R + i];
+                const float dh = s_dh[i];
+                const float dn = dh * (1.f - uu), du = dh * (hp[i] - nn);
+                const float dnp = dn * (1.f - nn * nn), dup = du * uu * (1.f - uu);
+                const float drp = dnp * ghn * rr * (1.f - rr);
+                s_dgi[i] = drp; s_dgi[R + i] = dup; s_dgi[2 * R + i] = dnp;
+                s_dgh[i] = drp; s_dgh[R + i] = dup; s_dgh[2 * R + i] = dnp * rr;
+                s_dhn[i] = dh * uu;
+            }
+            __syncthreads();
+            for (int i = tid; i < 3 * R; i += nt) { tp.dgi[row * 3 * R + i] = s_dgi[i]; tp.dgh[row * 3 * R + i] = s_dgh[i]; }
+            gemv_t(P.p[R_WHH], R, 3 * R, R, s_dgh, s_dhn, s_red, true);        // dh_{t-1} += W_hh^T dgh
+            for (int i = tid; i < R; i += nt) s_dh[i] = s_dhn[i];
+            __syncthreads();
+        }
+        // ---- sender (stream 2) ----
+        if (binary) {
+            const float wh = (L - tp.bs[row]) * cw_z[t];
+            for (int j = tid; j < W; j += nt) {
+                const float v = bit_seed(tp.z[row * W + j], tp.pz[row * W + j], wh, ce_z[t]);
+                s_dlz[j] = v; tp.dlz[row * W + j] = v;
+            }
+            __syncthreads();
+            gemv_t(P.p[S_BIN_W], H, W, H, s_dlz, s_da, s_red, false);          // da = W_b^T dlz
+            for (int i = tid; i < H; i += nt) {
+                const float a = tp.a[row * H + i];
+                const float v = s_da[i] * (1.f - a * a);
+                s_dpre[i] = v; tp.dpre[row * H + i] = v; s_dhx[i] += v;
+            }
+            __syncthreads();
+            if (t == 0) {                                                      // code_bias path (model.py:199)
+                gemv_t(P.p[S_CODE_W], W, H, W, s_dpre, s_dc0, s_red, false);
+                for (int j = tid; j < W; j += nt) tp.dc0[(size_t)b * W + j] = s_dc0[j];
+            }
+            // ---- baselines (MSE, model.py:971-988) ----
+            const float dbs = lc.cb[t] * (tp.bs[row] - L), dbr = lc.cb[t] * (tp.br[row] - L);
+            if (tid == 0) { tp.dbs[row] = dbs; tp.dbr[row] = dbr; }
+            const float* w2s = P.p[BS_L2_W]; const float* w2r = P.p[BR_L2_W];
+            for (int k = tid; k < K; k += nt) {
+                tp.dhid_s[row * K + k] = (tp.hid_s[row * K + k] > 0.f) ? dbs * w2s[k] : 0.f;
+                tp.dhid_r[row * K + k] = (tp.hid_r[row * K + k] > 0.f) ? dbr * w2r[k] : 0.f;
+            }
+        } else {
+            for (int i = tid; i < W; i += nt) tp.dlz[row * W + i] = 0.f;
+            for (int i = tid; i < H; i += nt) tp.dpre[row * H + i] = 0.f;
+            for (int i = tid; i < K; i += nt) { tp.dhid_s[row * K + i] = 0.f; tp.dhid_r[row * K + i] = 0.f; }
+            if (tid == 0) { tp.dbs[row] = 0.f; tp.dbr[row] = 0.f; }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < H; i += nt) tp.dhx[(size_t)b * H + i] = s_dhx[i];
+    if (!binary) for (int j = tid; j < W; j += nt) tp.dc0[(size_t)b * W + j] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dC: grid = D.  dC[d,r] = sum_b dy[b,d] * w_y2[r] * 1[A*[b,r] + Cd[d,r] > 0]   (-> y1.weight[:,R:], y1.bias)
+//                  Py2[d,r] = sum_b dy[b,d] * relu(A*[b,r] + Cd[d,r])              (-> y2.weight)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMG_BLOCK) void k_dC(Dims dm, Params P, Tape tp) {
+    __shared__ float s_c[MMG_BLOCK], s_p[MMG_BLOCK];
+    const int d = blockIdx.x, tid = threadIdx.x, R = dm.R, B = dm.B, D = dm.D;
+    const int cols = R < MMG_BLOCK ? R : MMG_BLOCK;
+    const int groups = MMG_BLOCK / cols;
+    const int g = tid / cols, rr = tid - g * cols;
+    const float* w2 = P.p[R_Y2_W];
+    for (int r0 = 0; r0 < R; r0 += cols) {
+        const int r = r0 + rr;
+        float dc = 0.f, py = 0.f;
+        if (g < groups && r < R) {
+            const float cv = tp.Cd[(size_t)d * R + r];
+            for (int b = g; b < B; b += groups) {
+                const float dyv = tp.dy[(size_t)b * D + d];
+                const float pre = tp.Astar[(size_t)b * R + r] + cv;
+                if (pre > 0.f) { dc += dyv; py = fmaf(dyv, pre, py); }
+            }
+            dc *= w2[r];
+        }
+        s_c[tid] = dc; s_p[tid] = py;
+        __syncthreads();
+        if (tid < cols && r0 + tid < R) {
+            float a = 0.f, c = 0.f;
+            for (int k = 0; k < groups; ++k) { a += s_c[k * cols + tid]; c += s_p[k * cols + tid]; }
+            tp.dC[(size_t)d * R + r0 + tid] = a;
+            tp.Py2[(size_t)d * R + r0 + tid] = c;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_wgrad: job table in the tape ("tables").  GEMM job: C[n,k] = sum_row A[row*lda + n] *
+// Bm[(row % bmod)*ldb + k]  -- both operands are tape arrays with the reduction dimension
+// (step, sample) as the slow axis, exactly the MFMA 16x16x4 fragment shape (A: 4 rows x 16 n,
+// B: 4 rows x 16 k per instruction).  One wave per 16x16 tile of dW.  Column job: dst[c] =
+// scale[c] * sum_row src[row*ld + c].
+// ---------------------------------------------------------------------------------------------
+enum { SRC_STATIC = 0, SRC_X = 1, SRC_DESC = 2 };
+struct GemmJob { const float* A; const float* Bm; float* C; int lda, ldb, ldc, rows, N, K, bmod, bsrc, tile_begin, tiles_k, pad; };
+struct ColJob { const float* src; float* dst; const float* scale; int ld, rows, cols, blk_begin; };
+#define MMG_MAX_GEMM 40
+#define MMG_MAX_COL 40
+struct NormPlan { int64_t begin[MMG_GN_BLOCKS], end[MMG_GN_BLOCKS]; int agent[MMG_GN_BLOCKS]; };
+struct JobTable {
+    int n_gemm, n_col, gemm_tiles, gemm_blocks, col_blocks, pad0, pad1, pad2;
+    GemmJob g[MMG_MAX_GEMM];
+    ColJob c[MMG_MAX_COL];
+    NormPlan np;
+};
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict__ jt, const float* __restrict__ x,
+                                                     const float* __restrict__ desc) {
+    __shared__ float s_part[MMG_BLOCK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x < jt->gemm_blocks) {
+        const int tile = blockIdx.x * 4 + wave;
+        if (tile >= jt->gemm_tiles) return;
+        int j = 0;
+        const int ng = jt->n_gemm;
+        while (j + 1 < ng && jt->g[j + 1].tile_begin <= tile) ++j;
+        const GemmJob& G = jt->g[j];
+        const int lt = tile - G.tile_begin;
+        const int tn = lt / G.tiles_k, tk = lt - tn * G.tiles_k;
+        const int n0 = tn * 16, k0 = tk * 16;
+        const int i = lane & 15, q = lane >> 4;
+        const float* Bbase = (G.bsrc == SRC_X) ? x : (G.bsrc == SRC_DESC) ? desc : G.Bm;
+        const bool nv = (n0 + i) < G.N, kv = (k0 + i) < G.K;
+        const float* Ap = G.A + (nv ? n0 + i : 0);
+        const float* Bp = Bbase + (kv ? k0 + i : 0);
+        const int rows = G.rows, lda = G.lda, ldb = G.ldb, bmod = G.bmod;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int r0 = 0; r0 < rows; r0 += 16) {
+            float a[4], bb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u * 4 + q;
+                const bool rv = r < rows;
+                const int rb = bmod ? (r % bmod) : r;
+                a[u] = (nv && rv) ? Ap[(size_t)r * lda] : 0.f;
+                bb[u] = (kv && rv) ? Bp[(size_t)rb * ldb] : 0.f;
+            }
+            acc0 = mfma16(a[0], bb[0], acc0); acc1 = mfma16(a[1], bb[1], acc1);
+            acc0 = mfma16(a[2], bb[2], acc0); acc1 = mfma16(a[3], bb[3], acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + q * 4 + r, k = k0 + i;
+            if (n < G.N && k < G.K) G.C[(size_t)n * G.ldc + k] = acc0[r] + acc1[r];
+        }
+        return;
+    }
+    // ---- column sums ----
+    const int cb = blockIdx.x - jt->gemm_blocks;
+    int j = 0;
+    const int nc = jt->n_col;
+    while (j + 1 < nc && jt->c[j + 1].blk_begin <= cb) ++j;
+    const ColJob& C = jt->c[j];
+    const int c0 = (cb - C.blk_begin) * 64;
+    const int cw = min(64, C.cols - c0);
+    const int groups = MMG_BLOCK / cw;
+    const int g = threadIdx.x / cw, cc = threadIdx.x - g * cw;
+    float acc = 0.f;
+    if (g < groups) {
+        const float* sp = C.src + c0 + cc;
+        for (int r = g; r < C.rows; r += groups) acc += sp[(size_t)r * C.ld];
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < cw) {
+        float v = 0.f;
+        for (int k = 0; k < groups; ++k) v += s_part[k * cw + threadIdx.x];
+        if (C.scale) v *= C.scale[c0 + threadIdx.x];
+        C.dst[c0 + threadIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-agent gradient norm (clip_grad_norm, model.py:1310) and the optimizer update.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMG_BLOCK) void k_gradnorm(const JobTable* __restrict__ jt, const float* __restrict__ grads,
+                                                        float* __restrict__ part, uint32_t* __restrict__ counter) {
+    __shared__ float s_red[8];
+    const int blk = blockIdx.x;
+    const int64_t b0 = jt->np.begin[blk], b1 = jt->np.end[blk];      // multiples of 4 floats
+    float acc = 0.f;
+    for (int64_t i = b0 + (int64_t)threadIdx.x * 4; i < b1; i += (int64_t)blockDim.x * 4) {
+        const float4 g = *reinterpret_cast<const float4*>(grads + i);
+        acc = fmaf(g.x, g.x, acc); acc = fmaf(g.y, g.y, acc); acc = fmaf(g.z, g.z, acc); acc = fmaf(g.w, g.w, acc);
+    }
+    acc = block_sum(acc, s_red);
+    if (threadIdx.x == 0) {
+        part[blk] = acc;
+        if (blk == 0) counter[1] += 1u;                               // optimizer step count (Adam bias correction)
+    }
+}
+
+struct OptArgs {
+    int optim_type, only_receiver;
+    float lr;
+    int64_t agent_begin[5];
+    int64_t total;
+};
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ jt, OptArgs oa, float* __restrict__ params,
+                                                   const float* __restrict__ grads, float* __restrict__ state,
+                                                   const float* __restrict__ part, const uint32_t* __restrict__ counter) {
+    __shared__ float s_coef[4];
+    if (threadIdx.x < 4) {
+        float ss = 0.f;
+        for (int k = 0; k < MMG_GN_BLOCKS; ++k) if (jt->np.agent[k] == (int)threadIdx.x) ss += part[k];
+        const float norm = sqrtf(ss);
+        const float coef = 1.0f / (norm + 1e-6f);                    // max_norm = 1 (model.py:1310)
+        s_coef[threadIdx.x] = coef < 1.f ? coef : 1.f;
+    }
+    __syncthreads();
+    const uint32_t step = counter[1];                                 // incremented by k_gradnorm
+    const float b1 = 0.9f, b2 = 0.999f;
+    float bc1 = 1.f, bc2s = 1.f;
+    if (oa.optim_type == MMG_OPT_ADAM) {
+        bc1 = 1.f - powf(b1, (float)step);
+        bc2s = sqrtf(1.f - powf(b2, (float)step));
+    }
+    float* st1 = state; float* st2 = state + oa.total;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < oa.total;
+         i += (int64_t)gridDim.x * blockDim.x * 4) {
+        int a = 0;
+        if (i >= oa.agent_begin[1]) a = 1;
+        if (i >= oa.agent_begin[2]) a = 2;
+        if (i >= oa.agent_begin[3]) a = 3;
+        if (oa.only_receiver && a != 0) continue;                     // model.py:1313
+        const float coef = s_coef[a];
+        float4 g = *reinterpret_cast<const float4*>(grads + i);
+        float4 w = *reinterpret_cast<float4*>(params + i);
+        float gv[4] = {g.x * coef, g.y * coef, g.z * coef, g.w * coef};
+        float wv[4] = {w.x, w.y, w.z, w.w};
+        if (oa.optim_type == MMG_OPT_RMSPROP) {                       // torch.optim.RMSprop defaults (model.py:1128)
+            float4 s = *reinterpret_cast<float4*>(st1 + i);
+            float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sv[k] = 0.99f * sv[k] + (1.f - 0.99f) * gv[k] * gv[k];
+                wv[k] -= oa.lr * gv[k] / (sqrtf(sv[k]) + 1e-8f);
+            }
+            *reinterpret_cast<float4*>(st1 + i) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        } else if (oa.optim_type == MMG_OPT_ADAM) {                   // torch.optim.Adam defaults (model.py:1120)
+            float4 m = *reinterpret_cast<float4*>(st1 + i), v = *reinterpret_cast<float4*>(st2 + i);
+            float mv[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mv[k] = mv[k] + (gv[k] - mv[k]) * (1.f - b1);
+                vv[k] = b2 * vv[k] + (1.f - b2) * gv[k] * gv[k];
+                const float denom = sqrtf(vv[k]) / bc2s + 1e-8f;
+                wv[k] -= (oa.lr / bc1) * mv[k] / denom;
+            }
+            *reinterpret_cast<float4*>(st1 + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            *reinterpret_cast<float4*>(st2 + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {                                                      // SGD (model.py:1112)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wv[k] -= oa.lr * gv[k];
+        }
+        *reinterpret_cast<float4*>(params + i) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    }
+}
+
+}  // namespace mmg

@@ -1,0 +1,544 @@
+// kernels_fwd.h -- forward kernels of the exchange path.
+//   k_prep          per-minibatch constants of the parameters (Cd, hw0, dsig)
+//   k_gemm_nt       out[M,N] = X[M,K] . W[N,K]^T + bias   (fp32 MFMA 16x16x4; h_x and baseline_sen's
+//                   h_x part -- computed ONCE per minibatch instead of once per step as model.py:195)
+//   k_conversation  one workgroup per sample runs the whole T-step conversation (model.py:801-866)
+//   k_baselines     both baselines over all (step, sample) rows, fp32 MFMA (model.py:835-843)
+#pragma once
+#include "device_utils.h"
+#include "layout.h"
+
+namespace mmg {
+
+// ---------------------------------------------------------------------------------------------
+// k_prep: grid = D + 1 blocks.  Block d < D: Cd[d,:] = W_y1[:, R:] . desc[d] + b_y1  (the
+// description half of y1 applied once per class instead of once per (sample, class) row of
+// build_inp, model.py:412/432 -- SURVEY.md Appendix A.2).  Block D: hw0 = code_layer(sigmoid(
+// code_bias)) (model.py:199-200) and dsig = sigmoid'(code_bias).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, const float* __restrict__ desc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < dm.D) {
+        const int d = blockIdx.x;
+        float* s_desc = smem;                       // [V]
+        for (int v = tid; v < dm.V; v += blockDim.x) s_desc[v] = desc[(size_t)d * dm.V + v];
+        __syncthreads();
+        const float* Wy1d = P.p[R_Y1_W] + dm.R;     // columns R.. of y1.weight (row stride R+V)
+        const float* by1 = P.p[R_Y1_B];
+        float* out = tp.Cd + (size_t)d * dm.R;
+        // Wy1d rows start at offset R: 16-byte alignment holds when R % 4 == 0 (gemv_rows checks)
+        gemv_rows(Wy1d, dm.R + dm.V, dm.R, dm.V, s_desc, [&](int n, float acc) { out[n] = acc + by1[n]; });
+    } else {
+        float* s_sig = smem;                        // [W]
+        const float* cb = P.p[S_CODE_BIAS];
+        for (int j = tid; j < dm.W; j += blockDim.x) {
+            const float sg = sigmoidf_(cb[j]);
+            s_sig[j] = sg;
+            tp.dsig[j] = sg * (1.f - sg);
+        }
+        if (tid == 0) tp.counter[0] += 1u;          // minibatch counter: the Philox stream of this conversation
+        __syncthreads();
+        const float* bc = P.p[S_CODE_B];
+        gemv_rows(P.p[S_CODE_W], dm.W, dm.H, dm.W, s_sig, [&](int n, float acc) { tp.hw0[n] = acc + bc[n]; });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_nt: out[m, n] = sum_k X[m*ldx + k] * Wm[n*ldw + k] + bias[n].  One workgroup per 16x16
+// output tile; its 4 waves split K and combine through LDS.  Fragments are read straight from
+// global memory (both operands have K contiguous): with K % 16 == 0 each lane fetches one float4
+// per operand per four MFMAs (the k index inside the group of 16 is permuted identically for A
+// and B, which leaves the sum unchanged).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMG_BLOCK) void k_gemm_nt(const float* __restrict__ X, int ldx,
+                                                       const float* __restrict__ Wm, int ldw,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ out, int ldo, int M, int N, int K) {
+    __shared__ float s_acc[4][16][17];
+    const int tiles_n = (N + 15) >> 4;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int m = tm * 16 + i, n = tn * 16 + i;
+    const bool mv = m < M, nv = n < N;
+    const float* xr = X + (size_t)(mv ? m : 0) * ldx;
+    const float* wr = Wm + (size_t)(nv ? n : 0) * ldw;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = ((K & 15) == 0) && ((ldx & 3) == 0) && ((ldw & 3) == 0) &&
+                     ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)Wm) & 15) == 0);
+    if (vec) {
+        const int kchunks = K >> 4;                       // groups of 16 k
+        const int per = (kchunks + 3) >> 2;
+        const int c0 = wave * per, c1 = min(kchunks, c0 + per);
+        for (int cch = c0; cch < c1; ++cch) {
+            const int k = cch * 16 + q * 4;
+            float4 a = mv ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 b = nv ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = mfma16(a.x, b.x, acc); acc = mfma16(a.y, b.y, acc);
+            acc = mfma16(a.z, b.z, acc); acc = mfma16(a.w, b.w, acc);
+        }
+    } else {
+        const int ksteps = (K + 3) >> 2;
+        const int per = (ksteps + 3) >> 2;
+        const int s0 = wave * per, s1 = min(ksteps, s0 + per);
+        for (int st = s0; st < s1; ++st) {
+            const int k = st * 4 + q;
+            const float a = (mv && k < K) ? xr[k] : 0.f;
+            const float b = (nv && k < K) ? wr[k] : 0.f;
+            acc = mfma16(a, b, acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = acc[r];
+    __syncthreads();
+    {
+        const int r = threadIdx.x >> 4, cidx = threadIdx.x & 15;       // 256 threads = 16x16 outputs
+        const int mo = tm * 16 + r, no = tn * 16 + cidx;
+        if (mo < M && no < N) {
+            float v = s_acc[0][r][cidx] + s_acc[1][r][cidx] + s_acc[2][r][cidx] + s_acc[3][r][cidx];
+            out[(size_t)mo * ldo + no] = v + (bias ? bias[no] : 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conversation
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* x;            // unused here (h_x precomputed) but kept for agent-level calls
+    const int64_t* target;     // [B] or NULL
+    const float* desc;         // [D,V]
+    const float* u_z;          // [T,B,W] or NULL
+    const float* u_s;          // [T,B]   or NULL
+    const float* u_w;          // [T,B,W] or NULL
+    uint64_t seed;
+    int train;                 // sample (1) or round (0)
+    int run_all;               // 1: every sample runs all steps
+    int t_begin, t_end;        // step window (whole conversation: 0, T)
+    int phases;                // bit 0 sender, bit 1 receiver
+    // agent-level I/O (NULL in the fused path: state lives in the tape)
+    const float* w_in;         // sender input code for t_begin > 0   [B,W]
+    float* h_state;            // receiver GRU state in/out           [B,R]
+    float* sprod_state;        // receiver running stop product       [B]
+    int sprod_first;
+};
+
+struct ConvSmem {
+    float *hx, *a, *c, *z, *w, *lp, *ne, *h, *hn, *A, *g, *g2, *gi, *gh, *y, *yout, *dbar, *red, *misc;
+};
+
+__device__ __forceinline__ int pad4(int n) { return (n + 3) & ~3; }
+
+__host__ __device__ inline int conv_smem_floats(const Dims& d) {
+    auto p4 = [](int n) { return (n + 3) & ~3; };
+    return 2 * p4(d.H) + 5 * p4(d.W) + 5 * p4(d.R) + 2 * p4(3 * d.R) + 2 * p4(d.D) + p4(d.V) + MMG_BLOCK + 32;
+}
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, Tape tp, ConvArgs ar) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
+    ConvSmem s;
+    {
+        float* p = smem;
+        s.hx = p; p += pad4(H);  s.a = p; p += pad4(H);
+        s.c = p; p += pad4(W);   s.z = p; p += pad4(W);  s.w = p; p += pad4(W);
+        s.lp = p; p += pad4(W);  s.ne = p; p += pad4(W);
+        s.h = p; p += pad4(R);   s.hn = p; p += pad4(R); s.A = p; p += pad4(R);
+        s.g = p; p += pad4(R);   s.g2 = p; p += pad4(R);
+        s.gi = p; p += pad4(3 * R); s.gh = p; p += pad4(3 * R);
+        s.y = p; p += pad4(D);   s.yout = p; p += pad4(D);
+        s.dbar = p; p += pad4(V);
+        s.red = p; p += MMG_BLOCK;
+        s.misc = p;
+    }
+    float* s_ne = s.ne;
+
+    const bool do_sen = ar.phases & 1, do_rec = ar.phases & 2;
+    const bool binary = dm.use_binary != 0;
+    const bool train = ar.train != 0;
+
+    // ---- conversation state ----
+    if (do_sen) for (int i = tid; i < H; i += nt) s.hx[i] = tp.hx[(size_t)b * H + i];
+    if (do_rec) {
+        for (int i = tid; i < R; i += nt)
+            s.h[i] = ar.h_state ? ar.h_state[(size_t)b * R + i] : (ar.t_begin == 0 ? 0.f : tp.h[((size_t)ar.t_begin * B + b) * R + i]);
+        if (ar.t_begin == 0 && !ar.h_state) for (int i = tid; i < R; i += nt) tp.h[(size_t)b * R + i] = 0.f;
+    }
+    for (int j = tid; j < W; j += nt) {
+        float wv = dm.first_rec;                                   // model.py:786
+        if (ar.t_begin > 0) wv = ar.w_in ? ar.w_in[(size_t)b * W + j] : tp.w[((size_t)(ar.t_begin - 1) * B + b) * W + j];
+        s.w[j] = wv;
+    }
+    if (tid == 0) {
+        s.misc[0] = 1.f;                                           // running stop mask m_t
+        s.misc[1] = -1.f;                                          // t* (not yet known)
+        s.misc[2] = (ar.sprod_state && !ar.sprod_first) ? ar.sprod_state[b] : 1.f;   // running prod of p_s
+        if (ar.t_begin == 0 && do_rec) tp.mask[b] = 1;             // stop_mask[0] = ones   model.py:775
+    }
+    __syncthreads();
+
+    const uint32_t mb_counter = tp.counter[0];
+    const uint32_t gb = (uint32_t)(dm.boff + b);                   // index inside the GLOBAL minibatch
+
+    int t = ar.t_begin;
+    for (; t < ar.t_end; ++t) {
+        const size_t row = (size_t)t * B + b;
+        // ================= Sender (model.py:193-238) =================
+        if (do_sen) {
+            // code input: sigmoid(code_bias) at t == 0 (hw0 precomputed), else the receiver's last message
+            for (int j = tid; j < W; j += nt) {
+                const float cv = s.w[j];
+                s.c[j] = cv;
+                tp.zr[row * W + j] = cv;                           // z_r fed to baseline_sen (model.py:836)
+                tp.c[row * W + j] = (t == 0) ? sigmoidf_(P.p[S_CODE_BIAS][j]) : cv;
+            }
+            __syncthreads();
+            if (t > 0) {
+                const float* bc = P.p[S_CODE_B];
+                gemv_rows(P.p[S_CODE_W], W, H, W, s.c, [&](int n, float acc) { s.a[n] = acc + bc[n]; });
+                __syncthreads();
+            }
+            for (int i = tid; i < H; i += nt) {
+                const float hw = (t == 0) ? tp.hw0[i] : s.a[i];
+                const float av = tanhf(s.hx[i] + hw);              // model.py:216
+                s.a[i] = av;
+                tp.a[row * H + i] = av;
+            }
+            __syncthreads();
+            {
+                const float* bb = P.p[S_BIN_B];
+                const float* uz = ar.u_z ? ar.u_z + row * W : nullptr;
+                gemv_rows(P.p[S_BIN_W], H, W, H, s.a, [&](int n, float acc) {
+                    const float lz = acc + bb[n];
+                    float zz = lz, lpv = 0.f, nev = 0.f;
+                    if (binary) {
+                        const float p = sigmoidf_(lz);             // model.py:223
+                        if (train) {
+                            const float u = uz ? uz[n] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + gb) * W + n), mb_counter, 0u);
+                            zz = (u < p) ? 1.f : 0.f;              // model.py:227
+                        } else {
+                            zz = rintf(p);                         // model.py:229 (torch.round = half-to-even)
+                        }
+                        tp.pz[row * W + n] = p;
+                        const float l1 = logf(p + MMG_EPS), l0 = logf(1.f - p + MMG_EPS);
+                        lpv = zz * l1 + (1.f - zz) * l0;           // model.py:908-910
+                        nev = p * l1 + (1.f - p) * l0;             // model.py:919-922
+                    }
+                    s.z[n] = zz; s.lp[n] = lpv; s_ne[n] = nev;
+                    tp.z[row * W + n] = zz;
+                });
+            }
+            __syncthreads();
+            if (binary) {
+                float lpv = 0.f, nev = 0.f;
+                for (int j = tid; j < W; j += nt) { lpv += s.lp[j]; nev += s_ne[j]; }
+                lpv = block_sum(lpv, s.misc + 8);
+                nev = block_sum(nev, s.misc + 16);
+                if (tid == 0) { tp.lp_z[row] = lpv; tp.ne_z[row] = nev; }
+            }
+        } else {
+            // receiver-only call: the message comes from the tape slot of this step
+            for (int j = tid; j < W; j += nt) s.z[j] = tp.z[row * W + j];
+            __syncthreads();
+        }
+        if (!do_rec) continue;
+
+        // ================= Receiver (model.py:333-342, 411-477) =================
+        {   // GRUCell (model.py:340); gate order r, z(u), n
+            const float* bih = P.p[R_BIH]; const float* bhh = P.p[R_BHH];
+            gemv_rows(P.p[R_WIH], W, 3 * R, W, s.z, [&](int n, float acc) { s.gi[n] = acc + bih[n]; });
+            gemv_rows(P.p[R_WHH], R, 3 * R, R, s.h, [&](int n, float acc) { s.gh[n] = acc + bhh[n]; });
+        }
+        __syncthreads();
+        for (int i = tid; i < R; i += nt) {
+            const float rr = sigmoidf_(s.gi[i] + s.gh[i]);
+            const float uu = sigmoidf_(s.gi[R + i] + s.gh[R + i]);
+            const float ghn = s.gh[2 * R + i];
+            const float nn = tanhf(s.gi[2 * R + i] + rr * ghn);
+            const float hv = nn + uu * (s.h[i] - nn);
+            s.hn[i] = hv;
+            float* gr = tp.gru + row * 4 * R;
+            gr[i] = rr; gr[R + i] = uu; gr[2 * R + i] = nn; gr[3 * R + i] = ghn;
+            tp.h[((size_t)(t + 1) * B + b) * R + i] = hv;
+        }
+        __syncthreads();
+        {   // stop head (model.py:414-427) and the h-half of y1 (Appendix A.2)
+            const float bsv = P.p[R_S_B][0];
+            gemv_rows(P.p[R_S_W], R, 1, R, s.hn, [&](int n, float acc) {
+                const float p = sigmoidf_(acc + bsv);
+                float sv;
+                if (train) {
+                    const float u = ar.u_s ? ar.u_s[row] : philox_uniform(ar.seed, (uint32_t)(t * dm.Bg + gb), mb_counter, 1u);
+                    sv = (u < p) ? 1.f : 0.f;                      // model.py:420
+                } else {
+                    const float prod = dm.s_prob_prod ? s.misc[2] * p : p;   // model.py:423-426 (misc[2] == 1 on a fresh conversation)
+                    s.misc[2] = prod;
+                    sv = rintf(prod);                              // model.py:427
+                }
+                tp.s[row] = sv; tp.ps[row] = p;
+                const float l1 = logf(p + MMG_EPS), l0 = logf(1.f - p + MMG_EPS);
+                tp.lp_s[row] = sv * l1 + (1.f - sv) * l0;
+                tp.ne_s[row] = p * l1 + (1.f - p) * l0;
+                s.misc[3] = sv;
+            });
+            gemv_rows(P.p[R_Y1_W], R + V, R, R, s.hn, [&](int n, float acc) { s.A[n] = acc; });
+        }
+        __syncthreads();
+        {   // y[d] = b_y2 + sum_r w_y2[r] * relu(A[r] + Cd[d,r])      (model.py:432-433)
+            const float* w2 = P.p[R_Y2_W];
+            const float b2 = P.p[R_Y2_B][0];
+            const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+            const bool vec = (R & 3) == 0;
+            const int items = vec ? (R >> 2) : R;
+            int G = 1; while (G < 64 && G < items) G <<= 1;
+            const int rpw = 64 / G, sub = lane / G, gl = lane - sub * G;
+            for (int d0 = wave * rpw; d0 < D; d0 += nw * rpw) {
+                const int d = d0 + sub;
+                float acc = 0.f;
+                if (d < D) {
+                    const float* crow = tp.Cd + (size_t)d * R;
+                    if (vec) {
+                        for (int k = gl; k < items; k += G) {
+                            const float4 cv = reinterpret_cast<const float4*>(crow)[k];
+                            const float4 av = reinterpret_cast<const float4*>(s.A)[k];
+                            const float4 wv = reinterpret_cast<const float4*>(w2)[k];
+                            acc = fmaf(wv.x, fmaxf(av.x + cv.x, 0.f), acc); acc = fmaf(wv.y, fmaxf(av.y + cv.y, 0.f), acc);
+                            acc = fmaf(wv.z, fmaxf(av.z + cv.z, 0.f), acc); acc = fmaf(wv.w, fmaxf(av.w + cv.w, 0.f), acc);
+                        }
+                    } else {
+                        for (int k = gl; k < items; k += G) acc = fmaf(w2[k], fmaxf(s.A[k] + crow[k], 0.f), acc);
+                    }
+                }
+                acc = group_sum(acc, G);
+                if (gl == 0 && d < D) { const float yv = acc + b2; s.y[d] = yv; tp.y[row * D + d] = yv; }
+            }
+        }
+        __syncthreads();
+        {   // stop-mask bookkeeping (model.py:852) -- uniform decision for the whole workgroup
+            const float m_t = s.misc[0], sv = s.misc[3];
+            const float m_next = fminf(m_t, sv);
+            const bool first_stop = (m_next == 0.f) && (s.misc[1] < 0.f);
+            const bool last = (t == T - 1);
+            if (first_stop || (last && s.misc[1] < 0.f)) {
+                for (int d = tid; d < D; d += nt) s.yout[d] = s.y[d];   // the output step (model.py:1261-1264)
+            }
+            __syncthreads();
+            if (tid == 0) {
+                tp.mask[(size_t)(t + 1) * B + b] = (uint8_t)(m_next != 0.f);
+                if (first_stop || (last && s.misc[1] < 0.f)) s.misc[1] = (float)t;
+                s.misc[0] = m_next;
+            }
+            __syncthreads();
+            // a sample whose conversation has ended contributes nothing further to any loss (its
+            // query w_t is never read: the receiver-message stream is active only while m_{t+1} == 1)
+            if (!ar.run_all && !dm.fixed && train && m_next == 0.f) { ++t; break; }
+        }
+        // softmax(y) (detached, model.py:441) and the description mixture (model.py:442-449)
+        float mx = -3.4e38f;
+        for (int d = tid; d < D; d += nt) mx = fmaxf(mx, s.y[d]);
+        mx = block_max(mx, s.misc + 8);
+        float se = 0.f;
+        for (int d = tid; d < D; d += nt) { const float e = expf(s.y[d] - mx); s.y[d] = e; se += e; }
+        se = block_sum(se, s.misc + 16);
+        const float inv = 1.f / se;
+        for (int d = tid; d < D; d += nt) s.y[d] *= inv;
+        __syncthreads();
+        gemv_t(ar.desc, V, D, V, s.y, s.dbar, s.red, false);
+        for (int v = tid; v < V; v += nt) tp.dbar[row * V + v] = s.dbar[v];
+        {   // h_w = tanh(w_h(h) + w_d(dbar))   (model.py:452)
+            const float* bh = P.p[R_WH_B];
+            gemv_rows(P.p[R_WH_W], R, R, R, s.hn, [&](int n, float acc) { s.g[n] = acc + bh[n]; });
+            gemv_rows(P.p[R_WD_W], V, R, V, s.dbar, [&](int n, float acc) { s.g2[n] = acc; });
+        }
+        __syncthreads();
+        for (int i = tid; i < R; i += nt) {
+            const float gv = tanhf(s.g[i] + s.g2[i]);
+            s.g[i] = gv;
+            tp.g[row * R + i] = gv;
+            s.h[i] = s.hn[i];                                       // advance the GRU state
+        }
+        __syncthreads();
+        {   // receiver message (model.py:454-475)
+            const float* bw = P.p[R_W_B];
+            const float* uw = ar.u_w ? ar.u_w + row * W : nullptr;
+            gemv_rows(P.p[R_W_W], R, W, R, s.g, [&](int n, float acc) {
+                const float lw = acc + bw[n];
+                float wv = lw, lpv = 0.f, nev = 0.f;
+                if (binary) {
+                    const float p = sigmoidf_(lw);
+                    if (train) {
+                        const float u = uw ? uw[n] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + gb) * W + n), mb_counter, 2u);
+                        wv = (u < p) ? 1.f : 0.f;                  // model.py:460
+                    } else {
+                        wv = rintf(p);                             // model.py:462
+                    }
+                    tp.pw[row * W + n] = p;
+                    const float l1 = logf(p + MMG_EPS), l0 = logf(1.f - p + MMG_EPS);
+                    lpv = wv * l1 + (1.f - wv) * l0;
+                    nev = p * l1 + (1.f - p) * l0;
+                }
+                s.w[n] = wv; s.lp[n] = lpv; s_ne[n] = nev;
+                tp.w[row * W + n] = wv;
+            });
+        }
+        __syncthreads();
+        if (binary) {
+            float lpv = 0.f, nev = 0.f;
+            for (int j = tid; j < W; j += nt) { lpv += s.lp[j]; nev += s_ne[j]; }
+            lpv = block_sum(lpv, s.misc + 8);
+            nev = block_sum(nev, s.misc + 16);
+            if (tid == 0) { tp.lp_w[row] = lpv; tp.ne_w[row] = nev; }
+        }
+        __syncthreads();
+    }
+    if (!do_rec) return;
+
+    // ---- agent-level state hand-back ----
+    if (ar.h_state) for (int i = tid; i < R; i += nt) ar.h_state[(size_t)b * R + i] = s.h[i];
+    if (ar.sprod_state && tid == 0) ar.sprod_state[b] = s.misc[2];
+    if (ar.t_end != T && s.misc[1] < 0.f) return;     // partial window without an output step
+    if (ar.t_begin != 0) return;
+
+    // ---- output selection, log-softmax, reward, top-k (model.py:1264-1275, 1333-1339) ----
+    const int tstar = dm.fixed ? (T - 1) : (int)s.misc[1];
+    if (dm.fixed) {
+        __syncthreads();
+        for (int d = tid; d < D; d += nt) s.yout[d] = tp.y[((size_t)(T - 1) * B + b) * D + d];
+        __syncthreads();
+    }
+    if (tid == 0) tp.tstar[b] = tstar;
+    float mx = -3.4e38f;
+    for (int d = tid; d < D; d += nt) mx = fmaxf(mx, s.yout[d]);
+    mx = block_max(mx, s.misc + 8);
+    float se = 0.f;
+    for (int d = tid; d < D; d += nt) se += expf(s.yout[d] - mx);
+    se = block_sum(se, s.misc + 16);
+    const float lse = mx + logf(se);
+    const int tgt = ar.target ? (int)ar.target[b] : -1;
+    const float dt = (tgt >= 0) ? (s.yout[tgt] - lse) : 0.f;
+    float above = 0.f;
+    for (int d = tid; d < D; d += nt) {
+        const float o = s.yout[d], ld = o - lse;
+        tp.outp[(size_t)b * D + d] = o;
+        tp.dist[(size_t)b * D + d] = ld;
+        tp.sm[(size_t)b * D + d] = expf(ld);
+        if (tgt >= 0 && ld > dt) above += 1.f;
+    }
+    above = block_sum(above, s.misc + 8);
+    if (tid == 0) {
+        tp.logs[b] = dt;
+        tp.hit[b] = (tgt >= 0 && above < (float)dm.top_k) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_baselines: grid (ceil(rows/16), 2).  blockIdx.y == 0: baseline_rec over [z_t || h_{t+1}]
+// (model.py:842-843), == 1: baseline_sen over [h_x || z_r] (model.py:835-836) with the h_x part
+// (Gs, incl. bias) added per sample.  Each workgroup owns 16 (step, sample) rows; its 4 waves take
+// every 4th 16-wide tile of the K hidden units (fp32 MFMA), apply relu, store the hidden tile for
+// the backward pass and reduce hidden . w2 to the score.
+// ---------------------------------------------------------------------------------------------
+struct BasArgs {
+    int rows;                 // T*B (fused) or B (agent-level)
+    const float* x1; int ld1, k1;     // first K segment of the input
+    const float* x2; int ld2, k2;     // second K segment (NULL if none)
+    const float* addend; int add_mod; // per-row pre-activation addend [rows % add_mod, K] (NULL if none)
+    const float* W1; int ldw, col0;   // linear1.weight, row stride, first column used
+    const float* b1;                  // NULL when folded into the addend
+    const float* W2; const float* b2;
+    float* hid;                       // [rows, K] or NULL
+    float* score;                     // [rows]
+};
+
+__device__ __forceinline__ void bas_accumulate(f32x4& acc, const float* __restrict__ xrow, bool xv,
+                                               const float* __restrict__ wrow, bool wv, int K, int q) {
+    const bool vec = ((K & 15) == 0) && ((((uintptr_t)xrow) & 15) == 0) && ((((uintptr_t)wrow) & 15) == 0);
+    // NB: `vec` must be wave-uniform: row strides are checked by the caller, bases differ only by rows
+    if (vec) {
+        for (int k = q * 4; k < K; k += 16) {
+            float4 a = xv ? *reinterpret_cast<const float4*>(xrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 b = wv ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = mfma16(a.x, b.x, acc); acc = mfma16(a.y, b.y, acc);
+            acc = mfma16(a.z, b.z, acc); acc = mfma16(a.w, b.w, acc);
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + q;
+            const float a = (xv && k < K) ? xrow[k] : 0.f;
+            const float b = (wv && k < K) ? wrow[k] : 0.f;
+            acc = mfma16(a, b, acc);
+        }
+    }
+}
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_baselines(int K, BasArgs rec, BasArgs sen) {
+    __shared__ float s_part[4][16];
+    const BasArgs& A = (blockIdx.y == 0) ? rec : sen;
+    const int row0 = blockIdx.x * 16;
+    if (row0 >= A.rows) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int xrow = row0 + i;
+    const bool xv = xrow < A.rows;
+    const size_t xr = xv ? xrow : 0;
+    // alignment of the vector path must hold for every row: require ld % 4 == 0, else force scalar by
+    // passing a K that fails the (K & 15) test -- done here by checking the strides once.
+    const bool ok1 = ((A.ld1 & 3) == 0) && ((A.ldw & 3) == 0) && ((A.col0 & 3) == 0);
+    const bool ok2 = A.x2 && ((A.ld2 & 3) == 0) && ((A.ldw & 3) == 0) && (((A.col0 + A.k1) & 3) == 0);
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ntiles = (K + 15) >> 4;
+    for (int tn = wave; tn < ntiles; tn += 4) {
+        const int n = tn * 16 + i;
+        const bool nv = n < K;
+        const float* wrow = A.W1 + (size_t)(nv ? n : 0) * A.ldw + A.col0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (ok1) bas_accumulate(acc, A.x1 + xr * A.ld1, xv, wrow, nv, A.k1, q);
+        else {
+            for (int k0 = 0; k0 < A.k1; k0 += 4) {
+                const int k = k0 + q;
+                acc = mfma16((xv && k < A.k1) ? A.x1[xr * A.ld1 + k] : 0.f, (nv && k < A.k1) ? wrow[k] : 0.f, acc);
+            }
+        }
+        if (A.x2) {
+            if (ok2) bas_accumulate(acc, A.x2 + xr * A.ld2, xv, wrow + A.k1, nv, A.k2, q);
+            else {
+                for (int k0 = 0; k0 < A.k2; k0 += 4) {
+                    const int k = k0 + q;
+                    acc = mfma16((xv && k < A.k2) ? A.x2[xr * A.ld2 + k] : 0.f, (nv && k < A.k2) ? wrow[A.k1 + k] : 0.f, acc);
+                }
+            }
+        }
+        // epilogue: this lane holds rows q*4 + r, column i of the tile
+        const int no = tn * 16 + i;
+        const float bias = (no < K && A.b1) ? A.b1[no] : 0.f;
+        const float w2 = (no < K) ? A.W2[no] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ro = row0 + q * 4 + r;
+            if (ro < A.rows && no < K) {
+                float v = acc[r] + bias;
+                if (A.addend) v += A.addend[(size_t)(ro % A.add_mod) * K + no];
+                v = fmaxf(v, 0.f);                                  // model.py:514
+                if (A.hid) A.hid[(size_t)ro * K + no] = v;
+                part[r] = fmaf(v, w2, part[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = part[r];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (i == 0) s_part[wave][q * 4 + r] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int ro = row0 + threadIdx.x;
+        if (ro < A.rows)
+            A.score[ro] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] +
+                          s_part[3][threadIdx.x] + A.b2[0];         // model.py:515
+    }
+}
+
+}  // namespace mmg

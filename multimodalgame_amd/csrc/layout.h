@@ -1,0 +1,226 @@
+// layout.h -- single source of truth for (a) the flat parameter buffer and (b) the workspace
+// ("tape") of the MI355X exchange path.  Host code only; kernels receive the resolved pointers
+// in `Params` / `Tape` structs passed by value.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include "../../include/mmg.h"
+#ifndef __HIPCC__
+#define __host__
+#define __device__
+#endif
+
+namespace mmg {
+
+// ---------------------------------------------------------------------------------------------
+// Parameters.  Order: receiver, sender, baseline_rec, baseline_sen -- the order of the four
+// update blocks at model.py:1307-1330; each agent's tensors are contiguous so that the per-agent
+// gradient norm is a reduction over one range.  Tensor names are the reference's state_dict keys.
+// ---------------------------------------------------------------------------------------------
+enum ParamId {
+    R_WIH, R_WHH, R_BIH, R_BHH, R_WH_W, R_WH_B, R_WD_W, R_W_W, R_W_B, R_Y1_W, R_Y1_B, R_Y2_W, R_Y2_B, R_S_W, R_S_B,
+    S_IMG_W, S_IMG_B, S_CODE_W, S_CODE_B, S_CODE_BIAS, S_BIN_W, S_BIN_B,
+    BR_L1_W, BR_L1_B, BR_L2_W, BR_L2_B,
+    BS_L1_W, BS_L1_B, BS_L2_W, BS_L2_B,
+    P_COUNT
+};
+
+struct ParamLayout {
+    int64_t off[P_COUNT];
+    int32_t rows[P_COUNT], cols[P_COUNT], agent[P_COUNT];
+    const char* name[P_COUNT];
+    int64_t agent_begin[5];   // agent a occupies [agent_begin[a], agent_begin[a+1])
+    int64_t total;
+};
+
+inline ParamLayout param_layout(const mmg_config& c) {
+    ParamLayout L;
+    const int H = c.h_dim, W = c.w_dim, R = c.rec_hidden, V = c.wv_dim, K = c.bas_hidden, F = c.feat_dim;
+    struct E { ParamId id; const char* n; int agent, rows, cols; };
+    const E tab[P_COUNT] = {
+        {R_WIH, "rnn.weight_ih", 0, 3 * R, W}, {R_WHH, "rnn.weight_hh", 0, 3 * R, R},
+        {R_BIH, "rnn.bias_ih", 0, 3 * R, 0}, {R_BHH, "rnn.bias_hh", 0, 3 * R, 0},
+        {R_WH_W, "w_h.weight", 0, R, R}, {R_WH_B, "w_h.bias", 0, R, 0}, {R_WD_W, "w_d.weight", 0, R, V},
+        {R_W_W, "w.weight", 0, W, R}, {R_W_B, "w.bias", 0, W, 0},
+        {R_Y1_W, "y1.weight", 0, R, R + V}, {R_Y1_B, "y1.bias", 0, R, 0},
+        {R_Y2_W, "y2.weight", 0, 1, R}, {R_Y2_B, "y2.bias", 0, 1, 0},
+        {R_S_W, "s.weight", 0, 1, R}, {R_S_B, "s.bias", 0, 1, 0},
+        {S_IMG_W, "image_layer.weight", 1, H, F}, {S_IMG_B, "image_layer.bias", 1, H, 0},
+        {S_CODE_W, "code_layer.weight", 1, H, W}, {S_CODE_B, "code_layer.bias", 1, H, 0},
+        {S_CODE_BIAS, "code_bias", 1, W, 0},
+        {S_BIN_W, "binary_layer.weight", 1, W, H}, {S_BIN_B, "binary_layer.bias", 1, W, 0},
+        {BR_L1_W, "linear1.weight", 2, K, W + R}, {BR_L1_B, "linear1.bias", 2, K, 0},
+        {BR_L2_W, "linear2.weight", 2, 1, K}, {BR_L2_B, "linear2.bias", 2, 1, 0},
+        {BS_L1_W, "linear1.weight", 3, K, H + W}, {BS_L1_B, "linear1.bias", 3, K, 0},
+        {BS_L2_W, "linear2.weight", 3, 1, K}, {BS_L2_B, "linear2.bias", 3, 1, 0},
+    };
+    int64_t o = 0;
+    int cur_agent = -1;
+    for (int i = 0; i < P_COUNT; ++i) {
+        const E& e = tab[i];
+        if (e.agent != cur_agent) { cur_agent = e.agent; L.agent_begin[cur_agent] = o; }
+        L.off[e.id] = o; L.rows[e.id] = e.rows; L.cols[e.id] = e.cols; L.agent[e.id] = e.agent; L.name[e.id] = e.n;
+        int64_t n = (int64_t)e.rows * (e.cols ? e.cols : 1);
+        o += (n + 3) & ~(int64_t)3;     // every tensor starts on a 16-byte boundary (float4 loads)
+    }
+    L.agent_begin[4] = o;
+    L.total = o;
+    return L;
+}
+
+// Resolved device pointers of all parameter tensors (into the flat buffer).
+struct Params { float* p[P_COUNT]; };
+
+inline Params resolve_params(const ParamLayout& L, float* base) {
+    Params P;
+    for (int i = 0; i < P_COUNT; ++i) P.p[i] = base + L.off[i];
+    return P;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tape.  X(name, ctype, dtype_code, ndim, d0, d1, d2)
+// Symbols available in the dims: B D F H W R V K T T1(=T+1) NSTAT NPART
+// ---------------------------------------------------------------------------------------------
+#define MMG_GN_BLOCKS 128      // blocks (= partial sums) of the gradient-norm kernel
+#define MMG_TAPE_LIST(X)                                                          \
+    /* ---- forward ---- */                                                        \
+    X(hx, float, 0, 2, B, H, 1)          /* image_layer(x)            model.py:195 */ \
+    X(Gs, float, 0, 2, B, K, 1)          /* baseline_sen linear1 over h_x (+bias)  */ \
+    X(Cd, float, 0, 2, D, R, 1)          /* desc . W_y1[:,R:]^T + b_y1 (App. A.2)  */ \
+    X(hw0, float, 0, 1, H, 1, 1)         /* code_layer(sigmoid(code_bias)) :199-200*/ \
+    X(dsig, float, 0, 1, W, 1, 1)        /* sigmoid'(code_bias)                    */ \
+    X(c, float, 0, 3, T, B, W)           /* sender code input per step             */ \
+    X(zr, float, 0, 3, T, B, W)          /* z_r: baseline_sen binary input   :836  */ \
+    X(a, float, 0, 3, T, B, H)           /* tanh(h_x + h_w)                  :216  */ \
+    X(z, float, 0, 3, T, B, W)           /* sender message (sen_feats)       :855  */ \
+    X(pz, float, 0, 3, T, B, W)          /* sender probs   (sen_probs)       :856  */ \
+    X(h, float, 0, 3, T1, B, R)          /* GRU state, h[0]=0, h[t+1]=h_z after t  */ \
+    X(gru, float, 0, 3, T, B, 4 * R)     /* r, u, n, W_hn h + b_hn per step        */ \
+    X(s, float, 0, 2, T, B, 1)           /* stop bits (stop_feat)            :853  */ \
+    X(ps, float, 0, 2, T, B, 1)          /* stop probs (stop_prob)           :854  */ \
+    X(sprod, float, 0, 1, B, 1, 1)       /* eval: running product of stop probs    */ \
+    X(y, float, 0, 3, T, B, D)           /* class logits per step            :859  */ \
+    X(dbar, float, 0, 3, T, B, V)        /* softmax(y) . desc                :449  */ \
+    X(g, float, 0, 3, T, B, R)           /* receiver.h_w                     :452  */ \
+    X(w, float, 0, 3, T, B, W)           /* receiver message (rec_feats)     :857  */ \
+    X(pw, float, 0, 3, T, B, W)          /* receiver probs (rec_probs)       :858  */ \
+    X(mask, uint8_t, 1, 2, T1, B, 1)     /* stop_mask list                   :775  */ \
+    X(tstar, int32_t, 2, 1, B, 1, 1)     /* step whose logits are the output :1261 */ \
+    X(lp_z, float, 0, 2, T, B, 1)        /* sum_j log-lik of sampled bits    :908  */ \
+    X(ne_z, float, 0, 2, T, B, 1)        /* sum_j neg-entropy terms          :919  */ \
+    X(lp_s, float, 0, 2, T, B, 1)                                                  \
+    X(ne_s, float, 0, 2, T, B, 1)                                                  \
+    X(lp_w, float, 0, 2, T, B, 1)                                                  \
+    X(ne_w, float, 0, 2, T, B, 1)                                                  \
+    X(hid_s, float, 0, 3, T, B, K)       /* baseline_sen relu hidden         :514  */ \
+    X(hid_r, float, 0, 3, T, B, K)                                                 \
+    X(bs, float, 0, 2, T, B, 1)          /* baseline_sen scores              :835  */ \
+    X(br, float, 0, 2, T, B, 1)          /* baseline_rec scores              :842  */ \
+    X(outp, float, 0, 2, B, D, 1)        /* get_rec_outp                     :1264 */ \
+    X(dist, float, 0, 2, B, D, 1)        /* log_softmax(outp)                :1267 */ \
+    X(sm, float, 0, 2, B, D, 1)          /* softmax(outp)                          */ \
+    X(logs, float, 0, 1, B, 1, 1)        /* loglikelihood(dist, target)      :1274 */ \
+    X(hit, int32_t, 2, 1, B, 1, 1)       /* target within top-k              :1333 */ \
+    X(stats, double, 3, 1, NSTAT, 1, 1)  /* batch statistics (all-reduced in DP)   */ \
+    X(losses, float, 0, 1, 8, 1, 1)      /* nll, bin_s, bin_rec, bin_sen, bas_rec, bas_sen, n_steps, hits */ \
+    X(counter, uint32_t, 2, 1, 4, 1, 1)  /* [0] minibatch counter (Philox), [1] optimizer step */ \
+    /* ---- backward ---- */                                                       \
+    X(dlz, float, 0, 3, T, B, W)         /* dL/d sender logits                     */ \
+    X(dpre, float, 0, 3, T, B, H)        /* dL/d (h_x + h_w)                       */ \
+    X(dhx, float, 0, 2, B, H, 1)         /* sum_t dpre                             */ \
+    X(dc0, float, 0, 2, B, W, 1)         /* W_c^T dpre_0 (code_bias path)          */ \
+    X(dls, float, 0, 2, T, B, 1)         /* dL/d stop logit                        */ \
+    X(dlw, float, 0, 3, T, B, W)         /* dL/d receiver message logits           */ \
+    X(dgpre, float, 0, 3, T, B, R)       /* dL/d pre-tanh of h_w                   */ \
+    X(dgi, float, 0, 3, T, B, 3 * R)     /* dL/d GRU input-side gate pre-acts      */ \
+    X(dgh, float, 0, 3, T, B, 3 * R)     /* dL/d GRU hidden-side gate pre-acts     */ \
+    X(dA, float, 0, 2, B, R, 1)          /* dL/d (W_y1h h) at t*                   */ \
+    X(Astar, float, 0, 2, B, R, 1)       /* W_y1h h at t*                          */ \
+    X(hstar, float, 0, 2, B, R, 1)       /* h at t*                                */ \
+    X(dy, float, 0, 2, B, D, 1)          /* dNLL/d outp                            */ \
+    X(dysum, float, 0, 1, B, 1, 1)                                                 \
+    X(dC, float, 0, 2, D, R, 1)          /* dL/d Cd                                */ \
+    X(Py2, float, 0, 2, D, R, 1)         /* per-class partials of dL/d w_y2        */ \
+    X(dhid_s, float, 0, 3, T, B, K)                                                \
+    X(dhid_r, float, 0, 3, T, B, K)                                                \
+    X(dbs, float, 0, 2, T, B, 1)                                                   \
+    X(dbr, float, 0, 2, T, B, 1)                                                   \
+    X(gnpart, float, 0, 2, 4, NPART, 1)  /* per-agent partial squared grad norms   */ \
+    X(tables, uint8_t, 1, 1, 65536, 1, 1) /* GEMM / column-sum job descriptors      */
+
+// statistics vector (f64).  Per stream (0 = stop bits, 1 = receiver msgs, 2 = sender msgs) and
+// step: n, sum w, sum w^2, sum w*logp, sum negent; per baseline (0 = rec, 1 = sen) and step:
+// sum (beta-L)^2; then sum logs, hits.
+#define MMG_ST_PER 5
+__host__ __device__ inline int stat_stream(int T, int stream, int t, int k) { return (stream * T + t) * MMG_ST_PER + k; }
+__host__ __device__ inline int stat_bas(int T, int which, int t) { return 3 * T * MMG_ST_PER + which * T + t; }
+__host__ __device__ inline int stat_glob(int T, int k) { return 3 * T * MMG_ST_PER + 2 * T + k; }
+__host__ __device__ inline int stat_count(int T) { return 3 * T * MMG_ST_PER + 2 * T + 4; }
+
+struct Tape {
+#define X(name, ctype, code, nd, d0, d1, d2) ctype* name;
+    MMG_TAPE_LIST(X)
+#undef X
+};
+
+struct TapeLayout {
+    int n;
+    mmg_tape_entry e[96];
+    int64_t total;
+};
+
+inline TapeLayout tape_layout(const mmg_config& c) {
+    TapeLayout L;
+    L.n = 0;
+    const int64_t B = c.batch, D = c.n_classes, F = c.feat_dim, H = c.h_dim, W = c.w_dim, R = c.rec_hidden,
+                  V = c.wv_dim, K = c.bas_hidden, T = c.max_exchange, T1 = T + 1,
+                  NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS;
+    (void)F; (void)V;
+    int64_t o = 0;
+    const int64_t esz[4] = {4, 1, 4, 8};
+#define X(name_, ctype, code, nd, d0, d1, d2)                                        \
+    {                                                                               \
+        mmg_tape_entry& e = L.e[L.n++];                                             \
+        memset(&e, 0, sizeof(e));                                                   \
+        strncpy(e.name, #name_, sizeof(e.name) - 1);                                \
+        e.dtype = code; e.ndim = nd;                                                \
+        e.dims[0] = (d0); e.dims[1] = (d1); e.dims[2] = (d2); e.dims[3] = 1;        \
+        e.offset = o;                                                               \
+        int64_t bytes = (int64_t)(d0) * (d1) * (d2) * esz[code];                    \
+        o += (bytes + 255) & ~(int64_t)255;                                         \
+    }
+    MMG_TAPE_LIST(X)
+#undef X
+    L.total = o;
+    return L;
+}
+
+inline Tape resolve_tape(const TapeLayout& L, void* base) {
+    Tape t;
+    int i = 0;
+#define X(name, ctype, code, nd, d0, d1, d2) t.name = (ctype*)((char*)base + L.e[i++].offset);
+    MMG_TAPE_LIST(X)
+#undef X
+    return t;
+}
+
+// Dimensions handed to every kernel.
+struct Dims {
+    int B, Bg, boff, D, F, H, W, R, V, K, T;
+    int use_binary, fixed, s_prob_prod, top_k;
+    int has_es, has_esen, has_erec;
+    float es, esen, erec, first_rec;
+};
+
+inline Dims make_dims(const mmg_config& c) {
+    Dims d;
+    d.B = c.batch; d.Bg = c.global_batch > 0 ? c.global_batch : c.batch; d.boff = c.batch_offset;
+    d.D = c.n_classes; d.F = c.feat_dim; d.H = c.h_dim; d.W = c.w_dim; d.R = c.rec_hidden; d.V = c.wv_dim;
+    d.K = c.bas_hidden; d.T = c.max_exchange;
+    d.use_binary = c.use_binary; d.fixed = c.fixed_exchange; d.s_prob_prod = c.s_prob_prod; d.top_k = c.top_k;
+    d.has_es = c.has_entropy_s; d.has_esen = c.has_entropy_sen; d.has_erec = c.has_entropy_rec;
+    d.es = c.entropy_s; d.esen = c.entropy_sen; d.erec = c.entropy_rec; d.first_rec = c.first_rec;
+    return d;
+}
+
+}  // namespace mmg

@@ -1,0 +1,480 @@
+// mmg.hip -- C-ABI (include/mmg.h) of the MI355X-native exchange path.  Host side: layout queries,
+// job-table construction, kernel launches on the caller's stream.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mmg.h"
+#include "layout.h"
+#include "device_utils.h"
+#include "kernels_fwd.h"
+#include "kernels_bwd.h"
+
+using namespace mmg;
+
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return -1;
+}
+#define HIP_OK(expr)                                                                      \
+    do { hipError_t e_ = (expr);                                                          \
+         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+struct KernelTimer { std::string name; hipEvent_t t0, t1; };
+
+struct mmg_handle {
+    mmg_config cfg;
+    Dims dm;
+    ParamLayout pl;
+    TapeLayout tl;
+    Params P, G;
+    Tape tp;
+    float *params, *grads, *opt_state;
+    void* ws;
+    JobTable* d_jt;
+    JobTable jt;
+    int conv_smem, bwd_smem, prep_smem;
+    bool profiling;
+    std::vector<KernelTimer> timers;
+    size_t timers_used;
+};
+
+extern "C" const char* mmg_last_error(void) { return g_err; }
+extern "C" int mmg_version(void) { return MMG_VERSION; }
+
+static int validate(const mmg_config* c) {
+    if (!c) return fail("config is NULL");
+    if (c->batch <= 0 || c->n_classes <= 0 || c->feat_dim <= 0 || c->h_dim <= 0 || c->w_dim <= 0 ||
+        c->rec_hidden <= 0 || c->wv_dim <= 0 || c->bas_hidden <= 0 || c->max_exchange <= 0)
+        return fail("all dimensions must be positive");
+    if (c->w_dim > MMG_BLOCK || c->rec_hidden > MMG_BLOCK)
+        return fail("w_dim and rec_hidden must be <= %d (got %d, %d)", MMG_BLOCK, c->w_dim, c->rec_hidden);
+    if (c->wv_dim > MMG_BLOCK) return fail("wv_dim must be <= %d", MMG_BLOCK);
+    if (c->optim_type < 0 || c->optim_type > 2) return fail("unknown optim_type %d", c->optim_type);
+    if (c->global_batch > 0 && c->global_batch < c->batch) return fail("global_batch < batch");
+    return 0;
+}
+
+extern "C" int64_t mmg_param_count(const mmg_config* cfg) {
+    if (validate(cfg)) return -1;
+    return param_layout(*cfg).total;
+}
+
+extern "C" int mmg_param_table(const mmg_config* cfg, mmg_param_entry* out, int max_entries) {
+    if (validate(cfg)) return -1;
+    ParamLayout L = param_layout(*cfg);
+    if (out) {
+        if (max_entries < P_COUNT) return fail("need room for %d entries", (int)P_COUNT);
+        for (int i = 0; i < P_COUNT; ++i) {
+            memset(&out[i], 0, sizeof(out[i]));
+            strncpy(out[i].name, L.name[i], sizeof(out[i].name) - 1);
+            out[i].agent = L.agent[i]; out[i].rows = L.rows[i]; out[i].cols = L.cols[i]; out[i].offset = L.off[i];
+        }
+    }
+    return P_COUNT;
+}
+
+extern "C" int64_t mmg_workspace_bytes(const mmg_config* cfg) {
+    if (validate(cfg)) return -1;
+    return tape_layout(*cfg).total;
+}
+
+extern "C" int mmg_tape_table(const mmg_config* cfg, mmg_tape_entry* out, int max_entries) {
+    if (validate(cfg)) return -1;
+    TapeLayout L = tape_layout(*cfg);
+    if (out) {
+        if (max_entries < L.n) return fail("need room for %d entries", L.n);
+        memcpy(out, L.e, sizeof(mmg_tape_entry) * L.n);
+    }
+    return L.n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// job table: every parameter tensor's gradient is produced by exactly one GEMM / column-sum job
+// (two for the matrices whose input is a concatenation: y1, both baselines' linear1).
+// ---------------------------------------------------------------------------------------------
+static int build_jobs(mmg_handle* h) {
+    JobTable& jt = h->jt;
+    memset(&jt, 0, sizeof(jt));
+    const Dims& d = h->dm;
+    const Tape& tp = h->tp;
+    const Params& G = h->G;
+    const int B = d.B, T = d.T, H = d.H, W = d.W, R = d.R, V = d.V, K = d.K, D = d.D, F = d.F;
+    const int TB = T * B;
+    int tiles = 0, ng = 0;
+    auto gemm = [&](const float* A, int lda, const float* Bm, int ldb, int bmod, int bsrc, float* C, int ldc,
+                    int rows, int N, int Kk) {
+        GemmJob& g = jt.g[ng++];
+        g.A = A; g.Bm = Bm; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.rows = rows; g.N = N; g.K = Kk;
+        g.bmod = bmod; g.bsrc = bsrc; g.tile_begin = tiles; g.tiles_k = (Kk + 15) / 16;
+        tiles += ((N + 15) / 16) * g.tiles_k;
+    };
+    int cblocks = 0, nc = 0;
+    auto col = [&](const float* src, int ld, int rows, int cols, float* dst, const float* scale) {
+        ColJob& c = jt.c[nc++];
+        c.src = src; c.dst = dst; c.scale = scale; c.ld = ld; c.rows = rows; c.cols = cols; c.blk_begin = cblocks;
+        cblocks += (cols + 63) / 64;
+    };
+    const bool bin = d.use_binary;
+    // ---- receiver ----
+    gemm(tp.dgi, 3 * R, tp.z, W, 0, SRC_STATIC, G.p[R_WIH], W, TB, 3 * R, W);          // rnn.weight_ih
+    gemm(tp.dgh, 3 * R, tp.h, R, 0, SRC_STATIC, G.p[R_WHH], R, TB, 3 * R, R);          // rnn.weight_hh (h before the step)
+    col(tp.dgi, 3 * R, TB, 3 * R, G.p[R_BIH], nullptr);
+    col(tp.dgh, 3 * R, TB, 3 * R, G.p[R_BHH], nullptr);
+    gemm(tp.dA, R, tp.hstar, R, 0, SRC_STATIC, G.p[R_Y1_W], R + V, B, R, R);           // y1.weight[:, :R]
+    gemm(tp.dC, R, nullptr, V, 0, SRC_DESC, G.p[R_Y1_W] + R, R + V, D, R, V);          // y1.weight[:, R:]
+    col(tp.dC, R, D, R, G.p[R_Y1_B], nullptr);
+    col(tp.Py2, R, D, R, G.p[R_Y2_W], nullptr);
+    col(tp.dysum, 1, B, 1, G.p[R_Y2_B], nullptr);
+    if (bin) {
+        gemm(tp.dgpre, R, tp.h + (size_t)B * R, R, 0, SRC_STATIC, G.p[R_WH_W], R, TB, R, R);   // w_h (h after the step)
+        col(tp.dgpre, R, TB, R, G.p[R_WH_B], nullptr);
+        gemm(tp.dgpre, R, tp.dbar, V, 0, SRC_STATIC, G.p[R_WD_W], V, TB, R, V);        // w_d
+        gemm(tp.dlw, W, tp.g, R, 0, SRC_STATIC, G.p[R_W_W], R, TB, W, R);              // w
+        col(tp.dlw, W, TB, W, G.p[R_W_B], nullptr);
+        gemm(tp.dls, 1, tp.h + (size_t)B * R, R, 0, SRC_STATIC, G.p[R_S_W], R, TB, 1, R);      // s
+        col(tp.dls, 1, TB, 1, G.p[R_S_B], nullptr);
+        // ---- sender ----
+        gemm(tp.dhx, H, nullptr, F, 0, SRC_X, G.p[S_IMG_W], F, B, H, F);               // image_layer (sum over steps first)
+        col(tp.dhx, H, B, H, G.p[S_IMG_B], nullptr);
+        gemm(tp.dpre, H, tp.c, W, 0, SRC_STATIC, G.p[S_CODE_W], W, TB, H, W);          // code_layer
+        col(tp.dpre, H, TB, H, G.p[S_CODE_B], nullptr);
+        col(tp.dc0, W, B, W, G.p[S_CODE_BIAS], tp.dsig);                               // code_bias
+        gemm(tp.dlz, W, tp.a, H, 0, SRC_STATIC, G.p[S_BIN_W], H, TB, W, H);            // binary_layer
+        col(tp.dlz, W, TB, W, G.p[S_BIN_B], nullptr);
+        // ---- baseline_rec: input [z || h_after] ----
+        gemm(tp.dhid_r, K, tp.z, W, 0, SRC_STATIC, G.p[BR_L1_W], W + R, TB, K, W);
+        gemm(tp.dhid_r, K, tp.h + (size_t)B * R, R, 0, SRC_STATIC, G.p[BR_L1_W] + W, W + R, TB, K, R);
+        col(tp.dhid_r, K, TB, K, G.p[BR_L1_B], nullptr);
+        gemm(tp.dbr, 1, tp.hid_r, K, 0, SRC_STATIC, G.p[BR_L2_W], K, TB, 1, K);
+        col(tp.dbr, 1, TB, 1, G.p[BR_L2_B], nullptr);
+        // ---- baseline_sen: input [h_x || z_r] ----
+        gemm(tp.dhid_s, K, tp.hx, H, B, SRC_STATIC, G.p[BS_L1_W], H + W, TB, K, H);
+        gemm(tp.dhid_s, K, tp.zr, W, 0, SRC_STATIC, G.p[BS_L1_W] + H, H + W, TB, K, W);
+        col(tp.dhid_s, K, TB, K, G.p[BS_L1_B], nullptr);
+        gemm(tp.dbs, 1, tp.hid_s, K, 0, SRC_STATIC, G.p[BS_L2_W], K, TB, 1, K);
+        col(tp.dbs, 1, TB, 1, G.p[BS_L2_B], nullptr);
+    }
+    if (ng > MMG_MAX_GEMM || nc > MMG_MAX_COL) return fail("job table overflow");
+    jt.n_gemm = ng; jt.n_col = nc; jt.gemm_tiles = tiles; jt.gemm_blocks = (tiles + 3) / 4; jt.col_blocks = cblocks;
+    // ---- gradient-norm plan: MMG_GN_BLOCKS chunks, each inside one agent ----
+    const ParamLayout& pl = h->pl;
+    int nb[4];
+    int left = MMG_GN_BLOCKS - 4;
+    for (int a = 0; a < 4; ++a) {
+        const double frac = (double)(pl.agent_begin[a + 1] - pl.agent_begin[a]) / (double)pl.total;
+        nb[a] = 1 + (int)(frac * left);
+    }
+    int blk = 0;
+    for (int a = 0; a < 4; ++a) {
+        const int64_t b0 = pl.agent_begin[a], b1 = pl.agent_begin[a + 1];
+        const int64_t quads = (b1 - b0) / 4;
+        for (int k = 0; k < nb[a]; ++k) {
+            jt.np.begin[blk] = b0 + 4 * (quads * k / nb[a]);
+            jt.np.end[blk] = b0 + 4 * (quads * (k + 1) / nb[a]);
+            jt.np.agent[blk] = a;
+            ++blk;
+        }
+    }
+    for (; blk < MMG_GN_BLOCKS; ++blk) { jt.np.begin[blk] = jt.np.end[blk] = 0; jt.np.agent[blk] = -1; }
+    if (sizeof(JobTable) > 65536) return fail("job table does not fit its tape slot");
+    return 0;
+}
+
+extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int64_t workspace_bytes,
+                                  float* d_params, float* d_grads, float* d_opt_state) {
+    if (validate(cfg)) return nullptr;
+    if (!d_workspace || !d_params || !d_grads || !d_opt_state) { fail("NULL device buffer"); return nullptr; }
+    mmg_handle* h = new mmg_handle();
+    h->cfg = *cfg;
+    if (h->cfg.global_batch <= 0) h->cfg.global_batch = h->cfg.batch;
+    h->dm = make_dims(h->cfg);
+    h->pl = param_layout(h->cfg);
+    h->tl = tape_layout(h->cfg);
+    if (workspace_bytes < h->tl.total) { fail("workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)h->tl.total); delete h; return nullptr; }
+    h->ws = d_workspace; h->params = d_params; h->grads = d_grads; h->opt_state = d_opt_state;
+    h->P = resolve_params(h->pl, d_params);
+    h->G = resolve_params(h->pl, d_grads);
+    h->tp = resolve_tape(h->tl, d_workspace);
+    h->d_jt = reinterpret_cast<JobTable*>(h->tp.tables);
+    h->profiling = false; h->timers_used = 0;
+    h->conv_smem = conv_smem_floats(h->dm) * 4;
+    h->bwd_smem = bwd_smem_floats(h->dm) * 4;
+    h->prep_smem = ((h->dm.V > h->dm.W ? h->dm.V : h->dm.W) + 4) * 4;
+    if (h->conv_smem > 160 * 1024 || h->bwd_smem > 160 * 1024) { fail("dimensions need more than 160 KB of LDS per sample"); delete h; return nullptr; }
+    hipError_t e = hipSuccess;
+    if (h->conv_smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_conversation, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
+    if (e == hipSuccess && h->bwd_smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_conv, hipFuncAttributeMaxDynamicSharedMemorySize, h->bwd_smem);
+    if (e == hipSuccess) e = hipMemset(d_workspace, 0, h->tl.total);
+    if (e == hipSuccess) e = hipMemset(d_grads, 0, sizeof(float) * h->pl.total);
+    if (e != hipSuccess) { fail("device init failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
+    if (build_jobs(h)) { delete h; return nullptr; }
+    e = hipMemcpy(h->d_jt, &h->jt, sizeof(JobTable), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { fail("job table upload failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
+    return h;
+}
+
+extern "C" void mmg_destroy(mmg_handle* h) {
+    if (!h) return;
+    for (auto& t : h->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
+    delete h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helper with optional HIP-event timing on the launch stream
+// ---------------------------------------------------------------------------------------------
+struct Scope {
+    mmg_handle* h; hipStream_t st; KernelTimer* kt;
+    Scope(mmg_handle* h_, hipStream_t st_, const char* name) : h(h_), st(st_), kt(nullptr) {
+        if (!h->profiling) return;
+        if (h->timers_used == h->timers.size()) {
+            KernelTimer t; hipEventCreate(&t.t0); hipEventCreate(&t.t1); h->timers.push_back(t);
+        }
+        kt = &h->timers[h->timers_used++];
+        kt->name = name;
+        hipEventRecord(kt->t0, st);
+    }
+    ~Scope() { if (kt) hipEventRecord(kt->t1, st); }
+};
+
+extern "C" int mmg_set_profiling(mmg_handle* h, int enabled) {
+    if (!h) return fail("NULL handle");
+    h->profiling = enabled != 0; h->timers_used = 0;
+    return 0;
+}
+
+extern "C" int mmg_get_kernel_times(mmg_handle* h, char* names, int names_bytes, float* ms, int max_kernels) {
+    if (!h) return fail("NULL handle");
+    int n = 0; std::string all;
+    for (size_t i = 0; i < h->timers_used && n < max_kernels; ++i, ++n) {
+        hipEventSynchronize(h->timers[i].t1);
+        float t = 0.f; hipEventElapsedTime(&t, h->timers[i].t0, h->timers[i].t1);
+        ms[n] = t;
+        all += h->timers[i].name; all += ";";
+    }
+    if (names && names_bytes > 0) { strncpy(names, all.c_str(), names_bytes - 1); names[names_bytes - 1] = 0; }
+    h->timers_used = 0;
+    return n;
+}
+
+static int launch_check(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+static int launch_gemm_nt(mmg_handle* h, hipStream_t st, const char* name, const float* X, int ldx, const float* Wm, int ldw,
+                          const float* bias, float* out, int ldo, int M, int N, int K) {
+    Scope sc(h, st, name);
+    const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
+    hipLaunchKernelGGL(k_gemm_nt, dim3(tiles), dim3(MMG_BLOCK), 0, st, X, ldx, Wm, ldw, bias, out, ldo, M, N, K);
+    return launch_check(name);
+}
+
+static int launch_prep(mmg_handle* h, hipStream_t st, const float* desc) {
+    Scope sc(h, st, "k_prep");
+    hipLaunchKernelGGL(k_prep, dim3(h->dm.D + 1), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc);
+    return launch_check("k_prep");
+}
+
+static int launch_baselines_fused(mmg_handle* h, hipStream_t st) {
+    const Dims& d = h->dm; const Tape& tp = h->tp; const Params& P = h->P;
+    const int rows = d.T * d.B;
+    BasArgs rec, sen;
+    memset(&rec, 0, sizeof(rec)); memset(&sen, 0, sizeof(sen));
+    rec.rows = rows; rec.x1 = tp.z; rec.ld1 = d.W; rec.k1 = d.W;
+    rec.x2 = tp.h + (size_t)d.B * d.R; rec.ld2 = d.R; rec.k2 = d.R;
+    rec.W1 = P.p[BR_L1_W]; rec.ldw = d.W + d.R; rec.col0 = 0; rec.b1 = P.p[BR_L1_B];
+    rec.W2 = P.p[BR_L2_W]; rec.b2 = P.p[BR_L2_B]; rec.hid = tp.hid_r; rec.score = tp.br;
+    sen.rows = rows; sen.x1 = tp.zr; sen.ld1 = d.W; sen.k1 = d.W; sen.x2 = nullptr;
+    sen.addend = tp.Gs; sen.add_mod = d.B;
+    sen.W1 = P.p[BS_L1_W]; sen.ldw = d.H + d.W; sen.col0 = d.H; sen.b1 = nullptr;
+    sen.W2 = P.p[BS_L2_W]; sen.b2 = P.p[BS_L2_B]; sen.hid = tp.hid_s; sen.score = tp.bs;
+    Scope sc(h, st, "k_baselines");
+    hipLaunchKernelGGL(k_baselines, dim3((rows + 15) / 16, 2), dim3(MMG_BLOCK), 0, st, d.K, rec, sen);
+    return launch_check("k_baselines");
+}
+
+extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
+                                    const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed,
+                                    int train, int run_all_steps, void* stream) {
+    if (!h) return fail("NULL handle");
+    if (!d_x || !d_desc) return fail("x / desc must not be NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const Dims& d = h->dm;
+    if (launch_prep(h, st, d_desc)) return -1;
+    if (launch_gemm_nt(h, st, "k_gemm_nt(h_x)", d_x, d.F, h->P.p[S_IMG_W], d.F, h->P.p[S_IMG_B], h->tp.hx, d.H, d.B, d.H, d.F)) return -1;
+    const bool bas = train && d.use_binary;
+    if (bas && launch_gemm_nt(h, st, "k_gemm_nt(bas_sen.h_x)", h->tp.hx, d.H, h->P.p[BS_L1_W], d.H + d.W, h->P.p[BS_L1_B],
+                              h->tp.Gs, d.K, d.B, d.K, d.H)) return -1;
+    ConvArgs ar;
+    memset(&ar, 0, sizeof(ar));
+    ar.x = d_x; ar.target = d_target; ar.desc = d_desc; ar.u_z = d_u_z; ar.u_s = d_u_s; ar.u_w = d_u_w; ar.seed = seed;
+    ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
+    {
+        Scope sc(h, st, "k_conversation");
+        hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
+        if (launch_check("k_conversation")) return -1;
+    }
+    if (bas && launch_baselines_fused(h, st)) return -1;
+    return 0;
+}
+
+extern "C" int mmg_loss_stats(mmg_handle* h, void* stream) {
+    if (!h) return fail("NULL handle");
+    hipStream_t st = (hipStream_t)stream;
+    Scope sc(h, st, "k_stats");
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(MMG_BLOCK), 0, st, h->dm, h->tp);
+    return launch_check("k_stats");
+}
+
+extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, void* stream) {
+    if (!h) return fail("NULL handle");
+    if (!d_x || !d_target || !d_desc) return fail("x / target / desc must not be NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const Dims& d = h->dm;
+    {
+        Scope sc(h, st, "k_bwd_conv");
+        hipLaunchKernelGGL(k_bwd_conv, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
+        if (launch_check("k_bwd_conv")) return -1;
+    }
+    {
+        Scope sc(h, st, "k_dC");
+        hipLaunchKernelGGL(k_dC, dim3(d.D), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
+        if (launch_check("k_dC")) return -1;
+    }
+    {
+        Scope sc(h, st, "k_wgrad");
+        hipLaunchKernelGGL(k_wgrad, dim3(h->jt.gemm_blocks + h->jt.col_blocks), dim3(MMG_BLOCK), 0, st,
+                           (const JobTable*)h->d_jt, d_x, d_desc);
+        if (launch_check("k_wgrad")) return -1;
+    }
+    return 0;
+}
+
+extern "C" int mmg_clip_step(mmg_handle* h, void* stream) {
+    if (!h) return fail("NULL handle");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(h, st, "k_gradnorm");
+        hipLaunchKernelGGL(k_gradnorm, dim3(MMG_GN_BLOCKS), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt,
+                           (const float*)h->grads, h->tp.gnpart, h->tp.counter);
+        if (launch_check("k_gradnorm")) return -1;
+    }
+    OptArgs oa;
+    oa.optim_type = h->cfg.optim_type; oa.only_receiver = h->cfg.use_binary ? 0 : 1; oa.lr = h->cfg.learning_rate;
+    for (int a = 0; a < 5; ++a) oa.agent_begin[a] = h->pl.agent_begin[a];
+    oa.total = h->pl.total;
+    int blocks = (int)((oa.total / 4 + MMG_BLOCK - 1) / MMG_BLOCK);
+    if (blocks > 1024) blocks = 1024;
+    {
+        Scope sc(h, st, "k_opt");
+        hipLaunchKernelGGL(k_opt, dim3(blocks), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt, oa, h->params,
+                           (const float*)h->grads, h->opt_state, (const float*)h->tp.gnpart, (const uint32_t*)h->tp.counter);
+        if (launch_check("k_opt")) return -1;
+    }
+    return 0;
+}
+
+extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
+                              const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed, void* stream) {
+    if (!h) return fail("NULL handle");
+    if (h->cfg.global_batch != h->cfg.batch) return fail("mmg_train_step is single-GPU; with several ranks all-reduce between the phases");
+    if (mmg_exchange_forward(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, 0, stream)) return -1;
+    if (mmg_loss_stats(h, stream)) return -1;
+    if (mmg_backward(h, d_x, d_target, d_desc, stream)) return -1;
+    return mmg_clip_step(h, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// agent-level entry points (one exchange step, forward only)
+// ---------------------------------------------------------------------------------------------
+extern "C" int mmg_sender_forward(mmg_handle* h, const float* d_x, const float* d_w, int t, int train,
+                                  const float* d_u_z, uint64_t seed, float* d_message, float* d_probs, float* d_h_x,
+                                  void* stream) {
+    if (!h) return fail("NULL handle");
+    if (!d_x || !d_message) return fail("x / message must not be NULL");
+    if (t < 0 || t >= h->dm.T) return fail("t out of range");
+    if (t > 0 && !d_w) return fail("w must not be NULL for t > 0");
+    hipStream_t st = (hipStream_t)stream;
+    const Dims& d = h->dm;
+    // k_prep needs a description matrix only for Cd (unused here); reuse the tape's zero-initialised Cd as a
+    // dummy source so that hw0 / dsig are refreshed from the current parameters.
+    {
+        Scope sc(h, st, "k_prep(sender)");
+        Dims d1 = h->dm; d1.D = 0;
+        hipLaunchKernelGGL(k_prep, dim3(1), dim3(MMG_BLOCK), h->prep_smem, st, d1, h->P, h->tp, (const float*)nullptr);
+        if (launch_check("k_prep")) return -1;
+    }
+    if (launch_gemm_nt(h, st, "k_gemm_nt(h_x)", d_x, d.F, h->P.p[S_IMG_W], d.F, h->P.p[S_IMG_B], h->tp.hx, d.H, d.B, d.H, d.F)) return -1;
+    ConvArgs ar;
+    memset(&ar, 0, sizeof(ar));
+    ar.x = d_x; ar.u_z = d_u_z ? d_u_z - (size_t)t * d.B * d.W : nullptr; ar.seed = seed; ar.train = train; ar.run_all = 1;
+    ar.t_begin = t; ar.t_end = t + 1; ar.phases = 1; ar.w_in = d_w;
+    hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
+    if (launch_check("k_conversation(sender)")) return -1;
+    const size_t off = (size_t)t * d.B * d.W;
+    HIP_OK(hipMemcpyAsync(d_message, h->tp.z + off, sizeof(float) * d.B * d.W, hipMemcpyDeviceToDevice, st));
+    if (d_probs && d.use_binary) HIP_OK(hipMemcpyAsync(d_probs, h->tp.pz + off, sizeof(float) * d.B * d.W, hipMemcpyDeviceToDevice, st));
+    if (d_h_x) HIP_OK(hipMemcpyAsync(d_h_x, h->tp.hx, sizeof(float) * d.B * d.H, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int mmg_receiver_forward(mmg_handle* h, const float* d_z, const float* d_desc, float* d_h_z,
+                                    float* d_s_prob_prod, int first, int t, int train,
+                                    const float* d_u_s, const float* d_u_w, uint64_t seed,
+                                    float* d_s, float* d_s_prob, float* d_w, float* d_w_probs, float* d_y,
+                                    float* d_h_w, void* stream) {
+    if (!h) return fail("NULL handle");
+    if (!d_z || !d_desc || !d_h_z) return fail("z / desc / h_z must not be NULL");
+    if (t < 0 || t >= h->dm.T) return fail("t out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const Dims& d = h->dm;
+    const size_t offW = (size_t)t * d.B * d.W, offB = (size_t)t * d.B;
+    HIP_OK(hipMemcpyAsync(h->tp.z + offW, d_z, sizeof(float) * d.B * d.W, hipMemcpyDeviceToDevice, st));
+    if (launch_prep(h, st, d_desc)) return -1;
+    ConvArgs ar;
+    memset(&ar, 0, sizeof(ar));
+    ar.desc = d_desc; ar.seed = seed; ar.train = train; ar.run_all = 1;
+    ar.u_s = d_u_s ? d_u_s - offB : nullptr; ar.u_w = d_u_w ? d_u_w - offW : nullptr;
+    ar.t_begin = t; ar.t_end = t + 1; ar.phases = 2; ar.h_state = d_h_z; ar.sprod_state = d_s_prob_prod; ar.sprod_first = first;
+    hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
+    if (launch_check("k_conversation(receiver)")) return -1;
+    if (d_s) HIP_OK(hipMemcpyAsync(d_s, h->tp.s + offB, sizeof(float) * d.B, hipMemcpyDeviceToDevice, st));
+    if (d_s_prob) HIP_OK(hipMemcpyAsync(d_s_prob, h->tp.ps + offB, sizeof(float) * d.B, hipMemcpyDeviceToDevice, st));
+    if (d_w) HIP_OK(hipMemcpyAsync(d_w, h->tp.w + offW, sizeof(float) * d.B * d.W, hipMemcpyDeviceToDevice, st));
+    if (d_w_probs && d.use_binary) HIP_OK(hipMemcpyAsync(d_w_probs, h->tp.pw + offW, sizeof(float) * d.B * d.W, hipMemcpyDeviceToDevice, st));
+    if (d_y) HIP_OK(hipMemcpyAsync(d_y, h->tp.y + (size_t)t * d.B * d.D, sizeof(float) * d.B * d.D, hipMemcpyDeviceToDevice, st));
+    if (d_h_w) HIP_OK(hipMemcpyAsync(d_h_w, h->tp.g + (size_t)t * d.B * d.R, sizeof(float) * d.B * d.R, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int mmg_baseline_forward(mmg_handle* h, int which, const float* d_x, const float* d_binary,
+                                    const float* d_inp, int rows, float* d_score, void* stream) {
+    if (!h) return fail("NULL handle");
+    if (!d_binary || !d_score || rows <= 0) return fail("binary / score must not be NULL, rows > 0");
+    hipStream_t st = (hipStream_t)stream;
+    const Dims& d = h->dm; const Params& P = h->P;
+    BasArgs rec, sen;
+    memset(&rec, 0, sizeof(rec)); memset(&sen, 0, sizeof(sen));
+    if (which == MMG_AGENT_BASELINE_REC) {
+        if (!d_inp) return fail("baseline_rec needs inp (receiver hidden state)");
+        rec.rows = rows; rec.x1 = d_binary; rec.ld1 = d.W; rec.k1 = d.W; rec.x2 = d_inp; rec.ld2 = d.R; rec.k2 = d.R;
+        rec.W1 = P.p[BR_L1_W]; rec.ldw = d.W + d.R; rec.b1 = P.p[BR_L1_B]; rec.W2 = P.p[BR_L2_W]; rec.b2 = P.p[BR_L2_B];
+        rec.score = d_score;
+    } else if (which == MMG_AGENT_BASELINE_SEN) {
+        if (!d_x) return fail("baseline_sen needs x (sender.h_x)");
+        sen.rows = rows; sen.x1 = d_x; sen.ld1 = d.H; sen.k1 = d.H; sen.x2 = d_binary; sen.ld2 = d.W; sen.k2 = d.W;
+        sen.W1 = P.p[BS_L1_W]; sen.ldw = d.H + d.W; sen.b1 = P.p[BS_L1_B]; sen.W2 = P.p[BS_L2_W]; sen.b2 = P.p[BS_L2_B];
+        sen.score = d_score;
+    } else {
+        return fail("which must be MMG_AGENT_BASELINE_REC or MMG_AGENT_BASELINE_SEN");
+    }
+    hipLaunchKernelGGL(k_baselines, dim3((rows + 15) / 16, 2), dim3(MMG_BLOCK), 0, st, d.K, rec, sen);
+    return launch_check("k_baselines(agent)");
+}

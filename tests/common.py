@@ -113,3 +113,91 @@ def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None):
             if a.size and not np.all(err <= tol):
                 problems.append("%s max err %.3e (tol %.1e)" % (k, float(err.max()), float(tol.flat[err.argmax()])))
     return problems
+
+
+# ----------------------------------------------------------------------------------------------
+# HIP path driven through the C-ABI (GPU tests only)
+# ----------------------------------------------------------------------------------------------
+class _SD(object):
+    def __init__(self, d):
+        self._d = d
+
+    def state_dict(self):
+        return self._d
+
+
+def engine_kwargs(meta, batch=None, **over):
+    fl = flags_from_meta(meta)
+    kw = dict(batch=batch or meta["batch"], n_classes=meta["n_classes"], feat_dim=fl.img_feat_dim, h_dim=fl.img_h_dim,
+              w_dim=fl.rec_w_dim, rec_hidden=fl.rec_hidden, wv_dim=fl.wv_dim, bas_hidden=fl.baseline_hid_dim,
+              max_exchange=fl.max_exchange, use_binary=fl.use_binary, fixed_exchange=fl.fixed_exchange,
+              s_prob_prod=fl.s_prob_prod, entropy_s=fl.entropy_s, entropy_sen=fl.entropy_sen,
+              entropy_rec=fl.entropy_rec, first_rec=fl.first_rec, optim_type=fl.optim_type,
+              learning_rate=fl.learning_rate, top_k=fl.top_k_train)
+    kw.update(over)
+    return kw
+
+
+def make_engine(meta, **over):
+    from multimodalgame_amd.engine import Engine
+    eng = Engine(**engine_kwargs(meta, **over))
+    shapes = {a: {k: tuple(v.shape) for k, v in d.items()} for a, d in eng.params.items()}
+    eng.load_state_dicts(cpu_ref.fill_state_dicts(shapes, seed=meta["seed_weights"]))
+    return eng
+
+
+def engine_result(eng, fl):
+    """Slice the tape the way exchange() returns it (lists over the executed steps)."""
+    torch.cuda.synchronize()
+    tp = {k: v.cpu() for k, v in eng.tape.items() if k in (
+        "mask", "s", "ps", "z", "pz", "w", "pw", "y", "bs", "br", "outp", "dist", "logs", "losses")}
+    losses = tp["losses"].tolist()
+    n = int(losses[6])
+    binary = fl.use_binary
+    masks = [tp["mask"][t].clone() for t in range(n + 1)]
+    masks[-1].zero_()                                                    # model.py:870
+    res = dict(n_steps=n, s_masks=masks,
+               s_feats=[tp["s"][t] for t in range(n)], s_probs=[tp["ps"][t] for t in range(n)],
+               sen_feats=[tp["z"][t] for t in range(n)], sen_probs=[tp["pz"][t] if binary else None for t in range(n)],
+               rec_feats=[tp["w"][t] for t in range(n)], rec_probs=[tp["pw"][t] if binary else None for t in range(n)],
+               y=[tp["y"][t] for t in range(n)], bs=[tp["bs"][t] for t in range(n)], br=[tp["br"][t] for t in range(n)],
+               outp=tp["outp"], dist=tp["dist"], logs=tp["logs"].view(-1, 1), hits=int(losses[7]))
+    for i, k in enumerate(("nll_loss", "loss_binary_s", "loss_binary_rec", "loss_binary_sen", "loss_bas_rec", "loss_bas_sen")):
+        res[k] = torch.tensor(losses[i])
+    return res
+
+
+def hip_train_case(name, meta, early_exit=False, fused=False):
+    """Run a golden train case on the GPU through the C-ABI; returns (packed dict, engine)."""
+    fl = flags_from_meta(meta)
+    eng = make_engine(meta)
+    dev = eng.device
+    out = {}
+    agents = ("receiver", "sender", "baseline_rec", "baseline_sen") if fl.use_binary else ("receiver",)
+    for i in range(meta["n_minibatches"]):
+        x, target, desc, (u_z, u_s, u_w) = case_inputs(meta, i, name)
+        xd, td, dd = torch.from_numpy(x).to(dev), torch.from_numpy(target).to(dev), torch.from_numpy(desc).to(dev)
+        uz, us, uw = [torch.from_numpy(np.ascontiguousarray(u)).to(dev) for u in (u_z, u_s[..., 0], u_w)]
+        if fused:
+            eng.train_step(xd, td, dd, uz, us, uw)
+        else:
+            eng.forward(xd, td, dd, uz, us, uw, train=True, run_all=not early_exit)
+            eng.loss_stats()
+            eng.backward(xd, td, dd)
+        res = engine_result(eng, fl)
+        grads, norms = {}, {}
+        for a in agents:
+            grads[a] = {k: v.detach().cpu().clone() for k, v in eng.grads[a].items()}
+            lo, hi = eng.agent_range[a]
+            norms[a] = float(eng.flat_grads[lo:hi].double().norm())
+        res["grads"], res["grad_norms"] = grads, norms
+        if not fused:
+            eng.clip_step()
+        torch.cuda.synchronize()
+        models = {a: _SD({k: v.detach().cpu() for k, v in eng.params[a].items()}) for a in _lib_agents()}
+        out.update(cpu_ref.pack_train(res, models, prefix="mb%d." % i))
+    return out, eng
+
+
+def _lib_agents():
+    return ("receiver", "sender", "baseline_rec", "baseline_sen")

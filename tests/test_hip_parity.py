@@ -1,0 +1,104 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle and with the golden vectors
+generated from the reference.  Tolerances: north_star asks for logits / losses within 1e-4 of the
+reference CPU path; sampled bits, masks, step counts and top-k hits must match exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 1e-4, 1e-3     # absolute 1e-4 on O(1) quantities; relative slack for large-magnitude entries
+
+
+def _skip_keys(meta):
+    # continuous mode: the reference runs the (unused) baselines forward, this path does not
+    return () if meta["use_binary"] else (".bs", ".br")
+
+
+@pytest.mark.parametrize("name", common.TRAIN_CASES)
+def test_train_case_vs_golden_and_oracle(name):
+    z, meta = common.load_golden(name)
+    got, _ = common.hip_train_case(name, meta)
+    problems = common.compare_packed(got, z, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta))
+    assert not problems, "vs golden:\n" + "\n".join(problems[:25])
+    want = common.oracle_train_case(name, meta)
+    problems = common.compare_packed(got, want, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta))
+    assert not problems, "vs oracle:\n" + "\n".join(problems[:25])
+
+
+@pytest.mark.parametrize("name", ["g2_adaptive_c1", "g5_one_active", "g3_tiny_adam"])
+def test_early_exit_and_fused_step_equal_run_all(name):
+    """A sample that stops computing after its own stop step (training mode) must give the same
+    losses, gradients and updated parameters as running every sample for all steps."""
+    z, meta = common.load_golden(name)
+    full, _ = common.hip_train_case(name, meta)
+    for kw in (dict(early_exit=True), dict(fused=True)):
+        got, _ = common.hip_train_case(name, meta, **kw)
+        keys = [k for k in full if (".g." in k or ".p." in k or k.endswith("losses") or "gradnorm" in k)]
+        for k in keys:
+            np.testing.assert_allclose(got[k], full[k], rtol=1e-6, atol=1e-7, err_msg="%s %s" % (kw, k))
+
+
+def test_eval_pass_vs_golden():
+    z, meta = common.load_golden("g4_eval_c1")
+    fl = common.flags_from_meta(meta)
+    eng = common.make_engine(meta)
+    eng.params["receiver"]["s.bias"].fill_(1.2)
+    x, target, desc = cpu_ref.synthetic_batch(meta["batch"], meta["n_classes"], 512, 100, seed=meta["seed_data"])
+    dev = eng.device
+    eng.forward(torch.from_numpy(x).to(dev), torch.from_numpy(target).to(dev), torch.from_numpy(desc).to(dev),
+                train=False, run_all=True)
+    torch.cuda.synchronize()
+    n = int(z["n_steps"])
+    tp = {k: v.cpu().numpy() for k, v in eng.tape.items() if k in ("mask", "s", "z", "w", "y", "dist", "tstar", "hit")}
+    # the global break step: first t at which every sample's mask is zero
+    alive = tp["mask"][1:, :, 0].sum(1)
+    assert int(np.argmax(alive == 0)) + 1 == n
+    np.testing.assert_array_equal(tp["s"][:n], z["s_feats"])
+    np.testing.assert_array_equal(tp["z"][:n], z["sen_feats"])
+    np.testing.assert_array_equal(tp["w"][:n], z["rec_feats"])
+    np.testing.assert_array_equal(tp["mask"][:n], z["s_masks"][:n])
+    np.testing.assert_allclose(tp["y"][:n], z["y"], atol=ATOL)
+    np.testing.assert_allclose(tp["dist"], z["dist"], atol=ATOL)
+    assert int(tp["hit"].sum()) == int(z["hits"])
+    np.testing.assert_array_equal(tp["s"][:n, :, 0].sum(0), z["conversation_lengths"])
+
+
+def test_agent_level_steps_vs_golden():
+    z, meta = common.load_golden("g1_agents_tiny")
+    eng = common.make_engine(meta)
+    dev = eng.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev)
+    x, desc = t(z["x"]), t(z["desc"])
+    u_z, u_s, u_w = z["u_z"], z["u_s"], z["u_w"]
+    z0, p0, hx = eng.sender_forward(x, None, 0, True, u_z=t(u_z[0]))
+    w_in = t(z["sen.w_in"])
+    z1, p1, _ = eng.sender_forward(x, w_in, 1, True, u_z=t(u_z[1]))
+    ze, pe, _ = eng.sender_forward(x, w_in, 1, False)
+    np.testing.assert_array_equal(z0.cpu().numpy(), z["sen.train.t0.z"])
+    np.testing.assert_array_equal(z1.cpu().numpy(), z["sen.train.t1.z"])
+    np.testing.assert_array_equal(ze.cpu().numpy(), z["sen.eval.t1.z"])
+    np.testing.assert_allclose(p0.cpu().numpy(), z["sen.train.t0.p"], atol=1e-5)
+    np.testing.assert_allclose(p1.cpu().numpy(), z["sen.train.t1.p"], atol=1e-5)
+    np.testing.assert_allclose(hx.cpu().numpy(), z["sen.h_x"], atol=1e-5)
+    for mode in ("train", "eval"):
+        h_z = torch.zeros(4, 5, device=dev)
+        sprod = torch.ones(4, device=dev)
+        for step, zin in enumerate((z0, z1)):
+            s, sp, w, wp, y, h_w = eng.receiver_forward(zin, desc, h_z, sprod, step == 0, step, mode == "train",
+                                                        u_s=t(u_s[step, :, 0]), u_w=t(u_w[step]))
+            pre = "rec.%s.t%d." % (mode, step)
+            np.testing.assert_array_equal(s.cpu().numpy(), z[pre + "s"])
+            np.testing.assert_array_equal(w.cpu().numpy(), z[pre + "w"])
+            np.testing.assert_allclose(sp.cpu().numpy(), z[pre + "s_prob"], atol=1e-5)
+            np.testing.assert_allclose(wp.cpu().numpy(), z[pre + "w_prob"], atol=1e-5)
+            np.testing.assert_allclose(y.cpu().numpy(), z[pre + "y"], atol=1e-5)
+            np.testing.assert_allclose(h_z.cpu().numpy(), z[pre + "h_z"], atol=1e-5)
+            np.testing.assert_allclose(h_w.cpu().numpy(), z[pre + "h_w"], atol=1e-5)
+    bs = eng.baseline_forward("baseline_sen", hx, w_in, None)
+    br = eng.baseline_forward("baseline_rec", None, z1, h_z)
+    np.testing.assert_allclose(bs.cpu().numpy(), z["bas_sen"], atol=1e-5)
+    np.testing.assert_allclose(br.cpu().numpy(), z["bas_rec"], atol=1e-5)
