@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Benchmark of the exchange path: exchange-steps/sec on BASELINE.json config 2
+(Adaptive 30-class, batch 64 per GPU, max_exchange 10, rec_w_dim 32, img_h_dim 256, rec_hidden 64).
+
+A bench "step" is one training minibatch (conversation + losses + backward + clip + RMSprop);
+the reported value counts EXCHANGE steps = iterations of the loop at model.py:801 that the
+reference semantics execute (up to the step at which every sample of the global minibatch has
+stopped, model.py:866), summed over the timed minibatches, divided by the wall time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: launched by torch.distributed.run, one rank per GPU; the global minibatch is 64*N
+  (weak scaling), sharded along the batch axis (multimodalgame_amd/dist.py).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+C2 = dict(n_classes=30, feat_dim=512, h_dim=256, w_dim=32, rec_hidden=64, wv_dim=100, bas_hidden=500,
+          max_exchange=10, use_binary=True, fixed_exchange=False, s_prob_prod=True, entropy_s=0.08,
+          entropy_sen=0.01, entropy_rec=0.01, first_rec=0.0, optim_type="RMSprop", learning_rate=1e-4, top_k=6)
+PER_GPU_BATCH = 64
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def synthetic_dataset(n_samples, n_classes, feat_dim, wv_dim, seed=1234):
+    """avgpool_512 = |N(0,1)|, Target uniform over classes, desc = 0.3 N(0,1)."""
+    rs = np.random.RandomState(seed)
+    feats = np.abs(rs.standard_normal((n_samples, feat_dim))).astype(np.float32)
+    target = rs.randint(0, n_classes, size=(n_samples,)).astype(np.int64)
+    desc = (0.3 * rs.standard_normal((n_classes, wv_dim))).astype(np.float32)
+    return feats, target, desc
+
+
+def algorithmic_work(kernel, d, B, t_steps):
+    """Algorithmic (minimal) work of one launch of `kernel`: (bound, amount) with amount in bytes for
+    HBM-bound kernels and flops for MFMA-bound ones.  B samples, t_steps = exchange steps the launch
+    covers per sample on average.  Formulas: DESIGN.md §Kernels."""
+    F, H, W, R, V, K, D, T = (d[k] for k in ("feat_dim", "h_dim", "w_dim", "rec_hidden", "wv_dim", "bas_hidden",
+                                             "n_classes", "max_exchange"))
+    rows = B * t_steps
+    p_sender = H * W + W * H + 2 * H + 2 * W
+    p_recv = 3 * R * (W + R) + 6 * R + R * R + R + R * V + W * R + W + R * R + 2 * R + 2 + D * R + D * V
+    if kernel == "k_conversation":
+        tape = rows * 4 * (H + 4 * W + 5 * R + R + D + V + 12)          # floats written per (step, sample)
+        return "hbm", 4 * (p_sender + p_recv) + tape + 4 * B * H
+    if kernel == "k_bwd_conv":
+        tape = rows * 4 * (2 * H + 6 * W + 13 * R + 2 * K + D + V + 16)  # read fwd tape + write delta tape
+        return "hbm", 4 * (p_sender + p_recv) + tape
+    if kernel == "k_wgrad":
+        TB = B * T
+        fl = 2 * TB * (3 * R * W + 3 * R * R + R * R + R * V + W * R + R + H * W + W * H + K * (W + R) + K + K * (H + W) + K)
+        fl += 2 * B * (R * R + H * F) + 2 * D * R * V
+        return "mfma", fl
+    if kernel == "k_baselines":
+        return "mfma", 2 * B * T * K * (W + R + W + 2)
+    if kernel.startswith("k_gemm_nt"):
+        return "mfma", 2 * B * H * F if "h_x)" in kernel and "bas" not in kernel else 2 * B * K * H
+    return "hbm", 0
+
+
+def run_gpu(args, rank, world, local_rank):
+    from multimodalgame_amd.engine import Engine
+    from multimodalgame_amd.dist import DataParallel
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    B = PER_GPU_BATCH
+    Bg = B * world
+    eng = Engine(device=dev, batch=B, global_batch=Bg, batch_offset=rank * B, **C2)
+    # random-init agents (reference init: Xavier-normal weights, zero biases, N(0,1) code_bias;
+    # baselines torch-default uniform) from a fixed seed -- identical on every rank
+    from multimodalgame_amd.agents import init_state_dicts
+    eng.load_state_dicts(init_state_dicts(eng, seed=0))
+    n_steps_total = args.steps + args.warmup
+    feats, target, desc = synthetic_dataset(100 * C2["n_classes"], C2["n_classes"], C2["feat_dim"], C2["wv_dim"])
+    # minibatches of the epoch loop, resident in HBM before the timed region (misc.py:257-302 order:
+    # seeded shuffle, sorted indices inside a batch, drop-last)
+    import random
+    order = list(range(feats.shape[0]))
+    random.seed(11)
+    random.shuffle(order)
+    nb = feats.shape[0] // Bg
+    xs, ts = [], []
+    for i in range(n_steps_total):
+        idx = sorted(order[(i % nb) * Bg:(i % nb + 1) * Bg])[rank * B:(rank + 1) * B]
+        xs.append(feats[idx]); ts.append(target[idx])
+    xs = torch.from_numpy(np.stack(xs)).to(dev)
+    ts = torch.from_numpy(np.stack(ts)).to(dev)
+    desc_d = torch.from_numpy(desc).to(dev)
+    dp = DataParallel(eng)
+    nsteps_log = torch.zeros(n_steps_total, device=dev)
+
+    def one(i):
+        if world > 1:
+            dp.train_step(xs[i], ts[i], desc_d, seed=args.seed)
+        else:
+            eng.train_step(xs[i], ts[i], desc_d, seed=args.seed)
+        nsteps_log[i] = eng.tape["losses"][6]          # device-side copy, no host sync
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        one(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps_total):
+        one(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ex_steps = float(nsteps_log[args.warmup:].sum().item())
+
+    # per-kernel launch durations of the same workload, HIP events on the launch stream (rank 0)
+    roof = None
+    kern_ms = {}
+    if rank == 0:
+        eng.set_profiling(True)
+        reps = min(20, args.steps)
+        for i in range(reps):
+            eng.set_profiling(True)
+            if world > 1:
+                dp.train_step(xs[args.warmup + i], ts[args.warmup + i], desc_d, seed=args.seed)
+            else:
+                eng.train_step(xs[args.warmup + i], ts[args.warmup + i], desc_d, seed=args.seed)
+            torch.cuda.synchronize(dev)
+            for name, ms in eng.kernel_times():
+                kern_ms.setdefault(name, []).append(ms)
+        eng.set_profiling(False)
+        avg = {k: float(np.mean(v)) for k, v in kern_ms.items()}
+        dom = max(avg, key=avg.get)
+        mean_t = ex_steps / max(1, args.steps)
+        # average steps a sample takes (early exit): take it from the tape of the last minibatch
+        tstar = eng.tape["tstar"].float().mean().item() + 1.0
+        bound, amount = algorithmic_work(dom, C2, B, tstar if dom in ("k_conversation", "k_bwd_conv") else mean_t)
+        secs = avg[dom] * 1e-3
+        if bound == "hbm":
+            achieved, peak, unit = amount / secs / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = amount / secs / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        roof = dict(bound=bound, kernel=dom, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                    traffic=None, launch_us=avg[dom] * 1e3,
+                    kernels_us={k: round(v * 1e3, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])})
+    return elapsed, ex_steps, roof
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (literal restatement of the reference, oracle/cpu_ref.py) timed on this host:
+    same config, same synthetic data, RMSprop, data loading excluded."""
+    from oracle import cpu_ref
+    fl = cpu_ref.Flags(use_binary=True, fixed_exchange=False, max_exchange=10, batch_size=64, learning_rate=1e-4,
+                       entropy_s=0.08, entropy_sen=0.01, entropy_rec=0.01, img_feat_dim=512, img_h_dim=256,
+                       rec_w_dim=32, sender_out_dim=32, rec_hidden=64, wv_dim=100, baseline_hid_dim=500,
+                       top_k_train=6)
+    feats, target, desc = synthetic_dataset(3000, 30, 512, 100)
+    desc_t = torch.from_numpy(desc)
+    out = {}
+    for label, threads in (("all", None), ("one", 1)):
+        if threads:
+            torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        models = cpu_ref.build_agents(fl)
+        opts = cpu_ref.build_optimizers(models, fl)
+        steps, n_mb, t_used = 0, 0, 0.0
+        for i in range(3 + 400):
+            idx = np.arange((i % 46) * 64, (i % 46 + 1) * 64)
+            x, t = torch.from_numpy(feats[idx]), torch.from_numpy(target[idx])
+            t0 = time.perf_counter()
+            res = cpu_ref.train_minibatch(models, opts, x, t, desc_t, fl)
+            dt = time.perf_counter() - t0
+            if i >= 3:
+                steps += res["n_steps"]; n_mb += 1; t_used += dt
+                if t_used > seconds_budget / 2:
+                    break
+        out[label] = dict(steps_per_s=steps / t_used, minibatches=n_mb, seconds=t_used, threads=torch.get_num_threads())
+    best = max(out.values(), key=lambda v: v["steps_per_s"])
+    return dict(value=best["steps_per_s"], unit="exchange-steps/s", cores=best["threads"], kind="port",
+                sample="%d minibatches of config 1 (B=64) in %.1f s on %d thread(s); single-thread: %.1f steps/s; "
+                       "all-thread (%d): %.1f steps/s; host has %d logical CPUs" % (
+                           best["minibatches"], best["seconds"], best["threads"], out["one"]["steps_per_s"],
+                           out["all"]["threads"], out["all"]["steps_per_s"], os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    elapsed, ex_steps, roof = run_gpu(args, rank, world, local_rank)
+    if rank == 0:
+        line = {
+            "metric": "exchange-steps/sec (whole node), 30-class Adaptive max_exchange=10 bs=64",
+            "value": ex_steps / elapsed, "unit": "exchange-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: Adaptive 30-class, batch 64 per GPU, max_exchange 10, rec_w_dim 32, "
+                                   "img_h_dim 256, rec_hidden 64, RMSprop; one bench step = one training minibatch",
+                       "global_batch": PER_GPU_BATCH * world, "parallelism": "dp%d" % world,
+                       "exchange_steps_per_minibatch": ex_steps / args.steps, "sampling": "in-kernel Philox4x32-10"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,15 +96,15 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(pz, float, 0, 3, T, B, W)          /* sender probs   (sen_probs)       :856  */ \
     X(h, float, 0, 3, T1, B, R)          /* GRU state, h[0]=0, h[t+1]=h_z after t  */ \
     X(gru, float, 0, 3, T, B, 4 * R)     /* r, u, n, W_hn h + b_hn per step        */ \
-    X(s, float, 0, 2, T, B, 1)           /* stop bits (stop_feat)            :853  */ \
-    X(ps, float, 0, 2, T, B, 1)          /* stop probs (stop_prob)           :854  */ \
+    X(s, float, 0, 3, T, B, 1)           /* stop bits (stop_feat)            :853  */ \
+    X(ps, float, 0, 3, T, B, 1)          /* stop probs (stop_prob)           :854  */ \
     X(sprod, float, 0, 1, B, 1, 1)       /* eval: running product of stop probs    */ \
     X(y, float, 0, 3, T, B, D)           /* class logits per step            :859  */ \
     X(dbar, float, 0, 3, T, B, V)        /* softmax(y) . desc                :449  */ \
     X(g, float, 0, 3, T, B, R)           /* receiver.h_w                     :452  */ \
     X(w, float, 0, 3, T, B, W)           /* receiver message (rec_feats)     :857  */ \
     X(pw, float, 0, 3, T, B, W)          /* receiver probs (rec_probs)       :858  */ \
-    X(mask, uint8_t, 1, 2, T1, B, 1)     /* stop_mask list                   :775  */ \
+    X(mask, uint8_t, 1, 3, T1, B, 1)     /* stop_mask list                   :775  */ \
     X(tstar, int32_t, 2, 1, B, 1, 1)     /* step whose logits are the output :1261 */ \
     X(lp_z, float, 0, 2, T, B, 1)        /* sum_j log-lik of sampled bits    :908  */ \
     X(ne_z, float, 0, 2, T, B, 1)        /* sum_j neg-entropy terms          :919  */ \
@@ -114,8 +114,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(ne_w, float, 0, 2, T, B, 1)                                                  \
     X(hid_s, float, 0, 3, T, B, K)       /* baseline_sen relu hidden         :514  */ \
     X(hid_r, float, 0, 3, T, B, K)                                                 \
-    X(bs, float, 0, 2, T, B, 1)          /* baseline_sen scores              :835  */ \
-    X(br, float, 0, 2, T, B, 1)          /* baseline_rec scores              :842  */ \
+    X(bs, float, 0, 3, T, B, 1)          /* baseline_sen scores              :835  */ \
+    X(br, float, 0, 3, T, B, 1)          /* baseline_rec scores              :842  */ \
     X(outp, float, 0, 2, B, D, 1)        /* get_rec_outp                     :1264 */ \
     X(dist, float, 0, 2, B, D, 1)        /* log_softmax(outp)                :1267 */ \
     X(sm, float, 0, 2, B, D, 1)          /* softmax(outp)                          */ \

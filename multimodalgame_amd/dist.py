@@ -1,0 +1,40 @@
+"""Data-parallel training step: one process per GPU, minibatch sharded along the batch axis,
+parameters / optimizer state replicated.
+
+Two collectives per optimizer step (RCCL over xGMI through torch.distributed backend "nccl"):
+  1. a ~1.4 KB float64 all-reduce of the batch statistics the REINFORCE losses couple the shards
+     through (per stream and step: n_t, sum w, sum w^2, ... -- SURVEY.md §8e option A), so every
+     rank scales its gradient seeds with the statistics of the WHOLE minibatch;
+  2. one all-reduce of the flat gradient buffer of all four agents.
+Gradient clipping uses the norm of the reduced gradient, so all ranks take the identical update
+(model.py:1310 semantics on the global batch)."""
+import torch
+import torch.distributed as dist
+
+
+class DataParallel(object):
+    """`engine` needs: forward(...), loss_stats(), backward(...), clip_step(), .stats (1-D f64 tensor),
+    .flat_grads (1-D f32 tensor).  multimodalgame_amd.engine.Engine satisfies this on a GPU."""
+
+    def __init__(self, engine, group=None):
+        self.engine = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def train_step(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0):
+        e = self.engine
+        e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=False)
+        e.loss_stats()
+        if self.world > 1:
+            dist.all_reduce(e.stats, op=dist.ReduceOp.SUM, group=self.group)
+        e.backward(x, target, desc)
+        if self.world > 1:
+            dist.all_reduce(e.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+        e.clip_step()
+
+
+def shard_range(global_batch, rank, world):
+    """Contiguous B/N rows per rank."""
+    assert global_batch % world == 0, "global batch must divide evenly over the ranks"
+    per = global_batch // world
+    return rank * per, per

@@ -11,7 +11,9 @@ _TORCH_DTYPE = {0: torch.float32, 1: torch.uint8, 2: torch.int32, 3: torch.float
 
 
 class Engine(object):
-    def __init__(self, device="cuda:0", **cfg_kwargs):
+    def __init__(self, device="cuda:0", share=None, **cfg_kwargs):
+        """share: another Engine whose flat parameter / gradient / optimizer-state buffers this one
+        uses too (same model, different batch size or class count)."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.MmgError("no GPU visible: the exchange path runs on MI355X only (no CPU fallback)")
@@ -23,9 +25,13 @@ class Engine(object):
             raise _lib.MmgError(self.lib.mmg_last_error().decode())
         self.n_params = int(n)
         with torch.cuda.device(self.device):
-            self.flat_params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
-            self.flat_grads = torch.zeros_like(self.flat_params)
-            self.opt_state = torch.zeros(2 * self.n_params, dtype=torch.float32, device=self.device)
+            if share is not None:
+                assert share.n_params == self.n_params and share.device == self.device
+                self.flat_params, self.flat_grads, self.opt_state = share.flat_params, share.flat_grads, share.opt_state
+            else:
+                self.flat_params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+                self.flat_grads = torch.zeros_like(self.flat_params)
+                self.opt_state = torch.zeros(2 * self.n_params, dtype=torch.float32, device=self.device)
             ws_bytes = int(self.lib.mmg_workspace_bytes(C.byref(self.cfg)))
             self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
             torch.cuda.synchronize(self.device)
@@ -57,6 +63,7 @@ class Engine(object):
                 numel *= d
             nbytes = numel * torch.empty((), dtype=dt).element_size()
             self.tape[e["name"]] = self.workspace[e["offset"]:e["offset"] + nbytes].view(dt).view(e["dims"])
+        self.stats = self.tape["stats"]
 
     def __del__(self):
         try:

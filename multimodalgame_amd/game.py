@@ -1,0 +1,205 @@
+"""exchange() and the per-minibatch training block of the reference (model.py:725-876, 1240-1339)
+on top of the HIP engine, with the reference's calling conventions and return structures."""
+import torch
+
+from . import flags as _flags
+from .engine import Engine
+
+
+class FlatOptimizer(object):
+    """Checkpoint-facing stand-in for the reference's four torch.optim objects (model.py:1110-1142):
+    the update itself runs inside libmmg (k_gradnorm/k_opt); this class only converts the agent's slice
+    of the flat optimizer state to and from torch.optim's state_dict layout (misc.py:61-62, 89-90)."""
+
+    def __init__(self, game, agent):
+        self.game, self.agent = game, agent
+
+    def _params(self):
+        return list(self.game.engine.params[self.agent].items())
+
+    def state_dict(self):
+        eng, kind = self.game.engine, self.game.cfg["optim_type"]
+        step = int(eng.tape["counter"][1].item())
+        n = eng.n_params
+        state = {}
+        for i, (name, view) in enumerate(self._params()):
+            off = view.storage_offset()
+            if step == 0 or kind == "SGD":
+                continue
+            if kind == "RMSprop":
+                state[i] = {"step": torch.tensor(float(step)),
+                            "square_avg": eng.opt_state[off:off + view.numel()].view(view.shape).cpu().clone()}
+            else:
+                state[i] = {"step": torch.tensor(float(step)),
+                            "exp_avg": eng.opt_state[off:off + view.numel()].view(view.shape).cpu().clone(),
+                            "exp_avg_sq": eng.opt_state[n + off:n + off + view.numel()].view(view.shape).cpu().clone()}
+        group = {"lr": self.game.cfg["learning_rate"], "params": list(range(len(self._params())))}
+        if kind == "RMSprop":
+            group.update(alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False)
+        elif kind == "Adam":
+            group.update(betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False)
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        eng, kind = self.game.engine, self.game.cfg["optim_type"]
+        n = eng.n_params
+        step = 0
+        for i, (name, view) in enumerate(self._params()):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is None:
+                continue
+            off = view.storage_offset()
+            step = max(step, int(float(st.get("step", 0))))
+            if kind == "RMSprop":
+                eng.opt_state[off:off + view.numel()].copy_(st["square_avg"].reshape(-1).to(eng.device))
+            elif kind == "Adam":
+                eng.opt_state[off:off + view.numel()].copy_(st["exp_avg"].reshape(-1).to(eng.device))
+                eng.opt_state[n + off:n + off + view.numel()].copy_(st["exp_avg_sq"].reshape(-1).to(eng.device))
+        if step:
+            eng.tape["counter"][1] = step
+
+
+class Game(object):
+    """Binds the four agent modules to one flat parameter buffer on the GPU and caches one libmmg
+    handle per (batch size, number of classes)."""
+
+    def __init__(self, sender, receiver, baseline_sen, baseline_rec, flags=None, device=None, seed=0):
+        fl = flags if flags is not None else _flags.FLAGS
+        self.modules = dict(sender=sender, receiver=receiver, baseline_sen=baseline_sen, baseline_rec=baseline_rec)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.max_exchange = fl.max_exchange
+        self.cfg = dict(feat_dim=sender.feat_dim, h_dim=sender.h_dim, w_dim=sender.w_dim, rec_hidden=receiver.hid_dim,
+                        wv_dim=receiver.desc_dim, bas_hidden=baseline_sen.hid_dim if baseline_sen is not None else 500,
+                        max_exchange=fl.max_exchange, use_binary=bool(sender.use_binary),
+                        fixed_exchange=bool(fl.fixed_exchange), s_prob_prod=bool(fl.s_prob_prod),
+                        entropy_s=fl.entropy_s, entropy_sen=fl.entropy_sen, entropy_rec=fl.entropy_rec,
+                        first_rec=fl.first_rec, optim_type=fl.optim_type, learning_rate=fl.learning_rate,
+                        top_k=fl.top_k_train)
+        assert sender.bin_dim_out == sender.w_dim == receiver.w_dim == receiver.z_dim, \
+            "Both sender and receiver should communicate with same dim vectors for now."     # model.py:1756
+        self.seed = seed
+        self._call = 0
+        self.engines = {}
+        self.engine = None            # the first engine owns the flat buffers
+        self.optimizers = None
+        for m in self.modules.values():
+            if m is not None:
+                m._game = self
+
+    # the reference's dict names (model.py:1139-1142)
+    def optimizers_dict(self):
+        return dict(optimizer_rec=FlatOptimizer(self, "receiver"), optimizer_sen=FlatOptimizer(self, "sender"),
+                    optimizer_bas_rec=FlatOptimizer(self, "baseline_rec"), optimizer_bas_sen=FlatOptimizer(self, "baseline_sen"))
+
+    def models_dict(self):
+        return dict(receiver=self.modules["receiver"], sender=self.modules["sender"],
+                    baseline_rec=self.modules["baseline_rec"], baseline_sen=self.modules["baseline_sen"])
+
+    def next_seed(self):
+        return self.seed
+
+    def _adopt(self, eng):
+        """Move the modules' parameters into the engine's flat buffer (values preserved)."""
+        for agent, m in self.modules.items():
+            if m is None:
+                continue
+            for name, p in m.named_parameters():
+                view = eng.params[agent][name]
+                view.copy_(p.data.to(eng.device))
+                p.data = view
+
+    def engine_for(self, batch, n_classes=None, global_batch=None, batch_offset=0):
+        n_classes = n_classes or getattr(self, "_last_classes", None) or 1
+        self._last_classes = n_classes
+        key = (batch, n_classes, global_batch or batch, batch_offset)
+        if key not in self.engines:
+            eng = Engine(device=self.device, share=self.engine, batch=batch, n_classes=n_classes,
+                         global_batch=global_batch, batch_offset=batch_offset, **self.cfg)
+            if self.engine is None:
+                self.engine = eng
+                self._adopt(eng)
+            self.engines[key] = eng
+        return self.engines[key]
+
+    # ------------------------------------------------------------------ model.py:725-876
+    def exchange(self, exchange_args):
+        data, target, desc = exchange_args["data"], exchange_args.get("target"), exchange_args["desc"]
+        train = exchange_args["train"]
+        break_early = exchange_args.get("break_early", False)
+        if exchange_args.get("corrupt", False):
+            raise NotImplementedError("-bit_flip message corruption is outside the accelerated hot path")
+        if exchange_args.get("data_context") is not None:
+            raise NotImplementedError("attention context is outside the accelerated hot path")
+        for k, m in self.modules.items():
+            if m is not None and (train or k in ("sender", "receiver")):
+                m.train(train)
+        B = data.size(0)
+        eng = self.engine_for(B, desc.size(0))
+        dev = eng.device
+        data = data.to(dev, torch.float32).contiguous().view(B, -1)
+        desc = desc.to(dev, torch.float32).contiguous()
+        target = None if target is None else target.to(dev, torch.int64).contiguous()
+        self._call += 1
+        eng.forward(data, target, desc, seed=self.seed, train=train, run_all=True)
+        tp = eng.tape
+        T = self.max_exchange
+        n = T
+        if break_early:                                                   # model.py:866 (one host sync)
+            alive = tp["mask"][1:, :, 0].sum(1).tolist()
+            for t, a in enumerate(alive):
+                if a == 0:
+                    n = t + 1
+                    break
+        binary = self.cfg["use_binary"]
+        masks = [tp["mask"][t].clone() for t in range(n + 1)]
+        masks[-1].zero_()                                                 # model.py:870
+        s = (masks, [tp["s"][t].clone() for t in range(n)], [tp["ps"][t].clone() for t in range(n)])
+        sen_w = ([tp["z"][t].clone() for t in range(n)], [tp["pz"][t].clone() if binary else None for t in range(n)])
+        rec_w = ([tp["w"][t].clone() for t in range(n)], [tp["pw"][t].clone() if binary else None for t in range(n)])
+        y = [tp["y"][t].clone() for t in range(n)]
+        bs = [tp["bs"][t].clone() for t in range(n)] if train and binary else []
+        br = [tp["br"][t].clone() for t in range(n)] if train and binary else []
+        self.modules["sender"].h_x = tp["hx"]
+        self.modules["receiver"].h_z = tp["h"][n]
+        self.modules["receiver"].h_w = tp["g"][n - 1]
+        return s, sen_w, rec_w, y, bs, br
+
+    # ------------------------------------------------------------------ model.py:1240-1339
+    def train_step(self, data, target, desc, uniforms=None):
+        """exchange + masks + losses + four backward/clip/optimizer blocks, fused on the device.
+        Nothing is copied to the host; read ``losses()`` when a log line needs them."""
+        B = data.size(0)
+        eng = self.engine_for(B, desc.size(0))
+        u = uniforms or (None, None, None)
+        eng.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed)
+        return eng
+
+    def losses(self, batch, n_classes):
+        return self.engine_for(batch, n_classes).losses()
+
+
+def exchange(sender, receiver, baseline_sen, baseline_rec, exchange_args):
+    """Drop-in for model.py:725: same arguments, same returned structure
+    ``(s, sen_w, rec_w, y, bs, br)`` of per-step tensor lists."""
+    game = getattr(sender, "_game", None)
+    if game is None:
+        game = Game(sender, receiver, baseline_sen, baseline_rec)
+    elif baseline_sen is not None and game.modules.get("baseline_sen") is None:
+        game.modules["baseline_sen"], game.modules["baseline_rec"] = baseline_sen, baseline_rec
+    return game.exchange(exchange_args)
+
+
+def get_rec_outp(y, masks):
+    """model.py:879-904 (host-side tensor ops on the returned lists; used by callers of exchange())."""
+    import torch.nn.functional as F
+
+    def negent(yy):
+        probs = F.softmax(yy, dim=1)
+        return (torch.log(probs + 1e-8) * probs).sum(1).mean()
+    negentropy = [negent(yy) for yy in y]
+    if masks is not None:
+        batch_size = y[0].size(0)
+        inp = torch.cat([yy.view(batch_size, 1, -1) for yy in y], 1)
+        mask = torch.cat(masks, 1).view(batch_size, len(masks), 1).expand_as(inp)
+        return torch.masked_select(inp, mask.bool()).view(batch_size, -1), negentropy
+    return y[-1], negentropy

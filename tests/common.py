@@ -84,10 +84,19 @@ def oracle_train_case(name, meta):
     return out
 
 
-def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None):
+SHIFT_INVARIANT = ("y", "outp")
+
+
+def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None, shift_invariant=False):
     """Compare two packed dicts.  Bit/mask/count entries must match exactly; float entries
-    within atol + rtol*|want|."""
-    exact = ("s_masks", "s_feats", "sen_feats", "n_steps", "hits")
+    within atol + rtol*|want|.
+
+    shift_invariant: compare the class logits (``y``, ``outp``) after removing each row's mean.
+    dL/d(y2.bias) is identically zero (softmax is shift invariant), so what reaches the optimizer
+    is rounding noise which RMSprop/Adam normalise into +-O(lr) steps: y2.bias (a common shift of
+    all logits of a sample, invisible to every loss and to top-k) performs an implementation-
+    dependent random walk in the reference too and cannot be pinned."""
+    exact = ("s_masks", "s_feats", "sen_feats", "rec_feats", "n_steps", "hits")
     problems = []
     for k in want.keys() if hasattr(want, "keys") else want.files:
         if k == "meta" or k.endswith(".u_s"):
@@ -104,7 +113,11 @@ def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None):
             problems.append("%s shape %s vs %s" % (k, a.shape, b.shape))
             continue
         tail = k.split(".")[-1]
-        if tail in exact:
+        if shift_invariant and tail in SHIFT_INVARIANT and a.size:
+            a = a - a.mean(-1, keepdims=True)
+            b = b - b.mean(-1, keepdims=True)
+        is_bits = b.size == 0 or bool(np.all((b == 0) | (b == 1))) or tail in ("n_steps", "hits")
+        if tail in exact and is_bits:      # continuous-mode messages are real-valued -> tolerance
             if not np.array_equal(a, b):
                 problems.append("%s differs (exact) in %d places" % (k, int((a != b).sum())))
         else:
