@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mmg.hip")
 OUT = os.path.join(HERE, "libmmg.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("mmg.hip", "layout.h", "device_utils.h", "kernels_fwd.h", "kernels_bwd.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("mmg.hip", "layout.h", "device_utils.h", "kernels_fwd.h", "kernels_bwd.h", "kernels_fast.h")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "mmg.h"))
 
 

@@ -19,11 +19,22 @@ namespace mmg {
 // model.py:870)  <=>  t < t*(b).  Fixed exchange has t* = T-1 for every sample, which reproduces the
 // unmasked sums over T (T-1 for the receiver messages, rec_feats[:-1] at model.py:1286).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MMG_BLOCK) void k_stats(Dims dm, Tape tp) {
+__device__ __forceinline__ float combine_score(const float* part, size_t row, int npb, float b2) {
+    float v = 0.f;
+    for (int j = 0; j < npb; ++j) v += part[row * npb + j];
+    return v + b2;                                                      // model.py:515
+}
+
+// from_parts: baseline scores arrive as per-64-hidden-unit partials (k_baselines2); the blocks of the
+// two baseline kinds also materialise bs / br on the tape (exchange() returns them, k_bwd_conv reads them).
+__global__ __launch_bounds__(64) void k_stats(Dims dm, Params P, Tape tp, int from_parts) {
     const int T = dm.T, B = dm.B;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int npb = (dm.K + 63) / 64;
+    const float b2s = P.p[BS_L2_B][0], b2r = P.p[BR_L2_B][0];
+    // grid = 5T + 2 blocks of one wave: every (stream, step) pair reduces concurrently
+    const int lane = threadIdx.x & 63;
     const int npairs = 5 * T + 2;
-    for (int p = wave; p < npairs; p += nw) {
+    for (int p = blockIdx.x; p < npairs; p += gridDim.x) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         if (p >= 5 * T) {                       // sum of rewards (-> NLL) and top-k hits
             const int which = p - 5 * T;
@@ -38,17 +49,25 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_stats(Dims dm, Tape tp) {
             for (int b = lane; b < B; b += 64) {
                 const int ts = tp.tstar[b];
                 const bool act = (kind == 1) ? (t < ts) : (t <= ts);
-                if (!act) continue;
                 const size_t row = (size_t)t * B + b;
+                if (from_parts && kind >= 3 && t <= ts) {
+                    if (kind == 3) tp.br[row] = combine_score(tp.br_part, row, npb, b2r);
+                    else tp.bs[row] = combine_score(tp.bs_part, row, npb, b2s);
+                }
+                if (!act) continue;
                 const float L = tp.logs[b];
                 if (kind < 3) {
-                    const float beta = (kind == 2) ? tp.bs[row] : tp.br[row];
+                    const float beta = from_parts ? ((kind == 2) ? combine_score(tp.bs_part, row, npb, b2s)
+                                                                 : combine_score(tp.br_part, row, npb, b2r))
+                                                  : ((kind == 2) ? tp.bs[row] : tp.br[row]);
                     const float lp = (kind == 0) ? tp.lp_s[row] : (kind == 1) ? tp.lp_w[row] : tp.lp_z[row];
                     const float ne = (kind == 0) ? tp.ne_s[row] : (kind == 1) ? tp.ne_w[row] : tp.ne_z[row];
                     const double wv = (double)(L - beta);          // model.py:912
                     a0 += 1.0; a1 += wv; a2 += wv * wv; a3 += wv * (double)lp; a4 += (double)ne;
                 } else {
-                    const float beta = (kind == 3) ? tp.br[row] : tp.bs[row];
+                    const float beta = from_parts ? ((kind == 3) ? combine_score(tp.br_part, row, npb, b2r)
+                                                                 : combine_score(tp.bs_part, row, npb, b2s))
+                                                  : ((kind == 3) ? tp.br[row] : tp.bs[row]);
                     const double dv = (double)(beta - L);          // model.py:972
                     a0 += dv * dv;
                 }
@@ -76,65 +95,68 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_stats(Dims dm, Tape tp) {
 struct LossCoef { float* cw; float* ce; float* cb; };   // LDS: cw[3*T], ce[3*T], cb[T]
 
 __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* st, LossCoef lc, float* losses_out) {
-    const int T = dm.T;
-    if (threadIdx.x == 0) {
-        double loss[3] = {0, 0, 0};
-        for (int k = 0; k < 3; ++k) {
+    // one thread per (stream, step): threads [0,3T) -> cw/ce, [3T,4T) -> cb; block-level sums for the
+    // logged losses go through LDS (lc.cw/ce/cb double as staging for the partial losses afterwards)
+    const int T = dm.T, tid = threadIdx.x;
+    __shared__ double s_part[5][64];
+    for (int i = tid; i < 5 * 64; i += blockDim.x) s_part[i / 64][i % 64] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < 4 * T; i += blockDim.x) {
+        const int k = i / T, t = i - k * T;
+        if (k < 3) {
             double nsum = 0;
-            for (int t = 0; t < T; ++t) nsum += st[stat_stream(T, k, t, 0)];
+            for (int tt = 0; tt < T; ++tt) nsum += st[stat_stream(T, k, tt, 0)];
             const int len = (k == 1) ? T - 1 : T;
             const float lam = (k == 0) ? dm.es : (k == 1) ? dm.erec : dm.esen;
             const bool has = (k == 0) ? dm.has_es : (k == 1) ? dm.has_erec : dm.has_esen;
-            for (int t = 0; t < T; ++t) {
-                const double* s5 = st + stat_stream(T, k, t, 0);
-                const double n = s5[0];
-                float cw = 0.f, ce = 0.f;
-                if (n > 0 && nsum > 0) {
-                    const double c_over_n = dm.fixed ? 1.0 / ((double)len * n) : 1.0 / nsum;
-                    double denom = 1.0;
-                    if (n > 1) {                                        // model.py:914-915
-                        const double mean = s5[1] / n;
-                        double var = (s5[2] - n * mean * mean) / (n - 1.0);
-                        if (var < 0) var = 0;
-                        const double sd = sqrt(var);
-                        denom = sd > 1.0 ? sd : 1.0;
-                    }
-                    cw = (float)(c_over_n / denom);
-                    ce = has ? (float)(c_over_n * (double)lam) : 0.f;
-                    loss[k] += -(double)cw * s5[3] + (double)ce * s5[4];
+            const double* s5 = st + stat_stream(T, k, t, 0);
+            const double n = s5[0];
+            float cw = 0.f, ce = 0.f;
+            if (n > 0 && nsum > 0) {
+                const double c_over_n = dm.fixed ? 1.0 / ((double)len * n) : 1.0 / nsum;
+                double denom = 1.0;
+                if (n > 1) {                                            // model.py:914-915
+                    const double mean = s5[1] / n;
+                    double var = (s5[2] - n * mean * mean) / (n - 1.0);
+                    if (var < 0) var = 0;
+                    const double sd = sqrt(var);
+                    denom = sd > 1.0 ? sd : 1.0;
                 }
-                lc.cw[k * T + t] = cw; lc.ce[k * T + t] = ce;
+                cw = (float)(c_over_n / denom);
+                ce = has ? (float)(c_over_n * (double)lam) : 0.f;
+                if (t < 64) s_part[k][t] = -(double)cw * s5[3] + (double)ce * s5[4];
             }
-        }
-        double lb[2] = {0, 0};
-        {
+            lc.cw[k * T + t] = cw; lc.ce[k * T + t] = ce;
+        } else {
             double nsum = 0;
-            for (int t = 0; t < T; ++t) nsum += st[stat_stream(T, 2, t, 0)];
-            for (int t = 0; t < T; ++t) {
-                const double n = st[stat_stream(T, 2, t, 0)];
-                float cb = 0.f;
-                if (n > 0 && nsum > 0) {
-                    const double c_over_n = dm.fixed ? 1.0 / ((double)T * n) : 1.0 / nsum;
-                    cb = (float)(2.0 * c_over_n);
-                    lb[0] += c_over_n * st[stat_bas(T, 0, t)];
-                    lb[1] += c_over_n * st[stat_bas(T, 1, t)];
-                }
-                lc.cb[t] = cb;
+            for (int tt = 0; tt < T; ++tt) nsum += st[stat_stream(T, 2, tt, 0)];
+            const double n = st[stat_stream(T, 2, t, 0)];
+            float cb = 0.f;
+            if (n > 0 && nsum > 0) {
+                const double c_over_n = dm.fixed ? 1.0 / ((double)T * n) : 1.0 / nsum;
+                cb = (float)(2.0 * c_over_n);
+                if (t < 64) { s_part[3][t] = c_over_n * st[stat_bas(T, 0, t)]; s_part[4][t] = c_over_n * st[stat_bas(T, 1, t)]; }
             }
+            lc.cb[t] = cb;
         }
-        if (losses_out) {
-            int nsteps = 0;
-            for (int t = 0; t < T; ++t) nsteps += (st[stat_stream(T, 2, t, 0)] > 0) ? 1 : 0;
-            if (!dm.use_binary) nsteps = T;
-            losses_out[0] = (float)(-st[stat_glob(T, 0)] / (double)dm.Bg);   // NLL (model.py:1271)
-            losses_out[1] = (float)loss[0];                                  // loss_binary_s
-            losses_out[2] = (float)loss[1];                                  // loss_binary_rec
-            losses_out[3] = (float)loss[2];                                  // loss_binary_sen
-            losses_out[4] = (float)lb[0];                                    // loss_bas_rec
-            losses_out[5] = (float)lb[1];                                    // loss_bas_sen
-            losses_out[6] = (float)nsteps;                                   // exchange steps the reference executes
-            losses_out[7] = (float)st[stat_glob(T, 1)];                      // top-k hits
+    }
+    __syncthreads();
+    if (losses_out && tid == 0) {
+        double acc[5] = {0, 0, 0, 0, 0};
+        int nsteps = 0;
+        for (int t = 0; t < T; ++t) {
+            for (int k = 0; k < 5; ++k) acc[k] += (t < 64) ? s_part[k][t] : 0.0;
+            nsteps += (st[stat_stream(T, 2, t, 0)] > 0) ? 1 : 0;
         }
+        if (!dm.use_binary) nsteps = T;
+        losses_out[0] = (float)(-st[stat_glob(T, 0)] / (double)dm.Bg);   // NLL (model.py:1271)
+        losses_out[1] = (float)acc[0];                                   // loss_binary_s
+        losses_out[2] = (float)acc[1];                                   // loss_binary_rec
+        losses_out[3] = (float)acc[2];                                   // loss_binary_sen
+        losses_out[4] = (float)acc[3];                                   // loss_bas_rec
+        losses_out[5] = (float)acc[4];                                   // loss_bas_sen
+        losses_out[6] = (float)nsteps;                                   // exchange steps the reference executes
+        losses_out[7] = (float)st[stat_glob(T, 1)];                      // top-k hits
     }
     __syncthreads();
 }
@@ -155,7 +177,7 @@ __host__ __device__ inline int bwd_smem_floats(const Dims& d) {
 __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T, K = dm.K;
+    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
     auto p4 = [](int n) { return (n + 3) & ~3; };
     float* p = smem;
     LossCoef lc; lc.cw = p; p += 3 * T; lc.ce = p; p += 3 * T; lc.cb = p; p += T;
@@ -188,7 +210,6 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
         for (int i = tid; i < H; i += nt) tp.dpre[row * H + i] = 0.f;
         for (int i = tid; i < R; i += nt) tp.dgpre[row * R + i] = 0.f;
         for (int i = tid; i < 3 * R; i += nt) { tp.dgi[row * 3 * R + i] = 0.f; tp.dgh[row * 3 * R + i] = 0.f; }
-        for (int i = tid; i < K; i += nt) { tp.dhid_s[row * K + i] = 0.f; tp.dhid_r[row * K + i] = 0.f; }
         if (tid == 0) { tp.dls[row] = 0.f; tp.dbs[row] = 0.f; tp.dbr[row] = 0.f; }
     }
 
@@ -295,16 +316,11 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
             }
             // ---- baselines (MSE, model.py:971-988) ----
             const float dbs = lc.cb[t] * (tp.bs[row] - L), dbr = lc.cb[t] * (tp.br[row] - L);
+            // d hidden = dbeta * w2 * 1[hidden > 0] is formed on the fly by k_wgrad (virtual operand)
             if (tid == 0) { tp.dbs[row] = dbs; tp.dbr[row] = dbr; }
-            const float* w2s = P.p[BS_L2_W]; const float* w2r = P.p[BR_L2_W];
-            for (int k = tid; k < K; k += nt) {
-                tp.dhid_s[row * K + k] = (tp.hid_s[row * K + k] > 0.f) ? dbs * w2s[k] : 0.f;
-                tp.dhid_r[row * K + k] = (tp.hid_r[row * K + k] > 0.f) ? dbr * w2r[k] : 0.f;
-            }
         } else {
             for (int i = tid; i < W; i += nt) tp.dlz[row * W + i] = 0.f;
             for (int i = tid; i < H; i += nt) tp.dpre[row * H + i] = 0.f;
-            for (int i = tid; i < K; i += nt) { tp.dhid_s[row * K + i] = 0.f; tp.dhid_r[row * K + i] = 0.f; }
             if (tid == 0) { tp.dbs[row] = 0.f; tp.dbr[row] = 0.f; }
         }
         __syncthreads();
@@ -320,23 +336,26 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
 __global__ __launch_bounds__(MMG_BLOCK) void k_dC(Dims dm, Params P, Tape tp) {
     __shared__ float s_c[MMG_BLOCK], s_p[MMG_BLOCK];
     const int d = blockIdx.x, tid = threadIdx.x, R = dm.R, B = dm.B, D = dm.D;
-    const int cols = R < MMG_BLOCK ? R : MMG_BLOCK;
+    const int cols = R < 64 ? R : 64;                 // up to 64 columns per pass, >= 4 sample groups
     const int groups = MMG_BLOCK / cols;
     const int g = tid / cols, rr = tid - g * cols;
     const float* w2 = P.p[R_Y2_W];
     for (int r0 = 0; r0 < R; r0 += cols) {
         const int r = r0 + rr;
-        float dc = 0.f, py = 0.f;
+        float dc0 = 0.f, dc1 = 0.f, py0 = 0.f, py1 = 0.f;
         if (g < groups && r < R) {
             const float cv = tp.Cd[(size_t)d * R + r];
-            for (int b = g; b < B; b += groups) {
-                const float dyv = tp.dy[(size_t)b * D + d];
-                const float pre = tp.Astar[(size_t)b * R + r] + cv;
-                if (pre > 0.f) { dc += dyv; py = fmaf(dyv, pre, py); }
+            for (int b = g; b < B; b += 2 * groups) {
+                const int b1 = b + groups;
+                const float y0 = tp.dy[(size_t)b * D + d], p0 = tp.Astar[(size_t)b * R + r] + cv;
+                const float y1 = b1 < B ? tp.dy[(size_t)b1 * D + d] : 0.f;
+                const float p1 = b1 < B ? tp.Astar[(size_t)b1 * R + r] + cv : 0.f;
+                if (p0 > 0.f) { dc0 += y0; py0 = fmaf(y0, p0, py0); }
+                if (p1 > 0.f) { dc1 += y1; py1 = fmaf(y1, p1, py1); }
             }
-            dc *= w2[r];
         }
-        s_c[tid] = dc; s_p[tid] = py;
+        s_c[tid] = (dc0 + dc1) * ((g < groups && r < R) ? w2[r] : 0.f);
+        s_p[tid] = py0 + py1;
         __syncthreads();
         if (tid < cols && r0 + tid < R) {
             float a = 0.f, c = 0.f;
@@ -356,25 +375,57 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_dC(Dims dm, Params P, Tape tp) {
 // scale[c] * sum_row src[row*ld + c].
 // ---------------------------------------------------------------------------------------------
 enum { SRC_STATIC = 0, SRC_X = 1, SRC_DESC = 2 };
-struct GemmJob { const float* A; const float* Bm; float* C; int lda, ldb, ldc, rows, N, K, bmod, bsrc, tile_begin, tiles_k, pad; };
-struct ColJob { const float* src; float* dst; const float* scale; int ld, rows, cols, blk_begin; };
+// vhid != NULL: the A operand is virtual,  A[row, n] = A[row] * vw2[n] * 1[vhid[row*lda + n] > 0]
+// (the baselines' d hidden = d score * linear2.weight * relu', never materialised)
+struct GemmJob { const float* A; const float* Bm; float* C; const float* vhid; const float* vw2;
+                 int lda, ldb, ldc, rows, N, K, bmod, bsrc, tile_begin, tiles_k; };
+// vbeta != NULL: virtual source,  src'[row, c] = vbeta[row] * vw2[c] * 1[src[row*ld + c] > 0]
+struct ColJob { const float* src; float* dst; const float* scale; const float* vbeta; const float* vw2;
+                int ld, rows, cols, blk_begin; };
 #define MMG_MAX_GEMM 40
 #define MMG_MAX_COL 40
 struct NormPlan { int64_t begin[MMG_GN_BLOCKS], end[MMG_GN_BLOCKS]; int agent[MMG_GN_BLOCKS]; };
+#define MMG_MAX_WBLOCKS 16384
 struct JobTable {
     int n_gemm, n_col, gemm_tiles, gemm_blocks, col_blocks, pad0, pad1, pad2;
     GemmJob g[MMG_MAX_GEMM];
     ColJob c[MMG_MAX_COL];
     NormPlan np;
+    int n_wblocks;                              // blocks of k_wgrad (= entries of its part[] output)
+    signed char wblock_agent[MMG_MAX_WBLOCKS];  // agent whose gradient block i of k_wgrad writes
 };
 
+// load 4 consecutive floats of one row with bounds / alignment handling (zeros outside)
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, size_t row_off, int col, int ncols, bool row_ok, bool vec_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!row_ok) return v;
+    const float* p = base + row_off + col;
+    if (vec_ok && col + 3 < ncols) return *reinterpret_cast<const float4*>(p);
+    if (col < ncols) v.x = p[0];
+    if (col + 1 < ncols) v.y = p[1];
+    if (col + 2 < ncols) v.z = p[2];
+    if (col + 3 < ncols) v.w = p[3];
+    return v;
+}
+
 __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict__ jt, const float* __restrict__ x,
-                                                     const float* __restrict__ desc) {
+                                                     const float* __restrict__ desc, float* __restrict__ part) {
+    // One workgroup per 16x16 tile of dW = A^T . Bm (A: [rows, N] gradient tape, Bm: [rows, K] input
+    // tape, reduction over the (step, sample) rows).  Rows are consumed in chunks of 64: every thread
+    // fetches 4 consecutive columns of one row of each operand (16-byte coalesced loads, 64 B per row),
+    // the chunk is staged in LDS (double-buffered, one barrier per chunk, next chunk's loads in flight
+    // during the MFMAs), wave w multiplies rows 16w..16w+15 of the chunk (4 x mfma_f32_16x16x4), and the
+    // four partial tiles are combined through LDS.  Every block also leaves the sum of squares of what it
+    // wrote in part[blockIdx.x] (clip_grad_norm partials, summed per agent by k_opt).
+    constexpr int CH = 64;
+    __shared__ float s_a[2][CH][17];
+    __shared__ float s_b[2][CH][17];
+    __shared__ float s_acc[4][16][17];
     __shared__ float s_part[MMG_BLOCK];
+    __shared__ float s_red[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((int)blockIdx.x < jt->gemm_blocks) {
-        const int tile = blockIdx.x * 4 + wave;
-        if (tile >= jt->gemm_tiles) return;
+    if ((int)blockIdx.x < jt->gemm_tiles) {
+        const int tile = blockIdx.x;
         int j = 0;
         const int ng = jt->n_gemm;
         while (j + 1 < ng && jt->g[j + 1].tile_begin <= tile) ++j;
@@ -384,54 +435,103 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const int n0 = tn * 16, k0 = tk * 16;
         const int i = lane & 15, q = lane >> 4;
         const float* Bbase = (G.bsrc == SRC_X) ? x : (G.bsrc == SRC_DESC) ? desc : G.Bm;
-        const bool nv = (n0 + i) < G.N, kv = (k0 + i) < G.K;
-        const float* Ap = G.A + (nv ? n0 + i : 0);
-        const float* Bp = Bbase + (kv ? k0 + i : 0);
-        const int rows = G.rows, lda = G.lda, ldb = G.ldb, bmod = G.bmod;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        for (int r0 = 0; r0 < rows; r0 += 16) {
-            float a[4], bb[4];
+        const bool virt = G.vhid != nullptr;
+        const float* Abase = virt ? G.vhid : G.A;
+        const int rows = G.rows, lda = G.lda, ldb = G.ldb, bmod = G.bmod, N = G.N, K = G.K;
+        const bool veca = ((lda & 3) == 0) && ((((uintptr_t)Abase) & 15) == 0);
+        const bool vecb = ((ldb & 3) == 0) && ((((uintptr_t)Bbase) & 15) == 0);
+        // loader role of this thread: row lr of the chunk, columns lc..lc+3 of the tile
+        const int lr = threadIdx.x >> 2, lc = (threadIdx.x & 3) * 4;
+        float4 vw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (virt) vw = load4_guard(G.vw2, 0, n0 + lc, N, true, false);
+        const int nchunks = (rows + CH - 1) / CH;
+        float4 ra, rb;
+        float beta = 0.f;
+        auto fetch = [&](int c) {
+            const int r = c * CH + lr;
+            const bool rv = r < rows;
+            ra = load4_guard(Abase, (size_t)(rv ? r : 0) * lda, n0 + lc, N, rv, veca);
+            const int rbm = bmod ? (r % bmod) : r;
+            rb = load4_guard(Bbase, (size_t)(rv ? rbm : 0) * ldb, k0 + lc, K, rv, vecb);
+            if (virt) beta = rv ? G.A[r] : 0.f;
+        };
+        fetch(0);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (virt) {
+                ra.x = ra.x > 0.f ? beta * vw.x : 0.f; ra.y = ra.y > 0.f ? beta * vw.y : 0.f;
+                ra.z = ra.z > 0.f ? beta * vw.z : 0.f; ra.w = ra.w > 0.f ? beta * vw.w : 0.f;
+            }
+            s_a[buf][lr][lc] = ra.x; s_a[buf][lr][lc + 1] = ra.y; s_a[buf][lr][lc + 2] = ra.z; s_a[buf][lr][lc + 3] = ra.w;
+            s_b[buf][lr][lc] = rb.x; s_b[buf][lr][lc + 1] = rb.y; s_b[buf][lr][lc + 2] = rb.z; s_b[buf][lr][lc + 3] = rb.w;
+            __syncthreads();
+            if (c + 1 < nchunks) fetch(c + 1);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * 4 + q;
-                const bool rv = r < rows;
-                const int rb = bmod ? (r % bmod) : r;
-                a[u] = (nv && rv) ? Ap[(size_t)r * lda] : 0.f;
-                bb[u] = (kv && rv) ? Bp[(size_t)rb * ldb] : 0.f;
+                const int r = wave * 16 + u * 4 + q;
+                acc = mfma16(s_a[buf][r][i], s_b[buf][r][i], acc);
             }
-            acc0 = mfma16(a[0], bb[0], acc0); acc1 = mfma16(a[1], bb[1], acc1);
-            acc0 = mfma16(a[2], bb[2], acc0); acc1 = mfma16(a[3], bb[3], acc1);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + q * 4 + r, k = k0 + i;
-            if (n < G.N && k < G.K) G.C[(size_t)n * G.ldc + k] = acc0[r] + acc1[r];
+        for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = acc[r];
+        __syncthreads();
+        const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        const int n = n0 + rr, k = k0 + cc;
+        float v = 0.f;
+        if (n < N && k < K) {
+            v = (s_acc[0][rr][cc] + s_acc[1][rr][cc]) + (s_acc[2][rr][cc] + s_acc[3][rr][cc]);
+            G.C[(size_t)n * G.ldc + k] = v;
         }
+        const float sq = block_sum(v * v, s_red);
+        if (threadIdx.x == 0) part[blockIdx.x] = sq;
         return;
     }
-    // ---- column sums ----
-    const int cb = blockIdx.x - jt->gemm_blocks;
+    // ---- column sums: 16 columns x 16 row groups per block, 4 independent loads in flight per thread
+    const int cb = blockIdx.x - jt->gemm_tiles;
     int j = 0;
     const int nc = jt->n_col;
     while (j + 1 < nc && jt->c[j + 1].blk_begin <= cb) ++j;
     const ColJob& C = jt->c[j];
-    const int c0 = (cb - C.blk_begin) * 64;
-    const int cw = min(64, C.cols - c0);
-    const int groups = MMG_BLOCK / cw;
-    const int g = threadIdx.x / cw, cc = threadIdx.x - g * cw;
-    float acc = 0.f;
-    if (g < groups) {
+    const int c0 = (cb - C.blk_begin) * 16;
+    const int cc = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const bool cv = (c0 + cc) < C.cols;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (cv) {
         const float* sp = C.src + c0 + cc;
-        for (int r = g; r < C.rows; r += groups) acc += sp[(size_t)r * C.ld];
+        const int rows = C.rows, ld = C.ld;
+        if (C.vbeta) {
+            const float vw = C.vw2[c0 + cc];
+            for (int r = g; r < rows; r += 64) {
+                const int r1 = r + 16, r2 = r + 32, r3 = r + 48;
+                const float h0 = sp[(size_t)r * ld], b0 = C.vbeta[r];
+                const float h1 = r1 < rows ? sp[(size_t)r1 * ld] : 0.f, b1 = r1 < rows ? C.vbeta[r1] : 0.f;
+                const float h2 = r2 < rows ? sp[(size_t)r2 * ld] : 0.f, b2 = r2 < rows ? C.vbeta[r2] : 0.f;
+                const float h3 = r3 < rows ? sp[(size_t)r3 * ld] : 0.f, b3 = r3 < rows ? C.vbeta[r3] : 0.f;
+                a0 += h0 > 0.f ? b0 * vw : 0.f; a1 += h1 > 0.f ? b1 * vw : 0.f;
+                a2 += h2 > 0.f ? b2 * vw : 0.f; a3 += h3 > 0.f ? b3 * vw : 0.f;
+            }
+        } else {
+            for (int r = g; r < rows; r += 64) {
+                const int r1 = r + 16, r2 = r + 32, r3 = r + 48;
+                const float h0 = sp[(size_t)r * ld];
+                const float h1 = r1 < rows ? sp[(size_t)r1 * ld] : 0.f;
+                const float h2 = r2 < rows ? sp[(size_t)r2 * ld] : 0.f;
+                const float h3 = r3 < rows ? sp[(size_t)r3 * ld] : 0.f;
+                a0 += h0; a1 += h1; a2 += h2; a3 += h3;
+            }
+        }
     }
-    s_part[threadIdx.x] = acc;
+    s_part[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if ((int)threadIdx.x < cw) {
-        float v = 0.f;
-        for (int k = 0; k < groups; ++k) v += s_part[k * cw + threadIdx.x];
+    float v = 0.f;
+    if (threadIdx.x < 16 && (c0 + (int)threadIdx.x) < C.cols) {
+        for (int k = 0; k < 16; ++k) v += s_part[k * 16 + threadIdx.x];
         if (C.scale) v *= C.scale[c0 + threadIdx.x];
         C.dst[c0 + threadIdx.x] = v;
     }
+    const float sq = block_sum(v * v, s_red);
+    if (threadIdx.x == 0) part[blockIdx.x] = sq;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -455,7 +555,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_gradnorm(const JobTable* __restri
 }
 
 struct OptArgs {
-    int optim_type, only_receiver;
+    int optim_type, only_receiver, from_wgrad, bump_step;
     float lr;
     int64_t agent_begin[5];
     int64_t total;
@@ -464,16 +564,32 @@ struct OptArgs {
 __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ jt, OptArgs oa, float* __restrict__ params,
                                                    const float* __restrict__ grads, float* __restrict__ state,
                                                    const float* __restrict__ part, const uint32_t* __restrict__ counter) {
+    // oa.from_wgrad: the squared-norm partials are the ones k_wgrad left per block (single GPU);
+    // otherwise the MMG_GN_BLOCKS partials of k_gradnorm over the all-reduced gradient (data parallel).
     __shared__ float s_coef[4];
-    if (threadIdx.x < 4) {
-        float ss = 0.f;
-        for (int k = 0; k < MMG_GN_BLOCKS; ++k) if (jt->np.agent[k] == (int)threadIdx.x) ss += part[k];
-        const float norm = sqrtf(ss);
-        const float coef = 1.0f / (norm + 1e-6f);                    // max_norm = 1 (model.py:1310)
-        s_coef[threadIdx.x] = coef < 1.f ? coef : 1.f;
+    __shared__ float s_ss[4][MMG_BLOCK];
+    {
+        const int n = oa.from_wgrad ? jt->n_wblocks : MMG_GN_BLOCKS;
+        float ss[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = threadIdx.x; k < n; k += MMG_BLOCK) {
+            const int a = oa.from_wgrad ? (int)jt->wblock_agent[k] : jt->np.agent[k];
+            const float v = part[k];
+            ss[0] += (a == 0) ? v : 0.f; ss[1] += (a == 1) ? v : 0.f;
+            ss[2] += (a == 2) ? v : 0.f; ss[3] += (a == 3) ? v : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s_ss[a][threadIdx.x] = ss[a];
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float tot = 0.f;
+            for (int k = 0; k < MMG_BLOCK; ++k) tot += s_ss[threadIdx.x][k];   // fixed order: deterministic
+            const float norm = sqrtf(tot);
+            const float coef = 1.0f / (norm + 1e-6f);                // max_norm = 1 (model.py:1310)
+            s_coef[threadIdx.x] = coef < 1.f ? coef : 1.f;
+        }
     }
     __syncthreads();
-    const uint32_t step = counter[1];                                 // incremented by k_gradnorm
+    const uint32_t step = counter[1] + (oa.bump_step ? 1u : 0u);      // k_gradnorm bumps it in the DP path
     const float b1 = 0.9f, b2 = 0.999f;
     float bc1 = 1.f, bc2s = 1.f;
     if (oa.optim_type == MMG_OPT_ADAM) {
@@ -519,6 +635,11 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
             for (int k = 0; k < 4; ++k) wv[k] -= oa.lr * gv[k];
         }
         *reinterpret_cast<float4*>(params + i) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    }
+    // every block has read counter[1] above; the bump is published by the kernel boundary
+    if (oa.bump_step && blockIdx.x == gridDim.x - 1) {
+        __syncthreads();
+        if (threadIdx.x == 0) const_cast<uint32_t*>(counter)[2] = step;   // committed to counter[1] by the next k_prep
     }
 }
 

@@ -1,0 +1,662 @@
+// kernels_fast.h -- register-resident specialisations of the two per-sample kernels for the
+// "small agent" shapes of BASELINE configs 1-3 (H=256, W=32, R=64, V=100, D<=32).
+//
+// Why: at these shapes one exchange step of one sample is ~107 k FMAs over 53.5 k weights.  The
+// generic kernel (kernels_fwd.h) re-reads every weight from L2 at every step and pays one L2 round
+// trip per layer on a dependent chain (~34 us per step measured).  Here one workgroup (4 waves, one
+// per SIMD, up to 512 VGPRs each) loads the 53.5 k per-step weights ONCE into registers -- ~280 per
+// lane, every layer with a fixed lane->weight mapping chosen at compile time -- and then runs the T
+// steps with activations in LDS: no global load sits on the critical path of the recurrence; tape
+// stores are fire-and-forget.
+//
+// Lane mappings (NT = 256 threads):
+//   code_layer  [H,W]   thread n owns row n (W regs): no reduction, tanh applied by the same lane
+//   binary_layer[W,H]   8 lanes per row, float4-interleaved K slices (conflict-free LDS reads), 3 shuffles
+//   GRU         [3R,W+R] thread n < 3R owns row n of W_ih and W_hh (W+R regs), operands broadcast from LDS
+//   y1[:, :R], w_h [R,R]  4 lanes per row (R/4 regs each), 2 shuffles
+//   y head      Cd [D,R]   8 lanes per class (R/8 regs of Cd and of w_y2), 3 shuffles
+//   softmax . desc        every wave redoes the D<=32-lane softmax; thread v < V owns column v of desc (D regs)
+//   w_d [R,V]   4 lanes per row (V/4 regs), w [W,R] 8 lanes per row (R/8 regs)
+#pragma once
+#include "device_utils.h"
+#include "kernels_fwd.h"
+#include "layout.h"
+
+namespace mmg {
+
+template <int H, int W, int R, int V, int D>
+struct FastDims {
+    static constexpr int NT = 256;
+    static constexpr bool ok = (H == NT) && (W == 32) && (R == 64) && (V % 4 == 0) && (V <= NT) && (D <= 32) && (3 * R <= NT);
+};
+
+// Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp): absolute error ~1e-7 on
+// sigmoid / tanh / log -- three orders of magnitude inside the 1e-4 parity bar.
+__device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ float flog(float x) { return __logf(x); }
+
+// dot product of NV float4 register quads with float4 operands read from LDS at base + stride*j,
+// as four independent FMA chains (x, y, z, w components) to keep the single wave per SIMD issuing.
+template <int NV>
+__device__ __forceinline__ float dot4(const float* __restrict__ w, const float* lds, int stride4) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(lds + stride4 * j);
+        a0 = fmaf(w[4 * j], v.x, a0); a1 = fmaf(w[4 * j + 1], v.y, a1);
+        a2 = fmaf(w[4 * j + 2], v.z, a2); a3 = fmaf(w[4 * j + 3], v.w, a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+template <int N>
+__device__ __forceinline__ float lane_group_sum(float v) {
+#pragma unroll
+    for (int off = N >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int H, int W, int R, int V, int D>
+__global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P, Tape tp, ConvArgs ar) {
+    constexpr int NT = 256;
+    static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
+    __shared__ __attribute__((aligned(16))) float s_a[H];
+    __shared__ __attribute__((aligned(16))) float s_c[W];      // sender code input / receiver message
+    __shared__ __attribute__((aligned(16))) float s_z[W];
+    __shared__ __attribute__((aligned(16))) float s_h[R];
+    __shared__ __attribute__((aligned(16))) float s_gi[3 * R];
+    __shared__ __attribute__((aligned(16))) float s_gh[3 * R];
+    __shared__ __attribute__((aligned(16))) float s_A[R];
+    __shared__ __attribute__((aligned(16))) float s_y[32];
+    __shared__ __attribute__((aligned(16))) float s_yout[32];
+    __shared__ __attribute__((aligned(16))) float s_dbar[V];
+    __shared__ __attribute__((aligned(16))) float s_g[R];
+    __shared__ float s_lp[W], s_ne[W], s_lpw[W], s_new[W];
+    __shared__ float s_misc[8];
+    // injected uniforms of this sample (the loop must not contain global loads: on gfx950 a load's
+    // s_waitcnt vmcnt also drains every outstanding tape store, ~1-2 us each)
+    constexpr int TMAX = 16;
+    __shared__ float s_uz[TMAX * W], s_uw[TMAX * W], s_us[TMAX];
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int B = dm.B, T = dm.T;
+    const bool binary = dm.use_binary != 0, train = ar.train != 0;
+    const bool inject = ar.u_s != nullptr;
+    if (train && inject) {
+        for (int i = tid; i < T * W; i += NT) {
+            const int t = i / W, j = i - t * W;
+            if (ar.u_z) s_uz[i] = ar.u_z[((size_t)t * B + b) * W + j];
+            if (ar.u_w) s_uw[i] = ar.u_w[((size_t)t * B + b) * W + j];
+        }
+        if (tid < T) s_us[tid] = ar.u_s[(size_t)tid * B + b];
+    }
+
+    // ------------------------------------------------------------ weights -> registers (once)
+    float wc[W];                                   // code_layer row tid
+    {
+        const float4* r4 = reinterpret_cast<const float4*>(P.p[S_CODE_W] + (size_t)tid * W);
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) { const float4 v = r4[j]; wc[4 * j] = v.x; wc[4 * j + 1] = v.y; wc[4 * j + 2] = v.z; wc[4 * j + 3] = v.w; }
+    }
+    const float bc = P.p[S_CODE_B][tid];
+    const float hw0 = tp.hw0[tid];
+    const float hx = tp.hx[(size_t)b * H + tid];
+    // binary_layer: row nb = tid/8, K slice kp = tid%8: k = kp*4 + 32*j + {0..3}
+    constexpr int LB = NT / W;                     // 8 lanes per row
+    constexpr int JB = H / (4 * LB);               // 8 float4 per lane
+    const int nb = tid / LB, kpb = tid % LB;
+    float wb[4 * JB];
+    {
+        const float* row = P.p[S_BIN_W] + (size_t)nb * H;
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(row + kpb * 4 + 4 * LB * j);
+            wb[4 * j] = v.x; wb[4 * j + 1] = v.y; wb[4 * j + 2] = v.z; wb[4 * j + 3] = v.w;
+        }
+    }
+    const float bb = P.p[S_BIN_B][nb];
+    // GRU rows
+    const bool gru_lane = tid < 3 * R;
+    float wih[W], whh[R];
+    float bih = 0.f, bhh = 0.f;
+    if (gru_lane) {
+        const float4* a4 = reinterpret_cast<const float4*>(P.p[R_WIH] + (size_t)tid * W);
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) { const float4 v = a4[j]; wih[4 * j] = v.x; wih[4 * j + 1] = v.y; wih[4 * j + 2] = v.z; wih[4 * j + 3] = v.w; }
+        const float4* b4 = reinterpret_cast<const float4*>(P.p[R_WHH] + (size_t)tid * R);
+#pragma unroll
+        for (int j = 0; j < R / 4; ++j) { const float4 v = b4[j]; whh[4 * j] = v.x; whh[4 * j + 1] = v.y; whh[4 * j + 2] = v.z; whh[4 * j + 3] = v.w; }
+        bih = P.p[R_BIH][tid]; bhh = P.p[R_BHH][tid];
+    } else {
+#pragma unroll
+        for (int j = 0; j < W; ++j) wih[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < R; ++j) whh[j] = 0.f;
+    }
+    // y1[:, :R] and w_h: row n4 = tid/4, K slice kp4 = tid%4: k = kp4*4 + 16*j + {0..3}
+    constexpr int L4 = NT / R;                     // 4 lanes per row
+    constexpr int J4 = R / (4 * L4);               // 4 float4 per lane
+    const int n4 = tid / L4, kp4 = tid % L4;
+    float wy1[4 * J4], wh[4 * J4];
+    {
+        const float* ry = P.p[R_Y1_W] + (size_t)n4 * (R + V);
+        const float* rh = P.p[R_WH_W] + (size_t)n4 * R;
+#pragma unroll
+        for (int j = 0; j < J4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(ry + kp4 * 4 + 4 * L4 * j);
+            wy1[4 * j] = v.x; wy1[4 * j + 1] = v.y; wy1[4 * j + 2] = v.z; wy1[4 * j + 3] = v.w;
+            const float4 u = *reinterpret_cast<const float4*>(rh + kp4 * 4 + 4 * L4 * j);
+            wh[4 * j] = u.x; wh[4 * j + 1] = u.y; wh[4 * j + 2] = u.z; wh[4 * j + 3] = u.w;
+        }
+    }
+    const float bh = P.p[R_WH_B][n4];
+    // w_d [R,V]: row n4, k = kp4 + 4*j
+    constexpr int JD = V / L4;
+    float wd[JD];
+    {
+        const float* rd = P.p[R_WD_W] + (size_t)n4 * V;
+#pragma unroll
+        for (int j = 0; j < JD; ++j) wd[j] = rd[kp4 + L4 * j];
+    }
+    // stop head: lane l of every wave holds w_s[l]
+    const float ws = P.p[R_S_W][lane];
+    const float bs = P.p[R_S_B][0];
+    // y head: class dy = tid/8 (< 32), K slice kpy = tid%8: k = kpy*4 + 32*j + {0..3}
+    constexpr int LY = 8, JY = R / (4 * LY);       // 2 float4 per lane
+    const int dy = tid / LY, kpy = tid % LY;
+    float cd[4 * JY], w2[4 * JY];
+    {
+        const float* rc = tp.Cd + (size_t)(dy < D ? dy : 0) * R;
+        const float* rw = P.p[R_Y2_W];
+#pragma unroll
+        for (int j = 0; j < JY; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(rc + kpy * 4 + 4 * LY * j);
+            cd[4 * j] = v.x; cd[4 * j + 1] = v.y; cd[4 * j + 2] = v.z; cd[4 * j + 3] = v.w;
+            const float4 u = *reinterpret_cast<const float4*>(rw + kpy * 4 + 4 * LY * j);
+            w2[4 * j] = u.x; w2[4 * j + 1] = u.y; w2[4 * j + 2] = u.z; w2[4 * j + 3] = u.w;
+        }
+    }
+    const float b2 = P.p[R_Y2_B][0];
+    // desc column v = tid (< V)
+    float dcol[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) dcol[d] = (tid < V) ? ar.desc[(size_t)d * V + tid] : 0.f;
+    // w [W,R]: row nb (= tid/8), k = kpb*4 + 32*j + {0..3}
+    constexpr int JW = R / (4 * LB);               // 2 float4 per lane
+    float ww[4 * JW];
+    {
+        const float* rw = P.p[R_W_W] + (size_t)nb * R;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(rw + kpb * 4 + 4 * LB * j);
+            ww[4 * j] = v.x; ww[4 * j + 1] = v.y; ww[4 * j + 2] = v.z; ww[4 * j + 3] = v.w;
+        }
+    }
+    const float bw = P.p[R_W_B][nb];
+    const float sig_cb = (tid < W) ? fsigmoid(P.p[S_CODE_BIAS][tid]) : 0.f;
+
+    // ------------------------------------------------------------ conversation state
+    if (tid < R) { s_h[tid] = 0.f; tp.h[(size_t)b * R + tid] = 0.f; }
+    if (tid < W) s_c[tid] = dm.first_rec;
+    if (tid == 0) { s_misc[0] = 1.f; s_misc[1] = -1.f; s_misc[2] = 1.f; tp.mask[b] = 1; }
+    __syncthreads();
+    const uint32_t mb_counter = tp.counter[0];
+    const uint32_t gb = (uint32_t)(dm.boff + b);
+
+    for (int t = 0; t < T; ++t) {
+        const size_t row = (size_t)t * B + b;
+        // ===== (1) sender: h_w = code_layer(c), a = tanh(h_x + h_w)  [thread n = tid]
+        float av;
+        {
+            float hw = hw0;
+            if (t > 0) {
+                hw = bc + dot4<W / 4>(wc, s_c, 4);
+            }
+            av = ftanh(hx + hw);
+            s_a[tid] = av;
+            tp.a[row * H + tid] = av;
+            if (tid < W) {
+                const float cv = s_c[tid];
+                tp.zr[row * W + tid] = cv;
+                tp.c[row * W + tid] = (t == 0) ? sig_cb : cv;
+            }
+        }
+        // GRU hidden-side product does not depend on this step's message: overlap it here
+        float ghv = bhh;
+        if (gru_lane) ghv += dot4<R / 4>(whh, s_h, 4);
+        __syncthreads();                                                   // B1: a ready
+        // ===== (2) sender: logits = binary_layer(a), Bernoulli sample
+        {
+            float acc = dot4<JB>(wb, s_a + kpb * 4, 4 * LB);
+            acc = lane_group_sum<LB>(acc);
+            if (kpb == 0) {
+                const float lz = acc + bb;
+                float zz = lz, lpv = 0.f, nev = 0.f;
+                if (binary) {
+                    const float p = fsigmoid(lz);
+                    if (train) {
+                        const float u = inject ? s_uz[t * W + nb]
+                                               : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + gb) * W + nb), mb_counter, 0u);
+                        zz = (u < p) ? 1.f : 0.f;
+                    } else {
+                        zz = rintf(p);
+                    }
+                    tp.pz[row * W + nb] = p;
+                    const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                    lpv = zz * l1 + (1.f - zz) * l0;
+                    nev = p * l1 + (1.f - p) * l0;
+                }
+                s_z[nb] = zz; s_lp[nb] = lpv; s_ne[nb] = nev;
+                tp.z[row * W + nb] = zz;
+            }
+        }
+        __syncthreads();                                                   // B2: z ready
+        // ===== (3) receiver GRU gate pre-activations  [thread n < 3R]
+        if (gru_lane) {
+            const float giv = bih + dot4<W / 4>(wih, s_z, 4);
+            s_gi[tid] = giv; s_gh[tid] = ghv;
+        }
+        if (binary && tid >= 192 && tid < 192 + 64) {                      // wave 3 is idle here: reduce the sender's log-lik terms
+            const int l = tid - 192;
+            float lpv = (l < W) ? s_lp[l] : 0.f, nev = (l < W) ? s_ne[l] : 0.f;
+            lpv = wave_sum(lpv); nev = wave_sum(nev);
+            if (l == 0) { tp.lp_z[row] = lpv; tp.ne_z[row] = nev; }
+        }
+        __syncthreads();                                                   // B3: gates ready
+        // ===== (4) GRU state update  [thread i < R]
+        if (tid < R) {
+            const float rr = fsigmoid(s_gi[tid] + s_gh[tid]);
+            const float uu = fsigmoid(s_gi[R + tid] + s_gh[R + tid]);
+            const float ghn = s_gh[2 * R + tid];
+            const float nn = ftanh(s_gi[2 * R + tid] + rr * ghn);
+            const float hv = nn + uu * (s_h[tid] - nn);
+            float* gr = tp.gru + row * 4 * R;
+            gr[tid] = rr; gr[R + tid] = uu; gr[2 * R + tid] = nn; gr[3 * R + tid] = ghn;
+            tp.h[((size_t)(t + 1) * B + b) * R + tid] = hv;
+            s_h[tid] = hv;                                                 // (s_h is only read again after B4)
+        }
+        __syncthreads();                                                   // B4: h ready
+        // ===== (5) heads on h: A = y1[:, :R] h, gh_ = w_h h + b_h (kept in registers), stop bit
+        float gpre_h;
+        {
+            float accA = dot4<J4>(wy1, s_h + kp4 * 4, 4 * L4);
+            float accH = dot4<J4>(wh, s_h + kp4 * 4, 4 * L4);
+            accA = lane_group_sum<L4>(accA);
+            accH = lane_group_sum<L4>(accH);
+            if (kp4 == 0) s_A[n4] = accA;
+            gpre_h = accH + bh;
+        }
+        if (tid < 64) {                                                    // stop head on wave 0
+            float sv = wave_sum(ws * s_h[lane]);
+            if (lane == 0) {
+                const float p = fsigmoid(sv + bs);
+                float sbit;
+                if (train) {
+                    const float u = inject ? s_us[t] : philox_uniform(ar.seed, (uint32_t)(t * dm.Bg + gb), mb_counter, 1u);
+                    sbit = (u < p) ? 1.f : 0.f;
+                } else {
+                    const float prod = dm.s_prob_prod ? s_misc[2] * p : p;
+                    s_misc[2] = prod;
+                    sbit = rintf(prod);
+                }
+                tp.s[row] = sbit; tp.ps[row] = p;
+                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                tp.lp_s[row] = sbit * l1 + (1.f - sbit) * l0;
+                tp.ne_s[row] = p * l1 + (1.f - p) * l0;
+                s_misc[3] = sbit;
+            }
+        }
+        __syncthreads();                                                   // B5: A, stop bit ready
+        // ===== (6) class logits
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < JY; ++j) {
+                const float4 a4 = *reinterpret_cast<const float4*>(s_A + kpy * 4 + 4 * LY * j);
+                acc = fmaf(w2[4 * j], fmaxf(a4.x + cd[4 * j], 0.f), acc);
+                acc = fmaf(w2[4 * j + 1], fmaxf(a4.y + cd[4 * j + 1], 0.f), acc);
+                acc = fmaf(w2[4 * j + 2], fmaxf(a4.z + cd[4 * j + 2], 0.f), acc);
+                acc = fmaf(w2[4 * j + 3], fmaxf(a4.w + cd[4 * j + 3], 0.f), acc);
+            }
+            acc = lane_group_sum<LY>(acc);
+            if (kpy == 0) {
+                const float yv = (dy < D) ? acc + b2 : -3.0e38f;
+                s_y[dy] = yv;
+                if (dy < D) tp.y[row * D + dy] = yv;
+            }
+        }
+        // stop-mask bookkeeping
+        const float m_t = s_misc[0], sbit = s_misc[3];
+        const float m_next = fminf(m_t, sbit);
+        const bool first_stop = (m_next == 0.f) && (s_misc[1] < 0.f);
+        const bool take_out = dm.fixed ? (t == T - 1) : (first_stop || ((t == T - 1) && (s_misc[1] < 0.f)));
+        __syncthreads();                                                   // B6: y ready (and everyone has read misc)
+        if (take_out && tid < 32) s_yout[tid] = s_y[tid];
+        if (tid == 0) {
+            tp.mask[(size_t)(t + 1) * B + b] = (uint8_t)(m_next != 0.f);
+            if (take_out) s_misc[1] = (float)t;
+            s_misc[0] = m_next;
+        }
+        if (!ar.run_all && !dm.fixed && train && m_next == 0.f) { ++t; __syncthreads(); break; }
+        // ===== (7) softmax (every wave redoes it on lanes d < D) and the description mixture
+        {
+            const float yv = (lane < 32) ? s_y[lane] : -3.0e38f;
+            const float mx = wave_max(yv);
+            const float e = (lane < D) ? __expf(yv - mx) : 0.f;
+            const float inv = 1.f / wave_sum(e);
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+            for (int d = 0; d + 3 < D; d += 4) {
+                q0 = fmaf(__shfl(e, d, 64), dcol[d], q0); q1 = fmaf(__shfl(e, d + 1, 64), dcol[d + 1], q1);
+                q2 = fmaf(__shfl(e, d + 2, 64), dcol[d + 2], q2); q3 = fmaf(__shfl(e, d + 3, 64), dcol[d + 3], q3);
+            }
+#pragma unroll
+            for (int d = D & ~3; d < D; ++d) q0 = fmaf(__shfl(e, d, 64), dcol[d], q0);
+            const float acc = ((q0 + q1) + (q2 + q3)) * inv;
+            if (tid < V) { s_dbar[tid] = acc; tp.dbar[row * V + tid] = acc; }
+        }
+        __syncthreads();                                                   // B7: dbar ready
+        // ===== (8) h_w = tanh(w_h h + b_h + w_d dbar)
+        {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int j = 0; j + 3 < JD; j += 4) {
+                a0 = fmaf(wd[j], s_dbar[kp4 + L4 * j], a0); a1 = fmaf(wd[j + 1], s_dbar[kp4 + L4 * (j + 1)], a1);
+                a2 = fmaf(wd[j + 2], s_dbar[kp4 + L4 * (j + 2)], a2); a3 = fmaf(wd[j + 3], s_dbar[kp4 + L4 * (j + 3)], a3);
+            }
+#pragma unroll
+            for (int j = JD & ~3; j < JD; ++j) a0 = fmaf(wd[j], s_dbar[kp4 + L4 * j], a0);
+            float acc = lane_group_sum<L4>((a0 + a1) + (a2 + a3));
+            if (kp4 == 0) {
+                const float gv = ftanh(gpre_h + acc);
+                s_g[n4] = gv;
+                tp.g[row * R + n4] = gv;
+            }
+        }
+        __syncthreads();                                                   // B8: g ready
+        // ===== (9) receiver message
+        {
+            float acc = dot4<JW>(ww, s_g + kpb * 4, 4 * LB);
+            acc = lane_group_sum<LB>(acc);
+            if (kpb == 0) {
+                const float lw = acc + bw;
+                float wv = lw, lpv = 0.f, nev = 0.f;
+                if (binary) {
+                    const float p = fsigmoid(lw);
+                    if (train) {
+                        const float u = inject ? s_uw[t * W + nb]
+                                               : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + gb) * W + nb), mb_counter, 2u);
+                        wv = (u < p) ? 1.f : 0.f;
+                    } else {
+                        wv = rintf(p);
+                    }
+                    tp.pw[row * W + nb] = p;
+                    const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                    lpv = wv * l1 + (1.f - wv) * l0;
+                    nev = p * l1 + (1.f - p) * l0;
+                }
+                s_c[nb] = wv; s_lpw[nb] = lpv; s_new[nb] = nev;
+                tp.w[row * W + nb] = wv;
+            }
+        }
+        __syncthreads();                                                   // B9: w ready
+        if (binary && tid < 64) {
+            float lpv = (lane < W) ? s_lpw[lane] : 0.f, nev = (lane < W) ? s_new[lane] : 0.f;
+            lpv = wave_sum(lpv); nev = wave_sum(nev);
+            if (lane == 0) { tp.lp_w[row] = lpv; tp.ne_w[row] = nev; }
+        }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------ output selection / reward / top-k
+    const int tstar = dm.fixed ? (T - 1) : (int)s_misc[1];
+    if (tid < 64) {
+        const float o = (lane < 32) ? s_yout[lane] : -3.0e38f;
+        const float mx = wave_max(o);
+        const float e = (lane < D) ? __expf(o - mx) : 0.f;
+        const float lse = mx + flog(wave_sum(e));
+        const int tgt = ar.target ? (int)ar.target[b] : -1;
+        const float dt = (tgt >= 0) ? (__shfl(o, tgt, 64) - lse) : 0.f;
+        const float ld = o - lse;
+        if (lane < D) {
+            tp.outp[(size_t)b * D + lane] = o;
+            tp.dist[(size_t)b * D + lane] = ld;
+            tp.sm[(size_t)b * D + lane] = __expf(ld);
+        }
+        const float above = wave_sum((lane < D && tgt >= 0 && ld > dt) ? 1.f : 0.f);
+        if (lane == 0) {
+            tp.tstar[b] = tstar;
+            tp.logs[b] = dt;
+            tp.hit[b] = (tgt >= 0 && above < (float)dm.top_k) ? 1 : 0;
+        }
+    }
+}
+
+}  // namespace mmg
+
+namespace mmg {
+
+// ---------------------------------------------------------------------------------------------
+// k_bwd_conv_fast: reverse-time pass of one sample with the TRANSPOSED weight fragments the
+// recurrence needs resident in registers (w^T: 8, w_h^T: 16, W_hh^T: 48, binary_layer^T: 32 per lane).
+// Same math, tape contract and zero-filling as k_bwd_conv (kernels_bwd.h); 5 barriers per step.
+// ---------------------------------------------------------------------------------------------
+template <int H, int W, int R, int V, int D>
+__global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target) {
+    constexpr int NT = 256, K4 = NT / R;          // 4 lanes per output unit of the R-wide transposed products
+    constexpr int TMAX = 16;
+    static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
+    __shared__ float s_coef[7 * 64];
+    __shared__ __attribute__((aligned(16))) float s_dh[R], s_dhs[R], s_dlw[W], s_dlz[W], s_dgpre[R], s_dgh[3 * R];
+    __shared__ __attribute__((aligned(16))) float s_dy[32], s_A[R], s_dA[R], s_dpre[H];
+    __shared__ float s_misc[8];
+    // forward tape of this sample, loaded once: the time loop then issues stores only (a load inside it
+    // would make its s_waitcnt vmcnt drain all outstanding delta-tape stores, ~1-2 us per wait on gfx950)
+    __shared__ float t_w[TMAX * W], t_pw[TMAX * W], t_z[TMAX * W], t_pz[TMAX * W], t_g[TMAX * R];
+    __shared__ float t_gru[TMAX * 4 * R], t_h[(TMAX + 1) * R], t_a[TMAX * H];
+    __shared__ float t_bs[TMAX], t_br[TMAX], t_s[TMAX], t_ps[TMAX];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int B = dm.B, T = dm.T;
+    const bool binary = dm.use_binary != 0;
+    const int tstar = tp.tstar[b];
+    const int nst = tstar + 1;
+    for (int i = tid; i < nst * W; i += NT) {
+        const int t = i / W, j = i - t * W;
+        const size_t o = ((size_t)t * B + b) * W + j;
+        t_w[i] = tp.w[o]; t_z[i] = tp.z[o];
+        if (binary) { t_pw[i] = tp.pw[o]; t_pz[i] = tp.pz[o]; }
+    }
+    for (int i = tid; i < nst * R; i += NT) { const int t = i / R, j = i - t * R; t_g[i] = tp.g[((size_t)t * B + b) * R + j]; }
+    for (int i = tid; i < nst * 4 * R; i += NT) { const int t = i / (4 * R), j = i - t * 4 * R; t_gru[i] = tp.gru[((size_t)t * B + b) * 4 * R + j]; }
+    for (int i = tid; i < (nst + 1) * R; i += NT) { const int t = i / R, j = i - t * R; t_h[i] = tp.h[((size_t)t * B + b) * R + j]; }
+    for (int i = tid; i < nst * H; i += NT) { const int t = i / H, j = i - t * H; t_a[i] = tp.a[((size_t)t * B + b) * H + j]; }
+    if (tid < nst) {
+        const size_t o = (size_t)tid * B + b;
+        t_bs[tid] = tp.bs[o]; t_br[tid] = tp.br[o]; t_s[tid] = tp.s[o]; t_ps[tid] = tp.ps[o];
+    }
+    LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
+    loss_coefficients(dm, tp.stats, lc, b == 0 ? tp.losses : nullptr);
+    const float L = tp.logs[b];
+    const float* cw_s = lc.cw, *cw_r = lc.cw + T, *cw_z = lc.cw + 2 * T;
+    const float* ce_s = lc.ce, *ce_r = lc.ce + T, *ce_z = lc.ce + 2 * T;
+
+    // ---- transposed fragments: output unit k4 = tid/4, reduction slice p4 = tid%4 (n = p4 + 4*i)
+    const int k4 = tid / K4, p4 = tid % K4;
+    float wwT[W / K4], whT[R / K4], whhT[3 * R / K4];
+#pragma unroll
+    for (int i = 0; i < W / K4; ++i) wwT[i] = P.p[R_W_W][(size_t)(p4 + K4 * i) * R + k4];
+#pragma unroll
+    for (int i = 0; i < R / K4; ++i) whT[i] = P.p[R_WH_W][(size_t)(p4 + K4 * i) * R + k4];
+#pragma unroll
+    for (int i = 0; i < 3 * R / K4; ++i) whhT[i] = P.p[R_WHH][(size_t)(p4 + K4 * i) * R + k4];
+    const float wsk = P.p[R_S_W][k4];
+    float wbT[W];                                  // binary_layer column tid: W_b[j][tid]
+#pragma unroll
+    for (int j = 0; j < W; ++j) wbT[j] = P.p[S_BIN_W][(size_t)j * H + tid];
+    // output-step quantities (one step per sample): fetch before the loop as well
+    const int tgt = (int)target[b];
+    float y1T[R / K4];                             // y1[:, :R]^T fragment
+#pragma unroll
+    for (int i = 0; i < R / K4; ++i) y1T[i] = P.p[R_Y1_W][(size_t)(p4 + K4 * i) * (R + V) + k4];
+    float y1r[R / K4];                             // y1[:, :R] row k4 fragment (forward product A = y1h . h*)
+#pragma unroll
+    for (int i = 0; i < R / K4; ++i) y1r[i] = P.p[R_Y1_W][(size_t)k4 * (R + V) + p4 + K4 * i];
+    const float dy_mine = (tid < D) ? (tp.sm[(size_t)b * D + tid] - (tid == tgt ? 1.f : 0.f)) / (float)dm.Bg : 0.f;
+    const float w2_mine = (tid < R) ? P.p[R_Y2_W][tid] : 0.f;
+    float cdcol[D];                                // Cd[:, tid] for tid < R
+#pragma unroll
+    for (int d = 0; d < D; ++d) cdcol[d] = (tid < R) ? tp.Cd[(size_t)d * R + tid] : 0.f;
+
+    if (tid < R) s_dh[tid] = 0.f;
+    float dhx_acc = 0.f;
+
+    // ---- zero the gradient tapes of steps this sample never took
+    for (int t = tstar + 1; t < T; ++t) {
+        const size_t row = (size_t)t * B + b;
+        if (tid < W) { tp.dlz[row * W + tid] = 0.f; tp.dlw[row * W + tid] = 0.f; }
+        tp.dpre[row * H + tid] = 0.f;
+        if (tid < R) tp.dgpre[row * R + tid] = 0.f;
+        if (tid < 3 * R) { tp.dgi[row * 3 * R + tid] = 0.f; tp.dgh[row * 3 * R + tid] = 0.f; }
+        if (tid == 0) { tp.dls[row] = 0.f; tp.dbs[row] = 0.f; tp.dbr[row] = 0.f; }
+    }
+    __syncthreads();
+
+    for (int t = tstar; t >= 0; --t) {
+        const size_t row = (size_t)t * B + b;
+        const bool act_next = binary && (t < tstar);
+        // ===== (1) gradient seeds of both message heads, of the stop bit and of the baselines
+        if (tid < W) {
+            float v = 0.f;
+            if (act_next) v = bit_seed(t_w[t * W + tid], t_pw[t * W + tid], (L - t_br[t]) * cw_r[t], ce_r[t]);
+            s_dlw[tid] = v; tp.dlw[row * W + tid] = v;
+        } else if (tid >= 64 && tid < 64 + W) {
+            const int j = tid - 64;
+            float v = 0.f;
+            if (binary) v = bit_seed(t_z[t * W + j], t_pz[t * W + j], (L - t_bs[t]) * cw_z[t], ce_z[t]);
+            s_dlz[j] = v; tp.dlz[row * W + j] = v;
+        } else if (tid == 128) {
+            float v = 0.f;
+            if (binary && !dm.fixed) v = bit_seed(t_s[t], t_ps[t], (L - t_br[t]) * cw_s[t], ce_s[t]);
+            s_misc[0] = v; tp.dls[row] = v;
+        } else if (tid == 192) {                                            // MSE seeds (model.py:971-988)
+            tp.dbs[row] = binary ? lc.cb[t] * (t_bs[t] - L) : 0.f;
+            tp.dbr[row] = binary ? lc.cb[t] * (t_br[t] - L) : 0.f;
+        }
+        if (t == tstar) {                                                   // NLL seed at the output step
+            if (tid < 64) {
+                if (lane < D) tp.dy[(size_t)b * D + lane] = dy_mine;
+                if (lane < 32) s_dy[lane] = dy_mine;
+                const float dsum = wave_sum(dy_mine);
+                if (lane == 0) tp.dysum[b] = dsum;
+            } else if (tid < 64 + R) {
+                tp.hstar[(size_t)b * R + tid - 64] = t_h[(t + 1) * R + tid - 64];
+            }
+        }
+        __syncthreads();                                                    // b1
+        // ===== (2) dg = W_w^T dlw -> dgpre ; sender: da = W_b^T dlz -> dpre
+        {
+            float acc = 0.f;
+            if (act_next) {
+#pragma unroll
+                for (int i = 0; i < W / K4; ++i) acc = fmaf(wwT[i], s_dlw[p4 + K4 * i], acc);
+            }
+            acc = lane_group_sum<K4>(acc);
+            if (p4 == 0) {
+                const float g = t_g[t * R + k4];
+                const float v = act_next ? acc * (1.f - g * g) : 0.f;
+                s_dgpre[k4] = v; tp.dgpre[row * R + k4] = v;
+            }
+        }
+        {
+            float v = 0.f;
+            if (binary) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int j = 0; j < W; j += 4) {
+                    a0 = fmaf(wbT[j], s_dlz[j], a0); a1 = fmaf(wbT[j + 1], s_dlz[j + 1], a1);
+                    a2 = fmaf(wbT[j + 2], s_dlz[j + 2], a2); a3 = fmaf(wbT[j + 3], s_dlz[j + 3], a3);
+                }
+                const float a = t_a[t * H + tid];
+                v = ((a0 + a1) + (a2 + a3)) * (1.f - a * a);
+            }
+            tp.dpre[row * H + tid] = v;
+            dhx_acc += v;
+            if (t == 0) s_dpre[tid] = v;
+        }
+        if (t == tstar) {                                                   // A = y1[:, :R] h*
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < R / K4; ++i) acc = fmaf(y1r[i], t_h[(t + 1) * R + p4 + K4 * i], acc);
+            acc = lane_group_sum<K4>(acc);
+            if (p4 == 0) s_A[k4] = acc;
+        }
+        __syncthreads();                                                    // b2
+        if (t == tstar) {
+            if (tid < R) {
+                const float a = s_A[tid];
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) acc += (a + cdcol[d] > 0.f) ? s_dy[d] : 0.f;
+                const float v = acc * w2_mine;
+                s_dA[tid] = v; tp.dA[(size_t)b * R + tid] = v; tp.Astar[(size_t)b * R + tid] = a;
+            }
+            __syncthreads();
+        }
+        // ===== (3) dh += W_h^T dgpre + w_s dls (+ W_y1h^T dA at the output step)
+        {
+            float acc = 0.f;
+            if (act_next) {
+#pragma unroll
+                for (int i = 0; i < R / K4; ++i) acc = fmaf(whT[i], s_dgpre[p4 + K4 * i], acc);
+            }
+            if (t == tstar) {
+#pragma unroll
+                for (int i = 0; i < R / K4; ++i) acc = fmaf(y1T[i], s_dA[p4 + K4 * i], acc);
+            }
+            acc = lane_group_sum<K4>(acc);
+            if (p4 == 0) s_dhs[k4] = s_dh[k4] + acc + wsk * s_misc[0];
+        }
+        __syncthreads();                                                    // b3
+        // ===== (4) GRU cell backward (thread i < R)
+        if (tid < R) {
+            const float* gr = t_gru + t * 4 * R;
+            const float rr = gr[tid], uu = gr[R + tid], nn = gr[2 * R + tid], ghn = gr[3 * R + tid];
+            const float hp = t_h[t * R + tid];
+            const float dh = s_dhs[tid];
+            const float dn = dh * (1.f - uu), du = dh * (hp - nn);
+            const float dnp = dn * (1.f - nn * nn), dup = du * uu * (1.f - uu);
+            const float drp = dnp * ghn * rr * (1.f - rr);
+            float* gi = tp.dgi + row * 3 * R; float* gh = tp.dgh + row * 3 * R;
+            gi[tid] = drp; gi[R + tid] = dup; gi[2 * R + tid] = dnp;
+            gh[tid] = drp; gh[R + tid] = dup; gh[2 * R + tid] = dnp * rr;
+            s_dgh[tid] = drp; s_dgh[R + tid] = dup; s_dgh[2 * R + tid] = dnp * rr;
+            s_dh[tid] = dh * uu;
+        }
+        __syncthreads();                                                    // b4
+        // ===== (5) dh_{t-1} = dh * u + W_hh^T dgh
+        {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3 * R / K4; i += 4) {
+                a0 = fmaf(whhT[i], s_dgh[p4 + K4 * i], a0); a1 = fmaf(whhT[i + 1], s_dgh[p4 + K4 * (i + 1)], a1);
+                a2 = fmaf(whhT[i + 2], s_dgh[p4 + K4 * (i + 2)], a2); a3 = fmaf(whhT[i + 3], s_dgh[p4 + K4 * (i + 3)], a3);
+            }
+            const float acc = lane_group_sum<K4>((a0 + a1) + (a2 + a3));
+            if (p4 == 0) s_dh[k4] += acc;
+        }
+        __syncthreads();                                                    // b5
+    }
+    tp.dhx[(size_t)b * H + tid] = dhx_acc;
+    // code_bias path: dc0 = W_c^T dpre_0   (once per sample)
+    if (binary) {
+        const int j = tid / 8, p8 = tid % 8;                                // 8 lanes per output, h = p8 + 8*i
+        float acc = 0.f;
+        for (int i = 0; i < H / 8; ++i) acc = fmaf(P.p[S_CODE_W][(size_t)(p8 + 8 * i) * W + j], s_dpre[p8 + 8 * i], acc);
+        acc = lane_group_sum<8>(acc);
+        if (p8 == 0) tp.dc0[(size_t)b * W + j] = acc;
+    } else if (tid < W) {
+        tp.dc0[(size_t)b * W + tid] = 0.f;
+    }
+}
+
+}  // namespace mmg

@@ -16,9 +16,19 @@ namespace mmg {
 // build_inp, model.py:412/432 -- SURVEY.md Appendix A.2).  Block D: hw0 = code_layer(sigmoid(
 // code_bias)) (model.py:199-200) and dsig = sigmoid'(code_bias).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, const float* __restrict__ desc) {
+__device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__ X, int ldx, const float* __restrict__ Wm, int ldw,
+                                             const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K);
+
+// blocks [0, D]: parameter-only constants; blocks (D, D + hx_tiles]: tiles of h_x = image_layer(x)
+// (model.py:195) -- independent work sharing one launch.
+__global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, const float* __restrict__ desc,
+                                                    const float* __restrict__ x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x > dm.D) {
+        gemm_nt_tile(blockIdx.x - dm.D - 1, x, dm.F, P.p[S_IMG_W], dm.F, P.p[S_IMG_B], tp.hx, dm.H, dm.B, dm.H, dm.F);
+        return;
+    }
     if ((int)blockIdx.x < dm.D) {
         const int d = blockIdx.x;
         float* s_desc = smem;                       // [V]
@@ -37,7 +47,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
             s_sig[j] = sg;
             tp.dsig[j] = sg * (1.f - sg);
         }
-        if (tid == 0) tp.counter[0] += 1u;          // minibatch counter: the Philox stream of this conversation
+        if (tid == 0) {
+            tp.counter[0] += 1u;                    // minibatch counter: the Philox stream of this conversation
+            if (tp.counter[2] > tp.counter[1]) tp.counter[1] = tp.counter[2];   // optimizer step bumped by k_opt
+        }
         __syncthreads();
         const float* bc = P.p[S_CODE_B];
         gemv_rows(P.p[S_CODE_W], dm.W, dm.H, dm.W, s_sig, [&](int n, float acc) { tp.hw0[n] = acc + bc[n]; });
@@ -51,13 +64,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
 // per operand per four MFMAs (the k index inside the group of 16 is permuted identically for A
 // and B, which leaves the sum unchanged).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MMG_BLOCK) void k_gemm_nt(const float* __restrict__ X, int ldx,
+__device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__ X, int ldx,
                                                        const float* __restrict__ Wm, int ldw,
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ out, int ldo, int M, int N, int K) {
     __shared__ float s_acc[4][16][17];
     const int tiles_n = (N + 15) >> 4;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int m = tm * 16 + i, n = tn * 16 + i;
@@ -100,6 +113,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_gemm_nt(const float* __restrict__
             out[(size_t)mo * ldo + no] = v + (bias ? bias[no] : 0.f);
         }
     }
+}
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_gemm_nt(const float* __restrict__ X, int ldx,
+                                                       const float* __restrict__ Wm, int ldw,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ out, int ldo, int M, int N, int K) {
+    gemm_nt_tile(blockIdx.x, X, ldx, Wm, ldw, bias, out, ldo, M, N, K);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -442,7 +462,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
 // ---------------------------------------------------------------------------------------------
 struct BasArgs {
     int rows;                 // T*B (fused) or B (agent-level)
-    const float* x1; int ld1, k1;     // first K segment of the input
+    const float* x1; int ld1, k1, mod1; // first K segment of the input (row index taken modulo mod1 if > 0)
     const float* x2; int ld2, k2;     // second K segment (NULL if none)
     const float* addend; int add_mod; // per-row pre-activation addend [rows % add_mod, K] (NULL if none)
     const float* W1; int ldw, col0;   // linear1.weight, row stride, first column used
@@ -494,11 +514,12 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines(int K, BasArgs rec, Bas
         const bool nv = n < K;
         const float* wrow = A.W1 + (size_t)(nv ? n : 0) * A.ldw + A.col0;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (ok1) bas_accumulate(acc, A.x1 + xr * A.ld1, xv, wrow, nv, A.k1, q);
+        const size_t xr1 = A.mod1 > 0 ? xr % (size_t)A.mod1 : xr;
+        if (ok1) bas_accumulate(acc, A.x1 + xr1 * A.ld1, xv, wrow, nv, A.k1, q);
         else {
             for (int k0 = 0; k0 < A.k1; k0 += 4) {
                 const int k = k0 + q;
-                acc = mfma16((xv && k < A.k1) ? A.x1[xr * A.ld1 + k] : 0.f, (nv && k < A.k1) ? wrow[k] : 0.f, acc);
+                acc = mfma16((xv && k < A.k1) ? A.x1[xr1 * A.ld1 + k] : 0.f, (nv && k < A.k1) ? wrow[k] : 0.f, acc);
             }
         }
         if (A.x2) {
@@ -538,6 +559,97 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines(int K, BasArgs rec, Bas
         if (ro < A.rows)
             A.score[ro] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] +
                           s_part[3][threadIdx.x] + A.b2[0];         // model.py:515
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_baselines2 (fused training path): grid (ceil(B/16), ceil(K/64), 2).  A workgroup owns 16 samples
+// and 4 sixteen-wide tiles of the K hidden units (one per wave) and walks the steps t itself:
+//   baseline_sen: the h_x . W1[:, :H]^T product (K = H, per SAMPLE, not per step) is accumulated once
+//                 and re-used as the MFMA C operand of every step's z_r . W1[:, H:]^T product;
+//   baseline_rec: [z_t || h_{t+1}] . W1^T per step.
+// Epilogue per step: relu, store the hidden tile (tape, for the backward pass), reduce hidden . w2
+// over the block's 64 hidden units and write that PARTIAL score to part[t, b, blockIdx.y]; k_stats
+// adds the ceil(K/64) partials and linear2.bias.  Steps beyond every sample's own last step are skipped.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void seg_accumulate(f32x4& acc, const float* __restrict__ xrow, bool xv,
+                                               const float* __restrict__ wrow, bool wv, int K, int q, bool vec) {
+    if (vec) {
+        for (int k = q * 4; k < K; k += 16) {
+            float4 a = xv ? *reinterpret_cast<const float4*>(xrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 b = wv ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = mfma16(a.x, b.x, acc); acc = mfma16(a.y, b.y, acc);
+            acc = mfma16(a.z, b.z, acc); acc = mfma16(a.w, b.w, acc);
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + q;
+            acc = mfma16((xv && k < K) ? xrow[k] : 0.f, (wv && k < K) ? wrow[k] : 0.f, acc);
+        }
+    }
+}
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tape tp, int skip_inactive) {
+    __shared__ float s_part[4][16];
+    __shared__ int s_tmax;
+    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, K = dm.K, T = dm.T;
+    const int which = blockIdx.z;                       // 0: baseline_rec, 1: baseline_sen
+    const int b0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int npb = gridDim.y;
+    const int tn = blockIdx.y * 4 + wave;
+    const int n = tn * 16 + i;
+    const bool nv = n < K;
+    const int bx = b0 + i;                              // sample whose input row this lane loads
+    const bool xv = bx < B;
+    if (threadIdx.x == 0) {
+        int tm = 0;
+        for (int k = 0; k < 16 && b0 + k < B; ++k) tm = max(tm, tp.tstar[b0 + k]);
+        s_tmax = (skip_inactive && !dm.fixed) ? tm : T - 1;
+    }
+    __syncthreads();
+    const int tmax = s_tmax;
+    const float* W1 = which ? P.p[BS_L1_W] : P.p[BR_L1_W];
+    const int ldw = which ? H + W : W + R;
+    const float* wrow = W1 + (size_t)(nv ? n : 0) * ldw;
+    const float bias = nv ? (which ? P.p[BS_L1_B][n] : P.p[BR_L1_B][n]) : 0.f;
+    const float w2 = nv ? (which ? P.p[BS_L2_W][n] : P.p[BR_L2_W][n]) : 0.f;
+    float* hid = which ? tp.hid_s : tp.hid_r;
+    float* part = which ? tp.bs_part : tp.br_part;
+    const bool vecH = ((H & 15) == 0) && ((ldw & 3) == 0);
+    const bool vecW = ((W & 15) == 0) && ((ldw & 3) == 0) && ((H & 3) == 0);
+    const bool vecR = ((R & 15) == 0) && ((ldw & 3) == 0) && ((W & 3) == 0);
+    f32x4 base = {0.f, 0.f, 0.f, 0.f};
+    if (which) seg_accumulate(base, tp.hx + (size_t)(xv ? bx : 0) * H, xv, wrow, nv, H, q, vecH);
+    for (int t = 0; t <= tmax; ++t) {
+        const size_t xrow = (size_t)t * B + (xv ? bx : 0);
+        f32x4 acc = base;
+        if (which) {
+            seg_accumulate(acc, tp.zr + xrow * W, xv, wrow + H, nv, W, q, vecW);
+        } else {
+            seg_accumulate(acc, tp.z + xrow * W, xv, wrow, nv, W, q, vecW);
+            seg_accumulate(acc, tp.h + ((size_t)(t + 1) * B + (xv ? bx : 0)) * R, xv, wrow + W, nv, R, q, vecR);
+        }
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bo = b0 + q * 4 + r;
+            float v = fmaxf(acc[r] + bias, 0.f);                        // model.py:514
+            if (bo < B && nv) hid[((size_t)t * B + bo) * K + n] = v; else v = 0.f;
+            v *= w2;
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            pr[r] = v;
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_part[wave][q * 4 + r] = pr[r];
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 && b0 + (int)threadIdx.x < B)
+            part[((size_t)t * B + b0 + threadIdx.x) * npb + blockIdx.y] =
+                (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+        __syncthreads();
     }
 }
 

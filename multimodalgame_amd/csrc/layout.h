@@ -85,7 +85,6 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
 #define MMG_TAPE_LIST(X)                                                          \
     /* ---- forward ---- */                                                        \
     X(hx, float, 0, 2, B, H, 1)          /* image_layer(x)            model.py:195 */ \
-    X(Gs, float, 0, 2, B, K, 1)          /* baseline_sen linear1 over h_x (+bias)  */ \
     X(Cd, float, 0, 2, D, R, 1)          /* desc . W_y1[:,R:]^T + b_y1 (App. A.2)  */ \
     X(hw0, float, 0, 1, H, 1, 1)         /* code_layer(sigmoid(code_bias)) :199-200*/ \
     X(dsig, float, 0, 1, W, 1, 1)        /* sigmoid'(code_bias)                    */ \
@@ -114,6 +113,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(ne_w, float, 0, 2, T, B, 1)                                                  \
     X(hid_s, float, 0, 3, T, B, K)       /* baseline_sen relu hidden         :514  */ \
     X(hid_r, float, 0, 3, T, B, K)                                                 \
+    X(bs_part, float, 0, 3, T, B, NPB)   /* partial scores per 64 hidden units     */ \
+    X(br_part, float, 0, 3, T, B, NPB)                                             \
     X(bs, float, 0, 3, T, B, 1)          /* baseline_sen scores              :835  */ \
     X(br, float, 0, 3, T, B, 1)          /* baseline_rec scores              :842  */ \
     X(outp, float, 0, 2, B, D, 1)        /* get_rec_outp                     :1264 */ \
@@ -141,12 +142,10 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(dysum, float, 0, 1, B, 1, 1)                                                 \
     X(dC, float, 0, 2, D, R, 1)          /* dL/d Cd                                */ \
     X(Py2, float, 0, 2, D, R, 1)         /* per-class partials of dL/d w_y2        */ \
-    X(dhid_s, float, 0, 3, T, B, K)                                                \
-    X(dhid_r, float, 0, 3, T, B, K)                                                \
     X(dbs, float, 0, 2, T, B, 1)                                                   \
     X(dbr, float, 0, 2, T, B, 1)                                                   \
-    X(gnpart, float, 0, 2, 4, NPART, 1)  /* per-agent partial squared grad norms   */ \
-    X(tables, uint8_t, 1, 1, 65536, 1, 1) /* GEMM / column-sum job descriptors      */
+    X(gnpart, float, 0, 1, 16384 + NPART, 1, 1)  /* squared grad-norm partials (k_wgrad blocks | k_gradnorm) */ \
+    X(tables, uint8_t, 1, 1, 98304, 1, 1) /* GEMM / column-sum job descriptors      */
 
 // statistics vector (f64).  Per stream (0 = stop bits, 1 = receiver msgs, 2 = sender msgs) and
 // step: n, sum w, sum w^2, sum w*logp, sum negent; per baseline (0 = rec, 1 = sen) and step:
@@ -174,8 +173,8 @@ inline TapeLayout tape_layout(const mmg_config& c) {
     L.n = 0;
     const int64_t B = c.batch, D = c.n_classes, F = c.feat_dim, H = c.h_dim, W = c.w_dim, R = c.rec_hidden,
                   V = c.wv_dim, K = c.bas_hidden, T = c.max_exchange, T1 = T + 1,
-                  NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS;
-    (void)F; (void)V;
+                  NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64;
+    (void)F; (void)V; (void)NPB;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \

@@ -13,6 +13,7 @@
 #include "device_utils.h"
 #include "kernels_fwd.h"
 #include "kernels_bwd.h"
+#include "kernels_fast.h"
 
 using namespace mmg;
 
@@ -40,6 +41,7 @@ struct mmg_handle {
     JobTable jt;
     int conv_smem, bwd_smem, prep_smem;
     bool profiling;
+    bool scores_in_parts;      // the last forward left baseline scores as partials (k_baselines2)
     std::vector<KernelTimer> timers;
     size_t timers_used;
 };
@@ -52,6 +54,7 @@ static int validate(const mmg_config* c) {
     if (c->batch <= 0 || c->n_classes <= 0 || c->feat_dim <= 0 || c->h_dim <= 0 || c->w_dim <= 0 ||
         c->rec_hidden <= 0 || c->wv_dim <= 0 || c->bas_hidden <= 0 || c->max_exchange <= 0)
         return fail("all dimensions must be positive");
+    if (c->max_exchange > 64) return fail("max_exchange must be <= 64");
     if (c->w_dim > MMG_BLOCK || c->rec_hidden > MMG_BLOCK)
         return fail("w_dim and rec_hidden must be <= %d (got %d, %d)", MMG_BLOCK, c->w_dim, c->rec_hidden);
     if (c->wv_dim > MMG_BLOCK) return fail("wv_dim must be <= %d", MMG_BLOCK);
@@ -112,14 +115,23 @@ static int build_jobs(mmg_handle* h) {
         GemmJob& g = jt.g[ng++];
         g.A = A; g.Bm = Bm; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.rows = rows; g.N = N; g.K = Kk;
         g.bmod = bmod; g.bsrc = bsrc; g.tile_begin = tiles; g.tiles_k = (Kk + 15) / 16;
+        g.vhid = nullptr; g.vw2 = nullptr;
         tiles += ((N + 15) / 16) * g.tiles_k;
+    };
+    // dW = (dbeta * w2 * relu'(hid))^T . input  with the first factor formed on the fly
+    auto gemm_virt = [&](const float* dbeta, const float* hid, const float* w2, const float* Bm, int ldb, int bmod,
+                         float* C, int ldc, int rows, int N, int Kk) {
+        gemm(dbeta, N, Bm, ldb, bmod, SRC_STATIC, C, ldc, rows, N, Kk);
+        jt.g[ng - 1].vhid = hid; jt.g[ng - 1].vw2 = w2;
     };
     int cblocks = 0, nc = 0;
     auto col = [&](const float* src, int ld, int rows, int cols, float* dst, const float* scale) {
         ColJob& c = jt.c[nc++];
         c.src = src; c.dst = dst; c.scale = scale; c.ld = ld; c.rows = rows; c.cols = cols; c.blk_begin = cblocks;
-        cblocks += (cols + 63) / 64;
+        c.vbeta = nullptr; c.vw2 = nullptr;
+        cblocks += (cols + 15) / 16;
     };
+    const Params& P = h->P;
     const bool bin = d.use_binary;
     // ---- receiver ----
     gemm(tp.dgi, 3 * R, tp.z, W, 0, SRC_STATIC, G.p[R_WIH], W, TB, 3 * R, W);          // rnn.weight_ih
@@ -148,20 +160,40 @@ static int build_jobs(mmg_handle* h) {
         gemm(tp.dlz, W, tp.a, H, 0, SRC_STATIC, G.p[S_BIN_W], H, TB, W, H);            // binary_layer
         col(tp.dlz, W, TB, W, G.p[S_BIN_B], nullptr);
         // ---- baseline_rec: input [z || h_after] ----
-        gemm(tp.dhid_r, K, tp.z, W, 0, SRC_STATIC, G.p[BR_L1_W], W + R, TB, K, W);
-        gemm(tp.dhid_r, K, tp.h + (size_t)B * R, R, 0, SRC_STATIC, G.p[BR_L1_W] + W, W + R, TB, K, R);
-        col(tp.dhid_r, K, TB, K, G.p[BR_L1_B], nullptr);
+        gemm_virt(tp.dbr, tp.hid_r, P.p[BR_L2_W], tp.z, W, 0, G.p[BR_L1_W], W + R, TB, K, W);
+        gemm_virt(tp.dbr, tp.hid_r, P.p[BR_L2_W], tp.h + (size_t)B * R, R, 0, G.p[BR_L1_W] + W, W + R, TB, K, R);
+        col(tp.hid_r, K, TB, K, G.p[BR_L1_B], nullptr);
+        jt.c[nc - 1].vbeta = tp.dbr; jt.c[nc - 1].vw2 = P.p[BR_L2_W];
         gemm(tp.dbr, 1, tp.hid_r, K, 0, SRC_STATIC, G.p[BR_L2_W], K, TB, 1, K);
         col(tp.dbr, 1, TB, 1, G.p[BR_L2_B], nullptr);
         // ---- baseline_sen: input [h_x || z_r] ----
-        gemm(tp.dhid_s, K, tp.hx, H, B, SRC_STATIC, G.p[BS_L1_W], H + W, TB, K, H);
-        gemm(tp.dhid_s, K, tp.zr, W, 0, SRC_STATIC, G.p[BS_L1_W] + H, H + W, TB, K, W);
-        col(tp.dhid_s, K, TB, K, G.p[BS_L1_B], nullptr);
+        gemm_virt(tp.dbs, tp.hid_s, P.p[BS_L2_W], tp.hx, H, B, G.p[BS_L1_W], H + W, TB, K, H);
+        gemm_virt(tp.dbs, tp.hid_s, P.p[BS_L2_W], tp.zr, W, 0, G.p[BS_L1_W] + H, H + W, TB, K, W);
+        col(tp.hid_s, K, TB, K, G.p[BS_L1_B], nullptr);
+        jt.c[nc - 1].vbeta = tp.dbs; jt.c[nc - 1].vw2 = P.p[BS_L2_W];
         gemm(tp.dbs, 1, tp.hid_s, K, 0, SRC_STATIC, G.p[BS_L2_W], K, TB, 1, K);
         col(tp.dbs, 1, TB, 1, G.p[BS_L2_B], nullptr);
     }
     if (ng > MMG_MAX_GEMM || nc > MMG_MAX_COL) return fail("job table overflow");
-    jt.n_gemm = ng; jt.n_col = nc; jt.gemm_tiles = tiles; jt.gemm_blocks = (tiles + 3) / 4; jt.col_blocks = cblocks;
+    jt.n_gemm = ng; jt.n_col = nc; jt.gemm_tiles = tiles; jt.gemm_blocks = tiles; jt.col_blocks = cblocks;
+    jt.n_wblocks = tiles + cblocks;
+    if (jt.n_wblocks > MMG_MAX_WBLOCKS) return fail("too many weight-gradient tiles (%d)", jt.n_wblocks);
+    {
+        auto agent_of = [&](const float* dst) {
+            const int64_t off = dst - h->grads;
+            int a = 0;
+            for (int k = 1; k < 4; ++k) if (off >= h->pl.agent_begin[k]) a = k;
+            return (signed char)a;
+        };
+        for (int g = 0; g < ng; ++g) {
+            const int end = (g + 1 < ng) ? jt.g[g + 1].tile_begin : tiles;
+            for (int t = jt.g[g].tile_begin; t < end; ++t) jt.wblock_agent[t] = agent_of(jt.g[g].C);
+        }
+        for (int c = 0; c < nc; ++c) {
+            const int end = (c + 1 < nc) ? jt.c[c + 1].blk_begin : cblocks;
+            for (int bk = jt.c[c].blk_begin; bk < end; ++bk) jt.wblock_agent[tiles + bk] = agent_of(jt.c[c].dst);
+        }
+    }
     // ---- gradient-norm plan: MMG_GN_BLOCKS chunks, each inside one agent ----
     const ParamLayout& pl = h->pl;
     int nb[4];
@@ -182,7 +214,7 @@ static int build_jobs(mmg_handle* h) {
         }
     }
     for (; blk < MMG_GN_BLOCKS; ++blk) { jt.np.begin[blk] = jt.np.end[blk] = 0; jt.np.agent[blk] = -1; }
-    if (sizeof(JobTable) > 65536) return fail("job table does not fit its tape slot");
+    if (sizeof(JobTable) > 98304) return fail("job table does not fit its tape slot");
     return 0;
 }
 
@@ -202,7 +234,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->G = resolve_params(h->pl, d_grads);
     h->tp = resolve_tape(h->tl, d_workspace);
     h->d_jt = reinterpret_cast<JobTable*>(h->tp.tables);
-    h->profiling = false; h->timers_used = 0;
+    h->profiling = false; h->timers_used = 0; h->scores_in_parts = false;
     h->conv_smem = conv_smem_floats(h->dm) * 4;
     h->bwd_smem = bwd_smem_floats(h->dm) * 4;
     h->prep_smem = ((h->dm.V > h->dm.W ? h->dm.V : h->dm.W) + 4) * 4;
@@ -276,9 +308,12 @@ static int launch_gemm_nt(mmg_handle* h, hipStream_t st, const char* name, const
     return launch_check(name);
 }
 
-static int launch_prep(mmg_handle* h, hipStream_t st, const float* desc) {
-    Scope sc(h, st, "k_prep");
-    hipLaunchKernelGGL(k_prep, dim3(h->dm.D + 1), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc);
+// x != NULL: also computes h_x = image_layer(x) in the same launch
+static int launch_prep(mmg_handle* h, hipStream_t st, const float* desc, const float* x) {
+    Scope sc(h, st, x ? "k_prep+h_x" : "k_prep");
+    const Dims& d = h->dm;
+    const int hx_tiles = x ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0;
+    hipLaunchKernelGGL(k_prep, dim3(d.D + 1 + hx_tiles), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc, x);
     return launch_check("k_prep");
 }
 
@@ -291,9 +326,9 @@ static int launch_baselines_fused(mmg_handle* h, hipStream_t st) {
     rec.x2 = tp.h + (size_t)d.B * d.R; rec.ld2 = d.R; rec.k2 = d.R;
     rec.W1 = P.p[BR_L1_W]; rec.ldw = d.W + d.R; rec.col0 = 0; rec.b1 = P.p[BR_L1_B];
     rec.W2 = P.p[BR_L2_W]; rec.b2 = P.p[BR_L2_B]; rec.hid = tp.hid_r; rec.score = tp.br;
-    sen.rows = rows; sen.x1 = tp.zr; sen.ld1 = d.W; sen.k1 = d.W; sen.x2 = nullptr;
-    sen.addend = tp.Gs; sen.add_mod = d.B;
-    sen.W1 = P.p[BS_L1_W]; sen.ldw = d.H + d.W; sen.col0 = d.H; sen.b1 = nullptr;
+    sen.rows = rows; sen.x1 = tp.hx; sen.ld1 = d.H; sen.k1 = d.H; sen.mod1 = d.B;      // h_x is per sample, not per step
+    sen.x2 = tp.zr; sen.ld2 = d.W; sen.k2 = d.W;
+    sen.W1 = P.p[BS_L1_W]; sen.ldw = d.H + d.W; sen.col0 = 0; sen.b1 = P.p[BS_L1_B];
     sen.W2 = P.p[BS_L2_W]; sen.b2 = P.p[BS_L2_B]; sen.hid = tp.hid_s; sen.score = tp.bs;
     Scope sc(h, st, "k_baselines");
     hipLaunchKernelGGL(k_baselines, dim3((rows + 15) / 16, 2), dim3(MMG_BLOCK), 0, st, d.K, rec, sen);
@@ -307,21 +342,33 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     if (!d_x || !d_desc) return fail("x / desc must not be NULL");
     hipStream_t st = (hipStream_t)stream;
     const Dims& d = h->dm;
-    if (launch_prep(h, st, d_desc)) return -1;
-    if (launch_gemm_nt(h, st, "k_gemm_nt(h_x)", d_x, d.F, h->P.p[S_IMG_W], d.F, h->P.p[S_IMG_B], h->tp.hx, d.H, d.B, d.H, d.F)) return -1;
+    if (launch_prep(h, st, d_desc, d_x)) return -1;
     const bool bas = train && d.use_binary;
-    if (bas && launch_gemm_nt(h, st, "k_gemm_nt(bas_sen.h_x)", h->tp.hx, d.H, h->P.p[BS_L1_W], d.H + d.W, h->P.p[BS_L1_B],
-                              h->tp.Gs, d.K, d.B, d.K, d.H)) return -1;
     ConvArgs ar;
     memset(&ar, 0, sizeof(ar));
     ar.x = d_x; ar.target = d_target; ar.desc = d_desc; ar.u_z = d_u_z; ar.u_s = d_u_s; ar.u_w = d_u_w; ar.seed = seed;
     ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
     {
         Scope sc(h, st, "k_conversation");
-        hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
+        const bool fast = !getenv("MMG_NO_FAST") && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
+        if (fast)
+            hipLaunchKernelGGL((k_conversation_fast<256, 32, 64, 100, 30>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, ar);
+        else
+            hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
         if (launch_check("k_conversation")) return -1;
     }
-    if (bas && launch_baselines_fused(h, st)) return -1;
+    h->scores_in_parts = false;
+    if (bas) {
+        if (run_all_steps) {                         // exchange(): every row, scores materialised directly
+            if (launch_baselines_fused(h, st)) return -1;
+        } else {
+            Scope sc(h, st, "k_baselines");
+            hipLaunchKernelGGL(k_baselines2, dim3((d.B + 15) / 16, (d.K + 63) / 64, 2), dim3(MMG_BLOCK), 0, st,
+                               h->dm, h->P, h->tp, 1);
+            if (launch_check("k_baselines2")) return -1;
+            h->scores_in_parts = true;
+        }
+    }
     return 0;
 }
 
@@ -329,7 +376,7 @@ extern "C" int mmg_loss_stats(mmg_handle* h, void* stream) {
     if (!h) return fail("NULL handle");
     hipStream_t st = (hipStream_t)stream;
     Scope sc(h, st, "k_stats");
-    hipLaunchKernelGGL(k_stats, dim3(1), dim3(MMG_BLOCK), 0, st, h->dm, h->tp);
+    hipLaunchKernelGGL(k_stats, dim3(5 * h->dm.T + 2), dim3(64), 0, st, h->dm, h->P, h->tp, h->scores_in_parts ? 1 : 0);
     return launch_check("k_stats");
 }
 
@@ -340,7 +387,11 @@ extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_ta
     const Dims& d = h->dm;
     {
         Scope sc(h, st, "k_bwd_conv");
-        hipLaunchKernelGGL(k_bwd_conv, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
+        const bool fast = !getenv("MMG_NO_FAST") && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
+        if (fast)
+            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target);
+        else
+            hipLaunchKernelGGL(k_bwd_conv, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
         if (launch_check("k_bwd_conv")) return -1;
     }
     {
@@ -350,24 +401,26 @@ extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_ta
     }
     {
         Scope sc(h, st, "k_wgrad");
-        hipLaunchKernelGGL(k_wgrad, dim3(h->jt.gemm_blocks + h->jt.col_blocks), dim3(MMG_BLOCK), 0, st,
-                           (const JobTable*)h->d_jt, d_x, d_desc);
+        hipLaunchKernelGGL(k_wgrad, dim3(h->jt.n_wblocks), dim3(MMG_BLOCK), 0, st,
+                           (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart);
         if (launch_check("k_wgrad")) return -1;
     }
     return 0;
 }
 
-extern "C" int mmg_clip_step(mmg_handle* h, void* stream) {
-    if (!h) return fail("NULL handle");
-    hipStream_t st = (hipStream_t)stream;
-    {
+static int clip_step_impl(mmg_handle* h, hipStream_t st, bool from_wgrad) {
+    // from_wgrad: use the squared-norm partials k_wgrad left behind (valid only if d_grads has not been
+    // modified since mmg_backward, i.e. single GPU); otherwise recompute them from d_grads.
+    float* part = h->tp.gnpart + (from_wgrad ? 0 : MMG_MAX_WBLOCKS);
+    if (!from_wgrad) {
         Scope sc(h, st, "k_gradnorm");
         hipLaunchKernelGGL(k_gradnorm, dim3(MMG_GN_BLOCKS), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt,
-                           (const float*)h->grads, h->tp.gnpart, h->tp.counter);
+                           (const float*)h->grads, part, h->tp.counter);
         if (launch_check("k_gradnorm")) return -1;
     }
     OptArgs oa;
     oa.optim_type = h->cfg.optim_type; oa.only_receiver = h->cfg.use_binary ? 0 : 1; oa.lr = h->cfg.learning_rate;
+    oa.from_wgrad = from_wgrad ? 1 : 0; oa.bump_step = from_wgrad ? 1 : 0;
     for (int a = 0; a < 5; ++a) oa.agent_begin[a] = h->pl.agent_begin[a];
     oa.total = h->pl.total;
     int blocks = (int)((oa.total / 4 + MMG_BLOCK - 1) / MMG_BLOCK);
@@ -375,10 +428,15 @@ extern "C" int mmg_clip_step(mmg_handle* h, void* stream) {
     {
         Scope sc(h, st, "k_opt");
         hipLaunchKernelGGL(k_opt, dim3(blocks), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt, oa, h->params,
-                           (const float*)h->grads, h->opt_state, (const float*)h->tp.gnpart, (const uint32_t*)h->tp.counter);
+                           (const float*)h->grads, h->opt_state, (const float*)part, (const uint32_t*)h->tp.counter);
         if (launch_check("k_opt")) return -1;
     }
     return 0;
+}
+
+extern "C" int mmg_clip_step(mmg_handle* h, void* stream) {
+    if (!h) return fail("NULL handle");
+    return clip_step_impl(h, (hipStream_t)stream, false);
 }
 
 extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
@@ -388,7 +446,7 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
     if (mmg_exchange_forward(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, 0, stream)) return -1;
     if (mmg_loss_stats(h, stream)) return -1;
     if (mmg_backward(h, d_x, d_target, d_desc, stream)) return -1;
-    return mmg_clip_step(h, stream);
+    return clip_step_impl(h, (hipStream_t)stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,7 +466,8 @@ extern "C" int mmg_sender_forward(mmg_handle* h, const float* d_x, const float* 
     {
         Scope sc(h, st, "k_prep(sender)");
         Dims d1 = h->dm; d1.D = 0;
-        hipLaunchKernelGGL(k_prep, dim3(1), dim3(MMG_BLOCK), h->prep_smem, st, d1, h->P, h->tp, (const float*)nullptr);
+        hipLaunchKernelGGL(k_prep, dim3(1), dim3(MMG_BLOCK), h->prep_smem, st, d1, h->P, h->tp, (const float*)nullptr,
+                           (const float*)nullptr);
         if (launch_check("k_prep")) return -1;
     }
     if (launch_gemm_nt(h, st, "k_gemm_nt(h_x)", d_x, d.F, h->P.p[S_IMG_W], d.F, h->P.p[S_IMG_B], h->tp.hx, d.H, d.B, d.H, d.F)) return -1;
@@ -437,7 +496,7 @@ extern "C" int mmg_receiver_forward(mmg_handle* h, const float* d_z, const float
     const Dims& d = h->dm;
     const size_t offW = (size_t)t * d.B * d.W, offB = (size_t)t * d.B;
     HIP_OK(hipMemcpyAsync(h->tp.z + offW, d_z, sizeof(float) * d.B * d.W, hipMemcpyDeviceToDevice, st));
-    if (launch_prep(h, st, d_desc)) return -1;
+    if (launch_prep(h, st, d_desc, nullptr)) return -1;
     ConvArgs ar;
     memset(&ar, 0, sizeof(ar));
     ar.desc = d_desc; ar.seed = seed; ar.train = train; ar.run_all = 1;

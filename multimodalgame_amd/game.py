@@ -19,7 +19,7 @@ class FlatOptimizer(object):
 
     def state_dict(self):
         eng, kind = self.game.engine, self.game.cfg["optim_type"]
-        step = int(eng.tape["counter"][1].item())
+        step = int(eng.tape["counter"][1:3].max().item())
         n = eng.n_params
         state = {}
         for i, (name, view) in enumerate(self._params()):
@@ -56,7 +56,7 @@ class FlatOptimizer(object):
                 eng.opt_state[off:off + view.numel()].copy_(st["exp_avg"].reshape(-1).to(eng.device))
                 eng.opt_state[n + off:n + off + view.numel()].copy_(st["exp_avg_sq"].reshape(-1).to(eng.device))
         if step:
-            eng.tape["counter"][1] = step
+            eng.tape["counter"][1:3] = step
 
 
 class Game(object):
