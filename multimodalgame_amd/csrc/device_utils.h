@@ -12,6 +12,40 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- DPP cross-lane adds: a VALU operand modifier, no LDS round trip (ds_bpermute costs ~60+ cycles
+// on a dependent chain).  quad_perm swaps inside quads, row_half_mirror / row_mirror fold 8 / 16 lanes.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+#define MMG_DPP_QUAD_1032 0xB1
+#define MMG_DPP_QUAD_2301 0x4E
+#define MMG_DPP_ROW_HALF_MIRROR 0x141
+#define MMG_DPP_ROW_MIRROR 0x140
+
+// sum over aligned groups of N lanes (N = 2, 4, 8, 16): every lane of the group gets the total
+template <int N>
+__device__ __forceinline__ float dpp_group_sum(float v) {
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16, "DPP group sums cover up to one row of 16 lanes");
+    if (N >= 2) v += dpp_f<MMG_DPP_QUAD_1032>(v);
+    if (N >= 4) v += dpp_f<MMG_DPP_QUAD_2301>(v);
+    if (N >= 8) v += dpp_f<MMG_DPP_ROW_HALF_MIRROR>(v);
+    if (N >= 16) v += dpp_f<MMG_DPP_ROW_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float dpp_wave_sum(float v) {            // all 64 lanes get the total
+    v = dpp_group_sum<16>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float dpp_wave_max(float v) {
+    v = fmaxf(v, dpp_f<MMG_DPP_QUAD_1032>(v)); v = fmaxf(v, dpp_f<MMG_DPP_QUAD_2301>(v));
+    v = fmaxf(v, dpp_f<MMG_DPP_ROW_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f<MMG_DPP_ROW_MIRROR>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
 // wave-level sum over aligned groups of G lanes (G power of two, <= 64)
 __device__ __forceinline__ float group_sum(float v, int G) {
     for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -51,11 +51,7 @@ __device__ __forceinline__ float dot4(const float* __restrict__ w, const float* 
 }
 
 template <int N>
-__device__ __forceinline__ float lane_group_sum(float v) {
-#pragma unroll
-    for (int off = N >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float lane_group_sum(float v) { return dpp_group_sum<N>(v); }
 
 template <int H, int W, int R, int V, int D>
 __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P, Tape tp, ConvArgs ar) {
@@ -260,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
         if (binary && tid >= 192 && tid < 192 + 64) {                      // wave 3 is idle here: reduce the sender's log-lik terms
             const int l = tid - 192;
             float lpv = (l < W) ? s_lp[l] : 0.f, nev = (l < W) ? s_ne[l] : 0.f;
-            lpv = wave_sum(lpv); nev = wave_sum(nev);
+            lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
             if (l == 0) { tp.lp_z[row] = lpv; tp.ne_z[row] = nev; }
         }
         __syncthreads();                                                   // B3: gates ready
@@ -288,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
             gpre_h = accH + bh;
         }
         if (tid < 64) {                                                    // stop head on wave 0
-            float sv = wave_sum(ws * s_h[lane]);
+            float sv = dpp_wave_sum(ws * s_h[lane]);
             if (lane == 0) {
                 const float p = fsigmoid(sv + bs);
                 float sbit;
@@ -342,9 +338,9 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
         // ===== (7) softmax (every wave redoes it on lanes d < D) and the description mixture
         {
             const float yv = (lane < 32) ? s_y[lane] : -3.0e38f;
-            const float mx = wave_max(yv);
+            const float mx = dpp_wave_max(yv);
             const float e = (lane < D) ? __expf(yv - mx) : 0.f;
-            const float inv = 1.f / wave_sum(e);
+            const float inv = 1.f / dpp_wave_sum(e);
             float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
             for (int d = 0; d + 3 < D; d += 4) {
@@ -403,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
         __syncthreads();                                                   // B9: w ready
         if (binary && tid < 64) {
             float lpv = (lane < W) ? s_lpw[lane] : 0.f, nev = (lane < W) ? s_new[lane] : 0.f;
-            lpv = wave_sum(lpv); nev = wave_sum(nev);
+            lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
             if (lane == 0) { tp.lp_w[row] = lpv; tp.ne_w[row] = nev; }
         }
     }
@@ -412,9 +408,9 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
     const int tstar = dm.fixed ? (T - 1) : (int)s_misc[1];
     if (tid < 64) {
         const float o = (lane < 32) ? s_yout[lane] : -3.0e38f;
-        const float mx = wave_max(o);
+        const float mx = dpp_wave_max(o);
         const float e = (lane < D) ? __expf(o - mx) : 0.f;
-        const float lse = mx + flog(wave_sum(e));
+        const float lse = mx + flog(dpp_wave_sum(e));
         const int tgt = ar.target ? (int)ar.target[b] : -1;
         const float dt = (tgt >= 0) ? (__shfl(o, tgt, 64) - lse) : 0.f;
         const float ld = o - lse;
@@ -423,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
             tp.dist[(size_t)b * D + lane] = ld;
             tp.sm[(size_t)b * D + lane] = __expf(ld);
         }
-        const float above = wave_sum((lane < D && tgt >= 0 && ld > dt) ? 1.f : 0.f);
+        const float above = dpp_wave_sum((lane < D && tgt >= 0 && ld > dt) ? 1.f : 0.f);
         if (lane == 0) {
             tp.tstar[b] = tstar;
             tp.logs[b] = dt;
@@ -546,7 +542,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             if (tid < 64) {
                 if (lane < D) tp.dy[(size_t)b * D + lane] = dy_mine;
                 if (lane < 32) s_dy[lane] = dy_mine;
-                const float dsum = wave_sum(dy_mine);
+                const float dsum = dpp_wave_sum(dy_mine);
                 if (lane == 0) tp.dysum[b] = dsum;
             } else if (tid < 64 + R) {
                 tp.hstar[(size_t)b * R + tid - 64] = t_h[(t + 1) * R + tid - 64];

