@@ -1,0 +1,214 @@
+"""`python -m multimodalgame_amd.model <reference flags>` -- the reference's entry point
+(model.py:1813-1820) on the MI355X path: same flags / presets / derived file names, same log-line
+templates (model.py:1348-1377, 1561-1584), same checkpoint dict (misc.py:58-75), same epoch / batch
+order (misc.py:257-302).  The per-minibatch block is ONE fused call (Game.train_step); scalars are read
+back only when a log line needs them."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import flags as _flags
+from .agents import Baseline, Receiver, Sender
+from .flags import FLAGS
+from .game import Game, exchange, get_rec_outp
+from .misc import (FileLogger, VisdomLogger, cbow, embed, load_hdf5, read_data, torch_load, torch_save,
+                   write_synthetic_dataset)
+from .sparks import sparks
+
+
+def _desc_matrix(csv_path, glove_path, wv_dim):
+    """model.py:1072-1104."""
+    descr, word_dict, _, label_id_to_idx, _ = read_data(csv_path)
+    word_dict = embed(word_dict, glove_path)
+    descr = cbow(descr, word_dict)
+    desc = torch.cat([descr[i]["cbow"].view(1, -1) for i in descr.keys()], 0)
+    return desc, (lambda x: label_id_to_idx.get(x))
+
+
+def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels, conf_mat_path, device):
+    """model.py:580-722: deterministic conversations on the dev set, top-k accuracy (nominal batch size in
+    the denominator, line 667), confusion matrix, conversation length and Hamming statistics."""
+    m = game.modules
+    conversation_lengths, hamming_sen, hamming_rec, true_labels, pred_labels = [], [], [], [], []
+    total, correct = 0.0, 0
+    for batch in load_hdf5(dev_file, batch_size, epoch, shuffle, truncate_final_batch=True, map_labels=map_labels,
+                           feats=(FLAGS.img_feat,), device=device):
+        target, data = batch["target"], batch[FLAGS.img_feat]
+        _bs = target.size(0)
+        args = dict(data=data, target=target, desc=desc, train=False, break_early=not FLAGS.fixed_exchange)
+        s, sen_w, rec_w, y, _, _ = exchange(m["sender"], m["receiver"], None, None, args)
+        s_masks, s_feats, _ = s
+        y_masks = None if FLAGS.fixed_exchange else [torch.min(1 - m1, m2) for m1, m2 in zip(s_masks[1:], s_masks[:-1])]
+        outp, _ = get_rec_outp(y, y_masks)
+        dist = F.log_softmax(outp, dim=1)
+        top_k_ind = torch.from_numpy(dist.cpu().numpy().argsort()[:, -top_k:]).long()          # model.py:658
+        pred_labels.append(dist.argmax(1).cpu().numpy())
+        true_labels.append(target.cpu().numpy().reshape(-1))
+        total += float(batch_size)                                                             # model.py:667
+        correct += int((top_k_ind == target.cpu().view(-1, 1).expand(_bs, top_k)).sum())
+        conversation_lengths += torch.cat(s_feats, 1).float().sum(1).view(-1).tolist()
+        for feats, acc in ((sen_w[0], hamming_sen), (rec_w[0], hamming_rec)):
+            prev, h = torch.zeros(_bs, FLAGS.rec_w_dim, device=device), 0.0
+            for msg in feats:
+                h += float((msg - prev).abs().sum(1).mean())
+                prev = msg
+            acc.append(h / float(len(feats)))
+    true_labels, pred_labels = np.concatenate(true_labels), np.concatenate(pred_labels)
+    n_cls = int(max(true_labels.max(), pred_labels.max())) + 1
+    conf = np.zeros((n_cls, n_cls), np.int64)
+    np.add.at(conf, (true_labels, pred_labels), 1)                      # sklearn.confusion_matrix (model.py:709)
+    np.savetxt(conf_mat_path, conf, delimiter=",", fmt="%d")
+    cl = np.array(conversation_lengths)
+    extra = dict(conversation_lengths_mean=cl.mean(), conversation_lengths_std=cl.std(),
+                 hamming_sen_mean=np.array(hamming_sen).mean(), hamming_rec_mean=np.array(hamming_rec).mean())
+    return correct / total, extra
+
+
+def run():
+    os.makedirs(FLAGS.log_path, exist_ok=True)
+    flogger = FileLogger(FLAGS.log_file)
+    VisdomLogger(env=FLAGS.env, experiment_name=FLAGS.experiment_name, enabled=FLAGS.visdom)
+    flogger.Log("Flag Values:\n" + json.dumps(FLAGS.FlagValuesDict(), indent=4, sort_keys=True))
+    if not os.path.exists(FLAGS.json_file):
+        with open(FLAGS.json_file, "w") as f:
+            f.write(json.dumps(FLAGS.FlagValuesDict(), indent=4, sort_keys=True))
+    if not torch.cuda.is_available():
+        raise RuntimeError("multimodalgame_amd runs on MI355X only: no GPU visible and there is no CPU fallback")
+    device = torch.device("cuda", 0)
+    torch.manual_seed(FLAGS.seed)
+
+    sender = Sender(feature_type=FLAGS.img_feat, feat_dim=FLAGS.img_feat_dim, h_dim=FLAGS.img_h_dim,
+                    w_dim=FLAGS.rec_w_dim, bin_dim_out=FLAGS.sender_out_dim, use_binary=FLAGS.use_binary,
+                    use_attn=FLAGS.visual_attn, attn_dim=FLAGS.attn_dim, attn_extra_context=FLAGS.attn_extra_context,
+                    attn_context_dim=FLAGS.attn_context_dim)
+    baseline_sen = Baseline(hid_dim=FLAGS.baseline_hid_dim, x_dim=FLAGS.img_h_dim, binary_dim=FLAGS.rec_w_dim, inp_dim=0)
+    receiver = Receiver(hid_dim=FLAGS.rec_hidden, out_dim=FLAGS.rec_out_dim, z_dim=FLAGS.sender_out_dim,
+                        desc_dim=FLAGS.wv_dim, w_dim=FLAGS.rec_w_dim, s_dim=FLAGS.rec_s_dim, use_binary=FLAGS.use_binary)
+    baseline_rec = Baseline(hid_dim=FLAGS.baseline_hid_dim, x_dim=0, binary_dim=FLAGS.rec_w_dim, inp_dim=FLAGS.rec_hidden)
+    for mod in (sender, baseline_sen, receiver, baseline_rec):
+        flogger.Log("Architecture: {}".format(mod))
+        flogger.Log("Total Parameters: {}".format(float(sum(p.numel() for p in mod.parameters()))))
+
+    if FLAGS.wv_type != "glove.6B":
+        raise NotImplementedError                                          # model.py:1108 (fake/none are broken upstream)
+    desc_train, map_labels_train = _desc_matrix(FLAGS.descr_train, FLAGS.glove_path, FLAGS.wv_dim)
+    desc_dev, map_labels_dev = _desc_matrix(FLAGS.descr_dev, FLAGS.glove_path, FLAGS.wv_dim)
+    desc_train, desc_dev = desc_train.to(device), desc_dev.to(device)
+
+    game = Game(sender, receiver, baseline_sen, baseline_rec, device=device, seed=FLAGS.seed)
+    game.engine_for(FLAGS.batch_size, desc_train.size(0))                # parameters move into the flat GPU buffer
+    models_dict, optimizers_dict = game.models_dict(), game.optimizers_dict()
+
+    epoch, step, best_dev_acc = 0, 0, 0
+    if os.path.exists(FLAGS.checkpoint):                                   # model.py:1150-1156
+        flogger.Log("Loading from: " + FLAGS.checkpoint)
+        data = torch_load(FLAGS.checkpoint, models_dict, optimizers_dict)
+        flogger.Log("Loaded at step: {} and best dev acc: {}".format(data["step"], data["best_dev_acc"]))
+        step, best_dev_acc = data["step"], data["best_dev_acc"]
+
+    def do_eval():
+        return eval_dev(FLAGS.dev_file, FLAGS.batch_size_dev, epoch, FLAGS.shuffle_dev, FLAGS.top_k_dev, game, desc_dev,
+                        map_labels_dev, FLAGS.conf_mat, device)
+
+    if FLAGS.eval_only:                                                    # model.py:1166-1180
+        if not os.path.exists(FLAGS.checkpoint):
+            raise Exception("Must provide valid checkpoint.")
+        dev_acc, extra = do_eval()
+        flogger.Log("Dev Accuracy: " + str(dev_acc))
+        with open(FLAGS.eval_csv_file, "w") as f:
+            f.write("checkpoint,eval_file,topk,step,best_dev_acc,eval_acc,convlen_mean,convlen_std\n")
+            f.write("{},{},{},{},{},{},{},{}\n".format(FLAGS.checkpoint, FLAGS.dev_file, FLAGS.top_k_dev, step,
+                                                       best_dev_acc, dev_acc, extra["conversation_lengths_mean"],
+                                                       extra["conversation_lengths_std"]))
+        return
+    if FLAGS.binary_only:
+        raise NotImplementedError("-binary_only (message dump, binary_vectors.py) is a 'next' row (SURVEY.md §8 f4)")
+
+    hits_ring = torch.zeros(max(FLAGS.log_interval, 1), device=device)
+    while epoch < FLAGS.max_epoch:
+        flogger.Log("Starting epoch: {}".format(epoch))
+        if FLAGS.images != "mammal":
+            raise NotImplementedError                                      # model.py:1211 (cifar branch is broken upstream)
+        for i_batch, batch in enumerate(load_hdf5(FLAGS.train_file, FLAGS.batch_size, epoch, FLAGS.shuffle_train,
+                                                  map_labels=map_labels_train, feats=(FLAGS.img_feat,), device=device)):
+            eng = game.train_step(batch[FLAGS.img_feat], batch["target"], desc_train)     # model.py:1240-1339
+            hits_ring[step % hits_ring.numel()] = eng.tape["losses"][7]
+            if step % FLAGS.log_interval == 0:                             # model.py:1342-1377
+                L = eng.losses()
+                n_seen = min(step + 1, hits_ring.numel())
+                avg_batch_acc = float(hits_ring[:n_seen].sum()) / float(FLAGS.batch_size) / n_seen
+                pre = "Epoch: {} Step: {} Batch: {} ".format(epoch, step, i_batch)
+                flogger.Log(pre + "Training Accuracy: {}".format(avg_batch_acc))
+                flogger.Log(pre + "Loss Sender: {}".format(L["loss_binary_sen"]))
+                flogger.Log(pre + "Loss Receiver (Y): {}".format(L["nll_loss"]))
+                if FLAGS.use_binary:
+                    flogger.Log(pre + "Loss Receiver (Z): {}".format(L["loss_binary_rec"]))
+                    if not FLAGS.fixed_exchange:
+                        flogger.Log(pre + "Loss Receiver (S): {}".format(L["loss_binary_s"]))
+                    flogger.Log(pre + "Loss Baseline (S): {}".format(L["loss_bas_sen"]))
+                    flogger.Log(pre + "Loss Baseline (R): {}".format(L["loss_bas_rec"]))
+                if FLAGS.exchange_samples > 0:                             # model.py:1411-1461 (train sample dump)
+                    flogger.Log(_sample_dump(eng, "Train:"))
+            if step % FLAGS.log_dev == 0:                                  # model.py:1545-1576
+                dev_acc, extra = do_eval()
+                pre = "Epoch: {} Step: {} Batch: {} ".format(epoch, step, i_batch)
+                flogger.Log(pre + "Development Accuracy: {}".format(dev_acc))
+                flogger.Log(pre + "Conversation Length (avg/std): {}/{}".format(
+                    extra["conversation_lengths_mean"], extra["conversation_lengths_std"]))
+                flogger.Log(pre + "Mean Hamming Distance (R/S): {}/{}".format(extra["hamming_rec_mean"], extra["hamming_sen_mean"]))
+                if step >= FLAGS.save_after and dev_acc > best_dev_acc:
+                    best_dev_acc = dev_acc
+                    flogger.Log("Checkpointing with best Development Accuracy: {}".format(best_dev_acc))
+                    torch_save(FLAGS.checkpoint + "_best", dict(step=step, best_dev_acc=best_dev_acc), models_dict, optimizers_dict)
+            if step >= FLAGS.save_after and step % FLAGS.save_interval == 0:   # model.py:1579-1584
+                flogger.Log("Checkpointing.")
+                torch_save(FLAGS.checkpoint, dict(step=step, best_dev_acc=best_dev_acc), models_dict, optimizers_dict)
+            step += 1
+            if FLAGS.max_steps and step >= FLAGS.max_steps:
+                flogger.Log("Finished training.")
+                return
+        epoch += 1
+    flogger.Log("Finished training.")
+
+
+def _sample_dump(eng, title):
+    """model.py:1415-1461: sparkline of the probabilities and the sampled bits of the first samples."""
+    tp = eng.tape
+    n = int(tp["losses"][6].item())
+    W = FLAGS.rec_w_dim
+    out = title
+    for i in range(min(FLAGS.exchange_samples, eng.cfg.batch)):
+        prev_sen, prev_rec = torch.zeros(W), torch.zeros(W)
+        ts = int(tp["tstar"][i].item())
+        for t in range(min(n, ts + 1)):
+            sp, rp, stp = tp["pz"][t, i].tolist(), tp["pw"][t, i].tolist(), tp["ps"][t, i].tolist()
+            sb, rb = tp["z"][t, i].cpu(), tp["w"][t, i].cpu()
+            sh, rh = float((prev_sen - sb).abs().sum()), float((prev_rec - rb).abs().sum())
+            prev_sen, prev_rec = sb, rb
+            out += ("\n{:>3}".format(i) if t == 0 else "\n   ")
+            out += "        {}".format(sparks([1] + sp)[1:]) + "           {}    {}".format(sparks([1] + stp)[1:], sparks([1] + rp)[1:])
+            out += "\n    {:>3} S: {} {:4}".format(t, "".join(str(int(v)) for v in sb.tolist()), sh)
+            out += "    s={} R: {} {:4}".format(int(tp["mask"][t + 1, i, 0].item()), "".join(str(int(v)) for v in rb.tolist()), rh)
+    return out + "\n"
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    _flags.define_flags()
+    FLAGS(argv)
+    if FLAGS.synthetic_data:
+        n_cls = 30
+        paths = write_synthetic_dataset(FLAGS.synthetic_data, n_classes=n_cls, feat_dim=512, wv_dim=FLAGS.wv_dim)
+        for k, v in paths.items():
+            if not any(a.lstrip("-").split("=")[0] == k for a in argv[1:]):
+                setattr(FLAGS, k, v)
+    _flags.default_flags(argv)
+    run()
+
+
+if __name__ == "__main__":
+    main()

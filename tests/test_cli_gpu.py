@@ -1,0 +1,46 @@
+"""End-to-end run of the reference's command line on the GPU path: synthetic HDF5 / descriptions / GloVe
+files in the reference's formats, a few optimizer steps, log lines, checkpoint save -> resume -> -eval_only."""
+import os
+import re
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _argv(tmp, name, extra=()):
+    return ["model.py", "-experiment_name", name, "-model_type", "Adaptive", "-max_exchange", "10", "-batch_size", "64",
+            "-rec_w_dim", "32", "-sender_out_dim", "32", "-img_h_dim", "256", "-rec_hidden", "64", "-learning_rate", "1e-4",
+            "-entropy_rec", "0.01", "-entropy_sen", "0.01", "-entropy_s", "0.08", "-use_binary", "-max_epoch", "1",
+            "-top_k_dev", "6", "-top_k_train", "6", "-wv_dim", "100", "-log_path", os.path.join(tmp, "logs"),
+            "-synthetic_data", os.path.join(tmp, "data"), "-log_interval", "5", "-log_dev", "10", "-save_after", "10",
+            "-save_interval", "10", "-exchange_samples", "2"] + list(extra)
+
+
+def test_train_checkpoint_resume_eval(tmp_path):
+    from multimodalgame_amd import model, flags
+    tmp = str(tmp_path)
+    flags.define_flags(); flags.FLAGS.Reset()
+    model.main(_argv(tmp, "demo", ["-max_steps", "21"]))
+    log = open(os.path.join(tmp, "logs", "demo.log")).read()
+    for pat in (r"\[1\] Starting epoch: 0", r"Epoch: 0 Step: 20 Batch: 20 Training Accuracy: ", r"Loss Receiver \(S\): ",
+                r"Loss Baseline \(R\): ", r"Development Accuracy: ", r"Conversation Length \(avg/std\): ", r"Checkpointing\.",
+                r"Train:\n"):
+        assert re.search(pat, log), pat
+    ck = torch.load(os.path.join(tmp, "logs", "demo.pt"), weights_only=False)
+    assert set(ck.keys()) == {"data", "optimizers", "models"}                     # misc.py:65-69
+    assert set(ck["models"].keys()) == {"receiver", "sender", "baseline_rec", "baseline_sen"}
+    assert set(ck["optimizers"].keys()) == {"optimizer_rec", "optimizer_sen", "optimizer_bas_rec", "optimizer_bas_sen"}
+    assert ck["data"]["step"] == 20 and "rnn.weight_ih" in ck["models"]["receiver"]
+    assert "square_avg" in ck["optimizers"]["optimizer_rec"]["state"][0]
+    assert os.path.exists(os.path.join(tmp, "logs", "demo.json")) and os.path.exists(os.path.join(tmp, "logs", "demo.conf_mat.txt"))
+    # resume + eval_only through -log_load (README.md:57-68 workflow)
+    flags.FLAGS.Reset()
+    model.main(["model.py", "-log_load", os.path.join(tmp, "logs", "demo.json"), "-eval_only", "-experiment_name", "demo-eval",
+                "-checkpoint", os.path.join(tmp, "logs", "demo.pt"), "-log_path", os.path.join(tmp, "logs")])
+    # -log_load restores every flag of the training run, derived file names included (model.py:1745-1750)
+    csv = open(os.path.join(tmp, "logs", "demo.eval.csv")).read().splitlines()
+    assert csv[0] == "checkpoint,eval_file,topk,step,best_dev_acc,eval_acc,convlen_mean,convlen_std"
+    assert csv[1].split(",")[3] == "20"
+    flags.FLAGS.Reset()

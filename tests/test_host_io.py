@@ -1,0 +1,69 @@
+"""Host-side pieces around the path ("next" rows of SURVEY.md §8f): HDF5 schema round trip through the
+ctypes->libhdf5 binding, the reference's batch-order semantics, description pipeline, logger format."""
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from multimodalgame_amd import hdf5io, misc
+
+
+def test_hdf5_roundtrip_reference_schema(tmp_path):
+    p = str(tmp_path / "f.hdf5")
+    feats = np.abs(np.random.RandomState(0).standard_normal((10, 1, 8))).astype(np.float32)
+    tgt = np.arange(10, dtype=np.int32)[::-1].copy()
+    loc = np.array([("img%d.jpg" % i).encode() for i in range(10)], dtype="S50")
+    with hdf5io.File(p, "w") as f:
+        f.write("avgpool_512", feats); f.write("Target", tgt); f.write("Location", loc)
+    with hdf5io.File(p, "r") as f:
+        assert "Target" in f and "nope" not in f
+        assert f.shape("avgpool_512") == (10, 1, 8)
+        np.testing.assert_array_equal(f.read("avgpool_512"), feats)
+        np.testing.assert_array_equal(f.read("Target"), tgt)
+        np.testing.assert_array_equal(f.read("Location"), loc)
+    with pytest.raises(hdf5io.Hdf5Error):
+        hdf5io.File(str(tmp_path / "missing.hdf5"), "r")
+
+
+def test_load_hdf5_order_semantics(tmp_path):
+    paths = misc.write_synthetic_dataset(str(tmp_path), n_classes=3, per_class=7, feat_dim=4, wv_dim=5)
+    batches = list(misc.load_hdf5(paths["train_file"], 4, 2, True))
+    assert len(batches) == 21 // 4                                           # drop-last (misc.py:274)
+    order = list(range(21)); random.seed(11 + 2); random.shuffle(order)      # misc.py:270-271
+    with hdf5io.File(paths["train_file"]) as f:
+        tgt, x = f.read("Target"), f.read("avgpool_512")
+    for i, b in enumerate(batches):
+        idx = sorted(order[i * 4:(i + 1) * 4])                               # misc.py:282
+        np.testing.assert_array_equal(b["target"].numpy(), tgt[idx])
+        np.testing.assert_array_equal(b["avgpool_512"].numpy(), x[idx, 0])   # squeezed (misc.py:296)
+    assert len(list(misc.load_hdf5(paths["dev_file"], 4, 0, False, truncate_final_batch=True))) == 6
+    assert list(misc.load_hdf5(paths["dev_file"], 4, 0, False, truncate_final_batch=True))[-1]["target"].shape[0] == 1
+
+
+def test_description_pipeline(tmp_path):
+    csv = tmp_path / "d.csv"
+    csv.write_text("7,agama,small terrestrial lizard of warm regions, of the Old World\n3,drake,adult male of a wild duck\n")
+    glove = tmp_path / "g.txt"
+    glove.write_text("small 1 0\nlizard 0 1\nduck 2 2\nmale 0 4\n")
+    descr, word_dict, dict_size, id2idx, idx2label = misc.read_data(str(csv))
+    assert id2idx == {7: 0, 3: 1} and idx2label == {0: "agama", 1: "drake"}
+    assert "of" not in descr[0]["desc"] and "lizard" in descr[0]["desc"] and "," not in descr[0]["desc"]
+    word_dict = misc.embed(word_dict, str(glove))
+    descr = misc.cbow(descr, word_dict)
+    np.testing.assert_allclose(descr[0]["cbow"].numpy(), [0.5, 0.5])         # mean over FOUND words only (misc.py:336)
+    np.testing.assert_allclose(descr[1]["cbow"].numpy(), [1.0, 3.0])
+
+
+def test_file_logger_format(tmp_path, capsys):
+    p = tmp_path / "x.log"
+    lg = misc.FileLogger(str(p))
+    lg.Log("Starting epoch: 0")
+    assert capsys.readouterr().err == "[1] Starting epoch: 0\n"              # misc.py:177
+    assert re.match(r"^\d\d-\d\d-\d\d \d\d:\d\d:\d\d \[1\] Starting epoch: 0\n$", p.read_text())   # misc.py:183
+
+
+def test_build_mask():
+    m = misc.build_mask("0:3,5", 8)
+    assert m.view(-1).tolist() == [1, 1, 1, 0, 0, 1, 0, 0]
