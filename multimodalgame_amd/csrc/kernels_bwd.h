@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64) void k_stats(Dims dm, Params P, Tape tp, int fr
 // ---------------------------------------------------------------------------------------------
 struct LossCoef { float* cw; float* ce; float* cb; };   // LDS: cw[3*T], ce[3*T], cb[T]
 
-__device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* st, LossCoef lc, float* losses_out) {
+__device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* st, LossCoef lc, float* losses_out,
+                                                  double* totals = nullptr) {
     // one thread per (stream, step): threads [0,3T) -> cw/ce, [3T,4T) -> cb; block-level sums for the
     // logged losses go through LDS (lc.cw/ce/cb double as staging for the partial losses afterwards)
     const int T = dm.T, tid = threadIdx.x;
@@ -157,6 +158,7 @@ __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* 
         losses_out[5] = (float)acc[4];                                   // loss_bas_sen
         losses_out[6] = (float)nsteps;                                   // exchange steps the reference executes
         losses_out[7] = (float)st[stat_glob(T, 1)];                      // top-k hits
+        if (totals) { totals[0] += (double)nsteps; totals[1] += st[stat_glob(T, 1)]; totals[2] += 1.0; }
     }
     __syncthreads();
 }
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
     float* s_red = p; p += MMG_BLOCK;
     float* s_misc = p;
 
-    loss_coefficients(dm, tp.stats, lc, b == 0 ? tp.losses : nullptr);
+    loss_coefficients(dm, tp.stats, lc, b == 0 ? tp.losses : nullptr, b == 0 ? tp.totals : nullptr);
 
     const bool binary = dm.use_binary != 0;
     const int tstar = tp.tstar[b];
@@ -391,6 +393,7 @@ struct JobTable {
     GemmJob g[MMG_MAX_GEMM];
     ColJob c[MMG_MAX_COL];
     NormPlan np;
+    int g_begin[64], c_begin[64];               // compact copies of tile_begin / blk_begin (lane-parallel lookup), INT_MAX padded
     int n_wblocks;                              // blocks of k_wgrad (= entries of its part[] output)
     signed char wblock_agent[MMG_MAX_WBLOCKS];  // agent whose gradient block i of k_wgrad writes
 };
@@ -420,15 +423,14 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     constexpr int CH = 64;
     __shared__ float s_a[2][CH][17];
     __shared__ float s_b[2][CH][17];
-    __shared__ float s_acc[4][16][17];
-    __shared__ float s_part[MMG_BLOCK];
+    float (*s_acc)[16][17] = reinterpret_cast<float (*)[16][17]>(&s_a[0][0][0]);   // reused after the row loop
+    float* s_part = &s_b[0][0][0];                                                   // column-sum staging
     __shared__ float s_red[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((int)blockIdx.x < jt->gemm_tiles) {
         const int tile = blockIdx.x;
-        int j = 0;
-        const int ng = jt->n_gemm;
-        while (j + 1 < ng && jt->g[j + 1].tile_begin <= tile) ++j;
+        // job lookup: lane l compares the l-th job's first tile, one ballot (no serial scalar loads)
+        const int j = __popcll(__ballot(jt->g_begin[lane] <= tile)) - 1;
         const GemmJob& G = jt->g[j];
         const int lt = tile - G.tile_begin;
         const int tn = lt / G.tiles_k, tk = lt - tn * G.tiles_k;
@@ -445,9 +447,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         float4 vw = make_float4(0.f, 0.f, 0.f, 0.f);
         if (virt) vw = load4_guard(G.vw2, 0, n0 + lc, N, true, false);
         const int nchunks = (rows + CH - 1) / CH;
-        float4 ra, rb;
-        float beta = 0.f;
-        auto fetch = [&](int c) {
+        // two register sets: chunk c is staged while c+1 and c+2 are in flight (prefetch depth 2)
+        float4 ra0, rb0, ra1, rb1;
+        float beta0 = 0.f, beta1 = 0.f;
+        auto fetch = [&](int c, float4& ra, float4& rb, float& beta) {
             const int r = c * CH + lr;
             const bool rv = r < rows;
             ra = load4_guard(Abase, (size_t)(rv ? r : 0) * lda, n0 + lc, N, rv, veca);
@@ -455,10 +458,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             rb = load4_guard(Bbase, (size_t)(rv ? rbm : 0) * ldb, k0 + lc, K, rv, vecb);
             if (virt) beta = rv ? G.A[r] : 0.f;
         };
-        fetch(0);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < nchunks; ++c) {
-            const int buf = c & 1;
+        auto stage_and_multiply = [&](int c, int buf, float4& ra, float4& rb, float& beta) {
             if (virt) {
                 ra.x = ra.x > 0.f ? beta * vw.x : 0.f; ra.y = ra.y > 0.f ? beta * vw.y : 0.f;
                 ra.z = ra.z > 0.f ? beta * vw.z : 0.f; ra.w = ra.w > 0.f ? beta * vw.w : 0.f;
@@ -466,13 +467,20 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             s_a[buf][lr][lc] = ra.x; s_a[buf][lr][lc + 1] = ra.y; s_a[buf][lr][lc + 2] = ra.z; s_a[buf][lr][lc + 3] = ra.w;
             s_b[buf][lr][lc] = rb.x; s_b[buf][lr][lc + 1] = rb.y; s_b[buf][lr][lc + 2] = rb.z; s_b[buf][lr][lc + 3] = rb.w;
             __syncthreads();
-            if (c + 1 < nchunks) fetch(c + 1);
+            if (c + 2 < nchunks) fetch(c + 2, ra, rb, beta);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = wave * 16 + u * 4 + q;
                 acc = mfma16(s_a[buf][r][i], s_b[buf][r][i], acc);
             }
+        };
+        fetch(0, ra0, rb0, beta0);
+        if (nchunks > 1) fetch(1, ra1, rb1, beta1);
+        for (int c = 0; c < nchunks; c += 2) {
+            stage_and_multiply(c, 0, ra0, rb0, beta0);
+            if (c + 1 < nchunks) stage_and_multiply(c + 1, 1, ra1, rb1, beta1);
         }
+        __syncthreads();                                   // every wave is done reading the staging buffers
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = acc[r];
         __syncthreads();
@@ -489,9 +497,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     }
     // ---- column sums: 16 columns x 16 row groups per block, 4 independent loads in flight per thread
     const int cb = blockIdx.x - jt->gemm_tiles;
-    int j = 0;
-    const int nc = jt->n_col;
-    while (j + 1 < nc && jt->c[j + 1].blk_begin <= cb) ++j;
+    const int j = __popcll(__ballot(jt->c_begin[lane] <= cb)) - 1;
     const ColJob& C = jt->c[j];
     const int c0 = (cb - C.blk_begin) * 16;
     const int cc = threadIdx.x & 15, g = threadIdx.x >> 4;

@@ -79,6 +79,11 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
     const int B = dm.B, T = dm.T;
     const bool binary = dm.use_binary != 0, train = ar.train != 0;
     const bool inject = ar.u_s != nullptr;
+    const uint32_t mb_counter = tp.counter[0];
+    const uint32_t gb = (uint32_t)(dm.boff + b);
+#ifdef MMG_TIMING
+    if (b == 0 && tid == 0) tp.dbg[0] = (long long)wall_clock64();
+#endif
     if (train && inject) {
         for (int i = tid; i < T * W; i += NT) {
             const int t = i / W, j = i - t * W;
@@ -86,6 +91,16 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
             if (ar.u_w) s_uw[i] = ar.u_w[((size_t)t * B + b) * W + j];
         }
         if (tid < T) s_us[tid] = ar.u_s[(size_t)tid * B + b];
+    } else if (train) {
+        // the draws do not depend on the conversation: generate all of them up front, in parallel, instead of
+        // running a serial 10-round Philox chain on one lane per bit inside every sampling phase
+        for (int i = tid; i < T * W; i += NT) {
+            const int t = i / W, j = i - t * W;
+            const uint32_t e = (uint32_t)((t * dm.Bg + gb) * W + j);
+            s_uz[i] = philox_uniform(ar.seed, e, mb_counter, 0u);
+            s_uw[i] = philox_uniform(ar.seed, e, mb_counter, 2u);
+        }
+        if (tid < T) s_us[tid] = philox_uniform(ar.seed, (uint32_t)(tid * dm.Bg + gb), mb_counter, 1u);
     }
 
     // ------------------------------------------------------------ weights -> registers (once)
@@ -192,16 +207,22 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
     const float bw = P.p[R_W_B][nb];
     const float sig_cb = (tid < W) ? fsigmoid(P.p[S_CODE_BIAS][tid]) : 0.f;
 
+#ifdef MMG_TIMING
+#define MMG_STAMP(slot) do { if (b == 0 && tid == 0) tp.dbg[(slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define MMG_STAMP(slot) do {} while (0)
+#endif
+    MMG_STAMP(1);
     // ------------------------------------------------------------ conversation state
     if (tid < R) { s_h[tid] = 0.f; tp.h[(size_t)b * R + tid] = 0.f; }
     if (tid < W) s_c[tid] = dm.first_rec;
     if (tid == 0) { s_misc[0] = 1.f; s_misc[1] = -1.f; s_misc[2] = 1.f; tp.mask[b] = 1; }
     __syncthreads();
-    const uint32_t mb_counter = tp.counter[0];
-    const uint32_t gb = (uint32_t)(dm.boff + b);
 
+    MMG_STAMP(2);
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)t * B + b;
+        MMG_STAMP(8 + 10 * t + 9);
         // ===== (1) sender: h_w = code_layer(c), a = tanh(h_x + h_w)  [thread n = tid]
         float av;
         {
@@ -221,33 +242,24 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
         // GRU hidden-side product does not depend on this step's message: overlap it here
         float ghv = bhh;
         if (gru_lane) ghv += dot4<R / 4>(whh, s_h, 4);
-        __syncthreads();                                                   // B1: a ready
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 0);                         // B1: a ready
         // ===== (2) sender: logits = binary_layer(a), Bernoulli sample
         {
             float acc = dot4<JB>(wb, s_a + kpb * 4, 4 * LB);
             acc = lane_group_sum<LB>(acc);
             if (kpb == 0) {
                 const float lz = acc + bb;
-                float zz = lz, lpv = 0.f, nev = 0.f;
+                float zz = lz, pp = 0.f;
                 if (binary) {
-                    const float p = fsigmoid(lz);
-                    if (train) {
-                        const float u = inject ? s_uz[t * W + nb]
-                                               : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + gb) * W + nb), mb_counter, 0u);
-                        zz = (u < p) ? 1.f : 0.f;
-                    } else {
-                        zz = rintf(p);
-                    }
-                    tp.pz[row * W + nb] = p;
-                    const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                    lpv = zz * l1 + (1.f - zz) * l0;
-                    nev = p * l1 + (1.f - p) * l0;
+                    pp = fsigmoid(lz);
+                    zz = train ? ((s_uz[t * W + nb] < pp) ? 1.f : 0.f) : rintf(pp);
+                    tp.pz[row * W + nb] = pp;
                 }
-                s_z[nb] = zz; s_lp[nb] = lpv; s_ne[nb] = nev;
+                s_z[nb] = zz; s_lp[nb] = pp;                               // log-lik / entropy terms: wave 3, next phase
                 tp.z[row * W + nb] = zz;
             }
         }
-        __syncthreads();                                                   // B2: z ready
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 1);                         // B2: z ready
         // ===== (3) receiver GRU gate pre-activations  [thread n < 3R]
         if (gru_lane) {
             const float giv = bih + dot4<W / 4>(wih, s_z, 4);
@@ -255,11 +267,17 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
         }
         if (binary && tid >= 192 && tid < 192 + 64) {                      // wave 3 is idle here: reduce the sender's log-lik terms
             const int l = tid - 192;
-            float lpv = (l < W) ? s_lp[l] : 0.f, nev = (l < W) ? s_ne[l] : 0.f;
+            float lpv = 0.f, nev = 0.f;
+            if (l < W) {
+                const float p = s_lp[l], zz = s_z[l];
+                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                lpv = zz * l1 + (1.f - zz) * l0;                             // model.py:908-910
+                nev = p * l1 + (1.f - p) * l0;                               // model.py:919-922
+            }
             lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
             if (l == 0) { tp.lp_z[row] = lpv; tp.ne_z[row] = nev; }
         }
-        __syncthreads();                                                   // B3: gates ready
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 2);                         // B3: gates ready
         // ===== (4) GRU state update  [thread i < R]
         if (tid < R) {
             const float rr = fsigmoid(s_gi[tid] + s_gh[tid]);
@@ -272,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
             tp.h[((size_t)(t + 1) * B + b) * R + tid] = hv;
             s_h[tid] = hv;                                                 // (s_h is only read again after B4)
         }
-        __syncthreads();                                                   // B4: h ready
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 3);                         // B4: h ready
         // ===== (5) heads on h: A = y1[:, :R] h, gh_ = w_h h + b_h (kept in registers), stop bit
         float gpre_h;
         {
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
                 const float p = fsigmoid(sv + bs);
                 float sbit;
                 if (train) {
-                    const float u = inject ? s_us[t] : philox_uniform(ar.seed, (uint32_t)(t * dm.Bg + gb), mb_counter, 1u);
+                    const float u = s_us[t];
                     sbit = (u < p) ? 1.f : 0.f;
                 } else {
                     const float prod = dm.s_prob_prod ? s_misc[2] * p : p;
@@ -303,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
                 s_misc[3] = sbit;
             }
         }
-        __syncthreads();                                                   // B5: A, stop bit ready
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 4);                         // B5: A, stop bit ready
         // ===== (6) class logits
         {
             float acc = 0.f;
@@ -327,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
         const float m_next = fminf(m_t, sbit);
         const bool first_stop = (m_next == 0.f) && (s_misc[1] < 0.f);
         const bool take_out = dm.fixed ? (t == T - 1) : (first_stop || ((t == T - 1) && (s_misc[1] < 0.f)));
-        __syncthreads();                                                   // B6: y ready (and everyone has read misc)
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 5);                         // B6: y ready (and everyone has read misc)
         if (take_out && tid < 32) s_yout[tid] = s_y[tid];
         if (tid == 0) {
             tp.mask[(size_t)(t + 1) * B + b] = (uint8_t)(m_next != 0.f);
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
             const float acc = ((q0 + q1) + (q2 + q3)) * inv;
             if (tid < V) { s_dbar[tid] = acc; tp.dbar[row * V + tid] = acc; }
         }
-        __syncthreads();                                                   // B7: dbar ready
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 6);                         // B7: dbar ready
         // ===== (8) h_w = tanh(w_h h + b_h + w_d dbar)
         {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -370,35 +388,32 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
                 tp.g[row * R + n4] = gv;
             }
         }
-        __syncthreads();                                                   // B8: g ready
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 7);                         // B8: g ready
         // ===== (9) receiver message
         {
             float acc = dot4<JW>(ww, s_g + kpb * 4, 4 * LB);
             acc = lane_group_sum<LB>(acc);
             if (kpb == 0) {
                 const float lw = acc + bw;
-                float wv = lw, lpv = 0.f, nev = 0.f;
+                float wv = lw, pp = 0.f;
                 if (binary) {
-                    const float p = fsigmoid(lw);
-                    if (train) {
-                        const float u = inject ? s_uw[t * W + nb]
-                                               : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + gb) * W + nb), mb_counter, 2u);
-                        wv = (u < p) ? 1.f : 0.f;
-                    } else {
-                        wv = rintf(p);
-                    }
-                    tp.pw[row * W + nb] = p;
-                    const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                    lpv = wv * l1 + (1.f - wv) * l0;
-                    nev = p * l1 + (1.f - p) * l0;
+                    pp = fsigmoid(lw);
+                    wv = train ? ((s_uw[t * W + nb] < pp) ? 1.f : 0.f) : rintf(pp);
+                    tp.pw[row * W + nb] = pp;
                 }
-                s_c[nb] = wv; s_lpw[nb] = lpv; s_new[nb] = nev;
+                s_c[nb] = wv; s_lpw[nb] = pp;
                 tp.w[row * W + nb] = wv;
             }
         }
-        __syncthreads();                                                   // B9: w ready
-        if (binary && tid < 64) {
-            float lpv = (lane < W) ? s_lpw[lane] : 0.f, nev = (lane < W) ? s_new[lane] : 0.f;
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 8);                         // B9: w ready
+        if (binary && tid >= 192) {                                        // wave 3 has no GRU rows: it overlaps with phase (1)
+            float lpv = 0.f, nev = 0.f;
+            if (lane < W) {
+                const float p = s_lpw[lane], wv = s_c[lane];
+                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                lpv = wv * l1 + (1.f - wv) * l0;
+                nev = p * l1 + (1.f - p) * l0;
+            }
             lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
             if (lane == 0) { tp.lp_w[row] = lpv; tp.ne_w[row] = nev; }
         }
@@ -471,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         t_bs[tid] = tp.bs[o]; t_br[tid] = tp.br[o]; t_s[tid] = tp.s[o]; t_ps[tid] = tp.ps[o];
     }
     LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
-    loss_coefficients(dm, tp.stats, lc, b == 0 ? tp.losses : nullptr);
+    loss_coefficients(dm, tp.stats, lc, b == 0 ? tp.losses : nullptr, b == 0 ? tp.totals : nullptr);
     const float L = tp.logs[b];
     const float* cw_s = lc.cw, *cw_r = lc.cw + T, *cw_z = lc.cw + 2 * T;
     const float* ce_s = lc.ce, *ce_r = lc.ce + T, *ce_z = lc.ce + 2 * T;

@@ -589,8 +589,29 @@ __device__ __forceinline__ void seg_accumulate(f32x4& acc, const float* __restri
     }
 }
 
+// fragment helpers for the vector path: a lane's share of one K segment is float4 chunks at k = q*4 + 16*j
+template <int MAXQ>
+__device__ __forceinline__ void frag_load(float4 (&f)[MAXQ], const float* __restrict__ row, bool valid, int K, int q) {
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) {
+        const int k = q * 4 + 16 * j;
+        f[j] = (valid && k < K) ? *reinterpret_cast<const float4*>(row + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int MAXQ>
+__device__ __forceinline__ void frag_mfma(f32x4& acc, const float4 (&a)[MAXQ], const float4 (&b)[MAXQ], int K, int q) {
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) {
+        if (q * 4 + 16 * j < K || j * 16 < K) {          // wave-uniform bound: j*16 < K
+            acc = mfma16(a[j].x, b[j].x, acc); acc = mfma16(a[j].y, b[j].y, acc);
+            acc = mfma16(a[j].z, b[j].z, acc); acc = mfma16(a[j].w, b[j].w, acc);
+        }
+    }
+}
+
 __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tape tp, int skip_inactive) {
-    __shared__ float s_part[4][16];
+    // s_part[t][wave][row]: partial scores of this block's 64 hidden units, combined once at the end
+    __shared__ float s_part[64][4][16];
     __shared__ int s_tmax;
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, K = dm.K, T = dm.T;
     const int which = blockIdx.z;                       // 0: baseline_rec, 1: baseline_sen
@@ -618,38 +639,67 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
     float* hid = which ? tp.hid_s : tp.hid_r;
     float* part = which ? tp.bs_part : tp.br_part;
     const bool vecH = ((H & 15) == 0) && ((ldw & 3) == 0);
+    // register-fragment path: message and state segments of at most 64 floats, 16-byte aligned rows
+    const bool frag = ((W & 15) == 0) && (W <= 64) && ((R & 15) == 0) && (R <= 64) && ((ldw & 3) == 0) && ((H & 3) == 0);
     const bool vecW = ((W & 15) == 0) && ((ldw & 3) == 0) && ((H & 3) == 0);
     const bool vecR = ((R & 15) == 0) && ((ldw & 3) == 0) && ((W & 3) == 0);
     f32x4 base = {0.f, 0.f, 0.f, 0.f};
     if (which) seg_accumulate(base, tp.hx + (size_t)(xv ? bx : 0) * H, xv, wrow, nv, H, q, vecH);
-    for (int t = 0; t <= tmax; ++t) {
-        const size_t xrow = (size_t)t * B + (xv ? bx : 0);
-        f32x4 acc = base;
-        if (which) {
-            seg_accumulate(acc, tp.zr + xrow * W, xv, wrow + H, nv, W, q, vecW);
-        } else {
-            seg_accumulate(acc, tp.z + xrow * W, xv, wrow, nv, W, q, vecW);
-            seg_accumulate(acc, tp.h + ((size_t)(t + 1) * B + (xv ? bx : 0)) * R, xv, wrow + W, nv, R, q, vecR);
-        }
-        float pr[4];
+    const size_t xs = (size_t)(xv ? bx : 0);
+
+    if (frag) {
+        // weights of the per-step segments stay in registers for the whole walk over t
+        float4 w_msg[4], w_st[4], x_msg[4], x_st[4], nx_msg[4], nx_st[4];
+        frag_load(w_msg, wrow + (which ? H : 0), nv, W, q);
+        if (!which) frag_load(w_st, wrow + W, nv, R, q);
+        const float* msg = which ? tp.zr : tp.z;
+        frag_load(x_msg, msg + xs * W, xv, W, q);
+        if (!which) frag_load(x_st, tp.h + ((size_t)B + xs) * R, xv, R, q);
+        for (int t = 0; t <= tmax; ++t) {
+            if (t < tmax) {                                               // next step's inputs in flight during the MFMAs
+                frag_load(nx_msg, msg + ((size_t)(t + 1) * B + xs) * W, xv, W, q);
+                if (!which) frag_load(nx_st, tp.h + ((size_t)(t + 2) * B + xs) * R, xv, R, q);
+            }
+            f32x4 acc = base;
+            frag_mfma(acc, x_msg, w_msg, W, q);
+            if (!which) frag_mfma(acc, x_st, w_st, R, q);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int bo = b0 + q * 4 + r;
-            float v = fmaxf(acc[r] + bias, 0.f);                        // model.py:514
-            if (bo < B && nv) hid[((size_t)t * B + bo) * K + n] = v; else v = 0.f;
-            v *= w2;
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            pr[r] = v;
-        }
-        if (i == 0) {
+            for (int r = 0; r < 4; ++r) {
+                const int bo = b0 + q * 4 + r;
+                float v = fmaxf(acc[r] + bias, 0.f);                        // model.py:514
+                if (bo < B && nv) hid[((size_t)t * B + bo) * K + n] = v; else v = 0.f;
+                v = dpp_group_sum<16>(v * w2);
+                if (i == 0) s_part[t][wave][q * 4 + r] = v;
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_part[wave][q * 4 + r] = pr[r];
+            for (int j = 0; j < 4; ++j) { x_msg[j] = nx_msg[j]; x_st[j] = nx_st[j]; }
         }
-        __syncthreads();
-        if (threadIdx.x < 16 && b0 + (int)threadIdx.x < B)
-            part[((size_t)t * B + b0 + threadIdx.x) * npb + blockIdx.y] =
-                (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
-        __syncthreads();
+    } else {
+        for (int t = 0; t <= tmax; ++t) {
+            const size_t xrow = (size_t)t * B + xs;
+            f32x4 acc = base;
+            if (which) {
+                seg_accumulate(acc, tp.zr + xrow * W, xv, wrow + H, nv, W, q, vecW);
+            } else {
+                seg_accumulate(acc, tp.z + xrow * W, xv, wrow, nv, W, q, vecW);
+                seg_accumulate(acc, tp.h + ((size_t)(t + 1) * B + xs) * R, xv, wrow + W, nv, R, q, vecR);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bo = b0 + q * 4 + r;
+                float v = fmaxf(acc[r] + bias, 0.f);
+                if (bo < B && nv) hid[((size_t)t * B + bo) * K + n] = v; else v = 0.f;
+                v = dpp_group_sum<16>(v * w2);
+                if (i == 0) s_part[t][wave][q * 4 + r] = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < (tmax + 1) * 16; idx += MMG_BLOCK) {
+        const int t = idx >> 4, r = idx & 15;
+        if (b0 + r < B)
+            part[((size_t)t * B + b0 + r) * npb + blockIdx.y] =
+                (s_part[t][0][r] + s_part[t][1][r]) + (s_part[t][2][r] + s_part[t][3][r]);
     }
 }
 

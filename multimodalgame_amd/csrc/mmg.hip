@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -177,6 +178,10 @@ static int build_jobs(mmg_handle* h) {
     if (ng > MMG_MAX_GEMM || nc > MMG_MAX_COL) return fail("job table overflow");
     jt.n_gemm = ng; jt.n_col = nc; jt.gemm_tiles = tiles; jt.gemm_blocks = tiles; jt.col_blocks = cblocks;
     jt.n_wblocks = tiles + cblocks;
+    for (int k = 0; k < 64; ++k) {
+        jt.g_begin[k] = k < ng ? jt.g[k].tile_begin : 0x7fffffff;
+        jt.c_begin[k] = k < nc ? jt.c[k].blk_begin : 0x7fffffff;
+    }
     if (jt.n_wblocks > MMG_MAX_WBLOCKS) return fail("too many weight-gradient tiles (%d)", jt.n_wblocks);
     {
         auto agent_of = [&](const float* dst) {

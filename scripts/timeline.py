@@ -1,0 +1,31 @@
+"""Per-phase timeline of k_conversation_fast for sample 0 (needs libmmg_timing.so: -DMMG_TIMING build)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from multimodalgame_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmmg_timing.so")
+from multimodalgame_amd.engine import Engine
+from multimodalgame_amd.agents import init_state_dicts
+import bench
+eng = Engine(batch=64, **bench.C2)
+eng.load_state_dicts(init_state_dicts(eng, 0))
+feats, target, desc = bench.synthetic_dataset(3000, 30, 512, 100)
+dev = eng.device
+x = torch.from_numpy(feats[:64]).to(dev); t = torch.from_numpy(target[:64]).to(dev); d = torch.from_numpy(desc).to(dev)
+for it in range(6):
+    eng.train_step(x, t, d, seed=0)
+torch.cuda.synchronize()
+dbg = eng.tape["dbg"].view(torch.int64).cpu().numpy()
+tick = 10.0  # wall_clock64: 100 MHz -> 10 ns
+t0 = dbg[0]
+print("tstar[0] =", int(eng.tape["tstar"][0]), " prologue(weights->regs) %.2f us, state init %.2f us" % ((dbg[1]-t0)*tick/1e3, (dbg[2]-dbg[1])*tick/1e3))
+names = ["(1)sender a", "(2)logits+sample", "(3)gates", "(4)h", "(5)heads", "(6)y", "(7)softmax.desc", "(8)g", "(9)w"]
+for st in range(int(eng.tape["tstar"][0]) + 1):
+    base = 8 + 10 * st
+    prev = dbg[base + 9]
+    parts = []
+    for k in range(9):
+        cur = dbg[base + k]
+        if cur == 0 or cur < prev: break
+        parts.append("%s %.2f" % (names[k], (cur - prev) * tick / 1e3)); prev = cur
+    print("step %d: total %.2f us | " % (st, (prev - dbg[base + 9]) * tick / 1e3) + " | ".join(parts))
