@@ -7,7 +7,8 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmmg_timing.so")
 from multimodalgame_amd.engine import Engine
 from multimodalgame_amd.agents import init_state_dicts
 import bench
-eng = Engine(batch=64, **bench.C2)
+cfg = dict(bench.C2); cfg["fixed_exchange"] = bool(int(os.environ.get("FIXED", "1")))
+eng = Engine(batch=64, **cfg)
 eng.load_state_dicts(init_state_dicts(eng, 0))
 feats, target, desc = bench.synthetic_dataset(3000, 30, 512, 100)
 dev = eng.device

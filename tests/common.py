@@ -60,7 +60,7 @@ def case_inputs(meta, i, name=None):
     x, target, desc = cpu_ref.synthetic_batch(meta["batch"], meta["n_classes"], fl.img_feat_dim, fl.wv_dim,
                                               seed=meta["seed_data"] + i)
     u = cpu_ref.draw_uniforms(fl.max_exchange, meta["batch"], fl.rec_w_dim, seed=meta["seed_uniforms"] + i)
-    if name in U_OVERRIDES:
+    if name is not None and name in U_OVERRIDES:
         u = U_OVERRIDES[name](i, *u)
     return x, target, desc, u
 
