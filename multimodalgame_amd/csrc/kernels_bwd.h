@@ -8,6 +8,7 @@
 //               bias gradients as column sums -- deterministic (no float atomics)
 //   k_gradnorm / k_opt   per-agent clip_grad_norm(1.0) + RMSprop / Adam / SGD on the flat buffers
 #pragma once
+#include <type_traits>
 #include "device_utils.h"
 #include "layout.h"
 
@@ -21,7 +22,15 @@ namespace mmg {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float combine_score(const float* part, size_t row, int npb, float b2) {
     float v = 0.f;
-    for (int j = 0; j < npb; ++j) v += part[row * npb + j];
+    if (npb <= 8) {                                                     // all partial loads in flight at once
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = (j < npb) ? part[row * npb + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += p[j];
+    } else {
+        for (int j = 0; j < npb; ++j) v += part[row * npb + j];
+    }
     return v + b2;                                                      // model.py:515
 }
 
@@ -47,28 +56,26 @@ __global__ __launch_bounds__(64) void k_stats(Dims dm, Params P, Tape tp, int fr
         const bool enabled = dm.use_binary && !(kind == 0 && dm.fixed);
         if (enabled) {
             for (int b = lane; b < B; b += 64) {
-                const int ts = tp.tstar[b];
-                const bool act = (kind == 1) ? (t < ts) : (t <= ts);
+                // every load is issued unconditionally (one memory round trip); the activity test masks afterwards
                 const size_t row = (size_t)t * B + b;
+                const int ts = tp.tstar[b];
+                const float L = tp.logs[b];
+                const bool sen_side = (kind == 2) || (kind == 4);
+                const float beta_all = from_parts ? combine_score(sen_side ? tp.bs_part : tp.br_part, row, npb, sen_side ? b2s : b2r)
+                                                  : (sen_side ? tp.bs[row] : tp.br[row]);
+                const float lp_all = (kind == 0) ? tp.lp_s[row] : (kind == 1) ? tp.lp_w[row] : (kind == 2) ? tp.lp_z[row] : 0.f;
+                const float ne_all = (kind == 0) ? tp.ne_s[row] : (kind == 1) ? tp.ne_w[row] : (kind == 2) ? tp.ne_z[row] : 0.f;
+                const bool act = (kind == 1) ? (t < ts) : (t <= ts);
                 if (from_parts && kind >= 3 && t <= ts) {
-                    if (kind == 3) tp.br[row] = combine_score(tp.br_part, row, npb, b2r);
-                    else tp.bs[row] = combine_score(tp.bs_part, row, npb, b2s);
+                    if (kind == 3) tp.br[row] = beta_all; else tp.bs[row] = beta_all;
                 }
                 if (!act) continue;
-                const float L = tp.logs[b];
                 if (kind < 3) {
-                    const float beta = from_parts ? ((kind == 2) ? combine_score(tp.bs_part, row, npb, b2s)
-                                                                 : combine_score(tp.br_part, row, npb, b2r))
-                                                  : ((kind == 2) ? tp.bs[row] : tp.br[row]);
-                    const float lp = (kind == 0) ? tp.lp_s[row] : (kind == 1) ? tp.lp_w[row] : tp.lp_z[row];
-                    const float ne = (kind == 0) ? tp.ne_s[row] : (kind == 1) ? tp.ne_w[row] : tp.ne_z[row];
+                    const float beta = beta_all, lp = lp_all, ne = ne_all;
                     const double wv = (double)(L - beta);          // model.py:912
                     a0 += 1.0; a1 += wv; a2 += wv * wv; a3 += wv * (double)lp; a4 += (double)ne;
                 } else {
-                    const float beta = from_parts ? ((kind == 3) ? combine_score(tp.br_part, row, npb, b2r)
-                                                                 : combine_score(tp.bs_part, row, npb, b2s))
-                                                  : ((kind == 3) ? tp.br[row] : tp.bs[row]);
-                    const double dv = (double)(beta - L);          // model.py:972
+                    const double dv = (double)(beta_all - L);      // model.py:972
                     a0 += dv * dv;
                 }
             }
@@ -347,13 +354,20 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_dC(Dims dm, Params P, Tape tp) {
         float dc0 = 0.f, dc1 = 0.f, py0 = 0.f, py1 = 0.f;
         if (g < groups && r < R) {
             const float cv = tp.Cd[(size_t)d * R + r];
-            for (int b = g; b < B; b += 2 * groups) {
-                const int b1 = b + groups;
-                const float y0 = tp.dy[(size_t)b * D + d], p0 = tp.Astar[(size_t)b * R + r] + cv;
-                const float y1 = b1 < B ? tp.dy[(size_t)b1 * D + d] : 0.f;
-                const float p1 = b1 < B ? tp.Astar[(size_t)b1 * R + r] + cv : 0.f;
-                if (p0 > 0.f) { dc0 += y0; py0 = fmaf(y0, p0, py0); }
-                if (p1 > 0.f) { dc1 += y1; py1 = fmaf(y1, p1, py1); }
+            for (int b = g; b < B; b += 8 * groups) {               // 8 samples (16 loads) in flight per thread
+                float yv[8], pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int bb = b + u * groups;
+                    const bool ok = bb < B;
+                    yv[u] = ok ? tp.dy[(size_t)bb * D + d] : 0.f;
+                    pv[u] = ok ? tp.Astar[(size_t)bb * R + r] + cv : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    if (pv[u] > 0.f) { dc0 += yv[u]; py0 = fmaf(yv[u], pv[u], py0); }
+                    if (pv[u + 1] > 0.f) { dc1 += yv[u + 1]; py1 = fmaf(yv[u + 1], pv[u + 1], py1); }
+                }
             }
         }
         s_c[tid] = (dc0 + dc1) * ((g < groups && r < R) ? w2[r] : 0.f);
@@ -412,7 +426,17 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, si
 }
 
 __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict__ jt, const float* __restrict__ x,
-                                                     const float* __restrict__ desc, float* __restrict__ part) {
+                                                     const float* __restrict__ desc, float* __restrict__ part
+#ifdef MMG_TIMING
+                                                     , long long* __restrict__ dbg2
+#endif
+                                                     ) {
+#ifdef MMG_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 4096) dbg2[2 * blockIdx.x] = (long long)wall_clock64();
+#define MMG_WG_END() do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) dbg2[2 * blockIdx.x + 1] = (long long)wall_clock64(); } while (0)
+#else
+#define MMG_WG_END() do {} while (0)
+#endif
     // One workgroup per 16x16 tile of dW = A^T . Bm (A: [rows, N] gradient tape, Bm: [rows, K] input
     // tape, reduction over the (step, sample) rows).  Rows are consumed in chunks of 64: every thread
     // fetches 4 consecutive columns of one row of each operand (16-byte coalesced loads, 64 B per row),
@@ -422,19 +446,25 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     // wrote in part[blockIdx.x] (clip_grad_norm partials, summed per agent by k_opt).
     constexpr int CH = 64;
     __shared__ float s_a[2][CH][17];
-    __shared__ float s_b[2][CH][17];
-    float (*s_acc)[16][17] = reinterpret_cast<float (*)[16][17]>(&s_a[0][0][0]);   // reused after the row loop
+    __shared__ float s_b[2][CH][33];                   // 32 output columns per block: the staged A chunk feeds two k-tiles
+    float (*s_acc)[16][33] = reinterpret_cast<float (*)[16][33]>(&s_b[0][0][0]);   // [4][16][33] reused after the row loop
     float* s_part = &s_b[0][0][0];                                                   // column-sum staging
     __shared__ float s_red[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((int)blockIdx.x < jt->gemm_tiles) {
-        const int tile = blockIdx.x;
+        // XCD-aware tile order: workgroup b is dispatched to XCD b % 8, and each XCD has its own 4 MB L2.  Giving
+        // every XCD a CONTIGUOUS range of tiles (= one or two jobs) keeps the operand tapes it re-reads
+        // (16-32 tiles share each of them) inside its L2; with the default order every XCD streams all ~7 MB
+        // of tapes through its L2 and the kernel is bound by L2-miss traffic.  (bijective remap, T1)
+        const int nwg = jt->gemm_tiles, xq = nwg >> 3, xr = nwg & 7;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
         // job lookup: lane l compares the l-th job's first tile, one ballot (no serial scalar loads)
         const int j = __popcll(__ballot(jt->g_begin[lane] <= tile)) - 1;
         const GemmJob& G = jt->g[j];
         const int lt = tile - G.tile_begin;
         const int tn = lt / G.tiles_k, tk = lt - tn * G.tiles_k;
-        const int n0 = tn * 16, k0 = tk * 16;
+        const int n0 = tn * 16, k0 = tk * 32;
         const int i = lane & 15, q = lane >> 4;
         const float* Bbase = (G.bsrc == SRC_X) ? x : (G.bsrc == SRC_DESC) ? desc : G.Bm;
         const bool virt = G.vhid != nullptr;
@@ -442,57 +472,124 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const int rows = G.rows, lda = G.lda, ldb = G.ldb, bmod = G.bmod, N = G.N, K = G.K;
         const bool veca = ((lda & 3) == 0) && ((((uintptr_t)Abase) & 15) == 0);
         const bool vecb = ((ldb & 3) == 0) && ((((uintptr_t)Bbase) & 15) == 0);
-        // loader role of this thread: row lr of the chunk, columns lc..lc+3 of the tile
-        const int lr = threadIdx.x >> 2, lc = (threadIdx.x & 3) * 4;
+        // loader roles: A row la, columns lac..+3 (64 rows x 16 cols); B row lb0 / lb0+32, columns lbc..+3 (64 x 32)
+        const int la = threadIdx.x >> 2, lac = (threadIdx.x & 3) * 4;
+        const int lb0 = threadIdx.x >> 3, lbc = (threadIdx.x & 7) * 4;
         float4 vw = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (virt) vw = load4_guard(G.vw2, 0, n0 + lc, N, true, false);
+        if (virt) vw = load4_guard(G.vw2, 0, n0 + lac, N, true, false);
         const int nchunks = (rows + CH - 1) / CH;
-        // two register sets: chunk c is staged while c+1 and c+2 are in flight (prefetch depth 2)
-        float4 ra0, rb0, ra1, rb1;
-        float beta0 = 0.f, beta1 = 0.f;
-        auto fetch = [&](int c, float4& ra, float4& rb, float& beta) {
-            const int r = c * CH + lr;
-            const bool rv = r < rows;
-            ra = load4_guard(Abase, (size_t)(rv ? r : 0) * lda, n0 + lc, N, rv, veca);
-            const int rbm = bmod ? (r % bmod) : r;
-            rb = load4_guard(Bbase, (size_t)(rv ? rbm : 0) * ldb, k0 + lc, K, rv, vecb);
-            if (virt) beta = rv ? G.A[r] : 0.f;
-        };
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        auto stage_and_multiply = [&](int c, int buf, float4& ra, float4& rb, float& beta) {
-            if (virt) {
-                ra.x = ra.x > 0.f ? beta * vw.x : 0.f; ra.y = ra.y > 0.f ? beta * vw.y : 0.f;
-                ra.z = ra.z > 0.f ? beta * vw.z : 0.f; ra.w = ra.w > 0.f ? beta * vw.w : 0.f;
-            }
-            s_a[buf][lr][lc] = ra.x; s_a[buf][lr][lc + 1] = ra.y; s_a[buf][lr][lc + 2] = ra.z; s_a[buf][lr][lc + 3] = ra.w;
-            s_b[buf][lr][lc] = rb.x; s_b[buf][lr][lc + 1] = rb.y; s_b[buf][lr][lc + 2] = rb.z; s_b[buf][lr][lc + 3] = rb.w;
-            __syncthreads();
-            if (c + 2 < nchunks) fetch(c + 2, ra, rb, beta);
+        constexpr int DEPTH = 3;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // Branch-free steady state: every load is unconditional (indices clamped, values masked afterwards), so the
+        // compiler keeps COUNTED s_waitcnt vmcnt(N).  With any branch around a load it falls back to vmcnt(0) at the
+        // join, which drains the prefetches and costs one full memory round trip (~1.5 us) per chunk.
+        // interior tiles: one 16-byte load per operand slice; edge tiles (N or K tail, unaligned rows): four clamped
+        // scalar loads -- the same pipeline either way.
+        const bool interior = veca && vecb && (n0 + 16 <= N) && (k0 + 32 <= K);
+        const int rlast = rows - 1;
+        const int bmodv = bmod ? bmod : 0x7fffffff;          // branch-free "row % bmod" (identity when unused)
+        const float* betap = G.A;                            // virt: d score per row; otherwise any valid address
+        auto run = [&](auto vec_tag) {
+            constexpr bool VEC = decltype(vec_tag)::value;
+            auto ld4 = [&](const float* rowp, int col, int ncols) -> float4 {
+                if (VEC) return *reinterpret_cast<const float4*>(rowp + col);
+                const int cm = ncols - 1;
+                float4 v;
+                v.x = rowp[min(col, cm)]; v.y = rowp[min(col + 1, cm)]; v.z = rowp[min(col + 2, cm)]; v.w = rowp[min(col + 3, cm)];
+                v.x = (col < ncols) ? v.x : 0.f; v.y = (col + 1 < ncols) ? v.y : 0.f;
+                v.z = (col + 2 < ncols) ? v.z : 0.f; v.w = (col + 3 < ncols) ? v.w : 0.f;
+                return v;
+            };
+            float4 ra[DEPTH], rb0[DEPTH], rb1[DEPTH];
+            float beta[DEPTH];
+            auto fetch = [&](int c, int u) {
+                const int r_ = c * CH + la, r0_ = c * CH + lb0, r1_ = r0_ + 32;
+                const int rc_ = min(r_, rlast), c0_ = min(r0_, rlast), c1_ = min(r1_, rlast);
+                ra[u] = ld4(Abase + (size_t)rc_ * lda, n0 + lac, N);
+                beta[u] = betap[virt ? rc_ : 0];
+                rb0[u] = ld4(Bbase + (size_t)(c0_ % bmodv) * ldb, k0 + lbc, K);
+                rb1[u] = ld4(Bbase + (size_t)(c1_ % bmodv) * ldb, k0 + lbc, K);
+            };
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = wave * 16 + u * 4 + q;
-                acc = mfma16(s_a[buf][r][i], s_b[buf][r][i], acc);
+            for (int u = 0; u < DEPTH - 1; ++u) fetch(u, u);
+            const int nouter = (nchunks + DEPTH - 1) / DEPTH;
+            for (int o = 0; o < nouter; ++o) {
+#pragma unroll
+                for (int u = 0; u < DEPTH; ++u) {
+                    const int c = o * DEPTH + u;
+                    const int buf = (o * DEPTH + u) & 1;
+                    const bool va = (c * CH + la) < rows, v0 = (c * CH + lb0) < rows, v1 = (c * CH + lb0 + 32) < rows;
+                    float4 av = ra[u];
+                    if (virt) {
+                        av.x = av.x > 0.f ? beta[u] * vw.x : 0.f; av.y = av.y > 0.f ? beta[u] * vw.y : 0.f;
+                        av.z = av.z > 0.f ? beta[u] * vw.z : 0.f; av.w = av.w > 0.f ? beta[u] * vw.w : 0.f;
+                    }
+                    const float ma = va ? 1.f : 0.f, m0 = v0 ? 1.f : 0.f, m1 = v1 ? 1.f : 0.f;
+                    s_a[buf][la][lac] = av.x * ma; s_a[buf][la][lac + 1] = av.y * ma; s_a[buf][la][lac + 2] = av.z * ma; s_a[buf][la][lac + 3] = av.w * ma;
+                    s_b[buf][lb0][lbc] = rb0[u].x * m0; s_b[buf][lb0][lbc + 1] = rb0[u].y * m0; s_b[buf][lb0][lbc + 2] = rb0[u].z * m0; s_b[buf][lb0][lbc + 3] = rb0[u].w * m0;
+                    s_b[buf][lb0 + 32][lbc] = rb1[u].x * m1; s_b[buf][lb0 + 32][lbc + 1] = rb1[u].y * m1; s_b[buf][lb0 + 32][lbc + 2] = rb1[u].z * m1; s_b[buf][lb0 + 32][lbc + 3] = rb1[u].w * m1;
+                    __syncthreads();
+                    fetch(c + DEPTH - 1, (u + DEPTH - 1) % DEPTH);        // unconditional: clamped beyond the last row
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int r = wave * 16 + v * 4 + q;
+                        const float a = s_a[buf][r][i];
+                        acc0 = mfma16(a, s_b[buf][r][i], acc0);
+                        acc1 = mfma16(a, s_b[buf][r][16 + i], acc1);
+                    }
+                }
             }
         };
-        fetch(0, ra0, rb0, beta0);
-        if (nchunks > 1) fetch(1, ra1, rb1, beta1);
-        for (int c = 0; c < nchunks; c += 2) {
-            stage_and_multiply(c, 0, ra0, rb0, beta0);
-            if (c + 1 < nchunks) stage_and_multiply(c + 1, 1, ra1, rb1, beta1);
+        if (interior) {
+            run(std::true_type{});
+        } else {
+            // edge tiles (N or K tail inside the tile, unaligned rows): guarded loads, one chunk at a time
+            for (int c = 0; c < nchunks; ++c) {
+                const int buf = c & 1;
+                const int r = c * CH + la;
+                const bool rv = r < rows;
+                float4 av = load4_guard(Abase, (size_t)(rv ? r : 0) * lda, n0 + lac, N, rv, veca);
+                if (virt) {
+                    const float be = rv ? G.A[r] : 0.f;
+                    av.x = av.x > 0.f ? be * vw.x : 0.f; av.y = av.y > 0.f ? be * vw.y : 0.f;
+                    av.z = av.z > 0.f ? be * vw.z : 0.f; av.w = av.w > 0.f ? be * vw.w : 0.f;
+                }
+                const int r0 = c * CH + lb0, r1 = r0 + 32;
+                const bool v0 = r0 < rows, v1 = r1 < rows;
+                const int m0 = bmod ? (r0 % bmod) : r0, m1 = bmod ? (r1 % bmod) : r1;
+                const float4 b0v = load4_guard(Bbase, (size_t)(v0 ? m0 : 0) * ldb, k0 + lbc, K, v0, vecb);
+                const float4 b1v = load4_guard(Bbase, (size_t)(v1 ? m1 : 0) * ldb, k0 + lbc, K, v1, vecb);
+                s_a[buf][la][lac] = av.x; s_a[buf][la][lac + 1] = av.y; s_a[buf][la][lac + 2] = av.z; s_a[buf][la][lac + 3] = av.w;
+                s_b[buf][lb0][lbc] = b0v.x; s_b[buf][lb0][lbc + 1] = b0v.y; s_b[buf][lb0][lbc + 2] = b0v.z; s_b[buf][lb0][lbc + 3] = b0v.w;
+                s_b[buf][lb0 + 32][lbc] = b1v.x; s_b[buf][lb0 + 32][lbc + 1] = b1v.y; s_b[buf][lb0 + 32][lbc + 2] = b1v.z; s_b[buf][lb0 + 32][lbc + 3] = b1v.w;
+                __syncthreads();
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int rr2 = wave * 16 + v * 4 + q;
+                    const float a = s_a[buf][rr2][i];
+                    acc0 = mfma16(a, s_b[buf][rr2][i], acc0);
+                    acc1 = mfma16(a, s_b[buf][rr2][16 + i], acc1);
+                }
+            }
         }
         __syncthreads();                                   // every wave is done reading the staging buffers
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = acc[r];
+        for (int r = 0; r < 4; ++r) { s_acc[wave][q * 4 + r][i] = acc0[r]; s_acc[wave][q * 4 + r][16 + i] = acc1[r]; }
         __syncthreads();
-        const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
-        const int n = n0 + rr, k = k0 + cc;
-        float v = 0.f;
-        if (n < N && k < K) {
-            v = (s_acc[0][rr][cc] + s_acc[1][rr][cc]) + (s_acc[2][rr][cc] + s_acc[3][rr][cc]);
-            G.C[(size_t)n * G.ldc + k] = v;
+        float sq = 0.f;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int rr = threadIdx.x >> 4, cc = (threadIdx.x & 15) + 16 * h2;
+            const int n = n0 + rr, k = k0 + cc;
+            if (n < N && k < K) {
+                const float v = (s_acc[0][rr][cc] + s_acc[1][rr][cc]) + (s_acc[2][rr][cc] + s_acc[3][rr][cc]);
+                G.C[(size_t)n * G.ldc + k] = v;
+                sq = fmaf(v, v, sq);
+            }
         }
-        const float sq = block_sum(v * v, s_red);
-        if (threadIdx.x == 0) part[blockIdx.x] = sq;
+        sq = block_sum(sq, s_red);
+        if (threadIdx.x == 0) part[tile] = sq;
+        MMG_WG_END();
         return;
     }
     // ---- column sums: 16 columns x 16 row groups per block, 4 independent loads in flight per thread
@@ -506,25 +603,26 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     if (cv) {
         const float* sp = C.src + c0 + cc;
         const int rows = C.rows, ld = C.ld;
-        if (C.vbeta) {
-            const float vw = C.vw2[c0 + cc];
-            for (int r = g; r < rows; r += 64) {
-                const int r1 = r + 16, r2 = r + 32, r3 = r + 48;
-                const float h0 = sp[(size_t)r * ld], b0 = C.vbeta[r];
-                const float h1 = r1 < rows ? sp[(size_t)r1 * ld] : 0.f, b1 = r1 < rows ? C.vbeta[r1] : 0.f;
-                const float h2 = r2 < rows ? sp[(size_t)r2 * ld] : 0.f, b2 = r2 < rows ? C.vbeta[r2] : 0.f;
-                const float h3 = r3 < rows ? sp[(size_t)r3 * ld] : 0.f, b3 = r3 < rows ? C.vbeta[r3] : 0.f;
-                a0 += h0 > 0.f ? b0 * vw : 0.f; a1 += h1 > 0.f ? b1 * vw : 0.f;
-                a2 += h2 > 0.f ? b2 * vw : 0.f; a3 += h3 > 0.f ? b3 * vw : 0.f;
+        constexpr int UN = 16;                         // rows in flight per thread (one round trip per 256 rows)
+        const bool virt = C.vbeta != nullptr;
+        const float vw = virt ? C.vw2[c0 + cc] : 0.f;
+        for (int r0 = g; r0 < rows; r0 += 16 * UN) {
+            float hv[UN], bv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int r = r0 + 16 * u;
+                const bool ok = r < rows;
+                hv[u] = ok ? sp[(size_t)r * ld] : 0.f;
+                bv[u] = (ok && virt) ? C.vbeta[r] : 0.f;
             }
-        } else {
-            for (int r = g; r < rows; r += 64) {
-                const int r1 = r + 16, r2 = r + 32, r3 = r + 48;
-                const float h0 = sp[(size_t)r * ld];
-                const float h1 = r1 < rows ? sp[(size_t)r1 * ld] : 0.f;
-                const float h2 = r2 < rows ? sp[(size_t)r2 * ld] : 0.f;
-                const float h3 = r3 < rows ? sp[(size_t)r3 * ld] : 0.f;
-                a0 += h0; a1 += h1; a2 += h2; a3 += h3;
+#pragma unroll
+            for (int u = 0; u < UN; u += 4) {
+                if (virt) {
+                    a0 += hv[u] > 0.f ? bv[u] * vw : 0.f; a1 += hv[u + 1] > 0.f ? bv[u + 1] * vw : 0.f;
+                    a2 += hv[u + 2] > 0.f ? bv[u + 2] * vw : 0.f; a3 += hv[u + 3] > 0.f ? bv[u + 3] * vw : 0.f;
+                } else {
+                    a0 += hv[u]; a1 += hv[u + 1]; a2 += hv[u + 2]; a3 += hv[u + 3];
+                }
             }
         }
     }
@@ -538,6 +636,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     }
     const float sq = block_sum(v * v, s_red);
     if (threadIdx.x == 0) part[blockIdx.x] = sq;
+    MMG_WG_END();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -577,11 +676,20 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
     {
         const int n = oa.from_wgrad ? jt->n_wblocks : MMG_GN_BLOCKS;
         float ss[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = threadIdx.x; k < n; k += MMG_BLOCK) {
-            const int a = oa.from_wgrad ? (int)jt->wblock_agent[k] : jt->np.agent[k];
-            const float v = part[k];
-            ss[0] += (a == 0) ? v : 0.f; ss[1] += (a == 1) ? v : 0.f;
-            ss[2] += (a == 2) ? v : 0.f; ss[3] += (a == 3) ? v : 0.f;
+        for (int k0 = threadIdx.x; k0 < n; k0 += 8 * MMG_BLOCK) {      // 8 partials (16 loads) in flight per thread
+            float v[8]; int a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * MMG_BLOCK;
+                const bool ok = k < n;
+                v[u] = ok ? part[k] : 0.f;
+                a[u] = ok ? (oa.from_wgrad ? (int)jt->wblock_agent[k] : jt->np.agent[k]) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ss[0] += (a[u] == 0) ? v[u] : 0.f; ss[1] += (a[u] == 1) ? v[u] : 0.f;
+                ss[2] += (a[u] == 2) ? v[u] : 0.f; ss[3] += (a[u] == 3) ? v[u] : 0.f;
+            }
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) s_ss[a][threadIdx.x] = ss[a];

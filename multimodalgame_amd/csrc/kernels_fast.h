@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
     const uint32_t mb_counter = tp.counter[0];
     const uint32_t gb = (uint32_t)(dm.boff + b);
 #ifdef MMG_TIMING
-    if (b == 0 && tid == 0) tp.dbg[0] = (long long)wall_clock64();
+    if (b == 0 && tid == 0) { tp.dbg[0] = (long long)wall_clock64(); tp.dbg[4] = (long long)clock64(); }
 #endif
     if (train && inject) {
         for (int i = tid; i < T * W; i += NT) {
@@ -419,6 +419,9 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P,
         }
     }
     __syncthreads();
+#ifdef MMG_TIMING
+    if (b == 0 && tid == 0) { tp.dbg[3] = (long long)wall_clock64(); tp.dbg[5] = (long long)clock64(); }
+#endif
     // ------------------------------------------------------------ output selection / reward / top-k
     const int tstar = dm.fixed ? (T - 1) : (int)s_misc[1];
     if (tid < 64) {

@@ -30,19 +30,35 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         return;
     }
     if ((int)blockIdx.x < dm.D) {
+        // Cd[d, r] = b_y1[r] + sum_v W_y1[r, R+v] * desc[d, v]: thread r owns output r and issues all of its
+        // row loads at once (one memory round trip per block instead of one per row pass)
         const int d = blockIdx.x;
+        const int R = dm.R, V = dm.V, ld = dm.R + dm.V;
         float* s_desc = smem;                       // [V]
-        for (int v = tid; v < dm.V; v += blockDim.x) s_desc[v] = desc[(size_t)d * dm.V + v];
+        for (int v = tid; v < V; v += blockDim.x) s_desc[v] = desc[(size_t)d * V + v];
         __syncthreads();
-        const float* Wy1d = P.p[R_Y1_W] + dm.R;     // columns R.. of y1.weight (row stride R+V)
         const float* by1 = P.p[R_Y1_B];
-        float* out = tp.Cd + (size_t)d * dm.R;
-        // Wy1d rows start at offset R: 16-byte alignment holds when R % 4 == 0 (gemv_rows checks)
-        gemv_rows(Wy1d, dm.R + dm.V, dm.R, dm.V, s_desc, [&](int n, float acc) { out[n] = acc + by1[n]; });
+        const bool vec = ((ld & 3) == 0) && ((R & 3) == 0) && ((V & 3) == 0);
+        for (int r = tid; r < R; r += blockDim.x) {
+            const float* wrow = P.p[R_Y1_W] + (size_t)r * ld + R;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            if (vec) {
+#pragma unroll 8
+                for (int v = 0; v < V; v += 4) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wrow + v);
+                    const float4 dv = *reinterpret_cast<const float4*>(s_desc + v);
+                    a0 = fmaf(wv.x, dv.x, a0); a1 = fmaf(wv.y, dv.y, a1); a2 = fmaf(wv.z, dv.z, a2); a3 = fmaf(wv.w, dv.w, a3);
+                }
+            } else {
+                for (int v = 0; v < V; ++v) a0 = fmaf(wrow[v], s_desc[v], a0);
+            }
+            tp.Cd[(size_t)d * R + r] = (a0 + a1) + (a2 + a3) + by1[r];
+        }
     } else {
         float* s_sig = smem;                        // [W]
         const float* cb = P.p[S_CODE_BIAS];
-        for (int j = tid; j < dm.W; j += blockDim.x) {
+        const int W = dm.W;
+        for (int j = tid; j < W; j += blockDim.x) {
             const float sg = sigmoidf_(cb[j]);
             s_sig[j] = sg;
             tp.dsig[j] = sg * (1.f - sg);
@@ -53,7 +69,22 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         }
         __syncthreads();
         const float* bc = P.p[S_CODE_B];
-        gemv_rows(P.p[S_CODE_W], dm.W, dm.H, dm.W, s_sig, [&](int n, float acc) { tp.hw0[n] = acc + bc[n]; });
+        const bool vec = (W & 3) == 0;
+        for (int n = tid; n < dm.H; n += blockDim.x) {          // thread n owns hw0[n]: all row loads in flight at once
+            const float* wrow = P.p[S_CODE_W] + (size_t)n * W;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            if (vec) {
+#pragma unroll 8
+                for (int k = 0; k < W; k += 4) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
+                    const float4 sv = *reinterpret_cast<const float4*>(s_sig + k);
+                    a0 = fmaf(wv.x, sv.x, a0); a1 = fmaf(wv.y, sv.y, a1); a2 = fmaf(wv.z, sv.z, a2); a3 = fmaf(wv.w, sv.w, a3);
+                }
+            } else {
+                for (int k = 0; k < W; ++k) a0 = fmaf(wrow[k], s_sig[k], a0);
+            }
+            tp.hw0[n] = (a0 + a1) + (a2 + a3) + bc[n];
+        }
     }
 }
 
@@ -84,12 +115,22 @@ __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__
         const int kchunks = K >> 4;                       // groups of 16 k
         const int per = (kchunks + 3) >> 2;
         const int c0 = wave * per, c1 = min(kchunks, c0 + per);
-        for (int cch = c0; cch < c1; ++cch) {
-            const int k = cch * 16 + q * 4;
-            float4 a = mv ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 b = nv ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            acc = mfma16(a.x, b.x, acc); acc = mfma16(a.y, b.y, acc);
-            acc = mfma16(a.z, b.z, acc); acc = mfma16(a.w, b.w, acc);
+        for (int cb0 = c0; cb0 < c1; cb0 += 8) {            // 8 chunks (16 float4 loads) in flight per pass
+            float4 a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = (cb0 + u) * 16 + q * 4;
+                const bool kv = (cb0 + u) < c1;
+                a[u] = (mv && kv) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                b[u] = (nv && kv) ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (cb0 + u < c1) {
+                    acc = mfma16(a[u].x, b[u].x, acc); acc = mfma16(a[u].y, b[u].y, acc);
+                    acc = mfma16(a[u].z, b[u].z, acc); acc = mfma16(a[u].w, b[u].w, acc);
+                }
+            }
         }
     } else {
         const int ksteps = (K + 3) >> 2;
@@ -649,20 +690,30 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
 
     if (frag) {
         // weights of the per-step segments stay in registers for the whole walk over t
-        float4 w_msg[4], w_st[4], x_msg[4], x_st[4], nx_msg[4], nx_st[4];
+        float4 w_msg[4], w_st[4];
+        float4 xm[4][4], xt[4][4];                                        // ring of 4 steps of inputs: 3 steps in flight
         frag_load(w_msg, wrow + (which ? H : 0), nv, W, q);
         if (!which) frag_load(w_st, wrow + W, nv, R, q);
         const float* msg = which ? tp.zr : tp.z;
-        frag_load(x_msg, msg + xs * W, xv, W, q);
-        if (!which) frag_load(x_st, tp.h + ((size_t)B + xs) * R, xv, R, q);
-        for (int t = 0; t <= tmax; ++t) {
-            if (t < tmax) {                                               // next step's inputs in flight during the MFMAs
-                frag_load(nx_msg, msg + ((size_t)(t + 1) * B + xs) * W, xv, W, q);
-                if (!which) frag_load(nx_st, tp.h + ((size_t)(t + 2) * B + xs) * R, xv, R, q);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (u <= tmax) {
+                frag_load(xm[u], msg + ((size_t)u * B + xs) * W, xv, W, q);
+                if (!which) frag_load(xt[u], tp.h + ((size_t)(u + 1) * B + xs) * R, xv, R, q);
+            }
+        }
+        for (int t0 = 0; t0 <= tmax; t0 += 4) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u;
+            if (t > tmax) break;
+            if (t + 3 <= tmax) {                                          // keep three steps of inputs in flight
+                frag_load(xm[(u + 3) & 3], msg + ((size_t)(t + 3) * B + xs) * W, xv, W, q);
+                if (!which) frag_load(xt[(u + 3) & 3], tp.h + ((size_t)(t + 4) * B + xs) * R, xv, R, q);
             }
             f32x4 acc = base;
-            frag_mfma(acc, x_msg, w_msg, W, q);
-            if (!which) frag_mfma(acc, x_st, w_st, R, q);
+            frag_mfma(acc, xm[u], w_msg, W, q);
+            if (!which) frag_mfma(acc, xt[u], w_st, R, q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int bo = b0 + q * 4 + r;
@@ -671,8 +722,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
                 v = dpp_group_sum<16>(v * w2);
                 if (i == 0) s_part[t][wave][q * 4 + r] = v;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { x_msg[j] = nx_msg[j]; x_st[j] = nx_st[j]; }
+          }
         }
     } else {
         for (int t = 0; t <= tmax; ++t) {

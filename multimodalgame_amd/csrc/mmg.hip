@@ -115,7 +115,7 @@ static int build_jobs(mmg_handle* h) {
                     int rows, int N, int Kk) {
         GemmJob& g = jt.g[ng++];
         g.A = A; g.Bm = Bm; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.rows = rows; g.N = N; g.K = Kk;
-        g.bmod = bmod; g.bsrc = bsrc; g.tile_begin = tiles; g.tiles_k = (Kk + 15) / 16;
+        g.bmod = bmod; g.bsrc = bsrc; g.tile_begin = tiles; g.tiles_k = (Kk + 31) / 32;     // 16 x 32 outputs per block
         g.vhid = nullptr; g.vw2 = nullptr;
         tiles += ((N + 15) / 16) * g.tiles_k;
     };
@@ -407,7 +407,11 @@ extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_ta
     {
         Scope sc(h, st, "k_wgrad");
         hipLaunchKernelGGL(k_wgrad, dim3(h->jt.n_wblocks), dim3(MMG_BLOCK), 0, st,
-                           (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart);
+                           (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart
+#ifdef MMG_TIMING
+                           , h->tp.dbg2
+#endif
+                           );
         if (launch_check("k_wgrad")) return -1;
     }
     return 0;

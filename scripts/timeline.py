@@ -30,3 +30,6 @@ for st in range(int(eng.tape["tstar"][0]) + 1):
         if cur == 0 or cur < prev: break
         parts.append("%s %.2f" % (names[k], (cur - prev) * tick / 1e3)); prev = cur
     print("step %d: total %.2f us | " % (st, (prev - dbg[base + 9]) * tick / 1e3) + " | ".join(parts))
+
+wall_us = (dbg[3] - dbg[0]) * tick / 1e3
+print("kernel body %.2f us, shader cycles %d -> shader clock %.0f MHz" % (wall_us, dbg[5] - dbg[4], (dbg[5] - dbg[4]) / wall_us))
