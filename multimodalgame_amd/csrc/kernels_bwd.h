@@ -396,8 +396,9 @@ enum { SRC_STATIC = 0, SRC_X = 1, SRC_DESC = 2 };
 struct GemmJob { const float* A; const float* Bm; float* C; const float* vhid; const float* vw2;
                  int lda, ldb, ldc, rows, N, K, bmod, bsrc, tile_begin, tiles_k; };
 // vbeta != NULL: virtual source,  src'[row, c] = vbeta[row] * vw2[c] * 1[src[row*ld + c] > 0]
-struct ColJob { const float* src; float* dst; const float* scale; const float* vbeta; const float* vw2;
-                int ld, rows, cols, blk_begin; };
+// wrow != NULL: row-weighted sum,  dst[c] = sum_row wrow[row] * src[row*ld + c]   (the N = 1 "GEMMs": d score^T . hidden)
+struct ColJob { const float* src; float* dst; const float* scale; const float* vbeta; const float* vw2; const float* wrow;
+                int ld, rows, cols, blk_begin, pad0, pad1; };
 #define MMG_MAX_GEMM 40
 #define MMG_MAX_COL 40
 struct NormPlan { int64_t begin[MMG_GN_BLOCKS], end[MMG_GN_BLOCKS]; int agent[MMG_GN_BLOCKS]; };
@@ -485,7 +486,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         // join, which drains the prefetches and costs one full memory round trip (~1.5 us) per chunk.
         // interior tiles: one 16-byte load per operand slice; edge tiles (N or K tail, unaligned rows): four clamped
         // scalar loads -- the same pipeline either way.
-        const bool interior = veca && vecb && (n0 + 16 <= N) && (k0 + 32 <= K);
+        // Tile tails may over-read: columns beyond N (A) / K (B) only feed output elements that are never stored, and
+        // every operand except x lives inside the workspace (the job tables follow the last operand array).
+        const bool interior = veca && vecb && ((G.bsrc != SRC_X) || (k0 + 32 <= K));
         const int rlast = rows - 1;
         const int bmodv = bmod ? bmod : 0x7fffffff;          // branch-free "row % bmod" (identity when unused)
         const float* betap = G.A;                            // virt: d score per row; otherwise any valid address
@@ -605,6 +608,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const int rows = C.rows, ld = C.ld;
         constexpr int UN = 16;                         // rows in flight per thread (one round trip per 256 rows)
         const bool virt = C.vbeta != nullptr;
+        const bool wsum = C.wrow != nullptr;
+        const float* rowv = virt ? C.vbeta : C.wrow;
         const float vw = virt ? C.vw2[c0 + cc] : 0.f;
         for (int r0 = g; r0 < rows; r0 += 16 * UN) {
             float hv[UN], bv[UN];
@@ -613,11 +618,14 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                 const int r = r0 + 16 * u;
                 const bool ok = r < rows;
                 hv[u] = ok ? sp[(size_t)r * ld] : 0.f;
-                bv[u] = (ok && virt) ? C.vbeta[r] : 0.f;
+                bv[u] = (ok && (virt || wsum)) ? rowv[r] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < UN; u += 4) {
-                if (virt) {
+                if (wsum) {
+                    a0 = fmaf(hv[u], bv[u], a0); a1 = fmaf(hv[u + 1], bv[u + 1], a1);
+                    a2 = fmaf(hv[u + 2], bv[u + 2], a2); a3 = fmaf(hv[u + 3], bv[u + 3], a3);
+                } else if (virt) {
                     a0 += hv[u] > 0.f ? bv[u] * vw : 0.f; a1 += hv[u + 1] > 0.f ? bv[u + 1] * vw : 0.f;
                     a2 += hv[u + 2] > 0.f ? bv[u + 2] * vw : 0.f; a3 += hv[u + 3] > 0.f ? bv[u + 3] * vw : 0.f;
                 } else {

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         const int d = blockIdx.x;
         const int R = dm.R, V = dm.V, ld = dm.R + dm.V;
         float* s_desc = smem;                       // [V]
-        for (int v = tid; v < V; v += blockDim.x) s_desc[v] = desc[(size_t)d * V + v];
+        for (int v = tid; v < V; v += blockDim.x) { const float dv = desc[(size_t)d * V + v]; s_desc[v] = dv; tp.descc[(size_t)d * V + v] = dv; }
         __syncthreads();
         const float* by1 = P.p[R_Y1_B];
         const bool vec = ((ld & 3) == 0) && ((R & 3) == 0) && ((V & 3) == 0);

@@ -86,6 +86,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     /* ---- forward ---- */                                                        \
     X(hx, float, 0, 2, B, H, 1)          /* image_layer(x)            model.py:195 */ \
     X(Cd, float, 0, 2, D, R, 1)          /* desc . W_y1[:,R:]^T + b_y1 (App. A.2)  */ \
+    X(descc, float, 0, 2, D, V, 1)       /* copy of the description matrix (GEMM operand inside the workspace) */ \
     X(hw0, float, 0, 1, H, 1, 1)         /* code_layer(sigmoid(code_bias)) :199-200*/ \
     X(dsig, float, 0, 1, W, 1, 1)        /* sigmoid'(code_bias)                    */ \
     X(c, float, 0, 3, T, B, W)           /* sender code input per step             */ \

@@ -129,7 +129,7 @@ static int build_jobs(mmg_handle* h) {
     auto col = [&](const float* src, int ld, int rows, int cols, float* dst, const float* scale) {
         ColJob& c = jt.c[nc++];
         c.src = src; c.dst = dst; c.scale = scale; c.ld = ld; c.rows = rows; c.cols = cols; c.blk_begin = cblocks;
-        c.vbeta = nullptr; c.vw2 = nullptr;
+        c.vbeta = nullptr; c.vw2 = nullptr; c.wrow = nullptr;
         cblocks += (cols + 15) / 16;
     };
     const Params& P = h->P;
@@ -140,7 +140,7 @@ static int build_jobs(mmg_handle* h) {
     col(tp.dgi, 3 * R, TB, 3 * R, G.p[R_BIH], nullptr);
     col(tp.dgh, 3 * R, TB, 3 * R, G.p[R_BHH], nullptr);
     gemm(tp.dA, R, tp.hstar, R, 0, SRC_STATIC, G.p[R_Y1_W], R + V, B, R, R);           // y1.weight[:, :R]
-    gemm(tp.dC, R, nullptr, V, 0, SRC_DESC, G.p[R_Y1_W] + R, R + V, D, R, V);          // y1.weight[:, R:]
+    gemm(tp.dC, R, tp.descc, V, 0, SRC_STATIC, G.p[R_Y1_W] + R, R + V, D, R, V);      // y1.weight[:, R:]
     col(tp.dC, R, D, R, G.p[R_Y1_B], nullptr);
     col(tp.Py2, R, D, R, G.p[R_Y2_W], nullptr);
     col(tp.dysum, 1, B, 1, G.p[R_Y2_B], nullptr);
@@ -150,7 +150,8 @@ static int build_jobs(mmg_handle* h) {
         gemm(tp.dgpre, R, tp.dbar, V, 0, SRC_STATIC, G.p[R_WD_W], V, TB, R, V);        // w_d
         gemm(tp.dlw, W, tp.g, R, 0, SRC_STATIC, G.p[R_W_W], R, TB, W, R);              // w
         col(tp.dlw, W, TB, W, G.p[R_W_B], nullptr);
-        gemm(tp.dls, 1, tp.h + (size_t)B * R, R, 0, SRC_STATIC, G.p[R_S_W], R, TB, 1, R);      // s
+        col(tp.h + (size_t)B * R, R, TB, R, G.p[R_S_W], nullptr);                      // s.weight = dls^T . h_after
+        jt.c[nc - 1].wrow = tp.dls;
         col(tp.dls, 1, TB, 1, G.p[R_S_B], nullptr);
         // ---- sender ----
         gemm(tp.dhx, H, nullptr, F, 0, SRC_X, G.p[S_IMG_W], F, B, H, F);               // image_layer (sum over steps first)
@@ -165,14 +166,16 @@ static int build_jobs(mmg_handle* h) {
         gemm_virt(tp.dbr, tp.hid_r, P.p[BR_L2_W], tp.h + (size_t)B * R, R, 0, G.p[BR_L1_W] + W, W + R, TB, K, R);
         col(tp.hid_r, K, TB, K, G.p[BR_L1_B], nullptr);
         jt.c[nc - 1].vbeta = tp.dbr; jt.c[nc - 1].vw2 = P.p[BR_L2_W];
-        gemm(tp.dbr, 1, tp.hid_r, K, 0, SRC_STATIC, G.p[BR_L2_W], K, TB, 1, K);
+        col(tp.hid_r, K, TB, K, G.p[BR_L2_W], nullptr);
+        jt.c[nc - 1].wrow = tp.dbr;
         col(tp.dbr, 1, TB, 1, G.p[BR_L2_B], nullptr);
         // ---- baseline_sen: input [h_x || z_r] ----
         gemm_virt(tp.dbs, tp.hid_s, P.p[BS_L2_W], tp.hx, H, B, G.p[BS_L1_W], H + W, TB, K, H);
         gemm_virt(tp.dbs, tp.hid_s, P.p[BS_L2_W], tp.zr, W, 0, G.p[BS_L1_W] + H, H + W, TB, K, W);
         col(tp.hid_s, K, TB, K, G.p[BS_L1_B], nullptr);
         jt.c[nc - 1].vbeta = tp.dbs; jt.c[nc - 1].vw2 = P.p[BS_L2_W];
-        gemm(tp.dbs, 1, tp.hid_s, K, 0, SRC_STATIC, G.p[BS_L2_W], K, TB, 1, K);
+        col(tp.hid_s, K, TB, K, G.p[BS_L2_W], nullptr);
+        jt.c[nc - 1].wrow = tp.dbs;
         col(tp.dbs, 1, TB, 1, G.p[BS_L2_B], nullptr);
     }
     if (ng > MMG_MAX_GEMM || nc > MMG_MAX_COL) return fail("job table overflow");
