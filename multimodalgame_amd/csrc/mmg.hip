@@ -359,7 +359,9 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     {
         Scope sc(h, st, "k_conversation");
         const bool fast = !getenv("MMG_NO_FAST") && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
-        if (fast)
+        if (fast && !getenv("MMG_CONV256"))
+            hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
+        else if (fast)
             hipLaunchKernelGGL((k_conversation_fast<256, 32, 64, 100, 30>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, ar);
         else
             hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
