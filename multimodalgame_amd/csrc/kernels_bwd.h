@@ -107,8 +107,10 @@ __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* 
     // logged losses go through LDS (lc.cw/ce/cb double as staging for the partial losses afterwards)
     const int T = dm.T, tid = threadIdx.x;
     __shared__ double s_part[5][64];
-    for (int i = tid; i < 5 * 64; i += blockDim.x) s_part[i / 64][i % 64] = 0.0;
-    __syncthreads();
+    if (losses_out) {
+        for (int i = tid; i < 5 * 64; i += blockDim.x) s_part[i / 64][i % 64] = 0.0;
+        __syncthreads();
+    }
     for (int i = tid; i < 4 * T; i += blockDim.x) {
         const int k = i / T, t = i - k * T;
         if (k < 3) {
@@ -132,7 +134,7 @@ __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* 
                 }
                 cw = (float)(c_over_n / denom);
                 ce = has ? (float)(c_over_n * (double)lam) : 0.f;
-                if (t < 64) s_part[k][t] = -(double)cw * s5[3] + (double)ce * s5[4];
+                if (t < 64 && losses_out) s_part[k][t] = -(double)cw * s5[3] + (double)ce * s5[4];
             }
             lc.cw[k * T + t] = cw; lc.ce[k * T + t] = ce;
         } else {
@@ -143,7 +145,7 @@ __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* 
             if (n > 0 && nsum > 0) {
                 const double c_over_n = dm.fixed ? 1.0 / ((double)T * n) : 1.0 / nsum;
                 cb = (float)(2.0 * c_over_n);
-                if (t < 64) { s_part[3][t] = c_over_n * st[stat_bas(T, 0, t)]; s_part[4][t] = c_over_n * st[stat_bas(T, 1, t)]; }
+                if (t < 64 && losses_out) { s_part[3][t] = c_over_n * st[stat_bas(T, 0, t)]; s_part[4][t] = c_over_n * st[stat_bas(T, 1, t)]; }
             }
             lc.cb[t] = cb;
         }
@@ -166,6 +168,62 @@ __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* 
         losses_out[6] = (float)nsteps;                                   // exchange steps the reference executes
         losses_out[7] = (float)st[stat_glob(T, 1)];                      // top-k hits
         if (totals) { totals[0] += (double)nsteps; totals[1] += st[stat_glob(T, 1)]; totals[2] += 1.0; }
+    }
+    __syncthreads();
+}
+
+// Split form of loss_coefficients for kernels that want the statistics loads in flight with everything else:
+// coef_load() (call first) fetches this thread's share, coef_compute() turns it into cw / ce / cb in LDS.
+struct CoefRegs { double s5[5]; double nsum; };
+
+__device__ __forceinline__ CoefRegs coef_load(const Dims& dm, const double* __restrict__ st) {
+    // thread i < 4T handles (k = i / T, t = i % T); k == 3 are the baseline coefficients (sender-stream counts)
+    CoefRegs c;
+    const int T = dm.T;
+    const int i = min((int)threadIdx.x, 4 * T - 1);
+    const int k = i / T, t = i - k * T;
+    const int ks = (k < 3) ? k : 2;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) c.s5[j] = st[stat_stream(T, ks, t, j)];
+    double nsum = 0;
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) {
+        const double v = st[stat_stream(T, ks, min(tt, T - 1), 0)];
+        nsum += (tt < T) ? v : 0.0;
+    }
+    c.nsum = nsum;
+    return c;
+}
+
+__device__ __forceinline__ void coef_compute(const Dims& dm, const CoefRegs& c, LossCoef lc) {
+    const int T = dm.T, i = threadIdx.x;
+    if (i < 4 * T) {
+        const int k = i / T, t = i - k * T;
+        const double n = c.s5[0];
+        if (k < 3) {
+            const int len = (k == 1) ? T - 1 : T;
+            const float lam = (k == 0) ? dm.es : (k == 1) ? dm.erec : dm.esen;
+            const bool has = (k == 0) ? dm.has_es : (k == 1) ? dm.has_erec : dm.has_esen;
+            float cw = 0.f, ce = 0.f;
+            if (n > 0 && c.nsum > 0) {
+                const double c_over_n = dm.fixed ? 1.0 / ((double)len * n) : 1.0 / c.nsum;
+                double denom = 1.0;
+                if (n > 1) {                                            // model.py:914-915
+                    const double mean = c.s5[1] / n;
+                    double var = (c.s5[2] - n * mean * mean) / (n - 1.0);
+                    if (var < 0) var = 0;
+                    const double sd = sqrt(var);
+                    denom = sd > 1.0 ? sd : 1.0;
+                }
+                cw = (float)(c_over_n / denom);
+                ce = has ? (float)(c_over_n * (double)lam) : 0.f;
+            }
+            lc.cw[k * T + t] = cw; lc.ce[k * T + t] = ce;
+        } else {
+            float cb = 0.f;
+            if (n > 0 && c.nsum > 0) cb = (float)(2.0 * (dm.fixed ? 1.0 / ((double)T * n) : 1.0 / c.nsum));
+            lc.cb[t] = cb;
+        }
     }
     __syncthreads();
 }
@@ -200,7 +258,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
     float* s_red = p; p += MMG_BLOCK;
     float* s_misc = p;
 
-    loss_coefficients(dm, tp.stats, lc, b == 0 ? tp.losses : nullptr, b == 0 ? tp.totals : nullptr);
+    loss_coefficients(dm, tp.stats, lc, nullptr, nullptr);        // logged losses: spare block of k_wgrad
 
     const bool binary = dm.use_binary != 0;
     const int tstar = tp.tstar[b];
@@ -427,7 +485,9 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, si
 }
 
 __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict__ jt, const float* __restrict__ x,
-                                                     const float* __restrict__ desc, float* __restrict__ part
+                                                     const float* __restrict__ desc, float* __restrict__ part,
+                                                     Dims dm, const double* __restrict__ stats, float* __restrict__ losses,
+                                                     double* __restrict__ totals
 #ifdef MMG_TIMING
                                                      , long long* __restrict__ dbg2
 #endif
@@ -452,6 +512,14 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     float* s_part = &s_b[0][0][0];                                                   // column-sum staging
     __shared__ float s_red[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x == jt->n_wblocks) {
+        // spare block: the six logged loss scalars, the semantic step count and the running totals (off every
+        // critical path: this launch lasts ~17 us, the bookkeeping ~3)
+        __shared__ float s_lc[7 * 64];
+        LossCoef lc; lc.cw = s_lc; lc.ce = s_lc + 3 * dm.T; lc.cb = s_lc + 6 * dm.T;
+        loss_coefficients(dm, stats, lc, losses, totals);
+        return;
+    }
     if ((int)blockIdx.x < jt->gemm_tiles) {
         // XCD-aware tile order: workgroup b is dispatched to XCD b % 8, and each XCD has its own 4 MB L2.  Giving
         // every XCD a CONTIGUOUS range of tiles (= one or two jobs) keeps the operand tapes it re-reads

@@ -472,29 +472,19 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int B = dm.B, T = dm.T;
     const bool binary = dm.use_binary != 0;
+#ifdef MMG_TIMING
+#define MMG_BSTAMP(slot) do { if (b == 0 && tid == 0) tp.dbg[128 + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define MMG_BSTAMP(slot) do {} while (0)
+#endif
+    MMG_BSTAMP(0);
+    // ---- prologue: issue EVERY independent global load before the first dependent use (one memory round trip for the
+    // weight fragments, overlapping the tstar -> tape-preload chain), then stage the tape into LDS.
+    const CoefRegs creg = coef_load(dm, tp.stats);      // statistics first: they gate the first arithmetic of the kernel
     const int tstar = tp.tstar[b];
-    const int nst = tstar + 1;
-    for (int i = tid; i < nst * W; i += NT) {
-        const int t = i / W, j = i - t * W;
-        const size_t o = ((size_t)t * B + b) * W + j;
-        t_w[i] = tp.w[o]; t_z[i] = tp.z[o];
-        if (binary) { t_pw[i] = tp.pw[o]; t_pz[i] = tp.pz[o]; }
-    }
-    for (int i = tid; i < nst * R; i += NT) { const int t = i / R, j = i - t * R; t_g[i] = tp.g[((size_t)t * B + b) * R + j]; }
-    for (int i = tid; i < nst * 4 * R; i += NT) { const int t = i / (4 * R), j = i - t * 4 * R; t_gru[i] = tp.gru[((size_t)t * B + b) * 4 * R + j]; }
-    for (int i = tid; i < (nst + 1) * R; i += NT) { const int t = i / R, j = i - t * R; t_h[i] = tp.h[((size_t)t * B + b) * R + j]; }
-    for (int i = tid; i < nst * H; i += NT) { const int t = i / H, j = i - t * H; t_a[i] = tp.a[((size_t)t * B + b) * H + j]; }
-    if (tid < nst) {
-        const size_t o = (size_t)tid * B + b;
-        t_bs[tid] = tp.bs[o]; t_br[tid] = tp.br[o]; t_s[tid] = tp.s[o]; t_ps[tid] = tp.ps[o];
-    }
-    LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
-    loss_coefficients(dm, tp.stats, lc, b == 0 ? tp.losses : nullptr, b == 0 ? tp.totals : nullptr);
+    const int tgt = (int)target[b];
     const float L = tp.logs[b];
-    const float* cw_s = lc.cw, *cw_r = lc.cw + T, *cw_z = lc.cw + 2 * T;
-    const float* ce_s = lc.ce, *ce_r = lc.ce + T, *ce_z = lc.ce + 2 * T;
-
-    // ---- transposed fragments: output unit k4 = tid/4, reduction slice p4 = tid%4 (n = p4 + 4*i)
+    // transposed fragments: output unit k4 = tid/4, reduction slice p4 = tid%4 (n = p4 + 4*i)
     const int k4 = tid / K4, p4 = tid % K4;
     float wwT[W / K4], whT[R / K4], whhT[3 * R / K4];
 #pragma unroll
@@ -507,19 +497,56 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     float wbT[W];                                  // binary_layer column tid: W_b[j][tid]
 #pragma unroll
     for (int j = 0; j < W; ++j) wbT[j] = P.p[S_BIN_W][(size_t)j * H + tid];
-    // output-step quantities (one step per sample): fetch before the loop as well
-    const int tgt = (int)target[b];
-    float y1T[R / K4];                             // y1[:, :R]^T fragment
+    float y1T[R / K4];                             // y1[:, :R]^T fragment (output step only)
 #pragma unroll
     for (int i = 0; i < R / K4; ++i) y1T[i] = P.p[R_Y1_W][(size_t)(p4 + K4 * i) * (R + V) + k4];
     float y1r[R / K4];                             // y1[:, :R] row k4 fragment (forward product A = y1h . h*)
 #pragma unroll
     for (int i = 0; i < R / K4; ++i) y1r[i] = P.p[R_Y1_W][(size_t)k4 * (R + V) + p4 + K4 * i];
-    const float dy_mine = (tid < D) ? (tp.sm[(size_t)b * D + tid] - (tid == tgt ? 1.f : 0.f)) / (float)dm.Bg : 0.f;
+    const float sm_mine = (tid < D) ? tp.sm[(size_t)b * D + tid] : 0.f;
     const float w2_mine = (tid < R) ? P.p[R_Y2_W][tid] : 0.f;
     float cdcol[D];                                // Cd[:, tid] for tid < R
 #pragma unroll
     for (int d = 0; d < D; ++d) cdcol[d] = (tid < R) ? tp.Cd[(size_t)d * R + tid] : 0.f;
+    // forward tape of this sample -> registers for ALL T steps (no dependence on tstar: every load of the prologue is
+    // in flight at once; indices are clamped instead of guarded so the compiler keeps counted waits), LDS stores below
+    constexpr int NW_ = TMAX * W / NT, NG_ = TMAX * R / NT, NU_ = TMAX * 4 * R / NT, NH_ = ((TMAX + 1) * R + NT - 1) / NT, NA_ = TMAX * H / NT;
+    float rw_[NW_], rz_[NW_], rpw_[NW_], rpz_[NW_], rg_[NG_], ru_[NU_], rh_[NH_], ra_[NA_];
+    const int Tm1 = T - 1;
+#pragma unroll
+    for (int u = 0; u < NW_; ++u) {
+        const int i = tid + NT * u, t = min(i / W, Tm1), j = i % W;
+        const size_t o = ((size_t)t * B + b) * W + j;
+        rw_[u] = tp.w[o]; rz_[u] = tp.z[o]; rpw_[u] = tp.pw[o]; rpz_[u] = tp.pz[o];
+    }
+#pragma unroll
+    for (int u = 0; u < NG_; ++u) { const int i = tid + NT * u, t = min(i / R, Tm1), j = i % R; rg_[u] = tp.g[((size_t)t * B + b) * R + j]; }
+#pragma unroll
+    for (int u = 0; u < NU_; ++u) { const int i = tid + NT * u, t = min(i / (4 * R), Tm1), j = i % (4 * R); ru_[u] = tp.gru[((size_t)t * B + b) * 4 * R + j]; }
+#pragma unroll
+    for (int u = 0; u < NH_; ++u) { const int i = tid + NT * u, t = min(i / R, T), j = i % R; rh_[u] = tp.h[((size_t)t * B + b) * R + j]; }
+#pragma unroll
+    for (int u = 0; u < NA_; ++u) { const int i = tid + NT * u, t = min(i / H, Tm1), j = i % H; ra_[u] = tp.a[((size_t)t * B + b) * H + j]; }
+    const size_t so = (size_t)min(tid, Tm1) * B + b;
+    const float rbs_ = tp.bs[so], rbr_ = tp.br[so], rs_ = tp.s[so], rps_ = tp.ps[so];
+    MMG_BSTAMP(1);
+    LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
+    coef_compute(dm, creg, lc);                                   // (the logged losses: a spare block of k_wgrad)
+#pragma unroll
+    for (int u = 0; u < NW_; ++u) { const int i = tid + NT * u; t_w[i] = rw_[u]; t_z[i] = rz_[u]; t_pw[i] = rpw_[u]; t_pz[i] = rpz_[u]; }
+#pragma unroll
+    for (int u = 0; u < NG_; ++u) t_g[tid + NT * u] = rg_[u];
+#pragma unroll
+    for (int u = 0; u < NU_; ++u) t_gru[tid + NT * u] = ru_[u];
+#pragma unroll
+    for (int u = 0; u < NH_; ++u) { const int i = tid + NT * u; if (i < (TMAX + 1) * R) t_h[i] = rh_[u]; }
+#pragma unroll
+    for (int u = 0; u < NA_; ++u) t_a[tid + NT * u] = ra_[u];
+    if (tid < TMAX) { t_bs[tid] = rbs_; t_br[tid] = rbr_; t_s[tid] = rs_; t_ps[tid] = rps_; }
+    MMG_BSTAMP(2);
+    const float* cw_s = lc.cw, *cw_r = lc.cw + T, *cw_z = lc.cw + 2 * T;
+    const float* ce_s = lc.ce, *ce_r = lc.ce + T, *ce_z = lc.ce + 2 * T;
+    const float dy_mine = (tid < D) ? (sm_mine - (tid == tgt ? 1.f : 0.f)) / (float)dm.Bg : 0.f;
 
     if (tid < R) s_dh[tid] = 0.f;
     float dhx_acc = 0.f;
@@ -534,10 +561,12 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         if (tid == 0) { tp.dls[row] = 0.f; tp.dbs[row] = 0.f; tp.dbr[row] = 0.f; }
     }
     __syncthreads();
+    MMG_BSTAMP(3);
 
     for (int t = tstar; t >= 0; --t) {
         const size_t row = (size_t)t * B + b;
         const bool act_next = binary && (t < tstar);
+        MMG_BSTAMP(8 + 6 * t);
         // ===== (1) gradient seeds of both message heads, of the stop bit and of the baselines
         if (tid < W) {
             float v = 0.f;
@@ -566,7 +595,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
                 tp.hstar[(size_t)b * R + tid - 64] = t_h[(t + 1) * R + tid - 64];
             }
         }
-        __syncthreads();                                                    // b1
+        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 1);                              // b1
         // ===== (2) dg = W_w^T dlw -> dgpre ; sender: da = W_b^T dlz -> dpre
         {
             float acc = 0.f;
@@ -604,7 +633,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             acc = lane_group_sum<K4>(acc);
             if (p4 == 0) s_A[k4] = acc;
         }
-        __syncthreads();                                                    // b2
+        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 2);                              // b2
         if (t == tstar) {
             if (tid < R) {
                 const float a = s_A[tid];
@@ -630,7 +659,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             acc = lane_group_sum<K4>(acc);
             if (p4 == 0) s_dhs[k4] = s_dh[k4] + acc + wsk * s_misc[0];
         }
-        __syncthreads();                                                    // b3
+        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 3);                              // b3
         // ===== (4) GRU cell backward (thread i < R)
         if (tid < R) {
             const float* gr = t_gru + t * 4 * R;
@@ -646,7 +675,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             s_dgh[tid] = drp; s_dgh[R + tid] = dup; s_dgh[2 * R + tid] = dnp * rr;
             s_dh[tid] = dh * uu;
         }
-        __syncthreads();                                                    // b4
+        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 4);                              // b4
         // ===== (5) dh_{t-1} = dh * u + W_hh^T dgh
         {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -658,8 +687,9 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             const float acc = lane_group_sum<K4>((a0 + a1) + (a2 + a3));
             if (p4 == 0) s_dh[k4] += acc;
         }
-        __syncthreads();                                                    // b5
+        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 5);                              // b5
     }
+    MMG_BSTAMP(4);
     tp.dhx[(size_t)b * H + tid] = dhx_acc;
     // code_bias path: dc0 = W_c^T dpre_0   (once per sample)
     if (binary) {

@@ -398,7 +398,7 @@ extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_ta
     {
         Scope sc(h, st, "k_bwd_conv");
         const bool fast = !getenv("MMG_NO_FAST") && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
-        if (fast)
+        if (fast)      // (a 512-thread variant of this kernel measured slower: 31.8 vs 28.8 us -- it is not issue-bound)
             hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target);
         else
             hipLaunchKernelGGL(k_bwd_conv, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
@@ -411,8 +411,9 @@ extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_ta
     }
     {
         Scope sc(h, st, "k_wgrad");
-        hipLaunchKernelGGL(k_wgrad, dim3(h->jt.n_wblocks), dim3(MMG_BLOCK), 0, st,
-                           (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart
+        hipLaunchKernelGGL(k_wgrad, dim3(h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
+                           (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
+                           h->tp.losses, h->tp.totals
 #ifdef MMG_TIMING
                            , h->tp.dbg2
 #endif

@@ -33,3 +33,15 @@ for st in range(int(eng.tape["tstar"][0]) + 1):
 
 wall_us = (dbg[3] - dbg[0]) * tick / 1e3
 print("kernel body %.2f us, shader cycles %d -> shader clock %.0f MHz" % (wall_us, dbg[5] - dbg[4], (dbg[5] - dbg[4]) / wall_us))
+
+bd = dbg[128:]
+print("== k_bwd_conv_fast (sample 0): tape preload %.2f us | loss coefficients %.2f us | weights+zero-fill %.2f us | loop %.2f us" % (
+    (bd[1]-bd[0])*tick/1e3, (bd[2]-bd[1])*tick/1e3, (bd[3]-bd[2])*tick/1e3, (bd[4]-bd[3])*tick/1e3))
+for st in range(int(eng.tape["tstar"][0]), -1, -1):
+    base = 8 + 6 * st
+    prev = bd[base]; parts = []
+    for k in range(1, 6):
+        cur = bd[base + k]
+        if cur < prev: break
+        parts.append("(%d) %.2f" % (k, (cur - prev) * tick / 1e3)); prev = cur
+    print("bwd step %d: total %.2f us | " % (st, (prev - bd[base]) * tick / 1e3) + " ".join(parts))
