@@ -36,6 +36,15 @@ __device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float ftanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 __device__ __forceinline__ float flog(float x) { return __logf(x); }
 
+// d loss / d logit of one Bernoulli unit (kernels_bwd.h: bit_seed) with hardware rcp / log
+__device__ __forceinline__ float bit_seed_fast(float q, float p, float wh, float ce) {
+    const float pe = p + MMG_EPS, qe = 1.f - p + MMG_EPS;
+    const float rp = __builtin_amdgcn_rcpf(pe), rq = __builtin_amdgcn_rcpf(qe);
+    float dLdp = -wh * (q * rp - (1.f - q) * rq);
+    if (ce != 0.f) dLdp += ce * (flog(pe) + p * rp - flog(qe) - (1.f - p) * rq);
+    return dLdp * p * (1.f - p);
+}
+
 // dot product of NV float4 register quads with float4 operands read from LDS at base + stride*j,
 // as four independent FMA chains (x, y, z, w components) to keep the single wave per SIMD issuing.
 template <int NV>
@@ -488,21 +497,21 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     const int k4 = tid / K4, p4 = tid % K4;
     float wwT[W / K4], whT[R / K4], whhT[3 * R / K4];
 #pragma unroll
-    for (int i = 0; i < W / K4; ++i) wwT[i] = P.p[R_W_W][(size_t)(p4 + K4 * i) * R + k4];
+    for (int i = 0; i < W / K4; ++i) wwT[i] = P.p[R_W_W][(size_t)(p4 * (W / K4) + i) * R + k4];
 #pragma unroll
-    for (int i = 0; i < R / K4; ++i) whT[i] = P.p[R_WH_W][(size_t)(p4 + K4 * i) * R + k4];
+    for (int i = 0; i < R / K4; ++i) whT[i] = P.p[R_WH_W][(size_t)(p4 * (R / K4) + i) * R + k4];
 #pragma unroll
-    for (int i = 0; i < 3 * R / K4; ++i) whhT[i] = P.p[R_WHH][(size_t)(p4 + K4 * i) * R + k4];
+    for (int i = 0; i < 3 * R / K4; ++i) whhT[i] = P.p[R_WHH][(size_t)(p4 * (3 * R / K4) + i) * R + k4];
     const float wsk = P.p[R_S_W][k4];
     float wbT[W];                                  // binary_layer column tid: W_b[j][tid]
 #pragma unroll
     for (int j = 0; j < W; ++j) wbT[j] = P.p[S_BIN_W][(size_t)j * H + tid];
     float y1T[R / K4];                             // y1[:, :R]^T fragment (output step only)
 #pragma unroll
-    for (int i = 0; i < R / K4; ++i) y1T[i] = P.p[R_Y1_W][(size_t)(p4 + K4 * i) * (R + V) + k4];
+    for (int i = 0; i < R / K4; ++i) y1T[i] = P.p[R_Y1_W][(size_t)(p4 * (R / K4) + i) * (R + V) + k4];
     float y1r[R / K4];                             // y1[:, :R] row k4 fragment (forward product A = y1h . h*)
 #pragma unroll
-    for (int i = 0; i < R / K4; ++i) y1r[i] = P.p[R_Y1_W][(size_t)k4 * (R + V) + p4 + K4 * i];
+    for (int i = 0; i < R / K4; ++i) y1r[i] = P.p[R_Y1_W][(size_t)k4 * (R + V) + p4 * (R / K4) + i];
     const float sm_mine = (tid < D) ? tp.sm[(size_t)b * D + tid] : 0.f;
     const float w2_mine = (tid < R) ? P.p[R_Y2_W][tid] : 0.f;
     float cdcol[D];                                // Cd[:, tid] for tid < R
@@ -570,16 +579,16 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         // ===== (1) gradient seeds of both message heads, of the stop bit and of the baselines
         if (tid < W) {
             float v = 0.f;
-            if (act_next) v = bit_seed(t_w[t * W + tid], t_pw[t * W + tid], (L - t_br[t]) * cw_r[t], ce_r[t]);
+            if (act_next) v = bit_seed_fast(t_w[t * W + tid], t_pw[t * W + tid], (L - t_br[t]) * cw_r[t], ce_r[t]);
             s_dlw[tid] = v; tp.dlw[row * W + tid] = v;
         } else if (tid >= 64 && tid < 64 + W) {
             const int j = tid - 64;
             float v = 0.f;
-            if (binary) v = bit_seed(t_z[t * W + j], t_pz[t * W + j], (L - t_bs[t]) * cw_z[t], ce_z[t]);
+            if (binary) v = bit_seed_fast(t_z[t * W + j], t_pz[t * W + j], (L - t_bs[t]) * cw_z[t], ce_z[t]);
             s_dlz[j] = v; tp.dlz[row * W + j] = v;
         } else if (tid == 128) {
             float v = 0.f;
-            if (binary && !dm.fixed) v = bit_seed(t_s[t], t_ps[t], (L - t_br[t]) * cw_s[t], ce_s[t]);
+            if (binary && !dm.fixed) v = bit_seed_fast(t_s[t], t_ps[t], (L - t_br[t]) * cw_s[t], ce_s[t]);
             s_misc[0] = v; tp.dls[row] = v;
         } else if (tid == 192) {                                            // MSE seeds (model.py:971-988)
             tp.dbs[row] = binary ? lc.cb[t] * (t_bs[t] - L) : 0.f;
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             float acc = 0.f;
             if (act_next) {
 #pragma unroll
-                for (int i = 0; i < W / K4; ++i) acc = fmaf(wwT[i], s_dlw[p4 + K4 * i], acc);
+                for (int i = 0; i < W / K4; ++i) acc = fmaf(wwT[i], s_dlw[p4 * (W / K4) + i], acc);
             }
             acc = lane_group_sum<K4>(acc);
             if (p4 == 0) {
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         if (t == tstar) {                                                   // A = y1[:, :R] h*
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < R / K4; ++i) acc = fmaf(y1r[i], t_h[(t + 1) * R + p4 + K4 * i], acc);
+            for (int i = 0; i < R / K4; ++i) acc = fmaf(y1r[i], t_h[(t + 1) * R + p4 * (R / K4) + i], acc);
             acc = lane_group_sum<K4>(acc);
             if (p4 == 0) s_A[k4] = acc;
         }
@@ -650,11 +659,11 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             float acc = 0.f;
             if (act_next) {
 #pragma unroll
-                for (int i = 0; i < R / K4; ++i) acc = fmaf(whT[i], s_dgpre[p4 + K4 * i], acc);
+                for (int i = 0; i < R / K4; ++i) acc = fmaf(whT[i], s_dgpre[p4 * (R / K4) + i], acc);
             }
             if (t == tstar) {
 #pragma unroll
-                for (int i = 0; i < R / K4; ++i) acc = fmaf(y1T[i], s_dA[p4 + K4 * i], acc);
+                for (int i = 0; i < R / K4; ++i) acc = fmaf(y1T[i], s_dA[p4 * (R / K4) + i], acc);
             }
             acc = lane_group_sum<K4>(acc);
             if (p4 == 0) s_dhs[k4] = s_dh[k4] + acc + wsk * s_misc[0];
@@ -681,8 +690,9 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
             for (int i = 0; i < 3 * R / K4; i += 4) {
-                a0 = fmaf(whhT[i], s_dgh[p4 + K4 * i], a0); a1 = fmaf(whhT[i + 1], s_dgh[p4 + K4 * (i + 1)], a1);
-                a2 = fmaf(whhT[i + 2], s_dgh[p4 + K4 * (i + 2)], a2); a3 = fmaf(whhT[i + 3], s_dgh[p4 + K4 * (i + 3)], a3);
+                const float4 dv = *reinterpret_cast<const float4*>(s_dgh + p4 * (3 * R / K4) + i);
+                a0 = fmaf(whhT[i], dv.x, a0); a1 = fmaf(whhT[i + 1], dv.y, a1);
+                a2 = fmaf(whhT[i + 2], dv.z, a2); a3 = fmaf(whhT[i + 3], dv.w, a3);
             }
             const float acc = lane_group_sum<K4>((a0 + a1) + (a2 + a3));
             if (p4 == 0) s_dh[k4] += acc;
