@@ -655,7 +655,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
     __shared__ float s_part[64][4][16];
     __shared__ int s_tmax;
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, K = dm.K, T = dm.T;
-    const int which = blockIdx.z;                       // 0: baseline_rec, 1: baseline_sen
+    const int which = blockIdx.z & 1;                   // 0: baseline_rec, 1: baseline_sen
+    const int tpart = blockIdx.z >> 1, tparts = gridDim.z >> 1;   // the steps are split over `tparts` workgroups
     const int b0 = blockIdx.x * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -671,7 +672,16 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
         s_tmax = (skip_inactive && !dm.fixed) ? tm : T - 1;
     }
     __syncthreads();
-    const int tmax = s_tmax;
+    const int tlast = s_tmax;
+    const int tper = (tlast + tparts) / tparts;          // ceil((tlast + 1) / tparts)
+    const int tbeg = tpart * tper, tmax = min(tlast, tbeg + tper - 1);
+    if (tbeg > tlast) return;
+#ifdef MMG_TIMING
+#define MMG_B2STAMP(slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) tp.dbg[64 + 32 * which + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define MMG_B2STAMP(slot) do {} while (0)
+#endif
+    MMG_B2STAMP(0);
     const float* W1 = which ? P.p[BS_L1_W] : P.p[BR_L1_W];
     const int ldw = which ? H + W : W + R;
     const float* wrow = W1 + (size_t)(nv ? n : 0) * ldw;
@@ -685,8 +695,32 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
     const bool vecW = ((W & 15) == 0) && ((ldw & 3) == 0) && ((H & 3) == 0);
     const bool vecR = ((R & 15) == 0) && ((ldw & 3) == 0) && ((W & 3) == 0);
     f32x4 base = {0.f, 0.f, 0.f, 0.f};
-    if (which) seg_accumulate(base, tp.hx + (size_t)(xv ? bx : 0) * H, xv, wrow, nv, H, q, vecH);
+    if (which) {
+        if (vecH && H == 256) {                          // every operand load in flight at once, two MFMA chains
+            const float* xr = tp.hx + (size_t)(xv ? bx : 0) * H;
+            float4 a[16], bq[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float4 av = *reinterpret_cast<const float4*>(xr + u * 16 + q * 4);
+                const float4 bv = *reinterpret_cast<const float4*>(wrow + u * 16 + q * 4);
+                a[u] = make_float4(xv ? av.x : 0.f, xv ? av.y : 0.f, xv ? av.z : 0.f, xv ? av.w : 0.f);
+                bq[u] = make_float4(nv ? bv.x : 0.f, nv ? bv.y : 0.f, nv ? bv.z : 0.f, nv ? bv.w : 0.f);
+            }
+            f32x4 b1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                base = mfma16(a[u].x, bq[u].x, base); b1 = mfma16(a[u + 1].x, bq[u + 1].x, b1);
+                base = mfma16(a[u].y, bq[u].y, base); b1 = mfma16(a[u + 1].y, bq[u + 1].y, b1);
+                base = mfma16(a[u].z, bq[u].z, base); b1 = mfma16(a[u + 1].z, bq[u + 1].z, b1);
+                base = mfma16(a[u].w, bq[u].w, base); b1 = mfma16(a[u + 1].w, bq[u + 1].w, b1);
+            }
+            base += b1;
+        } else {
+            seg_accumulate(base, tp.hx + (size_t)(xv ? bx : 0) * H, xv, wrow, nv, H, q, vecH);
+        }
+    }
     const size_t xs = (size_t)(xv ? bx : 0);
+    MMG_B2STAMP(1);
 
     if (frag) {
         // weights of the per-step segments stay in registers for the whole walk over t
@@ -697,23 +731,24 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
         const float* msg = which ? tp.zr : tp.z;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            if (u <= tmax) {
-                frag_load(xm[u], msg + ((size_t)u * B + xs) * W, xv, W, q);
-                if (!which) frag_load(xt[u], tp.h + ((size_t)(u + 1) * B + xs) * R, xv, R, q);
+            if (tbeg + u <= tmax) {
+                frag_load(xm[u], msg + ((size_t)(tbeg + u) * B + xs) * W, xv, W, q);
+                if (!which) frag_load(xt[u], tp.h + ((size_t)(tbeg + u + 1) * B + xs) * R, xv, R, q);
             }
         }
-        for (int t0 = 0; t0 <= tmax; t0 += 4) {
+        for (int t0 = tbeg; t0 <= tmax; t0 += 4) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int t = t0 + u;
             if (t > tmax) break;
+            MMG_B2STAMP(2 + t);
             if (t + 3 <= tmax) {                                          // keep three steps of inputs in flight
                 frag_load(xm[(u + 3) & 3], msg + ((size_t)(t + 3) * B + xs) * W, xv, W, q);
                 if (!which) frag_load(xt[(u + 3) & 3], tp.h + ((size_t)(t + 4) * B + xs) * R, xv, R, q);
             }
-            f32x4 acc = base;
+            f32x4 acc = base, acc2 = {0.f, 0.f, 0.f, 0.f};
             frag_mfma(acc, xm[u], w_msg, W, q);
-            if (!which) frag_mfma(acc, xt[u], w_st, R, q);
+            if (!which) { frag_mfma(acc2, xt[u], w_st, R, q); acc += acc2; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int bo = b0 + q * 4 + r;
@@ -725,7 +760,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
           }
         }
     } else {
-        for (int t = 0; t <= tmax; ++t) {
+        for (int t = tbeg; t <= tmax; ++t) {
             const size_t xrow = (size_t)t * B + xs;
             f32x4 acc = base;
             if (which) {
@@ -744,13 +779,15 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
             }
         }
     }
+    MMG_B2STAMP(20);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < (tmax + 1) * 16; idx += MMG_BLOCK) {
-        const int t = idx >> 4, r = idx & 15;
+    for (int idx = threadIdx.x; idx < (tmax - tbeg + 1) * 16; idx += MMG_BLOCK) {
+        const int t = tbeg + (idx >> 4), r = idx & 15;
         if (b0 + r < B)
             part[((size_t)t * B + b0 + r) * npb + blockIdx.y] =
                 (s_part[t][0][r] + s_part[t][1][r]) + (s_part[t][2][r] + s_part[t][3][r]);
     }
+    MMG_B2STAMP(21);
 }
 
 }  // namespace mmg

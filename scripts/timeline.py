@@ -45,3 +45,9 @@ for st in range(int(eng.tape["tstar"][0]), -1, -1):
         if cur < prev: break
         parts.append("(%d) %.2f" % (k, (cur - prev) * tick / 1e3)); prev = cur
     print("bwd step %d: total %.2f us | " % (st, (prev - bd[base]) * tick / 1e3) + " ".join(parts))
+
+for which, nm in ((0, "baseline_rec"), (1, "baseline_sen")):
+    d2 = dbg[64 + 32 * which:]
+    steps = [(d2[2 + t + 1] - d2[2 + t]) * tick / 1e3 for t in range(9) if d2[2 + t + 1] > d2[2 + t]]
+    print("== k_baselines2 %s block(0,0): setup+h_x product %.2f us | steps %s | last step+tail %.2f us | final reduce %.2f us" % (
+        nm, (d2[1] - d2[0]) * tick / 1e3, " ".join("%.2f" % v for v in steps), (d2[20] - d2[2 + len(steps)]) * tick / 1e3, (d2[21] - d2[20]) * tick / 1e3))
