@@ -152,8 +152,18 @@ def run_gpu(args, rank, world, local_rank):
             achieved, peak, unit = amount / secs / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             achieved, peak, unit = amount / secs / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        # HBM traffic of that kernel from the committed PMC summary (counters need their own rocprofv3 passes and
+        # cannot be collected inside this run): profiles/*_pmc_hbm_traffic.json, per-dispatch FETCH_SIZE/WRITE_SIZE
+        traffic = None
+        try:
+            import glob
+            pmc = json.load(open(sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_hbm_traffic.json")))[-1]))["kernels"]
+            key = {"k_conversation": "k_conversation_fast2", "k_bwd_conv": "k_bwd_conv_fast", "k_baselines": "k_baselines2"}.get(dom, dom)
+            traffic = pmc[key]["traffic_bytes_corrected"] if key in pmc else None
+        except Exception:
+            traffic = None
         roof = dict(bound=bound, kernel=dom, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                    traffic=None, launch_us=avg[dom] * 1e3,
+                    traffic=traffic, launch_us=avg[dom] * 1e3,
                     kernels_us={k: round(v * 1e3, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])})
     return elapsed, ex_steps, roof
 
