@@ -72,7 +72,7 @@ def run_gpu(args, rank, world, local_rank):
     from multimodalgame_amd.engine import Engine
     from multimodalgame_amd.dist import DataParallel
     import torch.distributed as dist
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (ranks may share a GPU in the gloo smoke test)
     torch.cuda.set_device(dev)
     B = PER_GPU_BATCH
     Bg = B * world
@@ -128,18 +128,19 @@ def run_gpu(args, rank, world, local_rank):
     # per-kernel launch durations of the same workload, HIP events on the launch stream (rank 0)
     roof = None
     kern_ms = {}
-    if rank == 0:
-        eng.set_profiling(True)
-        reps = min(20, args.steps)
-        for i in range(reps):
+    reps = min(20, args.steps)
+    for i in range(reps):                    # every rank runs these steps (collectives!); only rank 0 records timings
+        if rank == 0:
             eng.set_profiling(True)
-            if world > 1:
-                dp.train_step(xs[args.warmup + i], ts[args.warmup + i], desc_d, seed=args.seed)
-            else:
-                eng.train_step(xs[args.warmup + i], ts[args.warmup + i], desc_d, seed=args.seed)
-            torch.cuda.synchronize(dev)
+        if world > 1:
+            dp.train_step(xs[args.warmup + i], ts[args.warmup + i], desc_d, seed=args.seed)
+        else:
+            eng.train_step(xs[args.warmup + i], ts[args.warmup + i], desc_d, seed=args.seed)
+        torch.cuda.synchronize(dev)
+        if rank == 0:
             for name, ms in eng.kernel_times():
                 kern_ms.setdefault(name, []).append(ms)
+    if rank == 0:
         eng.set_profiling(False)
         avg = {k: float(np.mean(v)) for k, v in kern_ms.items()}
         dom = max(avg, key=avg.get)
@@ -220,7 +221,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; MMG_BENCH_BACKEND=gloo only exists to smoke-test this code path on a 1-GPU box
+        dist.init_process_group(os.environ.get("MMG_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     elapsed, ex_steps, roof = run_gpu(args, rank, world, local_rank)
     if rank == 0:
         line = {
