@@ -412,17 +412,17 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_dC(Dims dm, Params P, Tape tp) {
         float dc0 = 0.f, dc1 = 0.f, py0 = 0.f, py1 = 0.f;
         if (g < groups && r < R) {
             const float cv = tp.Cd[(size_t)d * R + r];
-            for (int b = g; b < B; b += 8 * groups) {               // 8 samples (16 loads) in flight per thread
-                float yv[8], pv[8];
+            for (int b = g; b < B; b += 16 * groups) {              // 16 samples (32 loads) in flight per thread
+                float yv[16], pv[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int bb = b + u * groups;
                     const bool ok = bb < B;
                     yv[u] = ok ? tp.dy[(size_t)bb * D + d] : 0.f;
                     pv[u] = ok ? tp.Astar[(size_t)bb * R + r] + cv : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u += 2) {
+                for (int u = 0; u < 16; u += 2) {
                     if (pv[u] > 0.f) { dc0 += yv[u]; py0 = fmaf(yv[u], pv[u], py0); }
                     if (pv[u + 1] > 0.f) { dc1 += yv[u + 1]; py1 = fmaf(yv[u + 1], pv[u + 1], py1); }
                 }
@@ -749,6 +749,16 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
     // otherwise the MMG_GN_BLOCKS partials of k_gradnorm over the all-reduced gradient (data parallel).
     __shared__ float s_coef[4];
     __shared__ float s_ss[4][MMG_BLOCK];
+    // this thread's element quad: issue its loads first so they share one memory round trip with the partials
+    float* st1 = state; float* st2 = state + oa.total;
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const bool have = i0 < oa.total;
+    const int64_t il = have ? i0 : 0;
+    const float4 g0 = *reinterpret_cast<const float4*>(grads + il);
+    const float4 w0 = *reinterpret_cast<const float4*>(params + il);
+    const float4 s0 = *reinterpret_cast<const float4*>(st1 + il);
+    const float4 v0 = (oa.optim_type == MMG_OPT_ADAM) ? *reinterpret_cast<const float4*>(st2 + il) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t step = counter[1] + (oa.bump_step ? 1u : 0u);      // k_gradnorm bumps it in the DP path
     {
         const int n = oa.from_wgrad ? jt->n_wblocks : MMG_GN_BLOCKS;
         float ss[4] = {0.f, 0.f, 0.f, 0.f};
@@ -779,29 +789,27 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
         }
     }
     __syncthreads();
-    const uint32_t step = counter[1] + (oa.bump_step ? 1u : 0u);      // k_gradnorm bumps it in the DP path
     const float b1 = 0.9f, b2 = 0.999f;
     float bc1 = 1.f, bc2s = 1.f;
     if (oa.optim_type == MMG_OPT_ADAM) {
         bc1 = 1.f - powf(b1, (float)step);
         bc2s = sqrtf(1.f - powf(b2, (float)step));
     }
-    float* st1 = state; float* st2 = state + oa.total;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < oa.total;
-         i += (int64_t)gridDim.x * blockDim.x * 4) {
+    for (int64_t i = i0; i < oa.total; i += (int64_t)gridDim.x * blockDim.x * 4) {
         int a = 0;
         if (i >= oa.agent_begin[1]) a = 1;
         if (i >= oa.agent_begin[2]) a = 2;
         if (i >= oa.agent_begin[3]) a = 3;
         if (oa.only_receiver && a != 0) continue;                     // model.py:1313
         const float coef = s_coef[a];
-        float4 g = *reinterpret_cast<const float4*>(grads + i);
-        float4 w = *reinterpret_cast<float4*>(params + i);
+        const bool first = (i == i0);
+        float4 g = first ? g0 : *reinterpret_cast<const float4*>(grads + i);
+        float4 w = first ? w0 : *reinterpret_cast<float4*>(params + i);
         float gv[4] = {g.x * coef, g.y * coef, g.z * coef, g.w * coef};
         float wv[4] = {w.x, w.y, w.z, w.w};
         if (oa.optim_type == MMG_OPT_RMSPROP) {                       // torch.optim.RMSprop defaults (model.py:1128)
-            float4 s = *reinterpret_cast<float4*>(st1 + i);
-            float sv[4] = {s.x, s.y, s.z, s.w};
+            float4 sq = first ? s0 : *reinterpret_cast<float4*>(st1 + i);
+            float sv[4] = {sq.x, sq.y, sq.z, sq.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 sv[k] = 0.99f * sv[k] + (1.f - 0.99f) * gv[k] * gv[k];
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
             }
             *reinterpret_cast<float4*>(st1 + i) = make_float4(sv[0], sv[1], sv[2], sv[3]);
         } else if (oa.optim_type == MMG_OPT_ADAM) {                   // torch.optim.Adam defaults (model.py:1120)
-            float4 m = *reinterpret_cast<float4*>(st1 + i), v = *reinterpret_cast<float4*>(st2 + i);
+            float4 m = first ? s0 : *reinterpret_cast<float4*>(st1 + i), v = first ? v0 : *reinterpret_cast<float4*>(st2 + i);
             float mv[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

@@ -48,6 +48,8 @@ def lib():
             ("H5Sclose", C.c_int, [i64]), ("H5Tget_class", C.c_int, [i64]), ("H5Tget_size", C.c_size_t, [i64]),
             ("H5Tcopy", i64, [i64]), ("H5Tset_size", C.c_int, [i64, C.c_size_t]), ("H5Tclose", C.c_int, [i64]),
             ("H5Lexists", C.c_int, [i64, C.c_char_p, i64]), ("H5Eset_auto2", C.c_int, [i64, C.c_void_p, C.c_void_p]),
+            ("H5Tcreate", i64, [C.c_int, C.c_size_t]), ("H5Tinsert", C.c_int, [i64, C.c_char_p, C.c_size_t, i64]),
+            ("H5Tarray_create2", i64, [i64, C.c_uint, C.POINTER(C.c_uint64)]),
         ]:
             f = getattr(L, name); f.restype = res; f.argtypes = args
         L.H5Eset_auto2(0, None, None)          # errors are reported through return codes -> exceptions
@@ -59,7 +61,32 @@ def _g(name):
 
 
 H5F_ACC_RDONLY, H5F_ACC_TRUNC, H5P_DEFAULT, H5S_ALL = 0, 2, 0, 0
-H5T_INTEGER, H5T_FLOAT, H5T_STRING = 0, 1, 3
+H5T_INTEGER, H5T_FLOAT, H5T_STRING, H5T_COMPOUND = 0, 1, 3, 6
+
+
+def _compound_type(dtype):
+    """HDF5 compound type mirroring a numpy structured dtype whose fields are S<n>, <i4, <f4 or <f4 sub-arrays
+    (the record layouts of binary_vectors.py:24-46).  Returns (type id, ids to close afterwards)."""
+    L = lib()
+    tid = L.H5Tcreate(H5T_COMPOUND, dtype.itemsize)
+    owned = [tid]
+    for name in dtype.names:
+        ft, off = dtype.fields[name][0], dtype.fields[name][1]
+        base, shape = (ft.subdtype if ft.subdtype else (ft, ()))
+        if base.kind == "S":
+            m = L.H5Tcopy(_g("H5T_C_S1_g")); L.H5Tset_size(m, base.itemsize); owned.append(m)
+        elif base.kind in "iu" and base.itemsize == 4:
+            m = _g("H5T_NATIVE_INT_g")
+        elif base.kind == "f" and base.itemsize == 4:
+            m = _g("H5T_NATIVE_FLOAT_g")
+        else:
+            raise Hdf5Error("unsupported field %s: %s" % (name, ft))
+        if shape:
+            dims = (C.c_uint64 * len(shape))(*shape)
+            m = L.H5Tarray_create2(m, len(shape), dims); owned.append(m)
+        if L.H5Tinsert(tid, name.encode(), off, m) < 0:
+            raise Hdf5Error("H5Tinsert failed for " + name)
+    return tid, owned
 
 
 class File(object):
@@ -128,6 +155,41 @@ class File(object):
             return out
         finally:
             L.H5Dclose(d)
+
+    def write_struct(self, name, records):
+        """1-D numpy structured array -> compound-type dataset."""
+        L = lib()
+        records = np.ascontiguousarray(records)
+        tid, owned = _compound_type(records.dtype)
+        dims = (C.c_uint64 * 1)(records.shape[0])
+        sp = L.H5Screate_simple(1, dims, None)
+        d = L.H5Dcreate2(self.fid, name.encode(), tid, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
+        if d < 0:
+            raise Hdf5Error("cannot create dataset " + name)
+        rc = L.H5Dwrite(d, tid, H5S_ALL, H5S_ALL, H5P_DEFAULT, records.ctypes.data_as(C.c_void_p)) if records.shape[0] else 0
+        L.H5Dclose(d); L.H5Sclose(sp)
+        for t in reversed(owned):
+            L.H5Tclose(t)
+        if rc < 0:
+            raise Hdf5Error("H5Dwrite failed for " + name)
+
+    def read_struct(self, name, dtype):
+        """Compound-type dataset -> numpy structured array of the given dtype (fields matched by name)."""
+        L = lib()
+        dtype = np.dtype(dtype)
+        n = self.shape(name)[0]
+        out = np.zeros(n, dtype)
+        d = L.H5Dopen2(self.fid, name.encode(), H5P_DEFAULT)
+        if d < 0:
+            raise KeyError(name)
+        tid, owned = _compound_type(dtype)
+        rc = L.H5Dread(d, tid, H5S_ALL, H5S_ALL, H5P_DEFAULT, out.ctypes.data_as(C.c_void_p)) if n else 0
+        L.H5Dclose(d)
+        for t in reversed(owned):
+            L.H5Tclose(t)
+        if rc < 0:
+            raise Hdf5Error("H5Dread failed for " + name)
+        return out
 
     def write(self, name, arr):
         L = lib()

@@ -125,8 +125,15 @@ def run():
                                                        best_dev_acc, dev_acc, extra["conversation_lengths_mean"],
                                                        extra["conversation_lengths_std"]))
         return
-    if FLAGS.binary_only:
-        raise NotImplementedError("-binary_only (message dump, binary_vectors.py) is a 'next' row (SURVEY.md §8 f4)")
+    if FLAGS.binary_only:                                                  # model.py:1181-1187
+        if not os.path.exists(FLAGS.checkpoint):
+            raise Exception("Must provide valid checkpoint.")
+        from .binary_vectors import extract_binary
+        game.engine_for(FLAGS.batch_size_dev, desc_dev.size(0))
+        extract_binary(FLAGS, FLAGS.dev_file, FLAGS.batch_size_dev, epoch, FLAGS.shuffle_dev, sender, receiver, desc_dev,
+                       map_labels_dev, device)
+        flogger.Log("Wrote " + FLAGS.binary_output)
+        return
 
     hits_ring = torch.zeros(max(FLAGS.log_interval, 1), device=device)
     while epoch < FLAGS.max_epoch:

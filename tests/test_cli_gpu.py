@@ -44,3 +44,35 @@ def test_train_checkpoint_resume_eval(tmp_path):
     assert csv[0] == "checkpoint,eval_file,topk,step,best_dev_acc,eval_acc,convlen_mean,convlen_std"
     assert csv[1].split(",")[3] == "20"
     flags.FLAGS.Reset()
+
+
+def test_binary_only_message_dump(tmp_path):
+    """README.md:57-68 workflow: train briefly, then -binary_only on a dev file whose batches hold one class each."""
+    import numpy as np
+    from multimodalgame_amd import model, flags, hdf5io
+    from multimodalgame_amd.binary_vectors import record_types
+    tmp = str(tmp_path)
+    flags.define_flags(); flags.FLAGS.Reset()
+    model.main(_argv(tmp, "bv", ["-max_steps", "11", "-max_exchange", "4"]))
+    rs = np.random.RandomState(3)
+    dev = os.path.join(tmp, "dev_sorted.hdf5")
+    with hdf5io.File(dev, "w") as f:                       # 3 classes x 10 samples, sorted: every batch of 10 has one target
+        f.write("avgpool_512", np.abs(rs.standard_normal((30, 1, 512))).astype(np.float32))
+        f.write("Target", np.repeat(np.arange(3), 10).astype(np.int32))
+        f.write("Location", np.array([("d%02d.jpg" % i).encode() for i in range(30)], dtype="S50"))
+    flags.FLAGS.Reset()
+    out = os.path.join(tmp, "logs", "bv.bv.hdf5")
+    model.main(["model.py", "-log_load", os.path.join(tmp, "logs", "bv.json"), "-binary_only", "-checkpoint",
+                os.path.join(tmp, "logs", "bv.pt"), "-dev_file", dev, "-batch_size_dev", "10", "-fixed_exchange",
+                "-binary_output", out, "-log_path", os.path.join(tmp, "logs")])
+    comm_t, preds_t = record_types(32, 30)
+    with hdf5io.File(out, "r") as f:
+        comm, preds = f.read_struct("Communication", comm_t), f.read_struct("Predictions", preds_t)
+    T = 4
+    assert len(comm) == 30 * T * 2 and len(preds) == 30 * T                 # one record per agent message / receiver step
+    assert set(comm["AgentId"].tolist()) == {b"S", b"R"} and set(comm["Index"].tolist()) == set(range(2 * T))
+    assert set(np.unique(comm["BinaryVec"]).tolist()) <= {0.0, 1.0}
+    assert ((comm["BinaryProb"] >= 0) & (comm["BinaryProb"] <= 1)).all()
+    np.testing.assert_array_equal(np.round(comm["BinaryProb"]), comm["BinaryVec"])   # eval mode: round(p)  (model.py:229, 462)
+    assert comm["ExampleId"][0] == b"d00.jpg" and (preds["Target"][:10 * 1] == 0).all()
+    flags.FLAGS.Reset()

@@ -67,3 +67,25 @@ def test_file_logger_format(tmp_path, capsys):
 def test_build_mask():
     m = misc.build_mask("0:3,5", 8)
     assert m.view(-1).tolist() == [1, 1, 1, 0, 0, 1, 0, 0]
+
+
+def test_hdf5_compound_roundtrip(tmp_path):
+    """The record layouts of binary_vectors.py:24-46 (message dump)."""
+    from multimodalgame_amd.binary_vectors import record_types
+    comm_t, preds_t = record_types(6, 3)
+    rs = np.random.RandomState(0)
+    comm = np.zeros(5, comm_t)
+    comm["ExampleId"] = [("img%d.jpg" % i).encode() for i in range(5)]
+    comm["AgentId"], comm["Index"], comm["Target"], comm["Rank"] = b"S", np.arange(5), 2, [3, 1, 2, 1, 3]
+    comm["BinaryProb"] = rs.rand(5, 6); comm["BinaryVec"] = (rs.rand(5, 6) < 0.5)
+    preds = np.zeros(2, preds_t)
+    preds["Predictions"] = rs.randn(2, 3); preds["StopProb"] = [[0.25], [0.75]]; preds["AgentId"] = b"R"
+    p = str(tmp_path / "bv.hdf5")
+    with hdf5io.File(p, "w") as f:
+        f.write_struct("Communication", comm); f.write_struct("Predictions", preds)
+    with hdf5io.File(p, "r") as f:
+        c2, p2 = f.read_struct("Communication", comm_t), f.read_struct("Predictions", preds_t)
+    for k in comm_t.names:
+        np.testing.assert_array_equal(c2[k], comm[k])
+    for k in preds_t.names:
+        np.testing.assert_array_equal(p2[k], preds[k])
