@@ -5,7 +5,10 @@
 A bench "step" is one training minibatch (conversation + losses + backward + clip + RMSprop);
 the reported value counts EXCHANGE steps = iterations of the loop at model.py:801 that the
 reference semantics execute (up to the step at which every sample of the global minibatch has
-stopped, model.py:866), summed over the timed minibatches, divided by the wall time.
+stopped, model.py:866), summed over the timed minibatches, divided by the wall time.  The unit is the metric's
+own: one exchange step of one 64-sample batch ("bs=64").  At N GPUs the global minibatch is 64*N samples, i.e.
+every exchange step of the sharded game advances N such batches, so value = N * loop iterations / wall time
+(the whole-job aggregate; identical to the 1-GPU definition at N = 1).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   N > 1: launched by torch.distributed.run, one rank per GPU; the global minibatch is 64*N
@@ -227,13 +230,15 @@ def main():
     if rank == 0:
         line = {
             "metric": "exchange-steps/sec (whole node), 30-class Adaptive max_exchange=10 bs=64",
-            "value": ex_steps / elapsed, "unit": "exchange-steps/s", "n_gpus": world, "steps": args.steps,
+            "value": world * ex_steps / elapsed, "unit": "exchange-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: Adaptive 30-class, batch 64 per GPU, max_exchange 10, rec_w_dim 32, "
                                    "img_h_dim 256, rec_hidden 64, RMSprop; one bench step = one training minibatch",
                        "global_batch": PER_GPU_BATCH * world, "parallelism": "dp%d" % world,
-                       "exchange_steps_per_minibatch": ex_steps / args.steps, "sampling": "in-kernel Philox4x32-10"},
+                       "exchange_steps_per_minibatch": ex_steps / args.steps, "sampling": "in-kernel Philox4x32-10",
+                       "unit_definition": "one exchange step (model.py:801 loop iteration) of one 64-sample batch; "
+                                          "a global minibatch of 64*N samples advances N of them per iteration"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -68,3 +68,31 @@ def test_two_ranks_on_one_gpu_equal_single_process(philox, tmp_path):
         if k == "receiver.y2.bias":
             continue
         np.testing.assert_allclose(r0[k], v, rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)          # "nccl" is RCCL on ROCm
+    from multimodalgame_amd.dist import DataParallel
+    z, meta = common.load_golden(NAME)
+    eng = common.make_engine(meta)
+    dp = DataParallel(eng)
+    dp.world = 2            # force both collectives to run even though the group has one member
+    out = _run(eng, dp, meta, 0, meta["batch"], True)
+    np.savez(os.path.join(out_dir, "rccl.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_on_engine_buffers(tmp_path):
+    """The production backend: RCCL all-reduces (f64 statistics vector, f32 flat gradient buffer) issued on the
+    engine's own device buffers between the C-ABI calls.  One box = one GPU, so the group has a single member:
+    the sums are identities and the result must equal the collective-free run bit for bit."""
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    z, meta = common.load_golden(NAME)
+    want = _run(common.make_engine(meta), None, meta, 0, meta["batch"], True)
+    got = np.load(tmp_path / "rccl.npz")
+    for k, v in want.items():
+        np.testing.assert_array_equal(got[k], v, err_msg=k)
