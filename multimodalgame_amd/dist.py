@@ -8,6 +8,8 @@ Two collectives per optimizer step (RCCL over xGMI through torch.distributed bac
   2. one all-reduce of the flat gradient buffer of all four agents.
 Gradient clipping uses the norm of the reduced gradient, so all ranks take the identical update
 (model.py:1310 semantics on the global batch)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -16,20 +18,35 @@ class DataParallel(object):
     """`engine` needs: forward(...), loss_stats(), backward(...), clip_step(), .stats (1-D f64 tensor),
     .flat_grads (1-D f32 tensor).  multimodalgame_amd.engine.Engine satisfies this on a GPU."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, direct=None):
+        """direct: enqueue the collectives on the engine's stream through multimodalgame_amd.rccl (default: when the
+        group's backend is "nccl" and MMG_DP_DIRECT_RCCL != "0"); otherwise torch.distributed.all_reduce."""
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.comm = None
+        if direct is None:
+            direct = (self.world > 1 and dist.get_backend(group) == "nccl"
+                      and os.environ.get("MMG_DP_DIRECT_RCCL", "1") != "0")
+        if direct:
+            from . import rccl
+            self.comm = rccl.try_create(engine.device, group)
+
+    def _all_reduce(self, tensor):
+        if self.comm is not None:
+            self.comm.all_reduce(tensor)
+        else:
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
 
     def train_step(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0):
         e = self.engine
         e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=False)
         e.loss_stats()
         if self.world > 1:
-            dist.all_reduce(e.stats, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(e.stats)
         e.backward(x, target, desc)
         if self.world > 1:
-            dist.all_reduce(e.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(e.flat_grads)
         e.clip_step()
 
 

@@ -70,7 +70,7 @@ def test_two_ranks_on_one_gpu_equal_single_process(philox, tmp_path):
         np.testing.assert_allclose(r0[k], v, rtol=2e-4, atol=2e-6, err_msg=k)
 
 
-def _rccl_worker(rank, world, port, out_dir):
+def _rccl_worker(rank, world, port, direct, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -78,21 +78,31 @@ def _rccl_worker(rank, world, port, out_dir):
     from multimodalgame_amd.dist import DataParallel
     z, meta = common.load_golden(NAME)
     eng = common.make_engine(meta)
-    dp = DataParallel(eng)
+    dp = DataParallel(eng, direct=direct)
+    assert (dp.comm is not None) == direct
     dp.world = 2            # force both collectives to run even though the group has one member
     out = _run(eng, dp, meta, 0, meta["batch"], True)
     np.savez(os.path.join(out_dir, "rccl.npz"), **out)
+    eng2 = common.make_engine(meta)
+    dp2 = DataParallel(eng2)
+    dp2.world = 1           # the same split call sequence without the collectives
+    np.savez(os.path.join(out_dir, "split.npz"), **_run(eng2, dp2, meta, 0, meta["batch"], True))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_rccl_collectives_on_engine_buffers(tmp_path):
-    """The production backend: RCCL all-reduces (f64 statistics vector, f32 flat gradient buffer) issued on the
+@pytest.mark.parametrize("direct", [False, True], ids=["torch.distributed", "direct-rccl"])
+def test_rccl_collectives_on_engine_buffers(direct, tmp_path):
+    """direct=True: multimodalgame_amd.rccl (ncclAllReduce on the engine's stream); False: torch.distributed.
+    The production backend: RCCL all-reduces (f64 statistics vector, f32 flat gradient buffer) issued on the
     engine's own device buffers between the C-ABI calls.  One box = one GPU, so the group has a single member:
-    the sums are identities and the result must equal the collective-free run bit for bit."""
-    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    the sums are identities and the result must equal the same call sequence without collectives bit for bit
+    (and the fused mmg_train_step within rounding: it takes the gradient norm from k_wgrad's partials)."""
+    mp.spawn(_rccl_worker, args=(1, _free_port(), direct, str(tmp_path)), nprocs=1, join=True)
     z, meta = common.load_golden(NAME)
-    want = _run(common.make_engine(meta), None, meta, 0, meta["batch"], True)
-    got = np.load(tmp_path / "rccl.npz")
-    for k, v in want.items():
-        np.testing.assert_array_equal(got[k], v, err_msg=k)
+    fused = _run(common.make_engine(meta), None, meta, 0, meta["batch"], True)
+    got, want = np.load(tmp_path / "rccl.npz"), np.load(tmp_path / "split.npz")
+    for k in want.files:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+        if k != "receiver.y2.bias":
+            np.testing.assert_allclose(got[k], fused[k], rtol=2e-4, atol=2e-6, err_msg=k)
