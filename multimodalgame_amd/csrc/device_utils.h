@@ -173,6 +173,41 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint
     return (float)(x0 >> 8) * (1.0f / 16777216.0f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dependencies between workgroup ROLES of one launch.  Several small kernels of the minibatch are latency
+// bound (4-7 us each, of which only 1-3 us is work); merging producer and consumer roles into one grid lets the
+// consumer's prologue (weights -> registers) run while the producer works, and replaces a kernel boundary by one
+// device-scope release/acquire pair.  Producers always have LOWER workgroup ids than their consumers and never
+// wait on a higher id, so with the in-order workgroup dispatch of the hardware the lowest unfinished workgroup can
+// always run: no deadlock.  The spin is bounded all the same: on expiry the error word sync[63] is set and the
+// workgroup continues (wrong numbers flagged, never a hung GPU).
+//   sync[2k] = arrivals of dependency k, sync[2k+1] = consumers that have passed it (the last one re-arms both).
+// ---------------------------------------------------------------------------------------------
+#define MMG_SYNC_ERR 63
+#define MMG_SPIN_LIMIT (1 << 22)
+__device__ __forceinline__ void role_signal(uint32_t* sync, int dep) {
+    __threadfence();                                    // every wave: its stores are written back (agent scope)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + 2 * dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int SLEEP = 1>
+__device__ __forceinline__ void role_wait(uint32_t* sync, int dep, uint32_t producers, uint32_t consumers) {
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(sync + 2 * dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < producers) {
+            __builtin_amdgcn_s_sleep(SLEEP);
+            if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(sync + MMG_SYNC_ERR, (uint32_t)(dep + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        const uint32_t passed = __hip_atomic_fetch_add(sync + 2 * dep + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (passed + 1 == consumers) {                  // everyone has seen the final count: re-arm for the next launch
+            __hip_atomic_store(sync + 2 * dep, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 2 * dep + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale cache lines before reading what the producers wrote
+}
+
 // one 16x16x4 fp32 MFMA step:  D += A(16x4) * B(4x16);  lane l holds A[l&15][l>>4], B[l>>4][l&15],
 // D[(l>>4)*4 + reg][l&15]   (cdna_hip_programming.md §3)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {

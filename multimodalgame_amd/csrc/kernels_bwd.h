@@ -36,14 +36,15 @@ __device__ __forceinline__ float combine_score(const float* part, size_t row, in
 
 // from_parts: baseline scores arrive as per-64-hidden-unit partials (k_baselines2); the blocks of the
 // two baseline kinds also materialise bs / br on the tape (exchange() returns them, k_bwd_conv reads them).
-__global__ __launch_bounds__(64) void k_stats(Dims dm, Params P, Tape tp, int from_parts) {
+// one wave reduces the (stream, step) pairs first, first + stride, ...
+__device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, const Tape& tp, int from_parts, int first, int stride) {
     const int T = dm.T, B = dm.B;
     const int npb = (dm.K + 63) / 64;
     const float b2s = P.p[BS_L2_B][0], b2r = P.p[BR_L2_B][0];
     // grid = 5T + 2 blocks of one wave: every (stream, step) pair reduces concurrently
     const int lane = threadIdx.x & 63;
     const int npairs = 5 * T + 2;
-    for (int p = blockIdx.x; p < npairs; p += gridDim.x) {
+    for (int p = first; p < npairs; p += stride) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         if (p >= 5 * T) {                       // sum of rewards (-> NLL) and top-k hits
             const int which = p - 5 * T;
@@ -90,6 +91,10 @@ __global__ __launch_bounds__(64) void k_stats(Dims dm, Params P, Tape tp, int fr
             }
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_stats(Dims dm, Params P, Tape tp, int from_parts) {
+    stats_pairs(dm, P, tp, from_parts, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -400,9 +405,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
 // k_dC: grid = D.  dC[d,r] = sum_b dy[b,d] * w_y2[r] * 1[A*[b,r] + Cd[d,r] > 0]   (-> y1.weight[:,R:], y1.bias)
 //                  Py2[d,r] = sum_b dy[b,d] * relu(A*[b,r] + Cd[d,r])              (-> y2.weight)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MMG_BLOCK) void k_dC(Dims dm, Params P, Tape tp) {
-    __shared__ float s_c[MMG_BLOCK], s_p[MMG_BLOCK];
-    const int d = blockIdx.x, tid = threadIdx.x, R = dm.R, B = dm.B, D = dm.D;
+__device__ __forceinline__ void dC_class(const Dims& dm, const Params& P, const Tape& tp, int d, float* s_c, float* s_p) {
+    const int tid = threadIdx.x, R = dm.R, B = dm.B, D = dm.D;
     const int cols = R < 64 ? R : 64;                 // up to 64 columns per pass, >= 4 sample groups
     const int groups = MMG_BLOCK / cols;
     const int g = tid / cols, rr = tid - g * cols;
@@ -439,6 +443,11 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_dC(Dims dm, Params P, Tape tp) {
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_dC(Dims dm, Params P, Tape tp) {
+    __shared__ float s_c[MMG_BLOCK], s_p[MMG_BLOCK];
+    dC_class(dm, P, tp, blockIdx.x, s_c, s_p);
 }
 
 // ---------------------------------------------------------------------------------------------

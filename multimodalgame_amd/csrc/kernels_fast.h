@@ -464,8 +464,14 @@ namespace mmg {
 // recurrence needs resident in registers (w^T: 8, w_h^T: 16, W_hh^T: 48, binary_layer^T: 32 per lane).
 // Same math, tape contract and zero-filling as k_bwd_conv (kernels_bwd.h); 5 barriers per step.
 // ---------------------------------------------------------------------------------------------
-template <int H, int W, int R, int V, int D>
-__global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target) {
+// MERGED: the grid starts with `n_stats` one-wave statistics roles (k_stats' pairs); the sample roles load their
+// weights and forward tape while those run and wait for them right before the loss coefficients (device_utils.h).
+// MERGE_DC: the grid ends with D class roles (k_dC).  Their inputs (dy, A*) exist after the FIRST reverse step of every
+// sample, so they run concurrently with the rest of the recurrence instead of after it.
+// (Rejected, measured: every sample role deriving the coefficients itself from the score partials -- in waves 0-3:
+//  +64 live registers, AGPR spills, +4 us; in a dedicated fifth wave: +8 us, it outlasts the weight prologue.)
+template <int H, int W, int R, int V, int D, bool MERGED, bool MERGE_DC>
+__global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int n_stats) {
     constexpr int NT = 256, K4 = NT / R;          // 4 lanes per output unit of the R-wide transposed products
     constexpr int TMAX = 16;
     static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
@@ -478,7 +484,19 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     __shared__ float t_w[TMAX * W], t_pw[TMAX * W], t_z[TMAX * W], t_pz[TMAX * W], t_g[TMAX * R];
     __shared__ float t_gru[TMAX * 4 * R], t_h[(TMAX + 1) * R], t_a[TMAX * H];
     __shared__ float t_bs[TMAX], t_br[TMAX], t_s[TMAX], t_ps[TMAX];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (MERGED && (int)blockIdx.x < n_stats) {
+        if (threadIdx.x >= 64) return;
+        stats_pairs(dm, P, tp, 1, blockIdx.x, n_stats);
+        role_signal(tp.sync, 0);
+        return;
+    }
+    if (MERGE_DC && (int)blockIdx.x >= n_stats + dm.B) {
+        float* s_c = t_a; float* s_p = t_a + 256;
+        role_wait<8>(tp.sync, 1, (uint32_t)dm.B, (uint32_t)D);
+        dC_class(dm, P, tp, (int)blockIdx.x - n_stats - dm.B, s_c, s_p);
+        return;
+    }
+    const int b = blockIdx.x - n_stats, tid = threadIdx.x, lane = tid & 63;
     const int B = dm.B, T = dm.T;
     const bool binary = dm.use_binary != 0;
 #ifdef MMG_TIMING
@@ -489,7 +507,8 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     MMG_BSTAMP(0);
     // ---- prologue: issue EVERY independent global load before the first dependent use (one memory round trip for the
     // weight fragments, overlapping the tstar -> tape-preload chain), then stage the tape into LDS.
-    const CoefRegs creg = coef_load(dm, tp.stats);      // statistics first: they gate the first arithmetic of the kernel
+    CoefRegs creg;
+    if (!MERGED) creg = coef_load(dm, tp.stats);        // statistics first: they gate the first arithmetic of the kernel
     const int tstar = tp.tstar[b];
     const int tgt = (int)target[b];
     const float L = tp.logs[b];
@@ -537,10 +556,12 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
 #pragma unroll
     for (int u = 0; u < NA_; ++u) { const int i = tid + NT * u, t = min(i / H, Tm1), j = i % H; ra_[u] = tp.a[((size_t)t * B + b) * H + j]; }
     const size_t so = (size_t)min(tid, Tm1) * B + b;
-    const float rbs_ = tp.bs[so], rbr_ = tp.br[so], rs_ = tp.s[so], rps_ = tp.ps[so];
+    float rbs_, rbr_;
+    if (!MERGED) { rbs_ = tp.bs[so]; rbr_ = tp.br[so]; }
+    const float rs_ = tp.s[so], rps_ = tp.ps[so];
     MMG_BSTAMP(1);
     LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
-    coef_compute(dm, creg, lc);                                   // (the logged losses: a spare block of k_wgrad)
+    if (!MERGED) coef_compute(dm, creg, lc);                      // (the logged losses: a spare block of k_wgrad)
 #pragma unroll
     for (int u = 0; u < NW_; ++u) { const int i = tid + NT * u; t_w[i] = rw_[u]; t_z[i] = rz_[u]; t_pw[i] = rpw_[u]; t_pz[i] = rpz_[u]; }
 #pragma unroll
@@ -551,7 +572,14 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     for (int u = 0; u < NH_; ++u) { const int i = tid + NT * u; if (i < (TMAX + 1) * R) t_h[i] = rh_[u]; }
 #pragma unroll
     for (int u = 0; u < NA_; ++u) t_a[tid + NT * u] = ra_[u];
-    if (tid < TMAX) { t_bs[tid] = rbs_; t_br[tid] = rbr_; t_s[tid] = rs_; t_ps[tid] = rps_; }
+    if (tid < TMAX) { t_s[tid] = rs_; t_ps[tid] = rps_; }
+    if (MERGED) {                                       // the statistics roles of this launch publish stats, bs, br
+        role_wait(tp.sync, 0, (uint32_t)n_stats, (uint32_t)B);
+        creg = coef_load(dm, tp.stats);
+        rbs_ = tp.bs[so]; rbr_ = tp.br[so];
+        coef_compute(dm, creg, lc);
+    }
+    if (tid < TMAX) { t_bs[tid] = rbs_; t_br[tid] = rbr_; }
     MMG_BSTAMP(2);
     const float* cw_s = lc.cw, *cw_r = lc.cw + T, *cw_z = lc.cw + 2 * T;
     const float* ce_s = lc.ce, *ce_r = lc.ce + T, *ce_z = lc.ce + 2 * T;
@@ -651,6 +679,10 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
                 for (int d = 0; d < D; ++d) acc += (a + cdcol[d] > 0.f) ? s_dy[d] : 0.f;
                 const float v = acc * w2_mine;
                 s_dA[tid] = v; tp.dA[(size_t)b * R + tid] = v; tp.Astar[(size_t)b * R + tid] = a;
+            }
+            if (MERGE_DC && tid == 0) {                  // wave 0 wrote dy and A*: release them to the class roles
+                __threadfence();
+                __hip_atomic_fetch_add(tp.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
         }

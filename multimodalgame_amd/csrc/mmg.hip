@@ -343,6 +343,10 @@ static int launch_baselines_fused(mmg_handle* h, hipStream_t st) {
     return launch_check("k_baselines");
 }
 
+static bool fast_shape(const Dims& d) {
+    return !getenv("MMG_NO_FAST") && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
+}
+
 extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
                                     const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed,
                                     int train, int run_all_steps, void* stream) {
@@ -358,7 +362,7 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
     {
         Scope sc(h, st, "k_conversation");
-        const bool fast = !getenv("MMG_NO_FAST") && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
+        const bool fast = fast_shape(d);
         if (fast && !getenv("MMG_CONV256"))
             hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
         else if (fast)
@@ -391,21 +395,29 @@ extern "C" int mmg_loss_stats(mmg_handle* h, void* stream) {
     return launch_check("k_stats");
 }
 
-extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, void* stream) {
-    if (!h) return fail("NULL handle");
-    if (!d_x || !d_target || !d_desc) return fail("x / target / desc must not be NULL");
-    hipStream_t st = (hipStream_t)stream;
+// single-GPU minibatch: the statistics run as extra roles of the backward launch (no all-reduce in between)
+static bool merge_stats(const mmg_handle* h) {
+    return fast_shape(h->dm) && h->dm.use_binary && h->scores_in_parts && !getenv("MMG_NO_MERGE");
+}
+
+static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, hipStream_t st, bool with_stats) {
     const Dims& d = h->dm;
     {
         Scope sc(h, st, "k_bwd_conv");
-        const bool fast = !getenv("MMG_NO_FAST") && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
-        if (fast)      // (a 512-thread variant of this kernel measured slower: 31.8 vs 28.8 us -- it is not issue-bound)
-            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target);
+        const bool fast = fast_shape(d);
+        const bool merge_dc = fast && !getenv("MMG_NO_MERGE");
+        if (fast && with_stats) {
+            const int n_stats = 5 * d.T + 2;
+            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats);
+        } else if (merge_dc)
+            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0);
+        else if (fast)      // (a 512-thread variant of this kernel measured slower: 31.8 vs 28.8 us -- it is not issue-bound)
+            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0);
         else
             hipLaunchKernelGGL(k_bwd_conv, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
         if (launch_check("k_bwd_conv")) return -1;
     }
-    {
+    if (!(fast_shape(d) && !getenv("MMG_NO_MERGE"))) {
         Scope sc(h, st, "k_dC");
         hipLaunchKernelGGL(k_dC, dim3(d.D), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
         if (launch_check("k_dC")) return -1;
@@ -422,6 +434,12 @@ extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_ta
         if (launch_check("k_wgrad")) return -1;
     }
     return 0;
+}
+
+extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, void* stream) {
+    if (!h) return fail("NULL handle");
+    if (!d_x || !d_target || !d_desc) return fail("x / target / desc must not be NULL");
+    return backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, false);
 }
 
 static int clip_step_impl(mmg_handle* h, hipStream_t st, bool from_wgrad) {
@@ -459,9 +477,11 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
                               const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed, void* stream) {
     if (!h) return fail("NULL handle");
     if (h->cfg.global_batch != h->cfg.batch) return fail("mmg_train_step is single-GPU; with several ranks all-reduce between the phases");
+    if (!d_target) return fail("target must not be NULL");
     if (mmg_exchange_forward(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, 0, stream)) return -1;
-    if (mmg_loss_stats(h, stream)) return -1;
-    if (mmg_backward(h, d_x, d_target, d_desc, stream)) return -1;
+    const bool merged = merge_stats(h);
+    if (!merged && mmg_loss_stats(h, stream)) return -1;
+    if (backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, merged)) return -1;
     return clip_step_impl(h, (hipStream_t)stream, true);
 }
 
