@@ -33,17 +33,41 @@ __device__ __forceinline__ float dpp_group_sum(float v) {
     if (N >= 16) v += dpp_f<MMG_DPP_ROW_MIRROR>(v);
     return v;
 }
-__device__ __forceinline__ float dpp_wave_sum(float v) {            // all 64 lanes get the total
+// Full-wave reductions: rows of 16 by the mirror steps above, then the classic GFX9 row broadcasts (lane 15 of a row into
+// the next row, lane 31 into rows 2-3) leave the total in lane 63, read back through an SGPR -- no ds_bpermute.
+#define MMG_DPP_ROW_BCAST15 0x142
+#define MMG_DPP_ROW_BCAST31 0x143
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_rows_f(float v, float old) {    // rows outside ROWS keep `old`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false));
+}
+__device__ __forceinline__ float dpp_wave_sum(float v) {            // all 64 lanes get the total (wave-uniform)
     v = dpp_group_sum<16>(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    v += dpp_rows_f<MMG_DPP_ROW_BCAST15, 0xA>(v, 0.f);
+    v += dpp_rows_f<MMG_DPP_ROW_BCAST31, 0xC>(v, 0.f);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float dpp_wave_max(float v) {
     v = fmaxf(v, dpp_f<MMG_DPP_QUAD_1032>(v)); v = fmaxf(v, dpp_f<MMG_DPP_QUAD_2301>(v));
     v = fmaxf(v, dpp_f<MMG_DPP_ROW_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f<MMG_DPP_ROW_MIRROR>(v));
-    v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    v = fmaxf(v, dpp_rows_f<MMG_DPP_ROW_BCAST15, 0xA>(v, v));
+    v = fmaxf(v, dpp_rows_f<MMG_DPP_ROW_BCAST31, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_d(double v) {                  // 64-bit value moved as two DPP dwords; other rows: 0.0
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, ROWS, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROWS, 0xF, false);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double dpp_wave_sum_d(double v) {        // same tree as dpp_wave_sum, in f64
+    v += dpp_d<MMG_DPP_QUAD_1032, 0xF>(v); v += dpp_d<MMG_DPP_QUAD_2301, 0xF>(v);
+    v += dpp_d<MMG_DPP_ROW_HALF_MIRROR, 0xF>(v); v += dpp_d<MMG_DPP_ROW_MIRROR, 0xF>(v);
+    v += dpp_d<MMG_DPP_ROW_BCAST15, 0xA>(v); v += dpp_d<MMG_DPP_ROW_BCAST31, 0xC>(v);
+    const long long bits = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)bits, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), 63);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
 }
 
 // wave-level sum over aligned groups of G lanes (G power of two, <= 64)

@@ -49,7 +49,7 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
         if (p >= 5 * T) {                       // sum of rewards (-> NLL) and top-k hits
             const int which = p - 5 * T;
             for (int b = lane; b < B; b += 64) a0 += which == 0 ? (double)tp.logs[b] : (double)tp.hit[b];
-            a0 = wave_sum_d(a0);
+            a0 = dpp_wave_sum_d(a0);
             if (lane == 0) tp.stats[stat_glob(T, which)] = a0;
             continue;
         }
@@ -81,7 +81,7 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
                 }
             }
         }
-        a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2); a3 = wave_sum_d(a3); a4 = wave_sum_d(a4);
+        a0 = dpp_wave_sum_d(a0); a1 = dpp_wave_sum_d(a1); a2 = dpp_wave_sum_d(a2); a3 = dpp_wave_sum_d(a3); a4 = dpp_wave_sum_d(a4);
         if (lane == 0) {
             if (kind < 3) {
                 double* st = tp.stats + stat_stream(T, kind, t, 0);
