@@ -760,9 +760,18 @@ namespace mmg {
 //   y head      16 lanes per class (4 + 4)     softmax.desc  2 lanes per column (15 regs), softmax via wave-private LDS
 //   w_d         8 lanes per row (13 regs)      w  16 lanes per row (4 regs)
 // ---------------------------------------------------------------------------------------------
+// Workgroups beyond the B sample roles (training launches only) are independent 16x16 tiles of
+//   basehx = h_x . baseline_sen.linear1.weight[:, :H]^T   [B, K]
+// -- work k_baselines2 needs next and that depends on nothing this launch produces: it runs on CUs the B <= 64 sample
+// roles leave idle instead of as a 4.7 us prologue of every sender-baseline workgroup of the next launch.
 template <int H, int W, int R, int V, int D>
 __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P, Tape tp, ConvArgs ar) {
     constexpr int NT = 512;
+    if ((int)blockIdx.x >= dm.B) {
+        if (threadIdx.x >= MMG_BLOCK) return;            // gemm_nt_tile is a 4-wave routine
+        gemm_nt_tile((int)blockIdx.x - dm.B, tp.hx, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H);
+        return;
+    }
     static_assert(FastDims<H, W, R, V, D>::ok && D <= 30 && V <= 200, "unsupported fast shape");
     __shared__ __attribute__((aligned(16))) float s_a[H];
     __shared__ __attribute__((aligned(16))) float s_c[W];
@@ -785,6 +794,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     const int B = dm.B, T = dm.T;
     const bool binary = dm.use_binary != 0, train = ar.train != 0;
     const bool inject = ar.u_s != nullptr;
+    MMG_STAMP(0);
     const uint32_t mb_counter = tp.counter[0];
     const uint32_t gb = (uint32_t)(dm.boff + b);
     if (train && inject) {
@@ -894,14 +904,17 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     for (int j = 0; j < DH; ++j) { const int d = h7 * DH + j; dcol[j] = (v7 < V && d < D) ? ar.desc[(size_t)d * V + v7] : 0.f; }
     const float sig_cb = (tid < W) ? fsigmoid(P.p[S_CODE_BIAS][tid]) : 0.f;
 
+    MMG_STAMP(1);
     // ------------------------------------------------------------ conversation state
     if (tid < R) { s_h[tid] = 0.f; tp.h[(size_t)b * R + tid] = 0.f; }
     if (tid < W) s_c[tid] = dm.first_rec;
     if (tid == 0) { s_misc[0] = 1.f; s_misc[1] = -1.f; s_misc[2] = 1.f; tp.mask[b] = 1; }
     __syncthreads();
 
+    MMG_STAMP(2);
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)t * B + b;
+        MMG_STAMP(8 + 10 * t + 9);
         // ===== (1) sender: h_w = code_layer(c), a = tanh(h_x + h_w)
         {
             float hw = hw0;
@@ -915,7 +928,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             }
         }
         float ghv = bhh + dpp_group_sum<2>(dot4<J3H>(whh, s_h + h3 * 4, 8));      // GRU hidden-side product (independent of z)
-        __syncthreads();                                                   // B1
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 0);                       // B1
         // ===== (2) sender logits + sample
         {
             float acc = dpp_group_sum<LB>(dot4<JB>(wb, s_a + kpb * 4, 4 * LB));
@@ -931,7 +944,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
                 tp.z[row * W + nb] = zz;
             }
         }
-        __syncthreads();                                                   // B2
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 1);                       // B2
         // ===== (3) GRU gate pre-activations
         {
             const float giv = bih + dpp_group_sum<2>(dot4<J3I>(wih, s_z + h3 * 4, 8));
@@ -948,7 +961,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
             if (lane == 0) { tp.lp_z[row] = lpv; tp.ne_z[row] = nev; }
         }
-        __syncthreads();                                                   // B3
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 2);                       // B3
         // ===== (4) GRU state update
         if (tid < R) {
             const float rr = fsigmoid(s_gi[tid] + s_gh[tid]);
@@ -961,7 +974,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             tp.h[((size_t)(t + 1) * B + b) * R + tid] = hv;
             s_h[tid] = hv;
         }
-        __syncthreads();                                                   // B4
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 3);                       // B4
         // ===== (5) heads on h
         float gpre_h;
         {
@@ -989,7 +1002,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
                 s_misc[3] = sbit;
             }
         }
-        __syncthreads();                                                   // B5
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 4);                       // B5
         // ===== (6) class logits
         {
             const float4 a4 = *reinterpret_cast<const float4*>(s_A + kpy * 4);
@@ -1008,7 +1021,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
         const float m_next = fminf(m_t, sbit);
         const bool first_stop = (m_next == 0.f) && (s_misc[1] < 0.f);
         const bool take_out = dm.fixed ? (t == T - 1) : (first_stop || ((t == T - 1) && (s_misc[1] < 0.f)));
-        __syncthreads();                                                   // B6
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 5);                       // B6
         if (take_out && tid < 32) s_yout[tid] = s_y[tid];
         if (tid == 0) {
             tp.mask[(size_t)(t + 1) * B + b] = (uint8_t)(m_next != 0.f);
@@ -1043,7 +1056,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             const float acc = dpp_group_sum<2>((q0 + q1) + q2);
             if (h7 == 0 && v7 < V) { s_dbar[v7] = acc; tp.dbar[row * V + v7] = acc; }
         }
-        __syncthreads();                                                   // B7
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 6);                       // B7
         // ===== (8) h_w = tanh(w_h h + b_h + w_d dbar)
         {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -1061,7 +1074,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
                 tp.g[row * R + n4] = gv;
             }
         }
-        __syncthreads();                                                   // B8
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 7);                       // B8
         // ===== (9) receiver message
         {
             float acc = dpp_group_sum<LB>(dot4<JW>(ww, s_g + kpb * 4, 4 * LB));
@@ -1077,7 +1090,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
                 tp.w[row * W + nb] = wv;
             }
         }
-        __syncthreads();                                                   // B9
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 8);                       // B9
         if (binary && wave == 7) {                                         // overlaps with phase (1) of the next step
             float lpv = 0.f, nev = 0.f;
             if (lane < W) {
@@ -1091,6 +1104,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
         }
     }
     __syncthreads();
+    MMG_STAMP(3);
     // ------------------------------------------------------------ output selection / reward / top-k
     const int tstar = dm.fixed ? (T - 1) : (int)s_misc[1];
     if (tid < 64) {

@@ -609,6 +609,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines(int K, BasArgs rec, Bas
 //   baseline_sen: the h_x . W1[:, :H]^T product (K = H, per SAMPLE, not per step) is accumulated once
 //                 and re-used as the MFMA C operand of every step's z_r . W1[:, H:]^T product;
 //   baseline_rec: [z_t || h_{t+1}] . W1^T per step.
+// (base_ready: that product was already formed, as tape.basehx, by idle workgroups of the conversation launch.)
 // Epilogue per step: relu, store the hidden tile (tape, for the backward pass), reduce hidden . w2
 // over the block's 64 hidden units and write that PARTIAL score to part[t, b, blockIdx.y]; k_stats
 // adds the ceil(K/64) partials and linear2.bias.  Steps beyond every sample's own last step are skipped.
@@ -650,7 +651,7 @@ __device__ __forceinline__ void frag_mfma(f32x4& acc, const float4 (&a)[MAXQ], c
     }
 }
 
-__global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tape tp, int skip_inactive) {
+__global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tape tp, int skip_inactive, int base_ready) {
     // s_part[t][wave][row]: partial scores of this block's 64 hidden units, combined once at the end
     __shared__ float s_part[64][4][16];
     __shared__ int s_tmax;
@@ -695,7 +696,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
     const bool vecW = ((W & 15) == 0) && ((ldw & 3) == 0) && ((H & 3) == 0);
     const bool vecR = ((R & 15) == 0) && ((ldw & 3) == 0) && ((W & 3) == 0);
     f32x4 base = {0.f, 0.f, 0.f, 0.f};
-    if (which) {
+    if (which && base_ready) {                           // formed by spare workgroups of the conversation launch (kernels_fast.h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bo = b0 + q * 4 + r;
+            base[r] = tp.basehx[(size_t)min(bo, B - 1) * K + min(n, K - 1)];
+        }
+    } else if (which) {
         if (vecH && H == 256) {                          // every operand load in flight at once, two MFMA chains
             const float* xr = tp.hx + (size_t)(xv ? bx : 0) * H;
             float4 a[16], bq[16];

@@ -114,6 +114,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(ne_w, float, 0, 2, T, B, 1)                                                  \
     X(hid_s, float, 0, 3, T, B, K)       /* baseline_sen relu hidden         :514  */ \
     X(hid_r, float, 0, 3, T, B, K)                                                 \
+    X(basehx, float, 0, 2, B, K, 1)      /* h_x . baseline_sen.linear1.weight[:, :H]^T (same for every step of a sample) */ \
     X(bs_part, float, 0, 3, T, B, NPB)   /* partial scores per 64 hidden units     */ \
     X(br_part, float, 0, 3, T, B, NPB)                                             \
     X(bs, float, 0, 3, T, B, 1)          /* baseline_sen scores              :835  */ \

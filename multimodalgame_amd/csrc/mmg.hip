@@ -360,11 +360,14 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     memset(&ar, 0, sizeof(ar));
     ar.x = d_x; ar.target = d_target; ar.desc = d_desc; ar.u_z = d_u_z; ar.u_s = d_u_s; ar.u_w = d_u_w; ar.seed = seed;
     ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
+    bool base_ready = false;
     {
         Scope sc(h, st, "k_conversation");
         const bool fast = fast_shape(d);
+        base_ready = fast && !getenv("MMG_CONV256") && bas && !run_all_steps && !getenv("MMG_NO_MERGE");
+        const int base_tiles = base_ready ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
         if (fast && !getenv("MMG_CONV256"))
-            hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
+            hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
         else if (fast)
             hipLaunchKernelGGL((k_conversation_fast<256, 32, 64, 100, 30>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, ar);
         else
@@ -379,7 +382,7 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
             Scope sc(h, st, "k_baselines");
             // grid.z = 2 baselines x 2 step ranges: 128 workgroups at config 1 instead of 64
             hipLaunchKernelGGL(k_baselines2, dim3((d.B + 15) / 16, (d.K + 63) / 64, 2 * (d.T >= 4 ? 2 : 1)), dim3(MMG_BLOCK), 0, st,
-                               h->dm, h->P, h->tp, 1);
+                               h->dm, h->P, h->tp, 1, base_ready ? 1 : 0);
             if (launch_check("k_baselines2")) return -1;
             h->scores_in_parts = true;
         }
