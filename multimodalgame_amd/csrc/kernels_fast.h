@@ -911,6 +911,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     if (tid == 0) { s_misc[0] = 1.f; s_misc[1] = -1.f; s_misc[2] = 1.f; tp.mask[b] = 1; }
     __syncthreads();
 
+    float stop_p = 0.5f, stop_bit = 0.f;
     MMG_STAMP(2);
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)t * B + b;
@@ -995,11 +996,9 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
                     s_misc[2] = prod;
                     sbit = rintf(prod);
                 }
+                s_misc[3] = sbit;                                          // (the barrier is waiting for this wave)
                 tp.s[row] = sbit; tp.ps[row] = p;
-                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                tp.lp_s[row] = sbit * l1 + (1.f - sbit) * l0;
-                tp.ne_s[row] = p * l1 + (1.f - p) * l0;
-                s_misc[3] = sbit;
+                stop_p = p; stop_bit = sbit;                               // log terms: after B9, off the critical path
             }
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 4);                       // B5
@@ -1028,7 +1027,14 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             if (take_out) s_misc[1] = (float)t;
             s_misc[0] = m_next;
         }
-        if (!ar.run_all && !dm.fixed && train && m_next == 0.f) { ++t; __syncthreads(); break; }
+        if (!ar.run_all && !dm.fixed && train && m_next == 0.f) {
+            if (wave == 7 && lane == 0) {
+                const float l1 = flog(stop_p + MMG_EPS), l0 = flog(1.f - stop_p + MMG_EPS);
+                tp.lp_s[row] = stop_bit * l1 + (1.f - stop_bit) * l0;
+                tp.ne_s[row] = stop_p * l1 + (1.f - stop_p) * l0;
+            }
+            ++t; __syncthreads(); break;
+        }
         // ===== (7) softmax (per wave, lanes < 32) -> wave-private LDS -> description mixture (2 lanes per column)
         {
             const float yv = (lane < 32) ? s_y[lane] : -3.0e38f;
@@ -1091,6 +1097,11 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             }
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 8);                       // B9
+        if (wave == 7 && lane == 0) {
+            const float l1 = flog(stop_p + MMG_EPS), l0 = flog(1.f - stop_p + MMG_EPS);
+            tp.lp_s[row] = stop_bit * l1 + (1.f - stop_bit) * l0;
+            tp.ne_s[row] = stop_p * l1 + (1.f - stop_p) * l0;
+        }
         if (binary && wave == 7) {                                         // overlaps with phase (1) of the next step
             float lpv = 0.f, nev = 0.f;
             if (lane < W) {
