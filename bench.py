@@ -127,6 +127,7 @@ def run_gpu(args, rank, world, local_rank):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ex_steps = float(eng.tape["totals"][0].item()) - steps_before
+    eng.check_sync()                                      # no in-launch dependency wait may have timed out
 
     # per-kernel launch durations of the same workload, HIP events on the launch stream (rank 0)
     roof = None

@@ -163,10 +163,18 @@ class Engine(object):
         nm = names.value.decode().split(";")[:n]
         return list(zip(nm, [float(ms[i]) for i in range(n)]))
 
+    def check_sync(self):
+        """Raise if an in-launch dependency wait (device_utils.h: role_wait) ever hit its spin bound: word 63 of the
+        tape array `sync` holds the dependency number + 1.  Synchronises the device; call it off the hot path."""
+        code = int(self.tape["sync"][63].item())
+        if code:
+            raise _lib.MmgError("in-launch dependency %d timed out on the device (workgroup roles out of order?)" % (code - 1))
+
     # ------------------------------------------------------------------ results
     def losses(self):
         """dict of the six scalars of model.py:1271-1294 plus n_steps / hits (one device->host copy)."""
         v = self.tape["losses"].cpu().tolist()
+        self.check_sync()
         keys = ("nll_loss", "loss_binary_s", "loss_binary_rec", "loss_binary_sen", "loss_bas_rec", "loss_bas_sen",
                 "n_steps", "hits")
         return dict(zip(keys, v))

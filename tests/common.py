@@ -162,6 +162,7 @@ def make_engine(meta, **over):
 def engine_result(eng, fl):
     """Slice the tape the way exchange() returns it (lists over the executed steps)."""
     torch.cuda.synchronize()
+    eng.check_sync()
     tp = {k: v.cpu() for k, v in eng.tape.items() if k in (
         "mask", "s", "ps", "z", "pz", "w", "pw", "y", "bs", "br", "outp", "dist", "logs", "losses")}
     losses = tp["losses"].tolist()
