@@ -3,20 +3,12 @@
 //
 // Why: at these shapes one exchange step of one sample is ~107 k FMAs over 53.5 k weights.  The
 // generic kernel (kernels_fwd.h) re-reads every weight from L2 at every step and pays one L2 round
-// trip per layer on a dependent chain (~34 us per step measured).  Here one workgroup (4 waves, one
-// per SIMD, up to 512 VGPRs each) loads the 53.5 k per-step weights ONCE into registers -- ~280 per
-// lane, every layer with a fixed lane->weight mapping chosen at compile time -- and then runs the T
-// steps with activations in LDS: no global load sits on the critical path of the recurrence; tape
-// stores are fire-and-forget.
-//
-// Lane mappings (NT = 256 threads):
-//   code_layer  [H,W]   thread n owns row n (W regs): no reduction, tanh applied by the same lane
-//   binary_layer[W,H]   8 lanes per row, float4-interleaved K slices (conflict-free LDS reads), 3 shuffles
-//   GRU         [3R,W+R] thread n < 3R owns row n of W_ih and W_hh (W+R regs), operands broadcast from LDS
-//   y1[:, :R], w_h [R,R]  4 lanes per row (R/4 regs each), 2 shuffles
-//   y head      Cd [D,R]   8 lanes per class (R/8 regs of Cd and of w_y2), 3 shuffles
-//   softmax . desc        every wave redoes the D<=32-lane softmax; thread v < V owns column v of desc (D regs)
-//   w_d [R,V]   4 lanes per row (V/4 regs), w [W,R] 8 lanes per row (R/8 regs)
+// trip per layer on a dependent chain (~34 us per step measured).  Here the workgroup of a sample loads
+// the per-step weights ONCE into registers, every layer with a fixed lane->weight mapping chosen at compile
+// time, and then runs the T steps with activations in LDS: no global load sits on the critical path of the
+// recurrence; tape stores are fire-and-forget.  The lane mappings are listed at each kernel.
+// (A first 256-thread / one-wave-per-SIMD forward kernel, ~270 weight registers per lane, was replaced by the
+// 512-thread k_conversation_fast2: 37 -> 27 us.)
 #pragma once
 #include "device_utils.h"
 #include "kernels_fwd.h"
@@ -62,398 +54,11 @@ __device__ __forceinline__ float dot4(const float* __restrict__ w, const float* 
 template <int N>
 __device__ __forceinline__ float lane_group_sum(float v) { return dpp_group_sum<N>(v); }
 
-template <int H, int W, int R, int V, int D>
-__global__ __launch_bounds__(256, 1) void k_conversation_fast(Dims dm, Params P, Tape tp, ConvArgs ar) {
-    constexpr int NT = 256;
-    static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
-    __shared__ __attribute__((aligned(16))) float s_a[H];
-    __shared__ __attribute__((aligned(16))) float s_c[W];      // sender code input / receiver message
-    __shared__ __attribute__((aligned(16))) float s_z[W];
-    __shared__ __attribute__((aligned(16))) float s_h[R];
-    __shared__ __attribute__((aligned(16))) float s_gi[3 * R];
-    __shared__ __attribute__((aligned(16))) float s_gh[3 * R];
-    __shared__ __attribute__((aligned(16))) float s_A[R];
-    __shared__ __attribute__((aligned(16))) float s_y[32];
-    __shared__ __attribute__((aligned(16))) float s_yout[32];
-    __shared__ __attribute__((aligned(16))) float s_dbar[V];
-    __shared__ __attribute__((aligned(16))) float s_g[R];
-    __shared__ float s_lp[W], s_ne[W], s_lpw[W], s_new[W];
-    __shared__ float s_misc[8];
-    // injected uniforms of this sample (the loop must not contain global loads: on gfx950 a load's
-    // s_waitcnt vmcnt also drains every outstanding tape store, ~1-2 us each)
-    constexpr int TMAX = 16;
-    __shared__ float s_uz[TMAX * W], s_uw[TMAX * W], s_us[TMAX];
-
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int B = dm.B, T = dm.T;
-    const bool binary = dm.use_binary != 0, train = ar.train != 0;
-    const bool inject = ar.u_s != nullptr;
-    const uint32_t mb_counter = tp.counter[0];
-    const uint32_t gb = (uint32_t)(dm.boff + b);
-#ifdef MMG_TIMING
-    if (b == 0 && tid == 0) { tp.dbg[0] = (long long)wall_clock64(); tp.dbg[4] = (long long)clock64(); }
-#endif
-    if (train && inject) {
-        for (int i = tid; i < T * W; i += NT) {
-            const int t = i / W, j = i - t * W;
-            if (ar.u_z) s_uz[i] = ar.u_z[((size_t)t * B + b) * W + j];
-            if (ar.u_w) s_uw[i] = ar.u_w[((size_t)t * B + b) * W + j];
-        }
-        if (tid < T) s_us[tid] = ar.u_s[(size_t)tid * B + b];
-    } else if (train) {
-        // the draws do not depend on the conversation: generate all of them up front, in parallel, instead of
-        // running a serial 10-round Philox chain on one lane per bit inside every sampling phase
-        for (int i = tid; i < T * W; i += NT) {
-            const int t = i / W, j = i - t * W;
-            const uint32_t e = (uint32_t)((t * dm.Bg + gb) * W + j);
-            s_uz[i] = philox_uniform(ar.seed, e, mb_counter, 0u);
-            s_uw[i] = philox_uniform(ar.seed, e, mb_counter, 2u);
-        }
-        if (tid < T) s_us[tid] = philox_uniform(ar.seed, (uint32_t)(tid * dm.Bg + gb), mb_counter, 1u);
-    }
-
-    // ------------------------------------------------------------ weights -> registers (once)
-    float wc[W];                                   // code_layer row tid
-    {
-        const float4* r4 = reinterpret_cast<const float4*>(P.p[S_CODE_W] + (size_t)tid * W);
-#pragma unroll
-        for (int j = 0; j < W / 4; ++j) { const float4 v = r4[j]; wc[4 * j] = v.x; wc[4 * j + 1] = v.y; wc[4 * j + 2] = v.z; wc[4 * j + 3] = v.w; }
-    }
-    const float bc = P.p[S_CODE_B][tid];
-    const float hw0 = tp.hw0[tid];
-    const float hx = tp.hx[(size_t)b * H + tid];
-    // binary_layer: row nb = tid/8, K slice kp = tid%8: k = kp*4 + 32*j + {0..3}
-    constexpr int LB = NT / W;                     // 8 lanes per row
-    constexpr int JB = H / (4 * LB);               // 8 float4 per lane
-    const int nb = tid / LB, kpb = tid % LB;
-    float wb[4 * JB];
-    {
-        const float* row = P.p[S_BIN_W] + (size_t)nb * H;
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(row + kpb * 4 + 4 * LB * j);
-            wb[4 * j] = v.x; wb[4 * j + 1] = v.y; wb[4 * j + 2] = v.z; wb[4 * j + 3] = v.w;
-        }
-    }
-    const float bb = P.p[S_BIN_B][nb];
-    // GRU rows
-    const bool gru_lane = tid < 3 * R;
-    float wih[W], whh[R];
-    float bih = 0.f, bhh = 0.f;
-    if (gru_lane) {
-        const float4* a4 = reinterpret_cast<const float4*>(P.p[R_WIH] + (size_t)tid * W);
-#pragma unroll
-        for (int j = 0; j < W / 4; ++j) { const float4 v = a4[j]; wih[4 * j] = v.x; wih[4 * j + 1] = v.y; wih[4 * j + 2] = v.z; wih[4 * j + 3] = v.w; }
-        const float4* b4 = reinterpret_cast<const float4*>(P.p[R_WHH] + (size_t)tid * R);
-#pragma unroll
-        for (int j = 0; j < R / 4; ++j) { const float4 v = b4[j]; whh[4 * j] = v.x; whh[4 * j + 1] = v.y; whh[4 * j + 2] = v.z; whh[4 * j + 3] = v.w; }
-        bih = P.p[R_BIH][tid]; bhh = P.p[R_BHH][tid];
-    } else {
-#pragma unroll
-        for (int j = 0; j < W; ++j) wih[j] = 0.f;
-#pragma unroll
-        for (int j = 0; j < R; ++j) whh[j] = 0.f;
-    }
-    // y1[:, :R] and w_h: row n4 = tid/4, K slice kp4 = tid%4: k = kp4*4 + 16*j + {0..3}
-    constexpr int L4 = NT / R;                     // 4 lanes per row
-    constexpr int J4 = R / (4 * L4);               // 4 float4 per lane
-    const int n4 = tid / L4, kp4 = tid % L4;
-    float wy1[4 * J4], wh[4 * J4];
-    {
-        const float* ry = P.p[R_Y1_W] + (size_t)n4 * (R + V);
-        const float* rh = P.p[R_WH_W] + (size_t)n4 * R;
-#pragma unroll
-        for (int j = 0; j < J4; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(ry + kp4 * 4 + 4 * L4 * j);
-            wy1[4 * j] = v.x; wy1[4 * j + 1] = v.y; wy1[4 * j + 2] = v.z; wy1[4 * j + 3] = v.w;
-            const float4 u = *reinterpret_cast<const float4*>(rh + kp4 * 4 + 4 * L4 * j);
-            wh[4 * j] = u.x; wh[4 * j + 1] = u.y; wh[4 * j + 2] = u.z; wh[4 * j + 3] = u.w;
-        }
-    }
-    const float bh = P.p[R_WH_B][n4];
-    // w_d [R,V]: row n4, k = kp4 + 4*j
-    constexpr int JD = V / L4;
-    float wd[JD];
-    {
-        const float* rd = P.p[R_WD_W] + (size_t)n4 * V;
-#pragma unroll
-        for (int j = 0; j < JD; ++j) wd[j] = rd[kp4 + L4 * j];
-    }
-    // stop head: lane l of every wave holds w_s[l]
-    const float ws = P.p[R_S_W][lane];
-    const float bs = P.p[R_S_B][0];
-    // y head: class dy = tid/8 (< 32), K slice kpy = tid%8: k = kpy*4 + 32*j + {0..3}
-    constexpr int LY = 8, JY = R / (4 * LY);       // 2 float4 per lane
-    const int dy = tid / LY, kpy = tid % LY;
-    float cd[4 * JY], w2[4 * JY];
-    {
-        const float* rc = tp.Cd + (size_t)(dy < D ? dy : 0) * R;
-        const float* rw = P.p[R_Y2_W];
-#pragma unroll
-        for (int j = 0; j < JY; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(rc + kpy * 4 + 4 * LY * j);
-            cd[4 * j] = v.x; cd[4 * j + 1] = v.y; cd[4 * j + 2] = v.z; cd[4 * j + 3] = v.w;
-            const float4 u = *reinterpret_cast<const float4*>(rw + kpy * 4 + 4 * LY * j);
-            w2[4 * j] = u.x; w2[4 * j + 1] = u.y; w2[4 * j + 2] = u.z; w2[4 * j + 3] = u.w;
-        }
-    }
-    const float b2 = P.p[R_Y2_B][0];
-    // desc column v = tid (< V)
-    float dcol[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) dcol[d] = (tid < V) ? ar.desc[(size_t)d * V + tid] : 0.f;
-    // w [W,R]: row nb (= tid/8), k = kpb*4 + 32*j + {0..3}
-    constexpr int JW = R / (4 * LB);               // 2 float4 per lane
-    float ww[4 * JW];
-    {
-        const float* rw = P.p[R_W_W] + (size_t)nb * R;
-#pragma unroll
-        for (int j = 0; j < JW; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(rw + kpb * 4 + 4 * LB * j);
-            ww[4 * j] = v.x; ww[4 * j + 1] = v.y; ww[4 * j + 2] = v.z; ww[4 * j + 3] = v.w;
-        }
-    }
-    const float bw = P.p[R_W_B][nb];
-    const float sig_cb = (tid < W) ? fsigmoid(P.p[S_CODE_BIAS][tid]) : 0.f;
-
 #ifdef MMG_TIMING
 #define MMG_STAMP(slot) do { if (b == 0 && tid == 0) tp.dbg[(slot)] = (long long)wall_clock64(); } while (0)
 #else
 #define MMG_STAMP(slot) do {} while (0)
 #endif
-    MMG_STAMP(1);
-    // ------------------------------------------------------------ conversation state
-    if (tid < R) { s_h[tid] = 0.f; tp.h[(size_t)b * R + tid] = 0.f; }
-    if (tid < W) s_c[tid] = dm.first_rec;
-    if (tid == 0) { s_misc[0] = 1.f; s_misc[1] = -1.f; s_misc[2] = 1.f; tp.mask[b] = 1; }
-    __syncthreads();
-
-    MMG_STAMP(2);
-    for (int t = 0; t < T; ++t) {
-        const size_t row = (size_t)t * B + b;
-        MMG_STAMP(8 + 10 * t + 9);
-        // ===== (1) sender: h_w = code_layer(c), a = tanh(h_x + h_w)  [thread n = tid]
-        float av;
-        {
-            float hw = hw0;
-            if (t > 0) {
-                hw = bc + dot4<W / 4>(wc, s_c, 4);
-            }
-            av = ftanh(hx + hw);
-            s_a[tid] = av;
-            tp.a[row * H + tid] = av;
-            if (tid < W) {
-                const float cv = s_c[tid];
-                tp.zr[row * W + tid] = cv;
-                tp.c[row * W + tid] = (t == 0) ? sig_cb : cv;
-            }
-        }
-        // GRU hidden-side product does not depend on this step's message: overlap it here
-        float ghv = bhh;
-        if (gru_lane) ghv += dot4<R / 4>(whh, s_h, 4);
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 0);                         // B1: a ready
-        // ===== (2) sender: logits = binary_layer(a), Bernoulli sample
-        {
-            float acc = dot4<JB>(wb, s_a + kpb * 4, 4 * LB);
-            acc = lane_group_sum<LB>(acc);
-            if (kpb == 0) {
-                const float lz = acc + bb;
-                float zz = lz, pp = 0.f;
-                if (binary) {
-                    pp = fsigmoid(lz);
-                    zz = train ? ((s_uz[t * W + nb] < pp) ? 1.f : 0.f) : rintf(pp);
-                    tp.pz[row * W + nb] = pp;
-                }
-                s_z[nb] = zz; s_lp[nb] = pp;                               // log-lik / entropy terms: wave 3, next phase
-                tp.z[row * W + nb] = zz;
-            }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 1);                         // B2: z ready
-        // ===== (3) receiver GRU gate pre-activations  [thread n < 3R]
-        if (gru_lane) {
-            const float giv = bih + dot4<W / 4>(wih, s_z, 4);
-            s_gi[tid] = giv; s_gh[tid] = ghv;
-        }
-        if (binary && tid >= 192 && tid < 192 + 64) {                      // wave 3 is idle here: reduce the sender's log-lik terms
-            const int l = tid - 192;
-            float lpv = 0.f, nev = 0.f;
-            if (l < W) {
-                const float p = s_lp[l], zz = s_z[l];
-                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                lpv = zz * l1 + (1.f - zz) * l0;                             // model.py:908-910
-                nev = p * l1 + (1.f - p) * l0;                               // model.py:919-922
-            }
-            lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
-            if (l == 0) { tp.lp_z[row] = lpv; tp.ne_z[row] = nev; }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 2);                         // B3: gates ready
-        // ===== (4) GRU state update  [thread i < R]
-        if (tid < R) {
-            const float rr = fsigmoid(s_gi[tid] + s_gh[tid]);
-            const float uu = fsigmoid(s_gi[R + tid] + s_gh[R + tid]);
-            const float ghn = s_gh[2 * R + tid];
-            const float nn = ftanh(s_gi[2 * R + tid] + rr * ghn);
-            const float hv = nn + uu * (s_h[tid] - nn);
-            float* gr = tp.gru + row * 4 * R;
-            gr[tid] = rr; gr[R + tid] = uu; gr[2 * R + tid] = nn; gr[3 * R + tid] = ghn;
-            tp.h[((size_t)(t + 1) * B + b) * R + tid] = hv;
-            s_h[tid] = hv;                                                 // (s_h is only read again after B4)
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 3);                         // B4: h ready
-        // ===== (5) heads on h: A = y1[:, :R] h, gh_ = w_h h + b_h (kept in registers), stop bit
-        float gpre_h;
-        {
-            float accA = dot4<J4>(wy1, s_h + kp4 * 4, 4 * L4);
-            float accH = dot4<J4>(wh, s_h + kp4 * 4, 4 * L4);
-            accA = lane_group_sum<L4>(accA);
-            accH = lane_group_sum<L4>(accH);
-            if (kp4 == 0) s_A[n4] = accA;
-            gpre_h = accH + bh;
-        }
-        if (tid < 64) {                                                    // stop head on wave 0
-            float sv = dpp_wave_sum(ws * s_h[lane]);
-            if (lane == 0) {
-                const float p = fsigmoid(sv + bs);
-                float sbit;
-                if (train) {
-                    const float u = s_us[t];
-                    sbit = (u < p) ? 1.f : 0.f;
-                } else {
-                    const float prod = dm.s_prob_prod ? s_misc[2] * p : p;
-                    s_misc[2] = prod;
-                    sbit = rintf(prod);
-                }
-                tp.s[row] = sbit; tp.ps[row] = p;
-                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                tp.lp_s[row] = sbit * l1 + (1.f - sbit) * l0;
-                tp.ne_s[row] = p * l1 + (1.f - p) * l0;
-                s_misc[3] = sbit;
-            }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 4);                         // B5: A, stop bit ready
-        // ===== (6) class logits
-        {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < JY; ++j) {
-                const float4 a4 = *reinterpret_cast<const float4*>(s_A + kpy * 4 + 4 * LY * j);
-                acc = fmaf(w2[4 * j], fmaxf(a4.x + cd[4 * j], 0.f), acc);
-                acc = fmaf(w2[4 * j + 1], fmaxf(a4.y + cd[4 * j + 1], 0.f), acc);
-                acc = fmaf(w2[4 * j + 2], fmaxf(a4.z + cd[4 * j + 2], 0.f), acc);
-                acc = fmaf(w2[4 * j + 3], fmaxf(a4.w + cd[4 * j + 3], 0.f), acc);
-            }
-            acc = lane_group_sum<LY>(acc);
-            if (kpy == 0) {
-                const float yv = (dy < D) ? acc + b2 : -3.0e38f;
-                s_y[dy] = yv;
-                if (dy < D) tp.y[row * D + dy] = yv;
-            }
-        }
-        // stop-mask bookkeeping
-        const float m_t = s_misc[0], sbit = s_misc[3];
-        const float m_next = fminf(m_t, sbit);
-        const bool first_stop = (m_next == 0.f) && (s_misc[1] < 0.f);
-        const bool take_out = dm.fixed ? (t == T - 1) : (first_stop || ((t == T - 1) && (s_misc[1] < 0.f)));
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 5);                         // B6: y ready (and everyone has read misc)
-        if (take_out && tid < 32) s_yout[tid] = s_y[tid];
-        if (tid == 0) {
-            tp.mask[(size_t)(t + 1) * B + b] = (uint8_t)(m_next != 0.f);
-            if (take_out) s_misc[1] = (float)t;
-            s_misc[0] = m_next;
-        }
-        if (!ar.run_all && !dm.fixed && train && m_next == 0.f) { ++t; __syncthreads(); break; }
-        // ===== (7) softmax (every wave redoes it on lanes d < D) and the description mixture
-        {
-            const float yv = (lane < 32) ? s_y[lane] : -3.0e38f;
-            const float mx = dpp_wave_max(yv);
-            const float e = (lane < D) ? __expf(yv - mx) : 0.f;
-            const float inv = 1.f / dpp_wave_sum(e);
-            float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
-#pragma unroll
-            for (int d = 0; d + 3 < D; d += 4) {
-                q0 = fmaf(__shfl(e, d, 64), dcol[d], q0); q1 = fmaf(__shfl(e, d + 1, 64), dcol[d + 1], q1);
-                q2 = fmaf(__shfl(e, d + 2, 64), dcol[d + 2], q2); q3 = fmaf(__shfl(e, d + 3, 64), dcol[d + 3], q3);
-            }
-#pragma unroll
-            for (int d = D & ~3; d < D; ++d) q0 = fmaf(__shfl(e, d, 64), dcol[d], q0);
-            const float acc = ((q0 + q1) + (q2 + q3)) * inv;
-            if (tid < V) { s_dbar[tid] = acc; tp.dbar[row * V + tid] = acc; }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 6);                         // B7: dbar ready
-        // ===== (8) h_w = tanh(w_h h + b_h + w_d dbar)
-        {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int j = 0; j + 3 < JD; j += 4) {
-                a0 = fmaf(wd[j], s_dbar[kp4 + L4 * j], a0); a1 = fmaf(wd[j + 1], s_dbar[kp4 + L4 * (j + 1)], a1);
-                a2 = fmaf(wd[j + 2], s_dbar[kp4 + L4 * (j + 2)], a2); a3 = fmaf(wd[j + 3], s_dbar[kp4 + L4 * (j + 3)], a3);
-            }
-#pragma unroll
-            for (int j = JD & ~3; j < JD; ++j) a0 = fmaf(wd[j], s_dbar[kp4 + L4 * j], a0);
-            float acc = lane_group_sum<L4>((a0 + a1) + (a2 + a3));
-            if (kp4 == 0) {
-                const float gv = ftanh(gpre_h + acc);
-                s_g[n4] = gv;
-                tp.g[row * R + n4] = gv;
-            }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 7);                         // B8: g ready
-        // ===== (9) receiver message
-        {
-            float acc = dot4<JW>(ww, s_g + kpb * 4, 4 * LB);
-            acc = lane_group_sum<LB>(acc);
-            if (kpb == 0) {
-                const float lw = acc + bw;
-                float wv = lw, pp = 0.f;
-                if (binary) {
-                    pp = fsigmoid(lw);
-                    wv = train ? ((s_uw[t * W + nb] < pp) ? 1.f : 0.f) : rintf(pp);
-                    tp.pw[row * W + nb] = pp;
-                }
-                s_c[nb] = wv; s_lpw[nb] = pp;
-                tp.w[row * W + nb] = wv;
-            }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 8);                         // B9: w ready
-        if (binary && tid >= 192) {                                        // wave 3 has no GRU rows: it overlaps with phase (1)
-            float lpv = 0.f, nev = 0.f;
-            if (lane < W) {
-                const float p = s_lpw[lane], wv = s_c[lane];
-                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                lpv = wv * l1 + (1.f - wv) * l0;
-                nev = p * l1 + (1.f - p) * l0;
-            }
-            lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
-            if (lane == 0) { tp.lp_w[row] = lpv; tp.ne_w[row] = nev; }
-        }
-    }
-    __syncthreads();
-#ifdef MMG_TIMING
-    if (b == 0 && tid == 0) { tp.dbg[3] = (long long)wall_clock64(); tp.dbg[5] = (long long)clock64(); }
-#endif
-    // ------------------------------------------------------------ output selection / reward / top-k
-    const int tstar = dm.fixed ? (T - 1) : (int)s_misc[1];
-    if (tid < 64) {
-        const float o = (lane < 32) ? s_yout[lane] : -3.0e38f;
-        const float mx = dpp_wave_max(o);
-        const float e = (lane < D) ? __expf(o - mx) : 0.f;
-        const float lse = mx + flog(dpp_wave_sum(e));
-        const int tgt = ar.target ? (int)ar.target[b] : -1;
-        const float dt = (tgt >= 0) ? (__shfl(o, tgt, 64) - lse) : 0.f;
-        const float ld = o - lse;
-        if (lane < D) {
-            tp.outp[(size_t)b * D + lane] = o;
-            tp.dist[(size_t)b * D + lane] = ld;
-            tp.sm[(size_t)b * D + lane] = __expf(ld);
-        }
-        const float above = dpp_wave_sum((lane < D && tgt >= 0 && ld > dt) ? 1.f : 0.f);
-        if (lane == 0) {
-            tp.tstar[b] = tstar;
-            tp.logs[b] = dt;
-            tp.hit[b] = (tgt >= 0 && above < (float)dm.top_k) ? 1 : 0;
-        }
-    }
-}
 
 }  // namespace mmg
 
@@ -751,8 +356,8 @@ namespace mmg {
 
 // ---------------------------------------------------------------------------------------------
 // k_conversation_fast2: the same register-resident conversation on 512 threads (8 waves = TWO per SIMD).
-// k_conversation_fast is bound by dependent-instruction issue of a single wave per SIMD (~5 cycles per
-// instruction, ~1800 instructions per step).  Spreading every layer over twice the lanes halves the
+// One wave per SIMD (256 threads) is bound by dependent-instruction issue (~5 cycles per instruction, ~1800
+// instructions per step).  Spreading every layer over twice the lanes halves the
 // per-lane FMA/operand work (136 weight registers per lane instead of ~270, no AGPR spill traffic) and gives
 // each SIMD a second wave to issue from while the first waits on LDS / DPP / transcendental latency.
 //   code_layer  2 lanes per row (16 regs)      binary_layer 16 lanes per row (16 regs)

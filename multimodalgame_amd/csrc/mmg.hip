@@ -43,6 +43,8 @@ struct mmg_handle {
     int conv_smem, bwd_smem, prep_smem;
     bool profiling;
     bool scores_in_parts;      // the last forward left baseline scores as partials (k_baselines2)
+    bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
+    bool merge_roles;          // MMG_NO_MERGE=1 keeps k_stats / k_dC / basehx as separate launches / in-kernel work
     std::vector<KernelTimer> timers;
     size_t timers_used;
 };
@@ -243,6 +245,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->tp = resolve_tape(h->tl, d_workspace);
     h->d_jt = reinterpret_cast<JobTable*>(h->tp.tables);
     h->profiling = false; h->timers_used = 0; h->scores_in_parts = false;
+    h->use_fast = !getenv("MMG_NO_FAST"); h->merge_roles = !getenv("MMG_NO_MERGE");
     h->conv_smem = conv_smem_floats(h->dm) * 4;
     h->bwd_smem = bwd_smem_floats(h->dm) * 4;
     h->prep_smem = ((h->dm.V > h->dm.W ? h->dm.V : h->dm.W) + 4) * 4;
@@ -343,8 +346,10 @@ static int launch_baselines_fused(mmg_handle* h, hipStream_t st) {
     return launch_check("k_baselines");
 }
 
-static bool fast_shape(const Dims& d) {
-    return !getenv("MMG_NO_FAST") && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
+// register-resident kernels exist for the agent shape of BASELINE configs 1-3
+static bool fast_shape(const mmg_handle* h) {
+    const Dims& d = h->dm;
+    return h->use_fast && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
 }
 
 extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
@@ -363,13 +368,11 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     bool base_ready = false;
     {
         Scope sc(h, st, "k_conversation");
-        const bool fast = fast_shape(d);
-        base_ready = fast && !getenv("MMG_CONV256") && bas && !run_all_steps && !getenv("MMG_NO_MERGE");
+        const bool fast = fast_shape(h);
+        base_ready = fast && bas && !run_all_steps && h->merge_roles;
         const int base_tiles = base_ready ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
-        if (fast && !getenv("MMG_CONV256"))
+        if (fast)
             hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
-        else if (fast)
-            hipLaunchKernelGGL((k_conversation_fast<256, 32, 64, 100, 30>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, ar);
         else
             hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
         if (launch_check("k_conversation")) return -1;
@@ -400,15 +403,15 @@ extern "C" int mmg_loss_stats(mmg_handle* h, void* stream) {
 
 // single-GPU minibatch: the statistics run as extra roles of the backward launch (no all-reduce in between)
 static bool merge_stats(const mmg_handle* h) {
-    return fast_shape(h->dm) && h->dm.use_binary && h->scores_in_parts && !getenv("MMG_NO_MERGE");
+    return fast_shape(h) && h->dm.use_binary && h->scores_in_parts && h->merge_roles;
 }
 
 static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, hipStream_t st, bool with_stats) {
     const Dims& d = h->dm;
     {
         Scope sc(h, st, "k_bwd_conv");
-        const bool fast = fast_shape(d);
-        const bool merge_dc = fast && !getenv("MMG_NO_MERGE");
+        const bool fast = fast_shape(h);
+        const bool merge_dc = fast && h->merge_roles;
         if (fast && with_stats) {
             const int n_stats = 5 * d.T + 2;
             hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats);
@@ -420,7 +423,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             hipLaunchKernelGGL(k_bwd_conv, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
         if (launch_check("k_bwd_conv")) return -1;
     }
-    if (!(fast_shape(d) && !getenv("MMG_NO_MERGE"))) {
+    if (!(fast_shape(h) && h->merge_roles)) {
         Scope sc(h, st, "k_dC");
         hipLaunchKernelGGL(k_dC, dim3(d.D), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
         if (launch_check("k_dC")) return -1;

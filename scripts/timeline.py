@@ -1,4 +1,4 @@
-"""Per-phase timeline of k_conversation_fast for sample 0 (needs libmmg_timing.so: -DMMG_TIMING build)."""
+"""Per-phase timeline of k_conversation_fast2 / k_bwd_conv_fast / k_baselines2 for sample 0 (needs libmmg_timing.so: -DMMG_TIMING build)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
