@@ -70,9 +70,19 @@ __device__ __forceinline__ double dpp_wave_sum_d(double v) {        // same tree
     return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// wave-level sum over aligned groups of G lanes (G power of two, <= 64)
+// wave-level sum over aligned groups of G lanes (G power of two, <= 64, wave-uniform): lane 0 of every group -- in fact
+// every lane of it -- gets the group's total.  DPP only (see above); all 64 lanes must be active.
 __device__ __forceinline__ float group_sum(float v, int G) {
-    for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (G >= 2) v += dpp_f<MMG_DPP_QUAD_1032>(v);
+    if (G >= 4) v += dpp_f<MMG_DPP_QUAD_2301>(v);
+    if (G >= 8) v += dpp_f<MMG_DPP_ROW_HALF_MIRROR>(v);
+    if (G >= 16) v += dpp_f<MMG_DPP_ROW_MIRROR>(v);
+    if (G >= 32) {
+        v += dpp_rows_f<MMG_DPP_ROW_BCAST15, 0xA>(v, 0.f);            // rows 1 and 3 now hold the sums of lanes 0-31 / 32-63
+        const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+        v = (G == 64) ? lo + hi : (((threadIdx.x & 63) < 32) ? lo : hi);
+    }
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum(v, 64); }
@@ -115,49 +125,133 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 // row.  Falls back to scalar loads when the row stride / base are not 16-byte aligned.
 // No barrier inside; callers __syncthreads() before consuming what the epilogue stored.
 // ---------------------------------------------------------------------------------------------
-template <class Epi>
+template <int U = 4, class Epi>
 __device__ __forceinline__ void gemv_rows(const float* __restrict__ Wm, int ld, int N, int K,
                                           const float* v, Epi epi) {
+    // U row passes are loaded together (row indices clamped, not predicated, so the loads stay branch-free and the
+    // compiler keeps counted waits): U float4 per lane in flight instead of one L2 round trip per pass.  Each row is
+    // still summed by the same lanes in the same order as a one-pass-at-a-time loop would.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const bool vec = ((ld & 3) == 0) && ((K & 3) == 0) && ((((uintptr_t)Wm) & 15) == 0);
     const int items = vec ? (K >> 2) : K;
     int G = 1;
     while (G < 64 && G < items) G <<= 1;
     const int rpw = 64 / G, sub = lane / G, gl = lane - sub * G;
-    for (int n0 = wave * rpw; n0 < N; n0 += nw * rpw) {
-        const int n = n0 + sub;
-        float acc = 0.f;
-        if (n < N) {
-            const float* row = Wm + (size_t)n * ld;
-            if (vec) {
-                const float4* r4 = reinterpret_cast<const float4*>(row);
-                const float4* v4 = reinterpret_cast<const float4*>(v);
-                for (int k = gl; k < items; k += G) {
-                    const float4 a = r4[k], b = v4[k];
-                    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
-                    acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+    const int stride = nw * rpw;                        // rows the workgroup covers per pass
+    for (int n0 = wave * rpw + sub; n0 < N + sub; n0 += stride * U) {    // (n0 - sub) is wave-uniform
+        float acc[U];
+        size_t roff[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc[u] = 0.f; roff[u] = (size_t)min(n0 + u * stride, N - 1) * ld; }
+        if (vec) {
+            const float4* v4 = reinterpret_cast<const float4*>(v);
+            for (int k = gl; k < items; k += G) {
+                float4 a[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) a[u] = reinterpret_cast<const float4*>(Wm + roff[u])[k];
+                const float4 bq = v4[k];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc[u] = fmaf(a[u].x, bq.x, acc[u]); acc[u] = fmaf(a[u].y, bq.y, acc[u]);
+                    acc[u] = fmaf(a[u].z, bq.z, acc[u]); acc[u] = fmaf(a[u].w, bq.w, acc[u]);
                 }
-            } else {
-                for (int k = gl; k < items; k += G) acc = fmaf(row[k], v[k], acc);
+            }
+        } else {
+            for (int k = gl; k < items; k += G) {
+                float a[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) a[u] = Wm[roff[u] + k];
+                const float bq = v[k];
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = fmaf(a[u], bq, acc[u]);
             }
         }
-        acc = group_sum(acc, G);
-        if (gl == 0 && n < N) epi(n, acc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = n0 + u * stride;
+            const float r = group_sum(acc[u], G);
+            if (gl == 0 && n < N) epi(n, r);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Transposed GEMV, lanes along the output:  out[k] (+)= sum_n W[n*ld + k] * d[n],  k < K.
-// d and out in LDS; `scratch` >= blockDim.x floats.  Ends with a barrier (out is ready).
+// d and out in LDS; `scratch` >= 4 * blockDim.x floats, 16-byte aligned.  Ends with a barrier (out is ready).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gemv_t(const float* __restrict__ Wm, int ld, int N, int K,
                                        const float* d, float* out, float* scratch, bool accumulate) {
+    // Rows n are walked 8 at a time with every load of the group issued before the first FMA;
+    // the FMA order per output is the plain n = 0, 1, 2, ... order.
     const int tid = threadIdx.x, nt = blockDim.x;
+    const bool vec = ((ld & 3) == 0) && ((K & 3) == 0) && ((((uintptr_t)Wm) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
+    if (vec && (K >> 2) >= nt) {                        // wide outputs: a lane owns 4 consecutive outputs per pass
+        constexpr int UN = 8;
+        const int K4 = K >> 2;
+        for (int k4 = tid; k4 < K4; k4 += nt) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int n = 0; n < N; n += UN) {
+                float4 w[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) w[u] = reinterpret_cast<const float4*>(Wm + (size_t)min(n + u, N - 1) * ld)[k4];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const float dv = (n + u < N) ? d[min(n + u, N - 1)] : 0.f;
+                    acc.x = fmaf(w[u].x, dv, acc.x); acc.y = fmaf(w[u].y, dv, acc.y);
+                    acc.z = fmaf(w[u].z, dv, acc.z); acc.w = fmaf(w[u].w, dv, acc.w);
+                }
+            }
+            float4* o4 = reinterpret_cast<float4*>(out) + k4;
+            if (accumulate) { const float4 o = *o4; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+            *o4 = acc;
+        }
+        __syncthreads();
+        return;
+    }
+    constexpr int UN = 8;
     if (K >= nt) {
         for (int k = tid; k < K; k += nt) {
             float acc = 0.f;
-            for (int n = 0; n < N; ++n) acc = fmaf(Wm[(size_t)n * ld + k], d[n], acc);
+            for (int n = 0; n < N; n += UN) {
+                float w[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) w[u] = Wm[(size_t)min(n + u, N - 1) * ld + k];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) acc = fmaf(w[u], (n + u < N) ? d[min(n + u, N - 1)] : 0.f, acc);
+            }
             out[k] = accumulate ? out[k] + acc : acc;
+        }
+        __syncthreads();
+        return;
+    }
+    if (vec) {                                          // narrow outputs: K/4 lanes per part, nt / (K/4) parts over n
+        const int K4 = K >> 2, parts = nt / K4;
+        const int part = tid / K4, k4 = tid - part * K4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (part < parts) {
+            for (int n = part; n < N; n += parts * UN) {
+                float4 w[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) w[u] = reinterpret_cast<const float4*>(Wm + (size_t)min(n + u * parts, N - 1) * ld)[k4];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const float dv = (n + u * parts < N) ? d[min(n + u * parts, N - 1)] : 0.f;
+                    acc.x = fmaf(w[u].x, dv, acc.x); acc.y = fmaf(w[u].y, dv, acc.y);
+                    acc.z = fmaf(w[u].z, dv, acc.z); acc.w = fmaf(w[u].w, dv, acc.w);
+                }
+            }
+            reinterpret_cast<float4*>(scratch)[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < K4) {
+            float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = 0; p < parts; ++p) {
+                const float4 q = reinterpret_cast<const float4*>(scratch)[p * K4 + tid];
+                sacc.x += q.x; sacc.y += q.y; sacc.z += q.z; sacc.w += q.w;
+            }
+            float4* o4 = reinterpret_cast<float4*>(out) + tid;
+            if (accumulate) { const float4 o = *o4; sacc.x += o.x; sacc.y += o.y; sacc.z += o.z; sacc.w += o.w; }
+            *o4 = sacc;
         }
         __syncthreads();
         return;
@@ -166,7 +260,13 @@ __device__ __forceinline__ void gemv_t(const float* __restrict__ Wm, int ld, int
     const int part = tid / K, k = tid - part * K;
     if (part < parts) {
         float acc = 0.f;
-        for (int n = part; n < N; n += parts) acc = fmaf(Wm[(size_t)n * ld + k], d[n], acc);
+        for (int n = part; n < N; n += parts * UN) {
+            float w[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) w[u] = Wm[(size_t)min(n + u * parts, N - 1) * ld + k];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc = fmaf(w[u], (n + u * parts < N) ? d[min(n + u * parts, N - 1)] : 0.f, acc);
+        }
         scratch[tid] = acc;
     }
     __syncthreads();

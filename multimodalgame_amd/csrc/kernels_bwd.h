@@ -243,7 +243,7 @@ __device__ __forceinline__ float bit_seed(float q, float p, float wh, float ce) 
 
 __host__ __device__ inline int bwd_smem_floats(const Dims& d) {
     auto p4 = [](int n) { return (n + 3) & ~3; };
-    return 7 * d.T + 3 * p4(d.H) + 3 * p4(d.W) + 6 * p4(d.R) + 2 * p4(3 * d.R) + p4(d.D) + MMG_BLOCK + 32;
+    return 7 * d.T + 3 * p4(d.H) + 3 * p4(d.W) + 6 * p4(d.R) + 2 * p4(3 * d.R) + p4(d.D) + 4 * MMG_BLOCK + 32;
 }
 
 __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
     float* s_A = p; p += p4(R);     float* s_dA = p; p += p4(R);   float* s_hs = p; p += p4(R);
     float* s_dgi = p; p += p4(3 * R); float* s_dgh = p; p += p4(3 * R);
     float* s_dy = p; p += p4(D);
-    float* s_red = p; p += MMG_BLOCK;
+    float* s_red = p; p += 4 * MMG_BLOCK;
     float* s_misc = p;
 
     loss_coefficients(dm, tp.stats, lc, nullptr, nullptr);        // logged losses: spare block of k_wgrad
@@ -341,7 +341,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
             for (int i = tid; i < R; i += nt) {
                 const float a = s_A[i];
                 float acc = 0.f;
-                for (int d = 0; d < D; ++d) acc += (a + tp.Cd[(size_t)d * R + i] > 0.f) ? s_dy[d] : 0.f;
+                for (int d = 0; d < D; d += 8) {                               // 8 class rows of Cd in flight, same add order
+                    float cv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cv[u] = tp.Cd[(size_t)min(d + u, D - 1) * R + i];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += (d + u < D && a + cv[u] > 0.f) ? s_dy[min(d + u, D - 1)] : 0.f;
+                }
                 const float v = acc * w2[i];
                 s_dA[i] = v; tp.dA[(size_t)b * R + i] = v; tp.Astar[(size_t)b * R + i] = a;
             }

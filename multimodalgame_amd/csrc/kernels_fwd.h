@@ -191,12 +191,16 @@ struct ConvSmem {
 
 __device__ __forceinline__ int pad4(int n) { return (n + 3) & ~3; }
 
-__host__ __device__ inline int conv_smem_floats(const Dims& d) {
+__host__ __device__ inline int conv_smem_floats(const Dims& d, int nthreads) {
     auto p4 = [](int n) { return (n + 3) & ~3; };
-    return 2 * p4(d.H) + 5 * p4(d.W) + 5 * p4(d.R) + 2 * p4(3 * d.R) + 2 * p4(d.D) + p4(d.V) + MMG_BLOCK + 32;
+    return 2 * p4(d.H) + 5 * p4(d.W) + 5 * p4(d.R) + 2 * p4(3 * d.R) + 2 * p4(d.D) + p4(d.V) + 4 * nthreads + 32;
 }
 
-__global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, Tape tp, ConvArgs ar) {
+// NT = 256 (many samples: occupancy) or 512 with deeper load batches (few samples, large weight matrices: the weights
+// stream from L2 every step, so what counts is bytes in flight per CU).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_conversation(Dims dm, Params P, Tape tp, ConvArgs ar) {
+    constexpr int GU = NT == 512 ? 8 : 4;               // row passes per load batch of gemv_rows
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
         s.gi = p; p += pad4(3 * R); s.gh = p; p += pad4(3 * R);
         s.y = p; p += pad4(D);   s.yout = p; p += pad4(D);
         s.dbar = p; p += pad4(V);
-        s.red = p; p += MMG_BLOCK;
+        s.red = p; p += 4 * NT;
         s.misc = p;
     }
     float* s_ne = s.ne;
@@ -257,12 +261,14 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
             }
             __syncthreads();
             if (t > 0) {
-                const float* bc = P.p[S_CODE_B];
-                gemv_rows(P.p[S_CODE_W], W, H, W, s.c, [&](int n, float acc) { s.a[n] = acc + bc[n]; });
+                // (epilogues only park the sums in LDS: a bias / uniform load inside them would be one dependent
+                //  global round trip per row pass, executed by a single lane of each group)
+                gemv_rows<GU>(P.p[S_CODE_W], W, H, W, s.c, [&](int n, float acc) { s.a[n] = acc; });
                 __syncthreads();
             }
+            const float* bc = P.p[S_CODE_B];
             for (int i = tid; i < H; i += nt) {
-                const float hw = (t == 0) ? tp.hw0[i] : s.a[i];
+                const float hw = (t == 0) ? tp.hw0[i] : s.a[i] + bc[i];
                 const float av = tanhf(s.hx[i] + hw);              // model.py:216
                 s.a[i] = av;
                 tp.a[row * H + i] = av;
@@ -271,8 +277,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
             {
                 const float* bb = P.p[S_BIN_B];
                 const float* uz = ar.u_z ? ar.u_z + row * W : nullptr;
-                gemv_rows(P.p[S_BIN_W], H, W, H, s.a, [&](int n, float acc) {
-                    const float lz = acc + bb[n];
+                gemv_rows<GU>(P.p[S_BIN_W], H, W, H, s.a, [&](int n, float acc) { s.z[n] = acc; });
+                __syncthreads();
+                for (int n = tid; n < W; n += nt) {
+                    const float lz = s.z[n] + bb[n];
                     float zz = lz, lpv = 0.f, nev = 0.f;
                     if (binary) {
                         const float p = sigmoidf_(lz);             // model.py:223
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
                     }
                     s.z[n] = zz; s.lp[n] = lpv; s_ne[n] = nev;
                     tp.z[row * W + n] = zz;
-                });
+                }
             }
             __syncthreads();
             if (binary) {
@@ -309,8 +317,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
         // ================= Receiver (model.py:333-342, 411-477) =================
         {   // GRUCell (model.py:340); gate order r, z(u), n
             const float* bih = P.p[R_BIH]; const float* bhh = P.p[R_BHH];
-            gemv_rows(P.p[R_WIH], W, 3 * R, W, s.z, [&](int n, float acc) { s.gi[n] = acc + bih[n]; });
-            gemv_rows(P.p[R_WHH], R, 3 * R, R, s.h, [&](int n, float acc) { s.gh[n] = acc + bhh[n]; });
+            gemv_rows<GU>(P.p[R_WIH], W, 3 * R, W, s.z, [&](int n, float acc) { s.gi[n] = acc; });
+            gemv_rows<GU>(P.p[R_WHH], R, 3 * R, R, s.h, [&](int n, float acc) { s.gh[n] = acc; });
+            __syncthreads();
+            for (int i = tid; i < 3 * R; i += nt) { s.gi[i] += bih[i]; s.gh[i] += bhh[i]; }
         }
         __syncthreads();
         for (int i = tid; i < R; i += nt) {
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
         __syncthreads();
         {   // stop head (model.py:414-427) and the h-half of y1 (Appendix A.2)
             const float bsv = P.p[R_S_B][0];
-            gemv_rows(P.p[R_S_W], R, 1, R, s.hn, [&](int n, float acc) {
+            gemv_rows<GU>(P.p[R_S_W], R, 1, R, s.hn, [&](int n, float acc) {
                 const float p = sigmoidf_(acc + bsv);
                 float sv;
                 if (train) {
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
                 tp.ne_s[row] = p * l1 + (1.f - p) * l0;
                 s.misc[3] = sv;
             });
-            gemv_rows(P.p[R_Y1_W], R + V, R, R, s.hn, [&](int n, float acc) { s.A[n] = acc; });
+            gemv_rows<GU>(P.p[R_Y1_W], R + V, R, R, s.hn, [&](int n, float acc) { s.A[n] = acc; });
         }
         __syncthreads();
         {   // y[d] = b_y2 + sum_r w_y2[r] * relu(A[r] + Cd[d,r])      (model.py:432-433)
@@ -355,25 +365,41 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
             const int items = vec ? (R >> 2) : R;
             int G = 1; while (G < 64 && G < items) G <<= 1;
             const int rpw = 64 / G, sub = lane / G, gl = lane - sub * G;
-            for (int d0 = wave * rpw; d0 < D; d0 += nw * rpw) {
-                const int d = d0 + sub;
-                float acc = 0.f;
-                if (d < D) {
-                    const float* crow = tp.Cd + (size_t)d * R;
-                    if (vec) {
-                        for (int k = gl; k < items; k += G) {
-                            const float4 cv = reinterpret_cast<const float4*>(crow)[k];
-                            const float4 av = reinterpret_cast<const float4*>(s.A)[k];
-                            const float4 wv = reinterpret_cast<const float4*>(w2)[k];
-                            acc = fmaf(wv.x, fmaxf(av.x + cv.x, 0.f), acc); acc = fmaf(wv.y, fmaxf(av.y + cv.y, 0.f), acc);
-                            acc = fmaf(wv.z, fmaxf(av.z + cv.z, 0.f), acc); acc = fmaf(wv.w, fmaxf(av.w + cv.w, 0.f), acc);
+            constexpr int U = 4;                                    // class passes loaded together (cf. gemv_rows)
+            const int stride = nw * rpw;
+            for (int d0 = wave * rpw + sub; d0 < D + sub; d0 += stride * U) {
+                float acc[U];
+                const float* crow[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { acc[u] = 0.f; crow[u] = tp.Cd + (size_t)min(d0 + u * stride, D - 1) * R; }
+                if (vec) {
+                    for (int k = gl; k < items; k += G) {
+                        float4 cv[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) cv[u] = reinterpret_cast<const float4*>(crow[u])[k];
+                        const float4 av = reinterpret_cast<const float4*>(s.A)[k];
+                        const float4 wv = reinterpret_cast<const float4*>(w2)[k];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            acc[u] = fmaf(wv.x, fmaxf(av.x + cv[u].x, 0.f), acc[u]); acc[u] = fmaf(wv.y, fmaxf(av.y + cv[u].y, 0.f), acc[u]);
+                            acc[u] = fmaf(wv.z, fmaxf(av.z + cv[u].z, 0.f), acc[u]); acc[u] = fmaf(wv.w, fmaxf(av.w + cv[u].w, 0.f), acc[u]);
                         }
-                    } else {
-                        for (int k = gl; k < items; k += G) acc = fmaf(w2[k], fmaxf(s.A[k] + crow[k], 0.f), acc);
+                    }
+                } else {
+                    for (int k = gl; k < items; k += G) {
+                        float cv[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) cv[u] = crow[u][k];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) acc[u] = fmaf(w2[k], fmaxf(s.A[k] + cv[u], 0.f), acc[u]);
                     }
                 }
-                acc = group_sum(acc, G);
-                if (gl == 0 && d < D) { const float yv = acc + b2; s.y[d] = yv; tp.y[row * D + d] = yv; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int d = d0 + u * stride;
+                    const float r = group_sum(acc[u], G);
+                    if (gl == 0 && d < D) { const float yv = r + b2; s.y[d] = yv; tp.y[row * D + d] = yv; }
+                }
             }
         }
         __syncthreads();
@@ -409,13 +435,12 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
         gemv_t(ar.desc, V, D, V, s.y, s.dbar, s.red, false);
         for (int v = tid; v < V; v += nt) tp.dbar[row * V + v] = s.dbar[v];
         {   // h_w = tanh(w_h(h) + w_d(dbar))   (model.py:452)
-            const float* bh = P.p[R_WH_B];
-            gemv_rows(P.p[R_WH_W], R, R, R, s.hn, [&](int n, float acc) { s.g[n] = acc + bh[n]; });
-            gemv_rows(P.p[R_WD_W], V, R, V, s.dbar, [&](int n, float acc) { s.g2[n] = acc; });
+            gemv_rows<GU>(P.p[R_WH_W], R, R, R, s.hn, [&](int n, float acc) { s.g[n] = acc; });
+            gemv_rows<GU>(P.p[R_WD_W], V, R, V, s.dbar, [&](int n, float acc) { s.g2[n] = acc; });
         }
         __syncthreads();
         for (int i = tid; i < R; i += nt) {
-            const float gv = tanhf(s.g[i] + s.g2[i]);
+            const float gv = tanhf((s.g[i] + P.p[R_WH_B][i]) + s.g2[i]);
             s.g[i] = gv;
             tp.g[row * R + i] = gv;
             s.h[i] = s.hn[i];                                       // advance the GRU state
@@ -424,8 +449,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
         {   // receiver message (model.py:454-475)
             const float* bw = P.p[R_W_B];
             const float* uw = ar.u_w ? ar.u_w + row * W : nullptr;
-            gemv_rows(P.p[R_W_W], R, W, R, s.g, [&](int n, float acc) {
-                const float lw = acc + bw[n];
+            gemv_rows<GU>(P.p[R_W_W], R, W, R, s.g, [&](int n, float acc) { s.w[n] = acc; });
+            __syncthreads();
+            for (int n = tid; n < W; n += nt) {
+                const float lw = s.w[n] + bw[n];
                 float wv = lw, lpv = 0.f, nev = 0.f;
                 if (binary) {
                     const float p = sigmoidf_(lw);
@@ -442,7 +469,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_conversation(Dims dm, Params P, T
                 }
                 s.w[n] = wv; s.lp[n] = lpv; s_ne[n] = nev;
                 tp.w[row * W + n] = wv;
-            });
+            }
         }
         __syncthreads();
         if (binary) {

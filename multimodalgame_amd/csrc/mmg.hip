@@ -40,7 +40,7 @@ struct mmg_handle {
     void* ws;
     JobTable* d_jt;
     JobTable jt;
-    int conv_smem, bwd_smem, prep_smem;
+    int conv_smem, conv_smem_agent, conv_threads, bwd_smem, prep_smem;
     bool profiling;
     bool scores_in_parts;      // the last forward left baseline scores as partials (k_baselines2)
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
@@ -246,12 +246,18 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->d_jt = reinterpret_cast<JobTable*>(h->tp.tables);
     h->profiling = false; h->timers_used = 0; h->scores_in_parts = false;
     h->use_fast = !getenv("MMG_NO_FAST"); h->merge_roles = !getenv("MMG_NO_MERGE");
-    h->conv_smem = conv_smem_floats(h->dm) * 4;
+    // few samples and large sender matrices: 512-thread variant of the generic conversation kernel
+    h->conv_threads = (h->dm.B <= 256 && (int64_t)h->dm.H * h->dm.W >= 65536) ? 512 : 256;
+    h->conv_smem = conv_smem_floats(h->dm, h->conv_threads) * 4;
+    h->conv_smem_agent = conv_smem_floats(h->dm, MMG_BLOCK) * 4;
     h->bwd_smem = bwd_smem_floats(h->dm) * 4;
     h->prep_smem = ((h->dm.V > h->dm.W ? h->dm.V : h->dm.W) + 4) * 4;
     if (h->conv_smem > 160 * 1024 || h->bwd_smem > 160 * 1024) { fail("dimensions need more than 160 KB of LDS per sample"); delete h; return nullptr; }
     hipError_t e = hipSuccess;
-    if (h->conv_smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_conversation, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
+    if (h->conv_smem > 48 * 1024) {
+        e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
+    }
     if (e == hipSuccess && h->bwd_smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_conv, hipFuncAttributeMaxDynamicSharedMemorySize, h->bwd_smem);
     if (e == hipSuccess) e = hipMemset(d_workspace, 0, h->tl.total);
     if (e == hipSuccess) e = hipMemset(d_grads, 0, sizeof(float) * h->pl.total);
@@ -374,7 +380,10 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
         if (fast)
             hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
         else
-            hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
+            if (h->conv_threads == 512)
+                hipLaunchKernelGGL(k_conversation<512>, dim3(d.B), dim3(512), h->conv_smem, st, h->dm, h->P, h->tp, ar);
+            else
+                hipLaunchKernelGGL(k_conversation<256>, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
         if (launch_check("k_conversation")) return -1;
     }
     h->scores_in_parts = false;
@@ -517,7 +526,7 @@ extern "C" int mmg_sender_forward(mmg_handle* h, const float* d_x, const float* 
     memset(&ar, 0, sizeof(ar));
     ar.x = d_x; ar.u_z = d_u_z ? d_u_z - (size_t)t * d.B * d.W : nullptr; ar.seed = seed; ar.train = train; ar.run_all = 1;
     ar.t_begin = t; ar.t_end = t + 1; ar.phases = 1; ar.w_in = d_w;
-    hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
+    hipLaunchKernelGGL(k_conversation<256>, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem_agent, st, h->dm, h->P, h->tp, ar);
     if (launch_check("k_conversation(sender)")) return -1;
     const size_t off = (size_t)t * d.B * d.W;
     HIP_OK(hipMemcpyAsync(d_message, h->tp.z + off, sizeof(float) * d.B * d.W, hipMemcpyDeviceToDevice, st));
@@ -544,7 +553,7 @@ extern "C" int mmg_receiver_forward(mmg_handle* h, const float* d_z, const float
     ar.desc = d_desc; ar.seed = seed; ar.train = train; ar.run_all = 1;
     ar.u_s = d_u_s ? d_u_s - offB : nullptr; ar.u_w = d_u_w ? d_u_w - offW : nullptr;
     ar.t_begin = t; ar.t_end = t + 1; ar.phases = 2; ar.h_state = d_h_z; ar.sprod_state = d_s_prob_prod; ar.sprod_first = first;
-    hipLaunchKernelGGL(k_conversation, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem, st, h->dm, h->P, h->tp, ar);
+    hipLaunchKernelGGL(k_conversation<256>, dim3(d.B), dim3(MMG_BLOCK), h->conv_smem_agent, st, h->dm, h->P, h->tp, ar);
     if (launch_check("k_conversation(receiver)")) return -1;
     if (d_s) HIP_OK(hipMemcpyAsync(d_s, h->tp.s + offB, sizeof(float) * d.B, hipMemcpyDeviceToDevice, st));
     if (d_s_prob) HIP_OK(hipMemcpyAsync(d_s_prob, h->tp.ps + offB, sizeof(float) * d.B, hipMemcpyDeviceToDevice, st));
