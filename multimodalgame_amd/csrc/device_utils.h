@@ -179,14 +179,14 @@ __device__ __forceinline__ void gemv_rows(const float* __restrict__ Wm, int ld, 
 // Transposed GEMV, lanes along the output:  out[k] (+)= sum_n W[n*ld + k] * d[n],  k < K.
 // d and out in LDS; `scratch` >= 4 * blockDim.x floats, 16-byte aligned.  Ends with a barrier (out is ready).
 // ---------------------------------------------------------------------------------------------
+template <int UN = 8>
 __device__ __forceinline__ void gemv_t(const float* __restrict__ Wm, int ld, int N, int K,
                                        const float* d, float* out, float* scratch, bool accumulate) {
-    // Rows n are walked 8 at a time with every load of the group issued before the first FMA;
+    // Rows n are walked UN at a time with every load of the group issued before the first FMA;
     // the FMA order per output is the plain n = 0, 1, 2, ... order.
     const int tid = threadIdx.x, nt = blockDim.x;
     const bool vec = ((ld & 3) == 0) && ((K & 3) == 0) && ((((uintptr_t)Wm) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
     if (vec && (K >> 2) >= nt) {                        // wide outputs: a lane owns 4 consecutive outputs per pass
-        constexpr int UN = 8;
         const int K4 = K >> 2;
         for (int k4 = tid; k4 < K4; k4 += nt) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -208,7 +208,6 @@ __device__ __forceinline__ void gemv_t(const float* __restrict__ Wm, int ld, int
         __syncthreads();
         return;
     }
-    constexpr int UN = 8;
     if (K >= nt) {
         for (int k = tid; k < K; k += nt) {
             float acc = 0.f;

@@ -246,7 +246,10 @@ __host__ __device__ inline int bwd_smem_floats(const Dims& d) {
     return 7 * d.T + 3 * p4(d.H) + 3 * p4(d.W) + 6 * p4(d.R) + 2 * p4(3 * d.R) + p4(d.D) + 4 * MMG_BLOCK + 32;
 }
 
-__global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target) {
+// MANY: thousands of samples -- occupancy matters more than load depth (<= 128 VGPRs, 4 workgroups per CU).
+template <bool MANY>
+__global__ __launch_bounds__(MMG_BLOCK, MANY ? 4 : 1) void k_bwd_conv(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target) {
+    constexpr int TU = MANY ? 2 : 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
@@ -300,14 +303,14 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
                 s_dlw[j] = v; tp.dlw[row * W + j] = v;
             }
             __syncthreads();
-            gemv_t(P.p[R_W_W], R, W, R, s_dlw, s_dg, s_red, false);            // dg = W_w^T dlw
+            gemv_t<TU>(P.p[R_W_W], R, W, R, s_dlw, s_dg, s_red, false);            // dg = W_w^T dlw
             for (int i = tid; i < R; i += nt) {
                 const float g = tp.g[row * R + i];
                 const float v = s_dg[i] * (1.f - g * g);
                 s_dg[i] = v; tp.dgpre[row * R + i] = v;
             }
             __syncthreads();
-            gemv_t(P.p[R_WH_W], R, R, R, s_dg, s_dh, s_red, true);             // dh += W_h^T dgpre
+            gemv_t<TU>(P.p[R_WH_W], R, R, R, s_dg, s_dh, s_red, true);             // dh += W_h^T dgpre
         } else {
             for (int j = tid; j < W; j += nt) tp.dlw[row * W + j] = 0.f;
             for (int i = tid; i < R; i += nt) tp.dgpre[row * R + i] = 0.f;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
             if (tid == 0) tp.dysum[b] = dsum;
             for (int i = tid; i < R; i += nt) { const float v = hn[i]; s_hs[i] = v; tp.hstar[(size_t)b * R + i] = v; }
             __syncthreads();
-            gemv_rows(P.p[R_Y1_W], R + V, R, R, s_hs, [&](int n, float acc) { s_A[n] = acc; });
+            gemv_rows<(MANY ? 2 : 4)>(P.p[R_Y1_W], R + V, R, R, s_hs, [&](int n, float acc) { s_A[n] = acc; });
             __syncthreads();
             const float* w2 = P.p[R_Y2_W];
             for (int i = tid; i < R; i += nt) {
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
                 s_dA[i] = v; tp.dA[(size_t)b * R + i] = v; tp.Astar[(size_t)b * R + i] = a;
             }
             __syncthreads();
-            gemv_t(P.p[R_Y1_W], R + V, R, R, s_dA, s_dh, s_red, true);         // dh += W_y1h^T dA
+            gemv_t<TU>(P.p[R_Y1_W], R + V, R, R, s_dA, s_dh, s_red, true);         // dh += W_y1h^T dA
         }
         // ---- GRU cell backward ----
         {
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
             }
             __syncthreads();
             for (int i = tid; i < 3 * R; i += nt) { tp.dgi[row * 3 * R + i] = s_dgi[i]; tp.dgh[row * 3 * R + i] = s_dgh[i]; }
-            gemv_t(P.p[R_WHH], R, 3 * R, R, s_dgh, s_dhn, s_red, true);        // dh_{t-1} += W_hh^T dgh
+            gemv_t<TU>(P.p[R_WHH], R, 3 * R, R, s_dgh, s_dhn, s_red, true);        // dh_{t-1} += W_hh^T dgh
             for (int i = tid; i < R; i += nt) s_dh[i] = s_dhn[i];
             __syncthreads();
         }
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
                 s_dlz[j] = v; tp.dlz[row * W + j] = v;
             }
             __syncthreads();
-            gemv_t(P.p[S_BIN_W], H, W, H, s_dlz, s_da, s_red, false);          // da = W_b^T dlz
+            gemv_t<TU>(P.p[S_BIN_W], H, W, H, s_dlz, s_da, s_red, false);          // da = W_b^T dlz
             for (int i = tid; i < H; i += nt) {
                 const float a = tp.a[row * H + i];
                 const float v = s_da[i] * (1.f - a * a);
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_conv(Dims dm, Params P, Tape 
             }
             __syncthreads();
             if (t == 0) {                                                      // code_bias path (model.py:199)
-                gemv_t(P.p[S_CODE_W], W, H, W, s_dpre, s_dc0, s_red, false);
+                gemv_t<TU>(P.p[S_CODE_W], W, H, W, s_dpre, s_dc0, s_red, false);
                 for (int j = tid; j < W; j += nt) tp.dc0[(size_t)b * W + j] = s_dc0[j];
             }
             // ---- baselines (MSE, model.py:971-988) ----

@@ -258,7 +258,8 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
     }
-    if (e == hipSuccess && h->bwd_smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_conv, hipFuncAttributeMaxDynamicSharedMemorySize, h->bwd_smem);
+    if (e == hipSuccess && h->bwd_smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->bwd_smem);
+    if (e == hipSuccess && h->bwd_smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->bwd_smem);
     if (e == hipSuccess) e = hipMemset(d_workspace, 0, h->tl.total);
     if (e == hipSuccess) e = hipMemset(d_grads, 0, sizeof(float) * h->pl.total);
     if (e != hipSuccess) { fail("device init failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
@@ -429,7 +430,10 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         else if (fast)      // (a 512-thread variant of this kernel measured slower: 31.8 vs 28.8 us -- it is not issue-bound)
             hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0);
         else
-            hipLaunchKernelGGL(k_bwd_conv, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
+            if (d.B > 512)
+                hipLaunchKernelGGL(k_bwd_conv<true>, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
+            else
+                hipLaunchKernelGGL(k_bwd_conv<false>, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
         if (launch_check("k_bwd_conv")) return -1;
     }
     if (!(fast_shape(h) && h->merge_roles)) {
