@@ -410,6 +410,25 @@ __global__ __launch_bounds__(MMG_BLOCK, MANY ? 4 : 1) void k_bwd_conv(Dims dm, P
     if (!binary) for (int j = tid; j < W; j += nt) tp.dc0[(size_t)b * W + j] = 0.f;
 }
 
+// Active rows.  Every gradient tape row (t, b) with t > t*(b) is zero, and with early stopping that is most of them
+// (config 2: ~140 of 640 rows are live).  One wave lists the live rows in (t, b) order; k_wgrad then reduces over
+// that list instead of over all T*B rows.  t*(b) comes from the conversation launch, so this runs anywhere after it.
+__device__ __forceinline__ void build_row_map(const Dims& dm, const Tape& tp) {
+    const int lane = threadIdx.x & 63, B = dm.B, T = dm.T;
+    int base = 0;
+    for (int t = 0; t < T; ++t) {
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + lane;
+            const bool act = (b < B) && (t <= tp.tstar[min(b, B - 1)]);
+            const unsigned long long m = __ballot(act);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (act) tp.rmap[pos] = t * B + b;
+            base += __popcll(m);
+        }
+    }
+    if (lane == 0) tp.rcount[0] = base;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_dC: grid = D.  dC[d,r] = sum_b dy[b,d] * w_y2[r] * 1[A*[b,r] + Cd[d,r] > 0]   (-> y1.weight[:,R:], y1.bias)
 //                  Py2[d,r] = sum_b dy[b,d] * relu(A*[b,r] + Cd[d,r])              (-> y2.weight)
@@ -470,11 +489,11 @@ enum { SRC_STATIC = 0, SRC_X = 1, SRC_DESC = 2 };
 // vhid != NULL: the A operand is virtual,  A[row, n] = A[row] * vw2[n] * 1[vhid[row*lda + n] > 0]
 // (the baselines' d hidden = d score * linear2.weight * relu', never materialised)
 struct GemmJob { const float* A; const float* Bm; float* C; const float* vhid; const float* vw2;
-                 int lda, ldb, ldc, rows, N, K, bmod, bsrc, tile_begin, tiles_k; };
+                 int lda, ldb, ldc, rows, N, K, bmod, bsrc, tile_begin, tiles_k, compact, pad; };   // compact: rows are (step, sample) rows
 // vbeta != NULL: virtual source,  src'[row, c] = vbeta[row] * vw2[c] * 1[src[row*ld + c] > 0]
 // wrow != NULL: row-weighted sum,  dst[c] = sum_row wrow[row] * src[row*ld + c]   (the N = 1 "GEMMs": d score^T . hidden)
 struct ColJob { const float* src; float* dst; const float* scale; const float* vbeta; const float* vw2; const float* wrow;
-                int ld, rows, cols, blk_begin, pad0, pad1; };
+                int ld, rows, cols, blk_begin, compact, pad1; };
 #define MMG_MAX_GEMM 40
 #define MMG_MAX_COL 40
 struct NormPlan { int64_t begin[MMG_GN_BLOCKS], end[MMG_GN_BLOCKS]; int agent[MMG_GN_BLOCKS]; };
@@ -505,7 +524,8 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, si
 __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict__ jt, const float* __restrict__ x,
                                                      const float* __restrict__ desc, float* __restrict__ part,
                                                      Dims dm, const double* __restrict__ stats, float* __restrict__ losses,
-                                                     double* __restrict__ totals
+                                                     double* __restrict__ totals, const int* __restrict__ rmap,
+                                                     const int* __restrict__ rcount
 #ifdef MMG_TIMING
                                                      , long long* __restrict__ dbg2
 #endif
@@ -529,6 +549,17 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     float (*s_acc)[16][33] = reinterpret_cast<float (*)[16][33]>(&s_b[0][0][0]);   // [4][16][33] reused after the row loop
     float* s_part = &s_b[0][0][0];                                                   // column-sum staging
     __shared__ float s_red[8];
+    // rmap != NULL: jobs whose rows are (step, sample) rows reduce over the compacted list of live rows only
+    // (build_row_map); the list is copied to LDS first thing, in the shadow of the job lookup below.
+    constexpr int MAXMAP = 2048;
+    __shared__ unsigned short s_map[MAXMAP];
+    const bool use_map = rmap != nullptr;
+    int nact = 0;
+    if (use_map) {
+        const int tb = dm.T * dm.B;
+        for (int i2 = threadIdx.x; i2 < tb; i2 += MMG_BLOCK) s_map[i2] = (unsigned short)rmap[i2];
+        nact = rcount[0];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((int)blockIdx.x == jt->n_wblocks) {
         // spare block: the six logged loss scalars, the semantic step count and the running totals (off every
@@ -556,7 +587,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const float* Bbase = (G.bsrc == SRC_X) ? x : (G.bsrc == SRC_DESC) ? desc : G.Bm;
         const bool virt = G.vhid != nullptr;
         const float* Abase = virt ? G.vhid : G.A;
-        const int rows = G.rows, lda = G.lda, ldb = G.ldb, bmod = G.bmod, N = G.N, K = G.K;
+        const bool cmp = use_map && G.compact;
+        const int rows = cmp ? nact : G.rows, lda = G.lda, ldb = G.ldb, bmod = G.bmod, N = G.N, K = G.K;
+        if (use_map) __syncthreads();                      // s_map is complete
         const bool veca = ((lda & 3) == 0) && ((((uintptr_t)Abase) & 15) == 0);
         const bool vecb = ((ldb & 3) == 0) && ((((uintptr_t)Bbase) & 15) == 0);
         // loader roles: A row la, columns lac..+3 (64 rows x 16 cols); B row lb0 / lb0+32, columns lbc..+3 (64 x 32)
@@ -593,7 +626,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             float beta[DEPTH];
             auto fetch = [&](int c, int u) {
                 const int r_ = c * CH + la, r0_ = c * CH + lb0, r1_ = r0_ + 32;
-                const int rc_ = min(r_, rlast), c0_ = min(r0_, rlast), c1_ = min(r1_, rlast);
+                int rc_ = min(r_, rlast), c0_ = min(r0_, rlast), c1_ = min(r1_, rlast);
+                if (cmp) { rc_ = s_map[rc_]; c0_ = s_map[c0_]; c1_ = s_map[c1_]; }      // (LDS reads: the global loads stay branch-free)
                 ra[u] = ld4(Abase + (size_t)rc_ * lda, n0 + lac, N);
                 beta[u] = betap[virt ? rc_ : 0];
                 rb0[u] = ld4(Bbase + (size_t)(c0_ % bmodv) * ldb, k0 + lbc, K);
@@ -635,16 +669,18 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             // edge tiles (N or K tail inside the tile, unaligned rows): guarded loads, one chunk at a time
             for (int c = 0; c < nchunks; ++c) {
                 const int buf = c & 1;
-                const int r = c * CH + la;
-                const bool rv = r < rows;
+                const int rl = c * CH + la;
+                const bool rv = rl < rows;
+                const int r = cmp ? (int)s_map[min(rl, rlast)] : rl;
                 float4 av = load4_guard(Abase, (size_t)(rv ? r : 0) * lda, n0 + lac, N, rv, veca);
                 if (virt) {
                     const float be = rv ? G.A[r] : 0.f;
                     av.x = av.x > 0.f ? be * vw.x : 0.f; av.y = av.y > 0.f ? be * vw.y : 0.f;
                     av.z = av.z > 0.f ? be * vw.z : 0.f; av.w = av.w > 0.f ? be * vw.w : 0.f;
                 }
-                const int r0 = c * CH + lb0, r1 = r0 + 32;
-                const bool v0 = r0 < rows, v1 = r1 < rows;
+                const int r0l = c * CH + lb0, r1l = r0l + 32;
+                const bool v0 = r0l < rows, v1 = r1l < rows;
+                const int r0 = cmp ? (int)s_map[min(r0l, rlast)] : r0l, r1 = cmp ? (int)s_map[min(r1l, rlast)] : r1l;
                 const int m0 = bmod ? (r0 % bmod) : r0, m1 = bmod ? (r1 % bmod) : r1;
                 const float4 b0v = load4_guard(Bbase, (size_t)(v0 ? m0 : 0) * ldb, k0 + lbc, K, v0, vecb);
                 const float4 b1v = load4_guard(Bbase, (size_t)(v1 ? m1 : 0) * ldb, k0 + lbc, K, v1, vecb);
@@ -685,13 +721,15 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     const int cb = blockIdx.x - jt->gemm_tiles;
     const int j = __popcll(__ballot(jt->c_begin[lane] <= cb)) - 1;
     const ColJob& C = jt->c[j];
+    const bool ccmp = use_map && C.compact;
+    if (use_map) __syncthreads();                          // s_map is complete
     const int c0 = (cb - C.blk_begin) * 16;
     const int cc = threadIdx.x & 15, g = threadIdx.x >> 4;
     const bool cv = (c0 + cc) < C.cols;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (cv) {
         const float* sp = C.src + c0 + cc;
-        const int rows = C.rows, ld = C.ld;
+        const int rows = ccmp ? nact : C.rows, ld = C.ld;
         constexpr int UN = 16;                         // rows in flight per thread (one round trip per 256 rows)
         const bool virt = C.vbeta != nullptr;
         const bool wsum = C.wrow != nullptr;
@@ -701,8 +739,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             float hv[UN], bv[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int r = r0 + 16 * u;
-                const bool ok = r < rows;
+                const int rl = r0 + 16 * u;
+                const bool ok = rl < rows;
+                const int r = (ccmp && ok) ? (int)s_map[rl] : rl;
                 hv[u] = ok ? sp[(size_t)r * ld] : 0.f;
                 bv[u] = (ok && (virt || wsum)) ? rowv[r] : 0.f;
             }

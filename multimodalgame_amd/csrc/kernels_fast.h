@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     }
     if (MERGE_DC && (int)blockIdx.x >= n_stats + dm.B) {
         float* s_c = t_a; float* s_p = t_a + 256;
+        if ((int)blockIdx.x == n_stats + dm.B && threadIdx.x < 64) build_row_map(dm, tp);   // while waiting: rows k_wgrad will reduce over
         role_wait<8>(tp.sync, 1, (uint32_t)dm.B, (uint32_t)D);
         dC_class(dm, P, tp, (int)blockIdx.x - n_stats - dm.B, s_c, s_p);
         return;

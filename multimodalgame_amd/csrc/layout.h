@@ -127,6 +127,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(stats, double, 3, 1, NSTAT, 1, 1)  /* batch statistics (all-reduced in DP)   */ \
     X(losses, float, 0, 1, 8, 1, 1)      /* nll, bin_s, bin_rec, bin_sen, bas_rec, bas_sen, n_steps, hits */ \
     X(counter, uint32_t, 2, 1, 4, 1, 1)  /* [0] minibatch counter (Philox), [1] optimizer step */ \
+    X(rmap, int32_t, 2, 1, T * B, 1, 1)  /* compacted list of the (step, sample) rows with t <= t*(b), in (t, b) order   */ \
+    X(rcount, int32_t, 2, 1, 4, 1, 1)    /* [0] its length (k_wgrad reduces over these rows only)                          */ \
     X(sync, uint32_t, 2, 1, 64, 1, 1)    /* in-launch dependency counters between workgroup roles (device_utils.h: role_signal) */ \
     X(dbg, long long, 3, 1, 256, 1, 1)   /* debug timestamps (MMG_TIMING builds) */ \
     X(dbg2, long long, 3, 1, 8192, 1, 1) /* per-block start/end stamps of k_wgrad (MMG_TIMING builds) */ \

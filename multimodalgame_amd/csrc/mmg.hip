@@ -118,7 +118,7 @@ static int build_jobs(mmg_handle* h) {
         GemmJob& g = jt.g[ng++];
         g.A = A; g.Bm = Bm; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.rows = rows; g.N = N; g.K = Kk;
         g.bmod = bmod; g.bsrc = bsrc; g.tile_begin = tiles; g.tiles_k = (Kk + 31) / 32;     // 16 x 32 outputs per block
-        g.vhid = nullptr; g.vw2 = nullptr;
+        g.vhid = nullptr; g.vw2 = nullptr; g.compact = (rows == TB) ? 1 : 0; g.pad = 0;
         tiles += ((N + 15) / 16) * g.tiles_k;
     };
     // dW = (dbeta * w2 * relu'(hid))^T . input  with the first factor formed on the fly
@@ -131,7 +131,7 @@ static int build_jobs(mmg_handle* h) {
     auto col = [&](const float* src, int ld, int rows, int cols, float* dst, const float* scale) {
         ColJob& c = jt.c[nc++];
         c.src = src; c.dst = dst; c.scale = scale; c.ld = ld; c.rows = rows; c.cols = cols; c.blk_begin = cblocks;
-        c.vbeta = nullptr; c.vw2 = nullptr; c.wrow = nullptr;
+        c.vbeta = nullptr; c.vw2 = nullptr; c.wrow = nullptr; c.compact = (rows == TB) ? 1 : 0; c.pad1 = 0;
         cblocks += (cols + 15) / 16;
     };
     const Params& P = h->P;
@@ -418,10 +418,12 @@ static bool merge_stats(const mmg_handle* h) {
 
 static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, hipStream_t st, bool with_stats) {
     const Dims& d = h->dm;
+    bool row_map = false;
     {
         Scope sc(h, st, "k_bwd_conv");
         const bool fast = fast_shape(h);
         const bool merge_dc = fast && h->merge_roles;
+        row_map = merge_dc && d.T * d.B <= 2048;         // class role 0 lists the live (step, sample) rows for k_wgrad
         if (fast && with_stats) {
             const int n_stats = 5 * d.T + 2;
             hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats);
@@ -445,7 +447,8 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         Scope sc(h, st, "k_wgrad");
         hipLaunchKernelGGL(k_wgrad, dim3(h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
                            (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
-                           h->tp.losses, h->tp.totals
+                           h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
+                           (const int*)(row_map ? h->tp.rcount : nullptr)
 #ifdef MMG_TIMING
                            , h->tp.dbg2
 #endif
