@@ -824,4 +824,75 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
     MMG_B2STAMP(21);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_baselines3: both baselines over the LIVE (step, sample) rows only -- rows (t, b) with t <= t*(b), in (t, b) order,
+// the same list build_row_map (kernels_bwd.h) leaves for k_wgrad.  With early stopping most of the T*B rows are dead
+// (config 2: ~140 of 640 live), and k_baselines2 walks every step up to the longest conversation of its 16 samples.
+// grid (ceil(T*B/16), ceil(K/64), 2): a workgroup owns 16 live rows x 64 hidden units of one baseline -- one MFMA pass,
+// no time loop; workgroups whose 16-row window lies beyond the live rows return after counting.
+// Needs B <= 64 (one lane per sample when listing rows), W and R multiples of 16 up to 64, tape.basehx.
+// Same operand order as k_baselines2, so hidden tiles and partial scores are bit-identical to it.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMG_BLOCK) void k_baselines3(Dims dm, Params P, Tape tp) {
+    __shared__ int s_rid[16];
+    __shared__ float s_part[4][16];
+    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, K = dm.K, T = dm.T;
+    const int which = blockIdx.z, lo = blockIdx.x * 16, byi = blockIdx.y, npb = gridDim.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int ts = tp.tstar[min(lane, B - 1)];           // (first: the row list depends on it)
+    const int n = (byi * 4 + wave) * 16 + i;
+    const bool nv = n < K;
+    const float* W1 = which ? P.p[BS_L1_W] : P.p[BR_L1_W];
+    const int ldw = which ? H + W : W + R;
+    const float* wrow = W1 + (size_t)(nv ? n : 0) * ldw;
+    const float bias = nv ? (which ? P.p[BS_L1_B][n] : P.p[BR_L1_B][n]) : 0.f;
+    const float w2 = nv ? (which ? P.p[BS_L2_W][n] : P.p[BR_L2_W][n]) : 0.f;
+    float4 w_msg[4], w_st[4];
+    frag_load(w_msg, wrow + (which ? H : 0), nv, W, q);
+    if (!which) frag_load(w_st, wrow + W, nv, R, q);
+    if (wave == 0) {                                     // entries [lo, lo + 16) of the live-row list
+        if (lane < 16) s_rid[lane] = -1;
+        int base = 0;
+        for (int t = 0; t < T && base < lo + 16; ++t) {
+            const bool act = (lane < B) && (t <= ts);
+            const unsigned long long m = __ballot(act);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (act && pos >= lo && pos < lo + 16) s_rid[pos - lo] = t * B + lane;
+            base += __popcll(m);
+        }
+    }
+    __syncthreads();
+    if (s_rid[0] < 0) return;                            // window beyond the live rows
+    const int rid = s_rid[i];
+    const bool xv = rid >= 0;
+    const size_t rr = (size_t)(xv ? rid : 0);
+    float4 xm[4], xt[4];
+    frag_load(xm, (which ? tp.zr : tp.z) + rr * W, xv, W, q);
+    if (!which) frag_load(xt, tp.h + (rr + B) * R, xv, R, q);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    int orow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        orow[r] = s_rid[q * 4 + r];
+        if (which) acc[r] = (orow[r] >= 0) ? tp.basehx[(size_t)(orow[r] % B) * K + min(n, K - 1)] : 0.f;
+    }
+    frag_mfma(acc, xm, w_msg, W, q);
+    if (!which) { frag_mfma(acc2, xt, w_st, R, q); acc += acc2; }
+    float* hid = which ? tp.hid_s : tp.hid_r;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = fmaxf(acc[r] + bias, 0.f);                                // model.py:514
+        if (orow[r] >= 0 && nv) hid[(size_t)orow[r] * K + n] = v; else v = 0.f;
+        v = dpp_group_sum<16>(v * w2);
+        if (i == 0) s_part[wave][q * 4 + r] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && s_rid[threadIdx.x] >= 0) {
+        float* part = which ? tp.bs_part : tp.br_part;
+        part[(size_t)s_rid[threadIdx.x] * npb + byi] =
+            (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+    }
+}
+
 }  // namespace mmg

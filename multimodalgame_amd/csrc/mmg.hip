@@ -393,10 +393,15 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
             if (launch_baselines_fused(h, st)) return -1;
         } else {
             Scope sc(h, st, "k_baselines");
-            // grid.z = 2 baselines x 2 step ranges: 128 workgroups at config 1 instead of 64
-            hipLaunchKernelGGL(k_baselines2, dim3((d.B + 15) / 16, (d.K + 63) / 64, 2 * (d.T >= 4 ? 2 : 1)), dim3(MMG_BLOCK), 0, st,
-                               h->dm, h->P, h->tp, 1, base_ready ? 1 : 0);
-            if (launch_check("k_baselines2")) return -1;
+            const bool live_rows = base_ready && d.B <= 64;      // k_baselines3: live (step, sample) rows only
+            if (live_rows) {
+                hipLaunchKernelGGL(k_baselines3, dim3((d.T * d.B + 15) / 16, (d.K + 63) / 64, 2), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
+            } else {
+                // grid.z = 2 baselines x 2 step ranges: 128 workgroups at config 1 instead of 64
+                hipLaunchKernelGGL(k_baselines2, dim3((d.B + 15) / 16, (d.K + 63) / 64, 2 * (d.T >= 4 ? 2 : 1)), dim3(MMG_BLOCK), 0, st,
+                                   h->dm, h->P, h->tp, 1, base_ready ? 1 : 0);
+            }
+            if (launch_check("k_baselines")) return -1;
             h->scores_in_parts = true;
         }
     }
