@@ -304,23 +304,21 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
                 for (int i = 0; i < R / K4; ++i) acc = fmaf(y1T[i], s_dA[p4 * (R / K4) + i], acc);
             }
             acc = lane_group_sum<K4>(acc);
-            if (p4 == 0) s_dhs[k4] = s_dh[k4] + acc + wsk * s_misc[0];
-        }
-        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 3);                              // b3
-        // ===== (4) GRU cell backward (thread i < R)
-        if (tid < R) {
+            // ===== (4) GRU cell backward, in the same phase: after the group sum all K4 lanes of unit k4 hold its dh,
+            // each forms the gate gradients and lane p4 stores the p4-th of them (no barrier between (3) and (4))
+            const float dh = s_dh[k4] + acc + wsk * s_misc[0];
             const float* gr = t_gru + t * 4 * R;
-            const float rr = gr[tid], uu = gr[R + tid], nn = gr[2 * R + tid], ghn = gr[3 * R + tid];
-            const float hp = t_h[t * R + tid];
-            const float dh = s_dhs[tid];
+            const float rr = gr[k4], uu = gr[R + k4], nn = gr[2 * R + k4], ghn = gr[3 * R + k4];
+            const float hp = t_h[t * R + k4];
             const float dn = dh * (1.f - uu), du = dh * (hp - nn);
             const float dnp = dn * (1.f - nn * nn), dup = du * uu * (1.f - uu);
             const float drp = dnp * ghn * rr * (1.f - rr);
             float* gi = tp.dgi + row * 3 * R; float* gh = tp.dgh + row * 3 * R;
-            gi[tid] = drp; gi[R + tid] = dup; gi[2 * R + tid] = dnp;
-            gh[tid] = drp; gh[R + tid] = dup; gh[2 * R + tid] = dnp * rr;
-            s_dgh[tid] = drp; s_dgh[R + tid] = dup; s_dgh[2 * R + tid] = dnp * rr;
-            s_dh[tid] = dh * uu;
+            static_assert(K4 == 4, "four lanes per unit share the stores");
+            if (p4 == 0)      { gi[k4] = drp; gh[k4] = drp; s_dgh[k4] = drp; }
+            else if (p4 == 1) { gi[R + k4] = dup; gh[R + k4] = dup; s_dgh[R + k4] = dup; }
+            else if (p4 == 2) { gi[2 * R + k4] = dnp; gh[2 * R + k4] = dnp * rr; s_dgh[2 * R + k4] = dnp * rr; }
+            else              { s_dh[k4] = dh * uu; }
         }
         __syncthreads(); MMG_BSTAMP(8 + 6 * t + 4);                              // b4
         // ===== (5) dh_{t-1} = dh * u + W_hh^T dgh
