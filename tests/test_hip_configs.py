@@ -112,3 +112,26 @@ def test_config3_global_batch_512_fixed_sharded_equals_unsharded():
             # summation order (|step| <= lr / sqrt(1 - alpha) = 10 lr): allow a vanishing fraction of those
             assert bad.mean() <= 1e-4 and np.abs(a - b).max() <= 2 * 10 * 1e-4, "%s.%s: %d bad" % (agent, k, bad.sum())
     np.testing.assert_allclose(shards[0].tape["losses"][:6].cpu().numpy(), full.tape["losses"][:6].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+C1 = dict(use_binary=True, fixed_exchange=False, max_exchange=10, learning_rate=1e-4, entropy_rec=0.01, entropy_sen=0.01,
+          entropy_s=0.08, img_feat_dim=512, img_h_dim=256, rec_w_dim=32, sender_out_dim=32, rec_hidden=64, wv_dim=100,
+          baseline_hid_dim=500, top_k_train=6)
+
+
+@pytest.mark.parametrize("batch", [1, 10, 50])
+def test_ragged_batches_fused_step_vs_oracle(batch):
+    """Batch sizes that fill neither a 16-row MFMA tile nor a wave: the fused training step (live-row list, k_baselines3,
+    compacted k_wgrad, role launches) against the oracle."""
+    meta = _meta(dict(C1, batch_size=batch), 30, batch, 2)
+    got, _ = common.hip_train_case(None, meta, fused=True)
+    want = common.oracle_train_case(None, meta)
+    # a sample stops computing after its own stop step in the fused path: per-step arrays differ in entries every loss
+    # masks out (test_hip_parity.py compares those in run-all mode); what training sees must agree
+    keep = ("losses", "n_steps", "hits", "logs", "outp", "dist", ".g.", ".p.", "gradnorm")
+    got = {k: v for k, v in got.items() if any(t in k for t in keep)}
+    want = {k: v for k, v in want.items() if any(t in k for t in keep)}
+    problems = common.compare_packed(got, want, atol=1e-4, rtol=1e-3, skip=("y2.bias",), shift_invariant=True)
+    hard = [p for p in problems if not any(t in p.split(" ")[0] for t in (".g.", ".p.", "gradnorm"))]
+    assert not hard, "\n".join(hard[:20])
+    assert len(problems) <= 6, "\n".join(problems[:20])
