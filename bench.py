@@ -59,13 +59,13 @@ def algorithmic_work(kernel, d, B, t_steps):
     if kernel == "k_bwd_conv":
         tape = rows * 4 * (2 * H + 6 * W + 13 * R + 2 * K + D + V + 16)  # read fwd tape + write delta tape
         return "hbm", 4 * (p_sender + p_recv) + tape
-    if kernel == "k_wgrad":
-        TB = B * T
+    if kernel == "k_wgrad":                   # reduces over the live (step, sample) rows only
+        TB = rows
         fl = 2 * TB * (3 * R * W + 3 * R * R + R * R + R * V + W * R + R + H * W + W * H + K * (W + R) + K + K * (H + W) + K)
         fl += 2 * B * (R * R + H * F) + 2 * D * R * V
         return "mfma", fl
-    if kernel == "k_baselines":
-        return "mfma", 2 * B * T * K * (W + R + W + 2)
+    if kernel == "k_baselines":               # live rows only (k_baselines3)
+        return "mfma", 2 * rows * K * (W + R + W + 2)
     if kernel.startswith("k_gemm_nt"):
         return "mfma", 2 * B * H * F if "h_x)" in kernel and "bas" not in kernel else 2 * B * K * H
     return "hbm", 0
@@ -148,10 +148,9 @@ def run_gpu(args, rank, world, local_rank):
         eng.set_profiling(False)
         avg = {k: float(np.mean(v)) for k, v in kern_ms.items()}
         dom = max(avg, key=avg.get)
-        mean_t = ex_steps / max(1, args.steps)
         # average steps a sample takes (early exit): take it from the tape of the last minibatch
         tstar = eng.tape["tstar"].float().mean().item() + 1.0
-        bound, amount = algorithmic_work(dom, C2, B, tstar if dom in ("k_conversation", "k_bwd_conv") else mean_t)
+        bound, amount = algorithmic_work(dom, C2, B, tstar)      # tstar = live steps per sample (B * tstar live rows)
         secs = avg[dom] * 1e-3
         if bound == "hbm":
             achieved, peak, unit = amount / secs / 1e9, HBM_PEAK_GBS, "GB/s"
