@@ -805,7 +805,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
     // oa.from_wgrad: the squared-norm partials are the ones k_wgrad left per block (single GPU);
     // otherwise the MMG_GN_BLOCKS partials of k_gradnorm over the all-reduced gradient (data parallel).
     __shared__ float s_coef[4];
-    __shared__ float s_ss[4][MMG_BLOCK];
+    __shared__ float s_ss[4][4];
     // this thread's element quad: issue its loads first so they share one memory round trip with the partials
     float* st1 = state; float* st2 = state + oa.total;
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -834,12 +834,15 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
                 ss[2] += (a[u] == 2) ? v[u] : 0.f; ss[3] += (a[u] == 3) ? v[u] : 0.f;
             }
         }
+        // fixed reduction tree (DPP inside a wave, then the four waves in order): deterministic
 #pragma unroll
-        for (int a = 0; a < 4; ++a) s_ss[a][threadIdx.x] = ss[a];
+        for (int a = 0; a < 4; ++a) {
+            const float wsum = dpp_wave_sum(ss[a]);
+            if ((threadIdx.x & 63) == 0) s_ss[a][threadIdx.x >> 6] = wsum;
+        }
         __syncthreads();
         if (threadIdx.x < 4) {
-            float tot = 0.f;
-            for (int k = 0; k < MMG_BLOCK; ++k) tot += s_ss[threadIdx.x][k];   // fixed order: deterministic
+            const float tot = (s_ss[threadIdx.x][0] + s_ss[threadIdx.x][1]) + (s_ss[threadIdx.x][2] + s_ss[threadIdx.x][3]);
             const float norm = sqrtf(tot);
             const float coef = 1.0f / (norm + 1e-6f);                // max_norm = 1 (model.py:1310)
             s_coef[threadIdx.x] = coef < 1.f ? coef : 1.f;
