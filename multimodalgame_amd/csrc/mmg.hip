@@ -430,7 +430,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         const bool merge_dc = fast && h->merge_roles;
         row_map = merge_dc && d.T * d.B <= 2048;         // class role 0 lists the live (step, sample) rows for k_wgrad
         if (fast && with_stats) {
-            const int n_stats = 5 * d.T + 2;
+            const int n_stats = (5 * d.T + 2 + 3) / 4;       // statistics roles: one (stream, step) pair per wave
             hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats);
         } else if (merge_dc)
             hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0);
