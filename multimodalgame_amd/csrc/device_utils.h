@@ -310,12 +310,11 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint
 #define MMG_SPIN_LIMIT (1 << 22)
 __device__ __forceinline__ void role_signal(uint32_t* sync, int dep) {
     // A device-scope release is an L2 write-back (buffer_wbl2) and those serialise across the chip (~0.1 us each: 971
-    // signalling workgroups once cost 100 us).  So: every wave only waits for its own stores to reach L2 (workgroup
-    // scope), and ONE wave per workgroup then releases at device scope on behalf of all of them.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // signalling workgroups once cost 100 us).  So: every wave only waits for its own stores to reach L2 (vmcnt),
+    // and ONE wave per workgroup then releases at device scope on behalf of all of them.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (a workgroup-scope fence does not wait for global stores)
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(sync + 2 * dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

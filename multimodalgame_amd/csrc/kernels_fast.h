@@ -229,7 +229,10 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         }
         if (t == tstar) {                                                   // NLL seed at the output step
             if (tid < 64) {
-                if (lane < D) tp.dy[(size_t)b * D + lane] = dy_mine;
+                if (lane < D) {                                     // (MERGE_DC: write-through store, see the signal below)
+                    if (MERGE_DC) __hip_atomic_store(&tp.dy[(size_t)b * D + lane], dy_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else tp.dy[(size_t)b * D + lane] = dy_mine;
+                }
                 if (lane < 32) s_dy[lane] = dy_mine;
                 const float dsum = dpp_wave_sum(dy_mine);
                 if (lane == 0) tp.dysum[b] = dsum;
@@ -283,10 +286,15 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
 #pragma unroll
                 for (int d = 0; d < D; ++d) acc += (a + cdcol[d] > 0.f) ? s_dy[d] : 0.f;
                 const float v = acc * w2_mine;
-                s_dA[tid] = v; tp.dA[(size_t)b * R + tid] = v; tp.Astar[(size_t)b * R + tid] = a;
+                s_dA[tid] = v; tp.dA[(size_t)b * R + tid] = v;
+                if (MERGE_DC) __hip_atomic_store(&tp.Astar[(size_t)b * R + tid], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else tp.Astar[(size_t)b * R + tid] = a;
             }
-            if (MERGE_DC && tid == 0) {                  // wave 0 wrote dy and A*: release them to the class roles
-                __threadfence();
+            if (MERGE_DC && tid == 0) {
+                // wave 0 wrote dy and A* with device-scope (write-through) stores: they need no L2 write-back, only to
+                // have completed before the counter moves -- 64 sample roles each doing a full device-scope release
+                // (buffer_wbl2) here would serialise on the L2s
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a workgroup-scope fence does not wait for global stores)
                 __hip_atomic_fetch_add(tp.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
