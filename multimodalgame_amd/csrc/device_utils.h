@@ -319,6 +319,13 @@ __device__ __forceinline__ void role_signal(uint32_t* sync, int dep) {
         __hip_atomic_fetch_add(sync + 2 * dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// Same for producers that wrote everything the consumers will read with device-scope (write-through) stores
+// (__hip_atomic_store, agent scope): nothing to write back, the stores only have to have completed.
+__device__ __forceinline__ void role_signal_wt(uint32_t* sync, int dep) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + 2 * dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int SLEEP = 1>
 __device__ __forceinline__ void role_wait(uint32_t* sync, int dep, uint32_t producers, uint32_t consumers) {
     if (threadIdx.x == 0) {

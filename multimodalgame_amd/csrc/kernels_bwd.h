@@ -37,7 +37,12 @@ __device__ __forceinline__ float combine_score(const float* part, size_t row, in
 // from_parts: baseline scores arrive as per-64-hidden-unit partials (k_baselines2); the blocks of the
 // two baseline kinds also materialise bs / br on the tape (exchange() returns them, k_bwd_conv reads them).
 // one wave reduces the (stream, step) pairs first, first + stride, ...
+// WT: results go out as device-scope (write-through) stores, so a role of a larger launch can publish them with a plain
+// counter increment instead of a device-scope release (= L2 write-back); see role_signal_wt.
+template <bool WT = false>
 __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, const Tape& tp, int from_parts, int first, int stride) {
+    auto put_d = [](double* p, double v) { if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
+    auto put_f = [](float* p, float v) { if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
     const int T = dm.T, B = dm.B;
     const int npb = (dm.K + 63) / 64;
     const float b2s = P.p[BS_L2_B][0], b2r = P.p[BR_L2_B][0];
@@ -50,7 +55,7 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
             const int which = p - 5 * T;
             for (int b = lane; b < B; b += 64) a0 += which == 0 ? (double)tp.logs[b] : (double)tp.hit[b];
             a0 = dpp_wave_sum_d(a0);
-            if (lane == 0) tp.stats[stat_glob(T, which)] = a0;
+            if (lane == 0) put_d(&tp.stats[stat_glob(T, which)], a0);
             continue;
         }
         const int kind = p / T, t = p - kind * T;
@@ -68,7 +73,7 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
                 const float ne_all = (kind == 0) ? tp.ne_s[row] : (kind == 1) ? tp.ne_w[row] : (kind == 2) ? tp.ne_z[row] : 0.f;
                 const bool act = (kind == 1) ? (t < ts) : (t <= ts);
                 if (from_parts && kind >= 3 && t <= ts) {
-                    if (kind == 3) tp.br[row] = beta_all; else tp.bs[row] = beta_all;
+                    put_f(kind == 3 ? &tp.br[row] : &tp.bs[row], beta_all);
                 }
                 if (!act) continue;
                 if (kind < 3) {
@@ -85,9 +90,9 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
         if (lane == 0) {
             if (kind < 3) {
                 double* st = tp.stats + stat_stream(T, kind, t, 0);
-                st[0] = a0; st[1] = a1; st[2] = a2; st[3] = a3; st[4] = a4;
+                put_d(st, a0); put_d(st + 1, a1); put_d(st + 2, a2); put_d(st + 3, a3); put_d(st + 4, a4);
             } else {
-                tp.stats[stat_bas(T, kind - 3, t)] = a0;
+                put_d(&tp.stats[stat_bas(T, kind - 3, t)], a0);
             }
         }
     }

@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     __shared__ float t_gru[TMAX * 4 * R], t_h[(TMAX + 1) * R], t_a[TMAX * H];
     __shared__ float t_bs[TMAX], t_br[TMAX], t_s[TMAX], t_ps[TMAX];
     if (MERGED && (int)blockIdx.x < n_stats) {          // four pairs per workgroup (one per wave): few releasing workgroups
-        stats_pairs(dm, P, tp, 1, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
-        role_signal(tp.sync, 0);
+        stats_pairs<true>(dm, P, tp, 1, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
+        role_signal_wt(tp.sync, 0);
         return;
     }
     if (MERGE_DC && (int)blockIdx.x >= n_stats + dm.B) {
