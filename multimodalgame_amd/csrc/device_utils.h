@@ -302,11 +302,14 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint
 // consumer's prologue (weights -> registers) run while the producer works, and replaces a kernel boundary by one
 // device-scope release/acquire pair.  Producers always have LOWER workgroup ids than their consumers and never
 // wait on a higher id, so with the in-order workgroup dispatch of the hardware the lowest unfinished workgroup can
-// always run: no deadlock.  The spin is bounded all the same: on expiry the error word sync[63] is set and the
+// always run: no deadlock.  The spin is bounded all the same: on expiry the error word sync[511] is set and the
 // workgroup continues (wrong numbers flagged, never a hung GPU).
-//   sync[2k] = arrivals of dependency k, sync[2k+1] = consumers that have passed it (the last one re-arms both).
+//   sync[128k] = arrivals of dependency k, sync[128k+64] = consumers that have passed it (the last one re-arms both).
 // ---------------------------------------------------------------------------------------------
-#define MMG_SYNC_ERR 63
+#define MMG_SYNC_ERR 511
+// every counter in its own 256-byte block (pollers of one dependency do not queue behind the increments of another)
+#define MMG_SYNC_ARR(dep) (128 * (dep))
+#define MMG_SYNC_PASS(dep) (128 * (dep) + 64)
 #define MMG_SPIN_LIMIT (1 << 22)
 __device__ __forceinline__ void role_signal(uint32_t* sync, int dep) {
     // A device-scope release is an L2 write-back (buffer_wbl2) and those serialise across the chip (~0.1 us each: 971
@@ -316,7 +319,7 @@ __device__ __forceinline__ void role_signal(uint32_t* sync, int dep) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(sync + 2 * dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(sync + MMG_SYNC_ARR(dep), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // Same for producers that wrote everything the consumers will read with device-scope (write-through) stores
@@ -324,20 +327,20 @@ __device__ __forceinline__ void role_signal(uint32_t* sync, int dep) {
 __device__ __forceinline__ void role_signal_wt(uint32_t* sync, int dep) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + 2 * dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + MMG_SYNC_ARR(dep), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int SLEEP = 1>
 __device__ __forceinline__ void role_wait(uint32_t* sync, int dep, uint32_t producers, uint32_t consumers) {
     if (threadIdx.x == 0) {
         int spins = 0;
-        while (__hip_atomic_load(sync + 2 * dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < producers) {
+        while (__hip_atomic_load(sync + MMG_SYNC_ARR(dep), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < producers) {
             __builtin_amdgcn_s_sleep(SLEEP);
             if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(sync + MMG_SYNC_ERR, (uint32_t)(dep + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
-        const uint32_t passed = __hip_atomic_fetch_add(sync + 2 * dep + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t passed = __hip_atomic_fetch_add(sync + MMG_SYNC_PASS(dep), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (passed + 1 == consumers) {                  // everyone has seen the final count: re-arm for the next launch
-            __hip_atomic_store(sync + 2 * dep, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sync + 2 * dep + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + MMG_SYNC_ARR(dep), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + MMG_SYNC_PASS(dep), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
                 // have completed before the counter moves -- 64 sample roles each doing a full device-scope release
                 // (buffer_wbl2) here would serialise on the L2s
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a workgroup-scope fence does not wait for global stores)
-                __hip_atomic_fetch_add(tp.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(tp.sync + MMG_SYNC_ARR(1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
         }

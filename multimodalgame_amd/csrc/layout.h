@@ -129,7 +129,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(counter, uint32_t, 2, 1, 4, 1, 1)  /* [0] minibatch counter (Philox), [1] optimizer step */ \
     X(rmap, int32_t, 2, 1, T * B, 1, 1)  /* compacted list of the (step, sample) rows with t <= t*(b), in (t, b) order   */ \
     X(rcount, int32_t, 2, 1, 4, 1, 1)    /* [0] its length (k_wgrad reduces over these rows only)                          */ \
-    X(sync, uint32_t, 2, 1, 64, 1, 1)    /* in-launch dependency counters between workgroup roles (device_utils.h: role_signal) */ \
+    X(sync, uint32_t, 2, 1, 512, 1, 1)    /* in-launch dependency counters between workgroup roles (device_utils.h: role_signal) */ \
     X(dbg, long long, 3, 1, 256, 1, 1)   /* debug timestamps (MMG_TIMING builds) */ \
     X(dbg2, long long, 3, 1, 8192, 1, 1) /* per-block start/end stamps of k_wgrad (MMG_TIMING builds) */ \
     X(totals, double, 3, 1, 4, 1, 1)     /* running sums over train steps: exchange steps, top-k hits, minibatches */ \

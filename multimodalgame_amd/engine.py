@@ -164,9 +164,9 @@ class Engine(object):
         return list(zip(nm, [float(ms[i]) for i in range(n)]))
 
     def check_sync(self):
-        """Raise if an in-launch dependency wait (device_utils.h: role_wait) ever hit its spin bound: word 63 of the
+        """Raise if an in-launch dependency wait (device_utils.h: role_wait) ever hit its spin bound: word 511 of the
         tape array `sync` holds the dependency number + 1.  Synchronises the device; call it off the hot path."""
-        code = int(self.tape["sync"][63].item())
+        code = int(self.tape["sync"][511].item())
         if code:
             raise _lib.MmgError("in-launch dependency %d timed out on the device (workgroup roles out of order?)" % (code - 1))
 
