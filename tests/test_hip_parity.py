@@ -138,3 +138,9 @@ def test_agent_level_steps_vs_golden():
     br = eng.baseline_forward("baseline_rec", None, z1, h_z)
     np.testing.assert_allclose(bs.cpu().numpy(), z["bas_sen"], atol=1e-5)
     np.testing.assert_allclose(br.cpu().numpy(), z["bas_rec"], atol=1e-5)
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke() entry point (one fused minibatch checked against oracle and golden vectors)."""
+    import __graft_entry__
+    __graft_entry__.smoke()
