@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
     __shared__ float s_coef[7 * 64];
     __shared__ __attribute__((aligned(16))) float s_dh[R], s_dhs[R], s_dlw[W], s_dlz[W], s_dgpre[R], s_dgh[3 * R];
-    __shared__ __attribute__((aligned(16))) float s_dy[32], s_A[R], s_dA[R], s_dpre[H];
+    __shared__ __attribute__((aligned(16))) float s_dy[32], s_A[R], s_dA[R];
     __shared__ float s_misc[8];
     // forward tape of this sample, loaded once: the time loop then issues stores only (a load inside it
     // would make its s_waitcnt vmcnt drain all outstanding delta-tape stores, ~1-2 us per wait on gfx950)
@@ -269,7 +269,6 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             }
             tp.dpre[row * H + tid] = v;
             dhx_acc += v;
-            if (t == 0) s_dpre[tid] = v;
         }
         if (t == tstar) {                                                   // A = y1[:, :R] h*
             float acc = 0.f;
@@ -344,16 +343,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     }
     MMG_BSTAMP(4);
     tp.dhx[(size_t)b * H + tid] = dhx_acc;
-    // code_bias path: dc0 = W_c^T dpre_0   (once per sample)
-    if (binary) {
-        const int j = tid / 8, p8 = tid % 8;                                // 8 lanes per output, h = p8 + 8*i
-        float acc = 0.f;
-        for (int i = 0; i < H / 8; ++i) acc = fmaf(P.p[S_CODE_W][(size_t)(p8 + 8 * i) * W + j], s_dpre[p8 + 8 * i], acc);
-        acc = lane_group_sum<8>(acc);
-        if (p8 == 0) tp.dc0[(size_t)b * W + j] = acc;
-    } else if (tid < W) {
-        tp.dc0[(size_t)b * W + tid] = 0.f;
-    }
+    // (code_bias: k_wgrad's special column job forms dsig * W_c^T (sum_b dpre_0) once, instead of W_c^T dpre_0 per sample here)
 }
 
 }  // namespace mmg

@@ -104,6 +104,8 @@ extern "C" int mmg_tape_table(const mmg_config* cfg, mmg_tape_entry* out, int ma
 // job table: every parameter tensor's gradient is produced by exactly one GEMM / column-sum job
 // (two for the matrices whose input is a concatenation: y1, both baselines' linear1).
 // ---------------------------------------------------------------------------------------------
+static bool fast_shape(const mmg_handle* h);
+
 static int build_jobs(mmg_handle* h) {
     JobTable& jt = h->jt;
     memset(&jt, 0, sizeof(jt));
@@ -131,7 +133,7 @@ static int build_jobs(mmg_handle* h) {
     auto col = [&](const float* src, int ld, int rows, int cols, float* dst, const float* scale) {
         ColJob& c = jt.c[nc++];
         c.src = src; c.dst = dst; c.scale = scale; c.ld = ld; c.rows = rows; c.cols = cols; c.blk_begin = cblocks;
-        c.vbeta = nullptr; c.vw2 = nullptr; c.wrow = nullptr; c.compact = (rows == TB) ? 1 : 0; c.pad1 = 0;
+        c.vbeta = nullptr; c.vw2 = nullptr; c.wrow = nullptr; c.compact = (rows == TB) ? 1 : 0; c.special = 0;
         cblocks += (cols + 15) / 16;
     };
     const Params& P = h->P;
@@ -160,7 +162,14 @@ static int build_jobs(mmg_handle* h) {
         col(tp.dhx, H, B, H, G.p[S_IMG_B], nullptr);
         gemm(tp.dpre, H, tp.c, W, 0, SRC_STATIC, G.p[S_CODE_W], W, TB, H, W);          // code_layer
         col(tp.dpre, H, TB, H, G.p[S_CODE_B], nullptr);
-        col(tp.dc0, W, B, W, G.p[S_CODE_BIAS], tp.dsig);                               // code_bias
+        if (fast_shape(h)) {
+            // code_bias: dsig[j] * sum_h code_layer.weight[h, j] * (sum_b dpre[t = 0, b, h]) -- one workgroup of k_wgrad;
+            // the register-resident backward kernel then needs no per-sample W_c^T dpre_0 product at its tail
+            col(tp.dpre, H, B, 1, G.p[S_CODE_BIAS], tp.dsig);
+            jt.c[nc - 1].special = 1; jt.c[nc - 1].wrow = P.p[S_CODE_W]; jt.c[nc - 1].compact = 0; jt.c[nc - 1].cols = W;
+        } else {
+            col(tp.dc0, W, B, W, G.p[S_CODE_BIAS], tp.dsig);                           // code_bias
+        }
         gemm(tp.dlz, W, tp.a, H, 0, SRC_STATIC, G.p[S_BIN_W], H, TB, W, H);            // binary_layer
         col(tp.dlz, W, TB, W, G.p[S_BIN_B], nullptr);
         // ---- baseline_rec: input [z || h_after] ----
