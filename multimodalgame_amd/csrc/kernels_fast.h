@@ -405,14 +405,6 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             if (ar.u_w) s_uw[i] = ar.u_w[((size_t)t * B + b) * W + j];
         }
         if (tid < T) s_us[tid] = ar.u_s[(size_t)tid * B + b];
-    } else if (train) {
-        for (int i = tid; i < T * W; i += NT) {
-            const int t = i / W, j = i - t * W;
-            const uint32_t e = (uint32_t)((t * dm.Bg + gb) * W + j);
-            s_uz[i] = philox_uniform(ar.seed, e, mb_counter, 0u);
-            s_uw[i] = philox_uniform(ar.seed, e, mb_counter, 2u);
-        }
-        if (tid < T) s_us[tid] = philox_uniform(ar.seed, (uint32_t)(tid * dm.Bg + gb), mb_counter, 1u);
     }
 
     // ------------------------------------------------------------ weights -> registers (once)
@@ -504,6 +496,15 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
 #pragma unroll
     for (int j = 0; j < DH; ++j) { const int d = h7 * DH + j; dcol[j] = (v7 < V && d < D) ? ar.desc[(size_t)d * V + v7] : 0.f; }
     const float sig_cb = (tid < W) ? fsigmoid(P.p[S_CODE_BIAS][tid]) : 0.f;
+    if (train && !inject) {                        // Philox draws of the whole conversation, while the weight loads are in flight
+        for (int i = tid; i < T * W; i += NT) {
+            const int t = i / W, j = i - t * W;
+            const uint32_t e = (uint32_t)((t * dm.Bg + gb) * W + j);
+            s_uz[i] = philox_uniform(ar.seed, e, mb_counter, 0u);
+            s_uw[i] = philox_uniform(ar.seed, e, mb_counter, 2u);
+        }
+        if (tid < T) s_us[tid] = philox_uniform(ar.seed, (uint32_t)(tid * dm.Bg + gb), mb_counter, 1u);
+    }
 
     MMG_STAMP(1);
     // ------------------------------------------------------------ conversation state
