@@ -14,7 +14,10 @@ CASES = {
     "c4 W=256 H=1024 B=64": dict(bench.C2, w_dim=256, h_dim=1024),
     "c5 continuous D=1000 B=2048": dict(bench.C2, use_binary=False, fixed_exchange=True, n_classes=1000, batch=2048),
 }
+only = sys.argv[1] if len(sys.argv) > 1 else None      # e.g. 'c4': run just the cases whose name starts with it
 for name, cfg in CASES.items():
+    if only and not name.startswith(only):
+        continue
     B = cfg.pop("batch", 64)
     eng = Engine(batch=B, **cfg)
     eng.load_state_dicts(init_state_dicts(eng, seed=0))
