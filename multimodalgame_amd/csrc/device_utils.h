@@ -90,10 +90,6 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
-__device__ __forceinline__ double wave_sum_d(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 
 // block-wide reductions through a small LDS scratch (>= 8 floats); every thread gets the result.
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
