@@ -76,7 +76,8 @@ namespace mmg {
 // (Rejected, measured: every sample role deriving the coefficients itself from the score partials -- in waves 0-3:
 //  +64 live registers, AGPR spills, +4 us; in a dedicated fifth wave: +8 us, it outlasts the weight prologue.)
 template <int H, int W, int R, int V, int D, bool MERGED, bool MERGE_DC>
-__global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int n_stats) {
+__global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int n_stats,
+                                                          int zero_dead) {
     constexpr int NT = 256, K4 = NT / R;          // 4 lanes per output unit of the R-wide transposed products
     constexpr int TMAX = 16;
     static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
@@ -193,8 +194,9 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     if (tid < R) s_dh[tid] = 0.f;
     float dhx_acc = 0.f;
 
-    // ---- zero the gradient tapes of steps this sample never took
-    for (int t = tstar + 1; t < T; ++t) {
+    // ---- zero the gradient tapes of steps this sample never took -- unless k_wgrad reduces over the live rows only
+    // (build_row_map) and never looks at them: ~1.7 MB of stores per minibatch at config 2
+    for (int t = zero_dead ? tstar + 1 : T; t < T; ++t) {
         const size_t row = (size_t)t * B + b;
         if (tid < W) { tp.dlz[row * W + tid] = 0.f; tp.dlw[row * W + tid] = 0.f; }
         tp.dpre[row * H + tid] = 0.f;

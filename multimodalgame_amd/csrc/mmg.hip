@@ -440,11 +440,11 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         row_map = merge_dc && d.T * d.B <= 2048;         // class role 0 lists the live (step, sample) rows for k_wgrad
         if (fast && with_stats) {
             const int n_stats = (5 * d.T + 2 + 3) / 4;       // statistics roles: one (stream, step) pair per wave
-            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats);
+            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1);
         } else if (merge_dc)
-            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0);
+            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1);
         else if (fast)      // (a 512-thread variant of this kernel measured slower: 31.8 vs 28.8 us -- it is not issue-bound)
-            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0);
+            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1);
         else
             if (d.B > 512)
                 hipLaunchKernelGGL(k_bwd_conv<true>, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
