@@ -113,7 +113,9 @@ void    mmg_destroy(mmg_handle* h);
  *   train==0: messages are round(p), stop bit round(prod p_s) (model.py:229, 423-427, 462).
  *   run_all_steps==1: every sample runs all T steps (what exchange() returns to Python);
  *   ==0: a sample stops computing once its own conversation has ended (its later steps are masked
- *   out of every loss, so training results are identical).
+ *   out of every loss, so training results are identical); per-(step, sample) arrays -- messages,
+ *   baseline scores and hiddens, gradient tapes -- are then defined on the LIVE rows only
+ *   (t <= the sample's own last step); the others keep whatever an earlier call left there.
  * Results land in the workspace arrays listed by mmg_tape_table(). */
 int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
                          const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed,
@@ -132,7 +134,8 @@ int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const
  * (use_binary==0) only the receiver is updated (model.py:1313). */
 int mmg_clip_step(mmg_handle* h, void* stream);
 
-/* forward(train) + stats + backward + clip_step for a single-GPU minibatch. */
+/* forward(train, run_all_steps = 0) + stats + backward + clip_step for a single-GPU minibatch, as six
+ * kernel launches; nothing returns to the host.  Equivalent to the four calls above in sequence. */
 int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
                    const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed, void* stream);
 
