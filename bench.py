@@ -116,7 +116,8 @@ def run_gpu(args, rank, world, local_rank):
     for i in range(args.warmup):
         one(i)
     sync()
-    steps_before = float(eng.tape["totals"][0].item())   # device-side running sum of semantic exchange steps
+    totals_before = eng.tape["totals"].cpu().numpy().copy()   # device-side running sums (semantic exchange steps, ..., sample-steps)
+    steps_before = float(totals_before[0])
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps_total):
         one(i)
@@ -126,7 +127,9 @@ def run_gpu(args, rank, world, local_rank):
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    ex_steps = float(eng.tape["totals"][0].item()) - steps_before
+    totals_after = eng.tape["totals"].cpu().numpy()
+    ex_steps = float(totals_after[0]) - steps_before
+    run_gpu.sample_steps = float(totals_after[3] - totals_before[3])   # sum_t n_active,t over the GLOBAL minibatches
     eng.check_sync()                                      # no in-launch dependency wait may have timed out
 
     # per-kernel launch durations of the same workload, HIP events on the launch stream (rank 0)
@@ -237,6 +240,8 @@ def main():
                                    "img_h_dim 256, rec_hidden 64, RMSprop; one bench step = one training minibatch",
                        "global_batch": PER_GPU_BATCH * world, "parallelism": "dp%d" % world,
                        "exchange_steps_per_minibatch": ex_steps / args.steps, "sampling": "in-kernel Philox4x32-10",
+                       "minibatches_per_s": world * args.steps / elapsed,          # 64-sample batches
+                       "sample_steps_per_s": run_gpu.sample_steps / elapsed,       # sum_t n_active,t per second, whole job
                        "unit_definition": "one exchange step (model.py:801 loop iteration) of one 64-sample batch; "
                                           "a global minibatch of 64*N samples advances N of them per iteration"},
             "roofline": roof,

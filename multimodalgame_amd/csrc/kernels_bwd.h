@@ -177,7 +177,12 @@ __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* 
         losses_out[5] = (float)acc[4];                                   // loss_bas_sen
         losses_out[6] = (float)nsteps;                                   // exchange steps the reference executes
         losses_out[7] = (float)st[stat_glob(T, 1)];                      // top-k hits
-        if (totals) { totals[0] += (double)nsteps; totals[1] += st[stat_glob(T, 1)]; totals[2] += 1.0; }
+        if (totals) {
+            double live = 0.0;                                           // sum_t |{b: step t is live}| = sample-steps
+            for (int t = 0; t < T; ++t) live += st[stat_stream(T, 2, t, 0)];
+            if (!dm.use_binary) live = (double)T * (double)dm.Bg;
+            totals[0] += (double)nsteps; totals[1] += st[stat_glob(T, 1)]; totals[2] += 1.0; totals[3] += live;
+        }
     }
     __syncthreads();
 }

@@ -132,7 +132,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(sync, uint32_t, 2, 1, 512, 1, 1)    /* in-launch dependency counters between workgroup roles (device_utils.h: role_signal) */ \
     X(dbg, long long, 3, 1, 256, 1, 1)   /* debug timestamps (MMG_TIMING builds) */ \
     X(dbg2, long long, 3, 1, 8192, 1, 1) /* per-block start/end stamps of k_wgrad (MMG_TIMING builds) */ \
-    X(totals, double, 3, 1, 4, 1, 1)     /* running sums over train steps: exchange steps, top-k hits, minibatches */ \
+    X(totals, double, 3, 1, 4, 1, 1)     /* running sums over train steps: exchange steps, top-k hits, minibatches, sample-steps */ \
     /* ---- backward ---- */                                                       \
     X(dlz, float, 0, 3, T, B, W)         /* dL/d sender logits                     */ \
     X(dpre, float, 0, 3, T, B, H)        /* dL/d (h_x + h_w)                       */ \
