@@ -554,8 +554,11 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     // four partial tiles are combined through LDS.  Every block also leaves the sum of squares of what it
     // wrote in part[blockIdx.x] (clip_grad_norm partials, summed per agent by k_opt).
     constexpr int CH = 64;
-    __shared__ float s_a[2][CH][17];
-    __shared__ float s_b[2][CH][33];                   // 32 output columns per block: the staged A chunk feeds two k-tiles
+    // row strides of 16 / 48 floats: an MFMA operand read touches rows r..r+3 x 16 columns, i.e. per 32-lane half two rows
+    // whose banks are i and 16 + i -- conflict-free (strides 17 / 33 measured 30 % bank-conflict cycles: SQ_LDS_BANK_CONFLICT);
+    // the staging stores are one aligned 16-byte write per operand slice
+    __shared__ __attribute__((aligned(16))) float s_a[2][CH][16];
+    __shared__ __attribute__((aligned(16))) float s_b[2][CH][48];   // 32 output columns per block: the staged A chunk feeds two k-tiles
     float (*s_acc)[16][33] = reinterpret_cast<float (*)[16][33]>(&s_b[0][0][0]);   // [4][16][33] reused after the row loop
     float* s_part = &s_b[0][0][0];                                                   // column-sum staging
     __shared__ float s_red[8];
@@ -658,9 +661,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                         av.z = av.z > 0.f ? beta[u] * vw.z : 0.f; av.w = av.w > 0.f ? beta[u] * vw.w : 0.f;
                     }
                     const float ma = va ? 1.f : 0.f, m0 = v0 ? 1.f : 0.f, m1 = v1 ? 1.f : 0.f;
-                    s_a[buf][la][lac] = av.x * ma; s_a[buf][la][lac + 1] = av.y * ma; s_a[buf][la][lac + 2] = av.z * ma; s_a[buf][la][lac + 3] = av.w * ma;
-                    s_b[buf][lb0][lbc] = rb0[u].x * m0; s_b[buf][lb0][lbc + 1] = rb0[u].y * m0; s_b[buf][lb0][lbc + 2] = rb0[u].z * m0; s_b[buf][lb0][lbc + 3] = rb0[u].w * m0;
-                    s_b[buf][lb0 + 32][lbc] = rb1[u].x * m1; s_b[buf][lb0 + 32][lbc + 1] = rb1[u].y * m1; s_b[buf][lb0 + 32][lbc + 2] = rb1[u].z * m1; s_b[buf][lb0 + 32][lbc + 3] = rb1[u].w * m1;
+                    *reinterpret_cast<float4*>(&s_a[buf][la][lac]) = make_float4(av.x * ma, av.y * ma, av.z * ma, av.w * ma);
+                    *reinterpret_cast<float4*>(&s_b[buf][lb0][lbc]) = make_float4(rb0[u].x * m0, rb0[u].y * m0, rb0[u].z * m0, rb0[u].w * m0);
+                    *reinterpret_cast<float4*>(&s_b[buf][lb0 + 32][lbc]) = make_float4(rb1[u].x * m1, rb1[u].y * m1, rb1[u].z * m1, rb1[u].w * m1);
                     __syncthreads();
                     fetch(c + DEPTH - 1, (u + DEPTH - 1) % DEPTH);        // unconditional: clamped beyond the last row
 #pragma unroll
@@ -694,9 +697,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                 const int m0 = bmod ? (r0 % bmod) : r0, m1 = bmod ? (r1 % bmod) : r1;
                 const float4 b0v = load4_guard(Bbase, (size_t)(v0 ? m0 : 0) * ldb, k0 + lbc, K, v0, vecb);
                 const float4 b1v = load4_guard(Bbase, (size_t)(v1 ? m1 : 0) * ldb, k0 + lbc, K, v1, vecb);
-                s_a[buf][la][lac] = av.x; s_a[buf][la][lac + 1] = av.y; s_a[buf][la][lac + 2] = av.z; s_a[buf][la][lac + 3] = av.w;
-                s_b[buf][lb0][lbc] = b0v.x; s_b[buf][lb0][lbc + 1] = b0v.y; s_b[buf][lb0][lbc + 2] = b0v.z; s_b[buf][lb0][lbc + 3] = b0v.w;
-                s_b[buf][lb0 + 32][lbc] = b1v.x; s_b[buf][lb0 + 32][lbc + 1] = b1v.y; s_b[buf][lb0 + 32][lbc + 2] = b1v.z; s_b[buf][lb0 + 32][lbc + 3] = b1v.w;
+                *reinterpret_cast<float4*>(&s_a[buf][la][lac]) = av;
+                *reinterpret_cast<float4*>(&s_b[buf][lb0][lbc]) = b0v;
+                *reinterpret_cast<float4*>(&s_b[buf][lb0 + 32][lbc]) = b1v;
                 __syncthreads();
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
