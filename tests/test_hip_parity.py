@@ -144,3 +144,19 @@ def test_graft_entry_smoke():
     """The driver's smoke() entry point (one fused minibatch checked against oracle and golden vectors)."""
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_live_row_list_matches_tstar():
+    """tape.rmap / rcount (device_utils: build_row_map, consumed by k_wgrad) = the (t, b) rows with t <= t*(b) in
+    (t, b) order; tape.totals[3] counts them across steps."""
+    name = "g2_adaptive_c1"
+    z, meta = common.load_golden(name)
+    _, eng = common.hip_train_case(name, meta, fused=True)
+    torch.cuda.synchronize()
+    tstar = eng.tape["tstar"].cpu().numpy()
+    B, T = meta["batch"], meta["max_exchange"]
+    want = [t * B + b for t in range(T) for b in range(B) if t <= tstar[b]]
+    n = int(eng.tape["rcount"][0].item())
+    assert n == len(want) == int((tstar + 1).sum())
+    np.testing.assert_array_equal(eng.tape["rmap"][:n].cpu().numpy(), np.asarray(want, dtype=np.int32))
+    assert float(eng.tape["totals"][3].item()) >= n          # running sum over the case's minibatches
