@@ -66,6 +66,15 @@ def algorithmic_work(kernel, d, B, t_steps):
         return "mfma", fl
     if kernel == "k_baselines":               # live rows only (k_baselines3)
         return "mfma", 2 * rows * K * (W + R + W + 2)
+    if kernel.startswith("k_prep"):           # h_x GEMM + Cd
+        return "mfma", 2 * B * H * F + 2 * D * R * V
+    if kernel == "k_opt":                     # read w, g, state; write w, state
+        p_total = ((H * F + H) + (H * W + H) + W + (W * H + W)                                   # sender        148 032
+                   + 3 * R * (W + R) + 6 * R + (R * R + R) + R * V + (W * R + W) + (R * (R + V) + R) + 2 * (R + 1)   # receiver 42 146
+                   + (K * (W + R) + K + K + 1) + (K * (H + W) + K + K + 1))                        # baselines     194 002
+        return "hbm", 4 * 5 * p_total
+    if kernel == "k_stats":
+        return "hbm", 5 * T * B * 16
     if kernel.startswith("k_gemm_nt"):
         return "mfma", 2 * B * H * F if "h_x)" in kernel and "bas" not in kernel else 2 * B * K * H
     return "hbm", 0
@@ -169,9 +178,17 @@ def run_gpu(args, rank, world, local_rank):
             traffic = pmc[key]["traffic_bytes_corrected"] if key in pmc else None
         except Exception:
             traffic = None
+        per_kernel = {}                          # the same figure for every launch of the minibatch (HIP-event durations)
+        for k, ms in avg.items():
+            bk, amt = algorithmic_work(k, C2, B, tstar)
+            if amt:
+                a_k = amt / (ms * 1e-3) / (1e9 if bk == "hbm" else 1e12)
+                per_kernel[k] = dict(bound=bk, achieved=round(a_k, 3), unit="GB/s" if bk == "hbm" else "TFLOP/s",
+                                     frac=round(a_k / (HBM_PEAK_GBS if bk == "hbm" else MFMA_F32_PEAK_TFLOPS), 5))
         roof = dict(bound=bound, kernel=dom, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
                     traffic=traffic, launch_us=avg[dom] * 1e3,
-                    kernels_us={k: round(v * 1e3, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])})
+                    kernels_us={k: round(v * 1e3, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
+                    per_kernel=per_kernel)
     return elapsed, ex_steps, roof
 
 
