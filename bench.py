@@ -31,6 +31,15 @@ C2 = dict(n_classes=30, feat_dim=512, h_dim=256, w_dim=32, rec_hidden=64, wv_dim
           max_exchange=10, use_binary=True, fixed_exchange=False, s_prob_prod=True, entropy_s=0.08,
           entropy_sen=0.01, entropy_rec=0.01, first_rec=0.0, optim_type="RMSprop", learning_rate=1e-4, top_k=6)
 PER_GPU_BATCH = 64
+# --workload: the other BASELINE.json configs (parity-test cases; the default and the reported metric is configs[1])
+WORKLOADS = {
+    "c2": (C2, 64, "configs[1]: Adaptive 30-class, batch 64 per GPU, max_exchange 10, rec_w_dim 32, img_h_dim 256, rec_hidden 64, "
+                   "RMSprop; one bench step = one training minibatch"),
+    "c3": (dict(C2, fixed_exchange=True), 64, "configs[2]: Fixed-exchange 30-class, global batch 512 = 64 per GPU on 8 GPUs, max_exchange 10"),
+    "c4": (dict(C2, w_dim=256, h_dim=1024), 64, "configs[3]: Adaptive 30-class, batch 64, rec_w_dim 256 / img_h_dim 1024 (generic kernels)"),
+    "c5": (dict(C2, use_binary=False, fixed_exchange=True, n_classes=1000), 256,
+           "configs[4]: 1000 classes, continuous messages, global batch 2048 = 256 per GPU on 8 GPUs (generic kernels)"),
+}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
 
@@ -86,15 +95,15 @@ def run_gpu(args, rank, world, local_rank):
     import torch.distributed as dist
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (ranks may share a GPU in the gloo smoke test)
     torch.cuda.set_device(dev)
-    B = PER_GPU_BATCH
+    CFG, B, _ = WORKLOADS[args.workload]
     Bg = B * world
-    eng = Engine(device=dev, batch=B, global_batch=Bg, batch_offset=rank * B, **C2)
+    eng = Engine(device=dev, batch=B, global_batch=Bg, batch_offset=rank * B, **CFG)
     # random-init agents (reference init: Xavier-normal weights, zero biases, N(0,1) code_bias;
     # baselines torch-default uniform) from a fixed seed -- identical on every rank
     from multimodalgame_amd.agents import init_state_dicts
     eng.load_state_dicts(init_state_dicts(eng, seed=0))
     n_steps_total = args.steps + args.warmup
-    feats, target, desc = synthetic_dataset(100 * C2["n_classes"], C2["n_classes"], C2["feat_dim"], C2["wv_dim"])
+    feats, target, desc = synthetic_dataset(max(100 * CFG["n_classes"], 4 * Bg), CFG["n_classes"], CFG["feat_dim"], CFG["wv_dim"])
     # minibatches of the epoch loop, resident in HBM before the timed region (misc.py:257-302 order:
     # seeded shuffle, sorted indices inside a batch, drop-last)
     import random
@@ -162,7 +171,7 @@ def run_gpu(args, rank, world, local_rank):
         dom = max(avg, key=avg.get)
         # average steps a sample takes (early exit): take it from the tape of the last minibatch
         tstar = eng.tape["tstar"].float().mean().item() + 1.0
-        bound, amount = algorithmic_work(dom, C2, B, tstar)      # tstar = live steps per sample (B * tstar live rows)
+        bound, amount = algorithmic_work(dom, CFG, B, tstar)     # tstar = live steps per sample (B * tstar live rows)
         secs = avg[dom] * 1e-3
         if bound == "hbm":
             achieved, peak, unit = amount / secs / 1e9, HBM_PEAK_GBS, "GB/s"
@@ -180,7 +189,7 @@ def run_gpu(args, rank, world, local_rank):
             traffic = None
         per_kernel = {}                          # the same figure for every launch of the minibatch (HIP-event durations)
         for k, ms in avg.items():
-            bk, amt = algorithmic_work(k, C2, B, tstar)
+            bk, amt = algorithmic_work(k, CFG, B, tstar)
             if amt:
                 a_k = amt / (ms * 1e-3) / (1e9 if bk == "hbm" else 1e12)
                 per_kernel[k] = dict(bound=bk, achieved=round(a_k, 3), unit="GB/s" if bk == "hbm" else "TFLOP/s",
@@ -237,6 +246,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+                    help="c2 = BASELINE.json's metric config (default); c3/c4/c5 = the other listed configs, for reference")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -249,21 +260,22 @@ def main():
     elapsed, ex_steps, roof = run_gpu(args, rank, world, local_rank)
     if rank == 0:
         line = {
-            "metric": "exchange-steps/sec (whole node), 30-class Adaptive max_exchange=10 bs=64",
+            "metric": ("exchange-steps/sec (whole node), 30-class Adaptive max_exchange=10 bs=64" if args.workload == "c2" else
+                       "exchange-steps/sec (whole node) of reference workload %s -- NOT BASELINE.json's metric" % args.workload),
             "value": world * ex_steps / elapsed, "unit": "exchange-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: Adaptive 30-class, batch 64 per GPU, max_exchange 10, rec_w_dim 32, "
-                                   "img_h_dim 256, rec_hidden 64, RMSprop; one bench step = one training minibatch",
-                       "global_batch": PER_GPU_BATCH * world, "parallelism": "dp%d" % world,
+            "config": {"workload": WORKLOADS[args.workload][2],
+                       "global_batch": WORKLOADS[args.workload][1] * world, "parallelism": "dp%d" % world,
                        "exchange_steps_per_minibatch": ex_steps / args.steps, "sampling": "in-kernel Philox4x32-10",
                        "minibatches_per_s": world * args.steps / elapsed,          # 64-sample batches
                        "sample_steps_per_s": run_gpu.sample_steps / elapsed,       # sum_t n_active,t per second, whole job
-                       "unit_definition": "one exchange step (model.py:801 loop iteration) of one 64-sample batch; "
-                                          "a global minibatch of 64*N samples advances N of them per iteration"},
+                       "unit_definition": "one exchange step (model.py:801 loop iteration) of one %d-sample batch; a global "
+                                          "minibatch of %d*N samples advances N of them per iteration" % (
+                                              WORKLOADS[args.workload][1], WORKLOADS[args.workload][1])},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
