@@ -255,8 +255,8 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->d_jt = reinterpret_cast<JobTable*>(h->tp.tables);
     h->profiling = false; h->timers_used = 0; h->scores_in_parts = false;
     h->use_fast = !getenv("MMG_NO_FAST"); h->merge_roles = !getenv("MMG_NO_MERGE");
-    // few samples and large sender matrices: 512-thread variant of the generic conversation kernel
-    h->conv_threads = (h->dm.B <= 256 && (int64_t)h->dm.H * h->dm.W >= 65536) ? 512 : 256;
+    // few samples and large sender matrices or class tables: 512-thread variant of the generic conversation kernel
+    h->conv_threads = (h->dm.B <= 256 && ((int64_t)h->dm.H * h->dm.W >= 65536 || (int64_t)h->dm.D * (h->dm.R + h->dm.V) >= 65536)) ? 512 : 256;
     h->conv_smem = conv_smem_floats(h->dm, h->conv_threads) * 4;
     h->conv_smem_agent = conv_smem_floats(h->dm, MMG_BLOCK) * 4;
     h->bwd_smem = bwd_smem_floats(h->dm) * 4;
