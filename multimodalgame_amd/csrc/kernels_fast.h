@@ -179,6 +179,50 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
 #pragma unroll
     for (int u = 0; u < NA_; ++u) t_a[tid + NT * u] = ra_[u];
     if (tid < TMAX) { t_s[tid] = rs_; t_ps[tid] = rps_; }
+    // ---- output step t*, the part that needs no loss coefficient: NLL seed dy, A* = y1[:, :R] h*, dA (and the release of
+    // dy / A* to the class roles).  Done here, while the statistics roles are still working, instead of inside the
+    // first reverse step.
+    const float dy_mine = (tid < D) ? (sm_mine - (tid == tgt ? 1.f : 0.f)) / (float)dm.Bg : 0.f;
+    __syncthreads();                                    // the forward tape is staged (t_h)
+    {
+        const int t = tstar;
+        if (tid < 64) {
+            if (lane < D) {                             // (MERGE_DC: write-through store, see the signal below)
+                if (MERGE_DC) __hip_atomic_store(&tp.dy[(size_t)b * D + lane], dy_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else tp.dy[(size_t)b * D + lane] = dy_mine;
+            }
+            if (lane < 32) s_dy[lane] = dy_mine;
+            const float dsum = dpp_wave_sum(dy_mine);
+            if (lane == 0) tp.dysum[b] = dsum;
+        } else if (tid < 64 + R) {
+            tp.hstar[(size_t)b * R + tid - 64] = t_h[(t + 1) * R + tid - 64];
+        }
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < R / K4; ++i) acc = fmaf(y1r[i], t_h[(t + 1) * R + p4 * (R / K4) + i], acc);
+            acc = lane_group_sum<K4>(acc);
+            if (p4 == 0) s_A[k4] = acc;
+        }
+        __syncthreads();
+        if (tid < R) {
+            const float a = s_A[tid];
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc += (a + cdcol[d] > 0.f) ? s_dy[d] : 0.f;
+            const float v = acc * w2_mine;
+            s_dA[tid] = v; tp.dA[(size_t)b * R + tid] = v;
+            if (MERGE_DC) __hip_atomic_store(&tp.Astar[(size_t)b * R + tid], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else tp.Astar[(size_t)b * R + tid] = a;
+        }
+        if (MERGE_DC && tid == 0) {
+            // wave 0 wrote dy and A* with device-scope (write-through) stores: they need no L2 write-back, only to
+            // have completed before the counter moves -- 64 sample roles each doing a full device-scope release
+            // (buffer_wbl2) here would serialise on the L2s
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a workgroup-scope fence does not wait for global stores)
+            __hip_atomic_fetch_add(tp.sync + MMG_SYNC_ARR(1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (MERGED) {                                       // the statistics roles of this launch publish stats, bs, br
         role_wait(tp.sync, 0, (uint32_t)n_stats, (uint32_t)B);
         creg = coef_load(dm, tp.stats);
@@ -189,8 +233,6 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     MMG_BSTAMP(2);
     const float* cw_s = lc.cw, *cw_r = lc.cw + T, *cw_z = lc.cw + 2 * T;
     const float* ce_s = lc.ce, *ce_r = lc.ce + T, *ce_z = lc.ce + 2 * T;
-    const float dy_mine = (tid < D) ? (sm_mine - (tid == tgt ? 1.f : 0.f)) / (float)dm.Bg : 0.f;
-
     if (tid < R) s_dh[tid] = 0.f;
     float dhx_acc = 0.f;
 
@@ -229,19 +271,6 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             tp.dbs[row] = binary ? lc.cb[t] * (t_bs[t] - L) : 0.f;
             tp.dbr[row] = binary ? lc.cb[t] * (t_br[t] - L) : 0.f;
         }
-        if (t == tstar) {                                                   // NLL seed at the output step
-            if (tid < 64) {
-                if (lane < D) {                                     // (MERGE_DC: write-through store, see the signal below)
-                    if (MERGE_DC) __hip_atomic_store(&tp.dy[(size_t)b * D + lane], dy_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else tp.dy[(size_t)b * D + lane] = dy_mine;
-                }
-                if (lane < 32) s_dy[lane] = dy_mine;
-                const float dsum = dpp_wave_sum(dy_mine);
-                if (lane == 0) tp.dysum[b] = dsum;
-            } else if (tid < 64 + R) {
-                tp.hstar[(size_t)b * R + tid - 64] = t_h[(t + 1) * R + tid - 64];
-            }
-        }
         __syncthreads(); MMG_BSTAMP(8 + 6 * t + 1);                              // b1
         // ===== (2) dg = W_w^T dlw -> dgpre ; sender: da = W_b^T dlz -> dpre
         {
@@ -272,34 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             tp.dpre[row * H + tid] = v;
             dhx_acc += v;
         }
-        if (t == tstar) {                                                   // A = y1[:, :R] h*
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < R / K4; ++i) acc = fmaf(y1r[i], t_h[(t + 1) * R + p4 * (R / K4) + i], acc);
-            acc = lane_group_sum<K4>(acc);
-            if (p4 == 0) s_A[k4] = acc;
-        }
         __syncthreads(); MMG_BSTAMP(8 + 6 * t + 2);                              // b2
-        if (t == tstar) {
-            if (tid < R) {
-                const float a = s_A[tid];
-                float acc = 0.f;
-#pragma unroll
-                for (int d = 0; d < D; ++d) acc += (a + cdcol[d] > 0.f) ? s_dy[d] : 0.f;
-                const float v = acc * w2_mine;
-                s_dA[tid] = v; tp.dA[(size_t)b * R + tid] = v;
-                if (MERGE_DC) __hip_atomic_store(&tp.Astar[(size_t)b * R + tid], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else tp.Astar[(size_t)b * R + tid] = a;
-            }
-            if (MERGE_DC && tid == 0) {
-                // wave 0 wrote dy and A* with device-scope (write-through) stores: they need no L2 write-back, only to
-                // have completed before the counter moves -- 64 sample roles each doing a full device-scope release
-                // (buffer_wbl2) here would serialise on the L2s
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a workgroup-scope fence does not wait for global stores)
-                __hip_atomic_fetch_add(tp.sync + MMG_SYNC_ARR(1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-        }
         // ===== (3) dh += W_h^T dgpre + w_s dls (+ W_y1h^T dA at the output step)
         {
             float acc = 0.f;
