@@ -74,6 +74,14 @@ def try_create(device, group=None):
     comm, ok = None, 1
     try:
         comm = RcclComm(device, group)
+        # self-check before trusting it with gradients: f32 and f64 sums over the ranks on the current stream
+        for dt in (torch.float32, torch.float64):
+            probe = torch.full((257,), float(comm.rank + 1), dtype=dt, device=comm.device)
+            comm.all_reduce(probe)
+            torch.cuda.synchronize(comm.device)
+            want = comm.world * (comm.world + 1) / 2.0
+            if not bool((probe == want).all().item()):
+                raise RuntimeError("direct RCCL all-reduce self-check failed")
     except Exception:                                   # noqa: BLE001 -- any failure means "use torch.distributed"
         ok = 0
     flag = torch.tensor([ok], dtype=torch.int32)
