@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mmg.hip")
 OUT = os.path.join(HERE, "libmmg.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("mmg.hip", "layout.h", "device_utils.h", "kernels_fwd.h", "kernels_bwd.h", "kernels_fast.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("mmg.hip", "layout.h", "device_utils.h", "kernels_fwd.h", "kernels_bwd.h", "kernels_fast.h", "kernels_tile.h")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "mmg.h"))
 
 
@@ -13,7 +13,7 @@ def build_library(force=False, verbose=True):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", OUT, SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         __syncthreads();
         const float* by1 = P.p[R_Y1_B];
         const bool vec = ((ld & 3) == 0) && ((R & 3) == 0) && ((V & 3) == 0);
+        float cy_part = 0.f;
         for (int r = tid; r < R; r += blockDim.x) {
             const float* wrow = P.p[R_Y1_W] + (size_t)r * ld + R;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -52,8 +53,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
             } else {
                 for (int v = 0; v < V; ++v) a0 = fmaf(wrow[v], s_desc[v], a0);
             }
-            tp.Cd[(size_t)d * R + r] = (a0 + a1) + (a2 + a3) + by1[r];
+            const float cdv = (a0 + a1) + (a2 + a3) + by1[r];
+            tp.Cd[(size_t)d * R + r] = cdv;
+            tp.CdT[(size_t)r * dm.D + d] = -cdv;      // NEGATED: relu(A + c) = max(A, -c) + c (kernels_tile.h, many-class y head)
+            cy_part = fmaf(P.p[R_Y2_W][r], cdv, cy_part);
         }
+        cy_part = block_sum(cy_part, smem + ((V + 3) & ~3));
+        if (tid == 0) tp.cy[d] = cy_part + P.p[R_Y2_B][0];
     } else {
         float* s_sig = smem;                        // [W]
         const float* cb = P.p[S_CODE_BIAS];
@@ -63,6 +69,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
             s_sig[j] = sg;
             tp.dsig[j] = sg * (1.f - sg);
         }
+        if (tid < dm.T + 2) tp.alive[tid] = (tid == 0) ? 1 : 0;     // per-step live-tile counts (kernels_tile.h)
         if (tid == 0) {
             tp.counter[0] += 1u;                    // minibatch counter: the Philox stream of this conversation
             if (tp.counter[2] > tp.counter[1]) tp.counter[1] = tp.counter[2];   // optimizer step bumped by k_opt

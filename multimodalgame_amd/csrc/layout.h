@@ -87,6 +87,10 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(hx, float, 0, 2, B, H, 1)          /* image_layer(x)            model.py:195 */ \
     X(Cd, float, 0, 2, D, R, 1)          /* desc . W_y1[:,R:]^T + b_y1 (App. A.2)  */ \
     X(descc, float, 0, 2, D, V, 1)       /* copy of the description matrix (GEMM operand inside the workspace) */ \
+    X(CdT, float, 0, 2, R, D, 1)         /* -Cd transposed: class index contiguous (kernels_tile.h, many-class y head) */ \
+    X(cy, float, 0, 1, D, 1, 1)          /* b_y2 + sum_r w_y2[r] Cd[d][r]                                              */ \
+    X(mstate, float, 0, 1, B, 1, 1)      /* running stop mask m_t between the per-step launches of one conversation */ \
+    X(alive, int32_t, 2, 1, T + 2, 1, 1) /* [t]: sample tiles with a live sample when step t starts (kernels_tile.h)  */ \
     X(hw0, float, 0, 1, H, 1, 1)         /* code_layer(sigmoid(code_bias)) :199-200*/ \
     X(dsig, float, 0, 1, W, 1, 1)        /* sigmoid'(code_bias)                    */ \
     X(c, float, 0, 3, T, B, W)           /* sender code input per step             */ \

@@ -15,6 +15,7 @@
 #include "kernels_fwd.h"
 #include "kernels_bwd.h"
 #include "kernels_fast.h"
+#include "kernels_tile.h"
 
 using namespace mmg;
 
@@ -45,6 +46,11 @@ struct mmg_handle {
     bool scores_in_parts;      // the last forward left baseline scores as partials (k_baselines2)
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
     bool merge_roles;          // MMG_NO_MERGE=1 keeps k_stats / k_dC / basehx as separate launches / in-kernel work
+    // sample-tile MFMA path (kernels_tile.h): every shape the register-resident kernels do not cover
+    bool tile_ok;              // its LDS plan fits (MMG_NO_TILE=1: never use it)
+    bool tile_force;           // MMG_TILE=1: use it even where the register-resident kernels apply (cross-checks)
+    bool tile_ext;             // the sender MLP of a step runs as its own chip-wide launches (k_send_s1 / k_send_s2)
+    int tile_nt, tile_smem;    // threads per tile workgroup, dynamic LDS bytes
     std::vector<KernelTimer> timers;
     size_t timers_used;
 };
@@ -260,9 +266,37 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->conv_smem = conv_smem_floats(h->dm, h->conv_threads) * 4;
     h->conv_smem_agent = conv_smem_floats(h->dm, MMG_BLOCK) * 4;
     h->bwd_smem = bwd_smem_floats(h->dm) * 4;
-    h->prep_smem = ((h->dm.V > h->dm.W ? h->dm.V : h->dm.W) + 4) * 4;
+    h->prep_smem = ((h->dm.V > h->dm.W ? h->dm.V : h->dm.W) + 16) * 4;
     if (h->conv_smem > 160 * 1024 || h->bwd_smem > 160 * 1024) { fail("dimensions need more than 160 KB of LDS per sample"); delete h; return nullptr; }
     hipError_t e = hipSuccess;
+    {
+        const Dims& d = h->dm;
+        const int tiles = (d.B + MMG_TM - 1) / MMG_TM;
+        // few tiles and a large sender MLP: one step's sender products as chip-wide launches of their own
+        h->tile_ext = tiles < 64 && (int64_t)d.H * d.W >= 65536 && !getenv("MMG_TILE_FUSED");
+        // one tile per CU up to 256 tiles: 16 waves hide the LDS / L2 latency of the tile's phases; beyond that several
+        // smaller workgroups share a CU.  Fewer waves also mean smaller split-K staging areas.
+        const int nts[3] = {1024, 512, 256};
+        for (int k = (tiles <= 512 ? 1 : 2); k < 3; ++k) {       // (the 1024-thread variant spills at 128 registers: MMG_TILE_NT=1024 to try it)
+            h->tile_nt = nts[k];
+            h->tile_smem = tile_lds(d, h->tile_nt / 64, !h->tile_ext).total * 4;
+            if (h->tile_smem <= 160 * 1024) break;
+        }
+        if (getenv("MMG_TILE_NT")) { h->tile_nt = atoi(getenv("MMG_TILE_NT")); h->tile_smem = tile_lds(d, h->tile_nt / 64, !h->tile_ext).total * 4; }
+        if (!h->tile_ext && d.H > h->tile_nt) {                      // the in-kernel sender keeps the tile's h_x in 16 registers per thread
+            h->tile_ext = true;
+            h->tile_smem = tile_lds(d, h->tile_nt / 64, false).total * 4;
+        }
+        // 16-byte aligned weight rows (float4 fragments): every BASELINE shape; odd dimensions take the per-sample kernels
+        const bool aligned = !(d.H & 3) && !(d.W & 3) && !(d.R & 3) && !(d.V & 3);
+        h->tile_ok = aligned && h->tile_smem <= 160 * 1024 && !getenv("MMG_NO_TILE");
+        h->tile_force = getenv("MMG_TILE") != nullptr;
+        if (h->tile_ok && h->tile_smem > 48 * 1024) {
+            e = hipFuncSetAttribute((const void*)k_conv_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
+        }
+    }
     if (h->conv_smem > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
@@ -365,7 +399,45 @@ static int launch_baselines_fused(mmg_handle* h, hipStream_t st) {
 // register-resident kernels exist for the agent shape of BASELINE configs 1-3
 static bool fast_shape(const mmg_handle* h) {
     const Dims& d = h->dm;
+    if (h->tile_ok && h->tile_force) return false;
     return h->use_fast && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
+}
+// every other shape: sample tiles on the matrix cores (kernels_tile.h); the per-sample generic kernels remain for
+// dimensions whose tile does not fit the LDS and for the agent-level entry points
+static bool tile_path(const mmg_handle* h) { return h->tile_ok && !fast_shape(h); }
+
+static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
+    const Dims& d = h->dm;
+    const int tiles = (d.B + MMG_TM - 1) / MMG_TM;
+    auto conv = [&](const ConvArgs& a) {
+        if (h->tile_nt == 1024) hipLaunchKernelGGL(k_conv_tile<1024>, dim3(tiles), dim3(1024), h->tile_smem, st, h->dm, h->P, h->tp, a);
+        else if (h->tile_nt == 512) hipLaunchKernelGGL(k_conv_tile<512>, dim3(tiles), dim3(512), h->tile_smem, st, h->dm, h->P, h->tp, a);
+        else hipLaunchKernelGGL(k_conv_tile<256>, dim3(tiles), dim3(256), h->tile_smem, st, h->dm, h->P, h->tp, a);
+    };
+    if (!h->tile_ext) {
+        Scope sc(h, st, "k_conv_tile");
+        ar.phases = 3; ar.t_begin = 0; ar.t_end = d.T;
+        conv(ar);
+        return launch_check("k_conv_tile");
+    }
+    const int skip = (!ar.run_all && !d.fixed && ar.train) ? 1 : 0;
+    for (int t = 0; t < d.T; ++t) {
+        {
+            Scope sc(h, st, "k_send_s1");
+            hipLaunchKernelGGL(k_send_s1, dim3(tiles * ((d.H + 15) / 16)), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, t, skip);
+        }
+        {
+            Scope sc(h, st, "k_send_s2");
+            hipLaunchKernelGGL(k_send_s2, dim3(tiles * ((d.W + 15) / 16)), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, ar, t, skip);
+        }
+        {
+            Scope sc(h, st, "k_conv_tile");
+            ar.phases = 2; ar.t_begin = t; ar.t_end = t + 1;
+            conv(ar);
+        }
+        if (launch_check("k_conv_tile (step)")) return -1;
+    }
+    return 0;
 }
 
 extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
@@ -382,7 +454,9 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     ar.x = d_x; ar.target = d_target; ar.desc = d_desc; ar.u_z = d_u_z; ar.u_s = d_u_s; ar.u_w = d_u_w; ar.seed = seed;
     ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
     bool base_ready = false;
-    {
+    if (tile_path(h)) {
+        if (launch_conv_tile(h, st, ar)) return -1;
+    } else {
         Scope sc(h, st, "k_conversation");
         const bool fast = fast_shape(h);
         base_ready = fast && bas && !run_all_steps && h->merge_roles;

@@ -1,0 +1,33 @@
+"""Per-phase timeline of k_conv_tile for tile 0 (needs libmmg_timing.so: -DMMG_TIMING build).  usage: tile_timeline.py c4|c5|<batch>"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from multimodalgame_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmmg_timing.so")
+from multimodalgame_amd.engine import Engine
+from multimodalgame_amd.agents import init_state_dicts
+import bench
+which = sys.argv[1] if len(sys.argv) > 1 else "c5"
+cfg, B, _ = bench.WORKLOADS[which]
+cfg = dict(cfg)
+eng = Engine(batch=B, **cfg)
+eng.load_state_dicts(init_state_dicts(eng, 0))
+feats, target, desc = bench.synthetic_dataset(max(3000, B), cfg["n_classes"], 512, 100)
+dev = eng.device
+x = torch.from_numpy(feats[:B]).to(dev); t = torch.from_numpy(target[:B]).to(dev); d = torch.from_numpy(desc).to(dev)
+for it in range(4):
+    eng.train_step(x, t, d, seed=0)
+torch.cuda.synchronize()
+dbg = eng.tape["dbg"].view(torch.int64).cpu().numpy()
+tick = 10.0
+print("prologue %.2f us ; loop+tail %.2f us" % ((dbg[1] - dbg[0]) * tick / 1e3, (dbg[2] - dbg[1]) * tick / 1e3))
+print("clock64 ticks per us: %.1f" % ((dbg[5] - dbg[4]) / ((dbg[2] - dbg[0]) * tick / 1e3)))
+names = ["ph0 s1+gh", "ph1 z", "ph2 gru", "ph3 heads", "ph4 y+softmax", "ph5 dbar", "ph6 g", "ph7 w"]
+for st in range(10):
+    base = 8 + 16 * st
+    if dbg[base] == 0: break
+    parts = []
+    for k in range(1, 8):
+        if dbg[base + k] < dbg[base + k - 1]: break
+        parts.append("%s %.2f" % (names[k - 1], (dbg[base + k] - dbg[base + k - 1]) * tick / 1e3))
+    print("step %d: " % st + " | ".join(parts))

@@ -59,7 +59,7 @@ def test_early_exit_and_fused_step_equal_run_all(name):
             np.testing.assert_allclose(got[k], full[k], rtol=2e-4, atol=2e-6, err_msg="%s %s" % (kw, k))
 
 
-@pytest.mark.parametrize("switch", ["MMG_NO_MERGE", "MMG_NO_FAST"])
+@pytest.mark.parametrize("switch", ["MMG_NO_MERGE", "MMG_NO_FAST", "MMG_TILE"])
 def test_kernel_variants_agree(switch, monkeypatch):
     """The same minibatches through (a) the default path (register-resident kernels; statistics / class reduction /
     basehx as workgroup roles of neighbouring launches), (b) MMG_NO_MERGE=1: those as their own launches,
