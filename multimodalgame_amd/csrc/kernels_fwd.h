@@ -25,8 +25,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
                                                     const float* __restrict__ x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x > dm.D) {
-        gemm_nt_tile(blockIdx.x - dm.D - 1, x, dm.F, P.p[S_IMG_W], dm.F, P.p[S_IMG_B], tp.hx, dm.H, dm.B, dm.H, dm.F);
+    const int HB = (dm.H + 63) / 64;                 // blocks [D, D + HB): 64 rows of hw0 each
+    if ((int)blockIdx.x >= dm.D + HB) {
+        gemm_nt_tile(blockIdx.x - dm.D - HB, x, dm.F, P.p[S_IMG_W], dm.F, P.p[S_IMG_B], tp.hx, dm.H, dm.B, dm.H, dm.F);
         return;
     }
     if ((int)blockIdx.x < dm.D) {
@@ -67,31 +68,41 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         for (int j = tid; j < W; j += blockDim.x) {
             const float sg = sigmoidf_(cb[j]);
             s_sig[j] = sg;
-            tp.dsig[j] = sg * (1.f - sg);
+            if ((int)blockIdx.x == dm.D) tp.dsig[j] = sg * (1.f - sg);
         }
-        if (tid < dm.T + 2) tp.alive[tid] = (tid == 0) ? 1 : 0;     // per-step live-tile counts (kernels_tile.h)
-        if (tid == 0) {
+        const bool first = (int)blockIdx.x == dm.D;
+        if (first && tid < dm.T + 2) tp.alive[tid] = (tid == 0) ? 1 : 0;     // per-step live-tile counts (kernels_tile.h)
+        if (first && tid == 0) {
             tp.counter[0] += 1u;                    // minibatch counter: the Philox stream of this conversation
             if (tp.counter[2] > tp.counter[1]) tp.counter[1] = tp.counter[2];   // optimizer step bumped by k_opt
         }
         __syncthreads();
+        // hw0 = code_layer(sigmoid(code_bias)): four lanes per row, interleaved float4 slices (64 contiguous bytes per row step),
+        // 8 loads in flight per lane
         const float* bc = P.p[S_CODE_B];
-        const bool vec = (W & 3) == 0;
-        for (int n = tid; n < dm.H; n += blockDim.x) {          // thread n owns hw0[n]: all row loads in flight at once
-            const float* wrow = P.p[S_CODE_W] + (size_t)n * W;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            if (vec) {
-#pragma unroll 8
-                for (int k = 0; k < W; k += 4) {
-                    const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
-                    const float4 sv = *reinterpret_cast<const float4*>(s_sig + k);
-                    a0 = fmaf(wv.x, sv.x, a0); a1 = fmaf(wv.y, sv.y, a1); a2 = fmaf(wv.z, sv.z, a2); a3 = fmaf(wv.w, sv.w, a3);
+        const int n = ((int)blockIdx.x - dm.D) * 64 + (tid >> 2), p4 = tid & 3;
+        const int nc = min(n, dm.H - 1);
+        const float* wrow = P.p[S_CODE_W] + (size_t)nc * W;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if ((W & 3) == 0) {
+            const int W4 = W >> 2;
+            for (int k0 = p4; k0 < W4; k0 += 32) {
+                float4 wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const float4*>(wrow + 4 * min(k0 + 4 * u, W4 - 1));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + 4 * u < W4) {
+                        const float4 sv = *reinterpret_cast<const float4*>(s_sig + 4 * (k0 + 4 * u));
+                        a0 = fmaf(wv[u].x, sv.x, a0); a1 = fmaf(wv[u].y, sv.y, a1); a2 = fmaf(wv[u].z, sv.z, a2); a3 = fmaf(wv[u].w, sv.w, a3);
+                    }
                 }
-            } else {
-                for (int k = 0; k < W; ++k) a0 = fmaf(wrow[k], s_sig[k], a0);
             }
-            tp.hw0[n] = (a0 + a1) + (a2 + a3) + bc[n];
+        } else {
+            for (int k = p4; k < W; k += 4) a0 = fmaf(wrow[k], s_sig[k], a0);
         }
+        const float tot = dpp_group_sum<4>((a0 + a1) + (a2 + a3));
+        if (p4 == 0 && n < dm.H) tp.hw0[n] = tot + bc[n];
     }
 }
 

@@ -276,13 +276,23 @@ __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, Co
         if (t0 == 0 && tid < nb) tp.mask[b0 + tid] = 1;                // stop_mask[0] = ones   model.py:775
     }
     {
-        auto vec = [&](int off, const float* src, int n) { batched_for<NT, 2>(n, [&](int i) { return src[i]; }, [&](int i, float v) { smem[off + i] = v; }); };
-        if (do_sen) {
-            vec(L.bc, P.p[S_CODE_B], H); vec(L.hw0, tp.hw0, H); vec(L.bb, P.p[S_BIN_B], W);
-            batched_for<NT, 2>(W, [&](int i) { return P.p[S_CODE_BIAS][i]; }, [&](int i, float v) { smem[L.sc + i] = fsigmoid(v); });
-        }
-        vec(L.bih, P.p[R_BIH], 3 * R); vec(L.bhh, P.p[R_BHH], 3 * R); vec(L.bh, P.p[R_WH_B], R); vec(L.bw, P.p[R_W_B], W);
-        vec(L.ws, P.p[R_S_W], R); vec(L.w2, P.p[R_Y2_W], R);
+        // per-column vectors -> LDS as ONE batched gather over the concatenation of the nine segments (one memory round trip)
+        const float* sp[10]; int sl[10], so[10], ns = 0;
+        auto seg = [&](int off, const float* src, int n) { sp[ns] = src; sl[ns] = n; so[ns] = off; ++ns; };
+        if (do_sen) { seg(L.bc, P.p[S_CODE_B], H); seg(L.hw0, tp.hw0, H); seg(L.bb, P.p[S_BIN_B], W); seg(L.sc, P.p[S_CODE_BIAS], W); }
+        seg(L.bih, P.p[R_BIH], 3 * R); seg(L.bhh, P.p[R_BHH], 3 * R); seg(L.bh, P.p[R_WH_B], R); seg(L.bw, P.p[R_W_B], W);
+        seg(L.ws, P.p[R_S_W], R); seg(L.w2, P.p[R_Y2_W], R);
+        int total = 0;
+        for (int k = 0; k < ns; ++k) total += sl[k];
+        struct PV { float v; int off; };
+        batched_for<NT, 4>(total, [&](int idx) {
+                const float* src = sp[0]; int off = so[0], base = 0, acc = 0;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    if (k < ns) { if (idx >= acc) { src = sp[k]; off = so[k]; base = acc; } acc += sl[k]; }
+                }
+                return PV{src[idx - base], off + idx - base};
+            }, [&](int, PV q) { smem[q.off] = (do_sen && q.off >= L.sc && q.off < L.sc + L.ldW) ? fsigmoid(q.v) : q.v; });
     }
     if (t0 == 0) {
         for (int idx = tid; idx < nb * R; idx += NT) tp.h[(size_t)b0 * R + idx] = 0.f;          // h_{-1} = 0 (rows b0 .. b0+nb-1 are contiguous)
@@ -830,4 +840,338 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_send_s2(Dims dm, Params P, Tape t
     }
 }
 
+}  // namespace mmg
+
+namespace mmg {
+
+// ---------------------------------------------------------------------------------------------
+// k_bwd_tile: reverse-time pass of one 16-sample tile (same math and tape contract as k_bwd_conv, kernels_bwd.h):
+// output step: dy = (softmax - onehot)/B, A* = W_y1[:, :R] h*, dA (class-side sum over the D rows of Cd, streamed once per
+// tile); then per step, back to front: REINFORCE / entropy seeds of the receiver's message and stop heads (App. A.4),
+// dg = dlw W_w, dh += dgpre W_h + dls w_s (+ dA W_y1h at the sample's output step), GRU cell backward, dh_{t-1} = dh u +
+// dgh W_hh -- the transposed products as [16, K] x [K, N] MFMA tiles ("NN" form: the PyTorch [out,in] matrix IS [K, N]).
+// The sender's backward is not recurrent (its input is detached) and runs over all (step, sample) rows in k_send_bwd.
+// Rows of steps a sample never took are zero-filled when zero_dead != 0 (no live-row list for k_wgrad), else untouched.
+// ---------------------------------------------------------------------------------------------
+struct BwdLds { int dh, dlw, dgp, dgh, dAm, dA, A, hs, dy, ws, w2, coef, raw0, raw1, misc, total; int ldW, ldR, ld3R, ldD; };
+__host__ __device__ inline BwdLds bwd_tile_lds(const Dims& d, int nw) {
+    BwdLds L;
+    L.ldW = ld16(d.W); L.ldR = ld16(d.R); L.ld3R = ld16(3 * d.R); L.ldD = ((d.D + 31) & ~31) + 4;      // (dA streams classes 32 at a time)
+    int o = 0;
+    auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };
+    L.dh = take(MMG_TM * L.ldR); L.dlw = take(MMG_TM * L.ldW); L.dgp = take(MMG_TM * L.ldR); L.dgh = take(MMG_TM * L.ld3R);
+    L.dAm = take(MMG_TM * L.ldR); L.dA = take(MMG_TM * L.ldR); L.A = take(MMG_TM * L.ldR); L.hs = take(MMG_TM * L.ldR);
+    L.dy = take(MMG_TM * L.ldD); L.ws = take(L.ldR); L.w2 = take(L.ldR); L.coef = take(7 * 64);
+    const int r = tile_raw_floats_nn(d.R, nw) > tile_raw_floats(d.R, nw) ? tile_raw_floats_nn(d.R, nw) : tile_raw_floats(d.R, nw);
+    L.raw0 = take(r); L.raw1 = take(r);
+    L.misc = take(128);
+    L.total = o;
+    return L;
+}
+#define BL_TSTAR 0      // [0,16) t* of the tile's samples   [16,32) reward L   [32,48) dls of this step   [48,64) live this step
+#define BL_L 16
+#define BL_DLS 32
+#define BL_LIVE 48
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int zero_dead, int make_map) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int nw = NT / 64;
+    const int B = dm.B, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
+    const int b0 = blockIdx.x * MMG_TM, nb = min(MMG_TM, B - b0);
+    const bool binary = dm.use_binary != 0;
+    const BwdLds L = bwd_tile_lds(dm, nw);
+    float* s_dh = smem + L.dh; float* s_dlw = smem + L.dlw; float* s_dgp = smem + L.dgp; float* s_dgh = smem + L.dgh;
+    float* s_dAm = smem + L.dAm; float* s_dA = smem + L.dA; float* s_A = smem + L.A; float* s_hs = smem + L.hs; float* s_dy = smem + L.dy;
+    float* s_ws = smem + L.ws; float* s_w2 = smem + L.w2; float* raw0 = smem + L.raw0; float* raw1 = smem + L.raw1; float* misc = smem + L.misc;
+    LossCoef lc; lc.cw = smem + L.coef; lc.ce = lc.cw + 3 * T; lc.cb = lc.cw + 6 * T;
+    {
+        const int tid = threadIdx.x;
+        for (int i = tid; i < L.total; i += NT) smem[i] = 0.f;
+        __syncthreads();
+        if (make_map && blockIdx.x == 0 && tid < 64) build_row_map(dm, tp);       // live (step, sample) rows for k_wgrad / k_send_bwd
+        if (tid < MMG_TM) {
+            const int b = min(b0 + tid, B - 1);
+            misc[BL_TSTAR + tid] = (tid < nb) ? (float)tp.tstar[b] : -1.f;          // padded rows: never live
+            misc[BL_L + tid] = tp.logs[b];
+        }
+        for (int r = tid; r < R; r += NT) { s_ws[r] = P.p[R_S_W][r]; s_w2[r] = P.p[R_Y2_W][r]; }
+    }
+    loss_coefficients(dm, tp.stats, lc, nullptr, nullptr);                  // (ends with a barrier)
+    int tmax = 0;
+    for (int m = 0; m < nb; ++m) tmax = max(tmax, (int)misc[BL_TSTAR + m]);
+    const int wave = threadIdx.x >> 6;
+
+    // ---------------- output step (model.py:1264-1275): dy, h*, A*, dA
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        for (int m = wave; m < nb; m += nw) {                              // dNLL/d outp, wave per sample
+            const int b = b0 + m, tgt = (int)target[b];
+            float dsum = 0.f;
+            for (int d0 = lane; d0 < D; d0 += 64 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = tp.sm[(size_t)b * D + min(d0 + 64 * u, D - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int d = d0 + 64 * u;
+                    if (d < D) {
+                        const float dv = (v[u] - (d == tgt ? 1.f : 0.f)) / (float)dm.Bg;
+                        s_dy[m * L.ldD + d] = dv; tp.dy[(size_t)b * D + d] = dv; dsum += dv;
+                    }
+                }
+            }
+            dsum = dpp_wave_sum(dsum);
+            if (lane == 0) tp.dysum[b] = dsum;
+        }
+        batched_for<NT, 4>(MMG_TM * R, [&](int idx) {
+                const int m = idx / R, r = idx - m * R;
+                const int ts = max((int)misc[BL_TSTAR + m], 0);
+                return tp.h[((size_t)(ts + 1) * B + min(b0 + m, B - 1)) * R + r];
+            }, [&](int idx, float v) {
+                const int m = idx / R, r = idx - m * R;
+                s_hs[m * L.ldR + r] = v;
+                if (m < nb) tp.hstar[(size_t)(b0 + m) * R + r] = v;
+            });
+        __syncthreads();
+        tgemm_nt_raw(s_hs, L.ldR, P.p[R_Y1_W], R + V, R, R, raw0, wave, nw);
+        __syncthreads();
+        {
+            const int kp = tile_kparts((R + 15) >> 4, nw);
+            for (int idx = tid; idx < MMG_TM * R; idx += NT) {
+                const int m = idx / R, r = idx - m * R;
+                const float a = raw_sum(raw0, L.ldR, kp, m, r);
+                s_A[m * L.ldR + r] = a;
+                if (m < nb) tp.Astar[(size_t)(b0 + m) * R + r] = a;
+            }
+        }
+        __syncthreads();
+        // dA[m][r] = w2[r] sum_d dy[m][d] 1[A*[m][r] + Cd[d][r] > 0]: one (sample, r) pair per thread pass, consecutive lanes on
+        // consecutive r (class rows read coalesced, 32 of them in flight), the sample's dy row broadcast from LDS
+        for (int idx = tid; idx < MMG_TM * R; idx += NT) {
+            const int m = idx / R, r1 = idx - m * R;
+            const float a = s_A[m * L.ldR + r1];
+            const float* dyr = s_dy + m * L.ldD;
+            float acc0 = 0.f, acc1 = 0.f;
+            for (int d0 = 0; d0 < D; d0 += 32) {
+                float cv[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) cv[u] = tp.Cd[(size_t)min(d0 + u, D - 1) * R + r1];
+#pragma unroll
+                for (int u = 0; u < 32; u += 2) {                          // (dy is zero beyond D: the LDS tile is zero padded)
+                    acc0 += (a + cv[u] > 0.f) ? dyr[d0 + u] : 0.f;
+                    acc1 += (a + cv[u + 1] > 0.f) ? dyr[d0 + u + 1] : 0.f;
+                }
+            }
+            const float v = (acc0 + acc1) * s_w2[r1];
+            s_dA[m * L.ldR + r1] = v;
+            if (m < nb) tp.dA[(size_t)(b0 + m) * R + r1] = v;
+        }
+        __syncthreads();
+    }
+
+    // ---------------- reverse time
+    struct Job { const float* A; const float* Wm; float* raw; int lda, ldw, N, K; };
+    for (int t = zero_dead ? T - 1 : tmax; t >= 0; --t) {
+        const size_t rowb = (size_t)t * B;
+        for (int ph = 0; ph < 4; ++ph) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            // ---------------- epilogue of the previous product / seeds
+            if (ph == 0) {
+                if (tid < MMG_TM) misc[BL_LIVE + tid] = ((float)t <= misc[BL_TSTAR + tid]) ? 1.f : 0.f;
+                // seeds of the receiver-message stream (active while m_{t+1} == 1, i.e. t < t*) and of the stop bit
+                if (binary) {
+                    batched_for<NT, 8>(MMG_TM * W, [&](int idx) {
+                            const int m = idx / W, j = idx - m * W;
+                            const size_t o = (rowb + min(b0 + m, B - 1)) * W + j;
+                            return F2{tp.w[o], tp.pw[o]};
+                        }, [&](int idx, F2 v) {
+                            const int m = idx / W, j = idx - m * W;
+                            const bool act = (float)t < misc[BL_TSTAR + m];
+                            float sv = 0.f;
+                            if (act) {
+                                const float wh = (misc[BL_L + m] - tp.br[rowb + b0 + m]) * lc.cw[T + t];
+                                sv = bit_seed_fast(v.x, v.y, wh, lc.ce[T + t]);
+                            }
+                            s_dlw[m * L.ldW + j] = sv;
+                            if (m < nb && (act || zero_dead || (float)t <= misc[BL_TSTAR + m])) tp.dlw[(rowb + b0 + m) * W + j] = sv;
+                        });
+                    if (tid < MMG_TM) {
+                        const int m = tid;
+                        const bool live = (float)t <= misc[BL_TSTAR + m];
+                        float dls = 0.f, dbs = 0.f, dbr = 0.f;
+                        if (live) {
+                            const float Lr = misc[BL_L + m], brv = tp.br[rowb + b0 + m], bsv = tp.bs[rowb + b0 + m];
+                            if (!dm.fixed) dls = bit_seed_fast(tp.s[rowb + b0 + m], tp.ps[rowb + b0 + m], (Lr - brv) * lc.cw[t], lc.ce[t]);
+                            dbs = lc.cb[t] * (bsv - Lr); dbr = lc.cb[t] * (brv - Lr);      // MSE seeds, model.py:971-988
+                        }
+                        misc[BL_DLS + m] = dls;
+                        if (m < nb && (live || zero_dead)) { tp.dls[rowb + b0 + m] = dls; tp.dbs[rowb + b0 + m] = dbs; tp.dbr[rowb + b0 + m] = dbr; }
+                    }
+                }
+                for (int idx = tid; idx < MMG_TM * R; idx += NT) {          // dA enters at the sample's output step
+                    const int m = idx / R, r = idx - m * R;
+                    s_dAm[m * L.ldR + r] = ((float)t == misc[BL_TSTAR + m]) ? s_dA[m * L.ldR + r] : 0.f;
+                }
+            } else if (ph == 1) {
+                if (binary) {                                                // dgpre = (dlw W_w) (1 - g^2)
+                    const int kp = tile_kparts((R + 63) >> 6, nw);
+                    batched_for<NT, 4>(MMG_TM * R, [&](int idx) { const int m = idx / R, r = idx - m * R; return tp.g[(rowb + min(b0 + m, B - 1)) * R + r]; },
+                        [&](int idx, float g) {
+                            const int m = idx / R, r = idx - m * R;
+                            const bool act = (float)t < misc[BL_TSTAR + m];
+                            const float v = act ? raw_sum(raw0, L.ldR, kp, m, r) * (1.f - g * g) : 0.f;
+                            s_dgp[m * L.ldR + r] = v;
+                            if (m < nb && (zero_dead || (float)t <= misc[BL_TSTAR + m])) tp.dgpre[(rowb + b0 + m) * R + r] = v;
+                        });
+                }
+            } else if (ph == 2) {
+                // dh += dgpre W_h + dA W_y1h + dls w_s ; GRU cell backward (model.py:340)
+                const int kp = tile_kparts((R + 63) >> 6, nw);
+                struct G5 { float rr, uu, nn, ghn, hp; };
+                batched_for<NT, 2>(MMG_TM * R, [&](int idx) {
+                        const int m = idx / R, i = idx - m * R, b = min(b0 + m, B - 1);
+                        const float* gr = tp.gru + (rowb + b) * 4 * R;
+                        return G5{gr[i], gr[R + i], gr[2 * R + i], gr[3 * R + i], tp.h[(rowb + b) * R + i]};
+                    }, [&](int idx, G5 gq) {
+                        const int m = idx / R, i = idx - m * R;
+                        const bool live = misc[BL_LIVE + m] != 0.f;
+                        float dh = s_dh[m * L.ldR + i] + raw_sum(raw1, L.ldR, kp, m, i) + misc[BL_DLS + m] * s_ws[i];
+                        if (binary) dh += raw_sum(raw0, L.ldR, kp, m, i);
+                        if (!live) dh = 0.f;
+                        const float dn = dh * (1.f - gq.uu), du = dh * (gq.hp - gq.nn);
+                        const float dnp = dn * (1.f - gq.nn * gq.nn), dup = du * gq.uu * (1.f - gq.uu);
+                        const float drp = dnp * gq.ghn * gq.rr * (1.f - gq.rr);
+                        float* dg = s_dgh + m * L.ld3R;
+                        dg[i] = drp; dg[R + i] = dup; dg[2 * R + i] = dnp * gq.rr;
+                        s_dh[m * L.ldR + i] = dh * gq.uu;
+                        if (m < nb && (live || zero_dead)) {
+                            float* gi = tp.dgi + (rowb + b0 + m) * 3 * R; float* gh = tp.dgh + (rowb + b0 + m) * 3 * R;
+                            gi[i] = drp; gi[R + i] = dup; gi[2 * R + i] = dnp;
+                            gh[i] = drp; gh[R + i] = dup; gh[2 * R + i] = dnp * gq.rr;
+                        }
+                    });
+            } else {
+                const int kp = tile_kparts((R + 63) >> 6, nw);
+                for (int idx = tid; idx < MMG_TM * R; idx += NT) {          // dh_{t-1} = dh u + dgh W_hh
+                    const int m = idx / R, i = idx - m * R;
+                    s_dh[m * L.ldR + i] += raw_sum(raw0, L.ldR, kp, m, i);
+                }
+            }
+            __syncthreads();
+            // ---------------- products feeding the next phase
+            Job j0, j1;
+            int nj = 0;
+            auto add = [&](const float* A, int lda, const float* Wm, int ldw, int N, int K, float* raw) {
+                Job& J = nj ? j1 : j0;
+                J.A = A; J.lda = lda; J.Wm = Wm; J.ldw = ldw; J.N = N; J.K = K; J.raw = raw; ++nj;
+            };
+            if (ph == 0) { if (binary) add(s_dlw, L.ldW, P.p[R_W_W], R, R, W, raw0); }
+            else if (ph == 1) { if (binary) add(s_dgp, L.ldR, P.p[R_WH_W], R, R, R, raw0); add(s_dAm, L.ldR, P.p[R_Y1_W], R + V, R, R, raw1); }
+            else if (ph == 2) add(s_dgh, L.ld3R, P.p[R_WHH], R, R, 3 * R, raw0);
+            for (int j = 0; j < nj; ++j) {
+                const float* jA = j ? j1.A : j0.A; const float* jW = j ? j1.Wm : j0.Wm; float* jr = j ? j1.raw : j0.raw;
+                tgemm_nn_raw(jA, j ? j1.lda : j0.lda, jW, j ? j1.ldw : j0.ldw, j ? j1.N : j0.N, j ? j1.K : j0.K, jr, wave, nw);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_send_bwd: sender backward over (step, sample) rows (binary mode): dlz = REINFORCE/entropy seed of the sender's bits,
+// dpre = (dlz W_b) (1 - a^2).  grid (ceil(rows/16), ceil(H/64/nw')): a workgroup owns 16 rows and a band of 64-column
+// groups of H; rows come from the live-row list (rmap) or are all T*B rows (dead rows zero-filled).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape tp, const int* __restrict__ rmap, const int* __restrict__ rcount) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = MMG_BLOCK, nw = NT / 64;
+    const int B = dm.B, H = dm.H, W = dm.W, T = dm.T;
+    const int ldW = ld16(W);
+    float* s_dlz = smem;                                   // [16][ldW]
+    float* s_coef = smem + MMG_TM * ldW;                   // 7*64
+    int* s_row = reinterpret_cast<int*>(s_coef + 7 * 64);  // [16] tape row of each tile row, -1: none
+    float* raw = s_coef + 7 * 64 + 16;                     // [16][ld16(64 * bands)]
+    LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int nrows = rmap ? rcount[0] : T * B;
+    const int r0 = blockIdx.x * MMG_TM;
+    if (r0 >= nrows) return;
+    for (int i = tid; i < MMG_TM * ldW; i += NT) s_dlz[i] = 0.f;
+    if (tid < MMG_TM) s_row[tid] = (r0 + tid < nrows) ? (rmap ? rmap[r0 + tid] : r0 + tid) : -1;
+    loss_coefficients(dm, tp.stats, lc, nullptr, nullptr);
+    batched_for<NT, 4>(MMG_TM * W, [&](int idx) {
+            const int m = idx / W, j = idx - m * W;
+            const size_t o = (size_t)max(s_row[m], 0) * W + j;
+            return F2{tp.z[o], tp.pz[o]};
+        }, [&](int idx, F2 v) {
+            const int m = idx / W, j = idx - m * W, row = s_row[m];
+            if (row < 0) return;
+            const int t = row / B, b = row - t * B;
+            float sv = 0.f;
+            if (t <= tp.tstar[b]) sv = bit_seed_fast(v.x, v.y, (tp.logs[b] - tp.bs[row]) * lc.cw[2 * T + t], lc.ce[2 * T + t]);
+            s_dlz[m * ldW + j] = sv;
+            if (blockIdx.y == 0) tp.dlz[(size_t)row * W + j] = sv;
+        });
+    __syncthreads();
+    // band of column groups handled by this workgroup: nw groups of 64 columns
+    const int n0 = blockIdx.y * 64 * nw, Nb = min(64 * nw, H - n0);
+    tgemm_nn_raw(s_dlz, ldW, P.p[S_BIN_W] + n0, H, Nb, W, raw, wave, nw);
+    __syncthreads();
+    const int ldr = ld16(Nb), kp = tile_kparts((Nb + 63) >> 6, nw);
+    batched_for<NT, 8>(MMG_TM * Nb, [&](int idx) {
+            const int m = idx / Nb, n = idx - m * Nb;
+            return tp.a[(size_t)max(s_row[m], 0) * H + n0 + n];
+        }, [&](int idx, float a) {
+            const int m = idx / Nb, n = idx - m * Nb;
+            if (s_row[m] >= 0) tp.dpre[(size_t)s_row[m] * H + n0 + n] = raw_sum(raw, ldr, kp, m, n) * (1.f - a * a);
+        });
+}
+
+}  // namespace mmg
+
+namespace mmg {
+// dhx[b, :] = sum over the sample's live steps of dpre[t, b, :]  (image_layer's gradient reduces over B rows instead of
+// over all live (step, sample) rows).  One float4 per thread, all of the sample's steps in flight.
+// Trailing blocks: u0[h] = sum_b dpre[t = 0, b, h] -- code_bias only sees step 0, where the code input sigmoid(code_bias) is
+// the same for every sample, so its gradient is dsig * W_c^T u0: a row-weighted column sum over code_layer.weight (k_wgrad).
+__global__ __launch_bounds__(MMG_BLOCK) void k_dhx(Dims dm, Tape tp, int nblk_dhx) {
+    const int H4 = dm.H >> 2;
+    if ((int)blockIdx.x >= nblk_dhx) {
+        __shared__ float4 s_p[4][64];
+        const int h4 = ((int)blockIdx.x - nblk_dhx) * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+        const int hc = min(h4, H4 - 1);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b0 = part; b0 < dm.B; b0 += 4 * 16) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = reinterpret_cast<const float4*>(tp.dpre + (size_t)min(b0 + 4 * u, dm.B - 1) * dm.H)[hc];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (b0 + 4 * u < dm.B) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        s_p[part][threadIdx.x & 63] = acc;
+        __syncthreads();
+        if (part == 0 && h4 < H4) {
+            const float4 a = s_p[0][threadIdx.x], b = s_p[1][threadIdx.x], c = s_p[2][threadIdx.x], d = s_p[3][threadIdx.x];
+            reinterpret_cast<float4*>(tp.u0)[h4] = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+        }
+        return;
+    }
+    const int idx = blockIdx.x * MMG_BLOCK + threadIdx.x;
+    if (idx >= dm.B * H4) return;
+    const int b = idx / H4, h4 = idx - b * H4;
+    const int ts = dm.use_binary ? tp.tstar[b] : -1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t0 = 0; t0 <= ts; t0 += 16) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = reinterpret_cast<const float4*>(tp.dpre + ((size_t)min(t0 + u, ts) * dm.B + b) * dm.H)[h4];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (t0 + u <= ts) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    reinterpret_cast<float4*>(tp.dhx + (size_t)b * dm.H)[h4] = acc;
+}
 }  // namespace mmg

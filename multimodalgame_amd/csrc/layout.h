@@ -142,6 +142,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(dpre, float, 0, 3, T, B, H)        /* dL/d (h_x + h_w)                       */ \
     X(dhx, float, 0, 2, B, H, 1)         /* sum_t dpre                             */ \
     X(dc0, float, 0, 2, B, W, 1)         /* W_c^T dpre_0 (code_bias path)          */ \
+    X(u0, float, 0, 1, H, 1, 1)          /* sum_b dpre_0[b, :] (code_bias path of the tile kernels) */ \
     X(dls, float, 0, 2, T, B, 1)         /* dL/d stop logit                        */ \
     X(dlw, float, 0, 3, T, B, W)         /* dL/d receiver message logits           */ \
     X(dgpre, float, 0, 3, T, B, R)       /* dL/d pre-tanh of h_w                   */ \

@@ -51,6 +51,7 @@ struct mmg_handle {
     bool tile_force;           // MMG_TILE=1: use it even where the register-resident kernels apply (cross-checks)
     bool tile_ext;             // the sender MLP of a step runs as its own chip-wide launches (k_send_s1 / k_send_s2)
     int tile_nt, tile_smem;    // threads per tile workgroup, dynamic LDS bytes
+    int tile_bwd_smem, send_bwd_smem;
     std::vector<KernelTimer> timers;
     size_t timers_used;
 };
@@ -111,6 +112,7 @@ extern "C" int mmg_tape_table(const mmg_config* cfg, mmg_tape_entry* out, int ma
 // (two for the matrices whose input is a concatenation: y1, both baselines' linear1).
 // ---------------------------------------------------------------------------------------------
 static bool fast_shape(const mmg_handle* h);
+static bool tile_path(const mmg_handle* h);
 
 static int build_jobs(mmg_handle* h) {
     JobTable& jt = h->jt;
@@ -168,7 +170,12 @@ static int build_jobs(mmg_handle* h) {
         col(tp.dhx, H, B, H, G.p[S_IMG_B], nullptr);
         gemm(tp.dpre, H, tp.c, W, 0, SRC_STATIC, G.p[S_CODE_W], W, TB, H, W);          // code_layer
         col(tp.dpre, H, TB, H, G.p[S_CODE_B], nullptr);
-        if (fast_shape(h)) {
+        if (tile_path(h)) {
+            // code_bias: dsig[j] * sum_h code_layer.weight[h, j] * u0[h], u0 = sum_b dpre[t = 0, b, :] (k_dhx): a row-weighted
+            // column sum over the weight matrix itself
+            col(P.p[S_CODE_W], W, H, W, G.p[S_CODE_BIAS], tp.dsig);
+            jt.c[nc - 1].wrow = tp.u0; jt.c[nc - 1].compact = 0;
+        } else if (fast_shape(h)) {
             // code_bias: dsig[j] * sum_h code_layer.weight[h, j] * (sum_b dpre[t = 0, b, h]) -- one workgroup of k_wgrad;
             // the register-resident backward kernel then needs no per-sample W_c^T dpre_0 product at its tail
             col(tp.dpre, H, B, 1, G.p[S_CODE_BIAS], tp.dsig);
@@ -291,6 +298,13 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         const bool aligned = !(d.H & 3) && !(d.W & 3) && !(d.R & 3) && !(d.V & 3);
         h->tile_ok = aligned && h->tile_smem <= 160 * 1024 && !getenv("MMG_NO_TILE");
         h->tile_force = getenv("MMG_TILE") != nullptr;
+        h->tile_bwd_smem = bwd_tile_lds(d, 512 / 64).total * 4;
+        h->send_bwd_smem = (MMG_TM * ld16(d.W) + 7 * 64 + 16 + tile_raw_floats_nn(256, MMG_BLOCK / 64)) * 4;
+        if (h->tile_bwd_smem > 160 * 1024) h->tile_ok = false;
+        if (h->tile_ok && e == hipSuccess && h->tile_bwd_smem > 48 * 1024)
+            e = hipFuncSetAttribute((const void*)k_bwd_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
+        if (h->tile_ok && e == hipSuccess && h->send_bwd_smem > 48 * 1024)
+            e = hipFuncSetAttribute((const void*)k_send_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, h->send_bwd_smem);
         if (h->tile_ok && h->tile_smem > 48 * 1024) {
             e = hipFuncSetAttribute((const void*)k_conv_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
@@ -374,7 +388,7 @@ static int launch_prep(mmg_handle* h, hipStream_t st, const float* desc, const f
     Scope sc(h, st, x ? "k_prep+h_x" : "k_prep");
     const Dims& d = h->dm;
     const int hx_tiles = x ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0;
-    hipLaunchKernelGGL(k_prep, dim3(d.D + 1 + hx_tiles), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc, x);
+    hipLaunchKernelGGL(k_prep, dim3(d.D + (d.H + 63) / 64 + hx_tiles), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc, x);
     return launch_check("k_prep");
 }
 
@@ -507,7 +521,24 @@ static bool merge_stats(const mmg_handle* h) {
 static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, hipStream_t st, bool with_stats) {
     const Dims& d = h->dm;
     bool row_map = false;
-    {
+    if (tile_path(h)) {
+        row_map = d.T * d.B <= 2048;                     // k_wgrad keeps the live-row list in LDS (2048 entries)
+        const int zero_dead = (!row_map && !d.fixed) ? 1 : 0;
+        const int tiles = (d.B + MMG_TM - 1) / MMG_TM;
+        {
+            Scope sc(h, st, "k_bwd_tile");
+            hipLaunchKernelGGL(k_bwd_tile<512>, dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+            if (launch_check("k_bwd_tile")) return -1;
+        }
+        if (d.use_binary) {
+            Scope sc(h, st, "k_send_bwd");
+            hipLaunchKernelGGL(k_send_bwd, dim3((d.T * d.B + MMG_TM - 1) / MMG_TM, (d.H + 255) / 256), dim3(MMG_BLOCK), h->send_bwd_smem, st,
+                               h->dm, h->P, h->tp, (const int*)(row_map ? h->tp.rmap : nullptr), (const int*)(row_map ? h->tp.rcount : nullptr));
+            const int nblk = (d.B * (d.H / 4) + MMG_BLOCK - 1) / MMG_BLOCK;
+            hipLaunchKernelGGL(k_dhx, dim3(nblk + (d.H / 4 + 63) / 64), dim3(MMG_BLOCK), 0, st, h->dm, h->tp, nblk);
+            if (launch_check("k_send_bwd")) return -1;
+        }
+    } else {
         Scope sc(h, st, "k_bwd_conv");
         const bool fast = fast_shape(h);
         const bool merge_dc = fast && h->merge_roles;
@@ -612,7 +643,7 @@ extern "C" int mmg_sender_forward(mmg_handle* h, const float* d_x, const float* 
     {
         Scope sc(h, st, "k_prep(sender)");
         Dims d1 = h->dm; d1.D = 0;
-        hipLaunchKernelGGL(k_prep, dim3(1), dim3(MMG_BLOCK), h->prep_smem, st, d1, h->P, h->tp, (const float*)nullptr,
+        hipLaunchKernelGGL(k_prep, dim3((d1.H + 63) / 64), dim3(MMG_BLOCK), h->prep_smem, st, d1, h->P, h->tp, (const float*)nullptr,
                            (const float*)nullptr);
         if (launch_check("k_prep")) return -1;
     }

@@ -28,6 +28,7 @@ for st in range(10):
     if dbg[base] == 0: break
     parts = []
     for k in range(1, 8):
+        if dbg[base + k] == 0: break
         if dbg[base + k] < dbg[base + k - 1]: break
         parts.append("%s %.2f" % (names[k - 1], (dbg[base + k] - dbg[base + k - 1]) * tick / 1e3))
     print("step %d: " % st + " | ".join(parts))
