@@ -499,7 +499,7 @@ enum { SRC_STATIC = 0, SRC_X = 1, SRC_DESC = 2 };
 // vhid != NULL: the A operand is virtual,  A[row, n] = A[row] * vw2[n] * 1[vhid[row*lda + n] > 0]
 // (the baselines' d hidden = d score * linear2.weight * relu', never materialised)
 struct GemmJob { const float* A; const float* Bm; float* C; const float* vhid; const float* vw2;
-                 int lda, ldb, ldc, rows, N, K, bmod, bsrc, tile_begin, tiles_k, compact, pad; };   // compact: rows are (step, sample) rows
+                 int lda, ldb, ldc, rows, N, K, bmod, bsrc, tile_begin, tiles_k, compact, nsplit; };   // compact: rows are (step, sample) rows; nsplit: row slices per output tile
 // vbeta != NULL: virtual source,  src'[row, c] = vbeta[row] * vw2[c] * 1[src[row*ld + c] > 0]
 // wrow != NULL: row-weighted sum,  dst[c] = sum_row wrow[row] * src[row*ld + c]   (the N = 1 "GEMMs": d score^T . hidden)
 struct ColJob { const float* src; float* dst; const float* scale; const float* vbeta; const float* vw2; const float* wrow;
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                                                      const float* __restrict__ desc, float* __restrict__ part,
                                                      Dims dm, const double* __restrict__ stats, float* __restrict__ losses,
                                                      double* __restrict__ totals, const int* __restrict__ rmap,
-                                                     const int* __restrict__ rcount
+                                                     const int* __restrict__ rcount, float* __restrict__ wpart
 #ifdef MMG_TIMING
                                                      , long long* __restrict__ dbg2
 #endif
@@ -593,7 +593,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         // job lookup: lane l compares the l-th job's first tile, one ballot (no serial scalar loads)
         const int j = __popcll(__ballot(jt->g_begin[lane] <= tile)) - 1;
         const GemmJob& G = jt->g[j];
-        const int lt = tile - G.tile_begin;
+        // many rows, few output tiles (thousands of samples): the rows of a tile are split over nsplit workgroups whose raw
+        // partial tiles k_wreduce adds in a fixed order
+        const int ns = G.nsplit > 1 ? G.nsplit : 1;
+        const int lts = tile - G.tile_begin, sp = lts % ns, lt = lts / ns;
         const int tn = lt / G.tiles_k, tk = lt - tn * G.tiles_k;
         const int n0 = tn * 16, k0 = tk * 32;
         const int i = lane & 15, q = lane >> 4;
@@ -610,7 +613,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const int lb0 = threadIdx.x >> 3, lbc = (threadIdx.x & 7) * 4;
         float4 vw = make_float4(0.f, 0.f, 0.f, 0.f);
         if (virt) vw = load4_guard(G.vw2, 0, n0 + lac, N, true, false);
-        const int nchunks = (rows + CH - 1) / CH;
+        const int nchunks_all = (rows + CH - 1) / CH, cps = (nchunks_all + ns - 1) / ns;
+        const int cbeg = sp * cps, cend = min(nchunks_all, cbeg + cps), nchunks = max(cend - cbeg, 0);
+        const int rows_end = min(rows, cend * CH);               // rows of this slice: [cbeg * CH, rows_end)
         constexpr int DEPTH = 3;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         // Branch-free steady state: every load is unconditional (indices clamped, values masked afterwards), so the
@@ -647,14 +652,14 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                 rb1[u] = ld4(Bbase + (size_t)(c1_ % bmodv) * ldb, k0 + lbc, K);
             };
 #pragma unroll
-            for (int u = 0; u < DEPTH - 1; ++u) fetch(u, u);
+            for (int u = 0; u < DEPTH - 1; ++u) fetch(cbeg + u, u);
             const int nouter = (nchunks + DEPTH - 1) / DEPTH;
             for (int o = 0; o < nouter; ++o) {
 #pragma unroll
                 for (int u = 0; u < DEPTH; ++u) {
-                    const int c = o * DEPTH + u;
+                    const int c = cbeg + o * DEPTH + u;
                     const int buf = (o * DEPTH + u) & 1;
-                    const bool va = (c * CH + la) < rows, v0 = (c * CH + lb0) < rows, v1 = (c * CH + lb0 + 32) < rows;
+                    const bool va = (c * CH + la) < rows_end, v0 = (c * CH + lb0) < rows_end, v1 = (c * CH + lb0 + 32) < rows_end;
                     float4 av = ra[u];
                     if (virt) {
                         av.x = av.x > 0.f ? beta[u] * vw.x : 0.f; av.y = av.y > 0.f ? beta[u] * vw.y : 0.f;
@@ -680,10 +685,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             run(std::true_type{});
         } else {
             // edge tiles (N or K tail inside the tile, unaligned rows): guarded loads, one chunk at a time
-            for (int c = 0; c < nchunks; ++c) {
+            for (int c = cbeg; c < cend; ++c) {
                 const int buf = c & 1;
                 const int rl = c * CH + la;
-                const bool rv = rl < rows;
+                const bool rv = rl < rows_end;
                 const int r = cmp ? (int)s_map[min(rl, rlast)] : rl;
                 float4 av = load4_guard(Abase, (size_t)(rv ? r : 0) * lda, n0 + lac, N, rv, veca);
                 if (virt) {
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                     av.z = av.z > 0.f ? be * vw.z : 0.f; av.w = av.w > 0.f ? be * vw.w : 0.f;
                 }
                 const int r0l = c * CH + lb0, r1l = r0l + 32;
-                const bool v0 = r0l < rows, v1 = r1l < rows;
+                const bool v0 = r0l < rows_end, v1 = r1l < rows_end;
                 const int r0 = cmp ? (int)s_map[min(r0l, rlast)] : r0l, r1 = cmp ? (int)s_map[min(r1l, rlast)] : r1l;
                 const int m0 = bmod ? (r0 % bmod) : r0, m1 = bmod ? (r1 % bmod) : r1;
                 const float4 b0v = load4_guard(Bbase, (size_t)(v0 ? m0 : 0) * ldb, k0 + lbc, K, v0, vecb);
@@ -719,8 +724,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         for (int h2 = 0; h2 < 2; ++h2) {
             const int rr = threadIdx.x >> 4, cc = (threadIdx.x & 15) + 16 * h2;
             const int n = n0 + rr, k = k0 + cc;
-            if (n < N && k < K) {
-                const float v = (s_acc[0][rr][cc] + s_acc[1][rr][cc]) + (s_acc[2][rr][cc] + s_acc[3][rr][cc]);
+            const float v = (s_acc[0][rr][cc] + s_acc[1][rr][cc]) + (s_acc[2][rr][cc] + s_acc[3][rr][cc]);
+            if (ns > 1) wpart[(size_t)tile * 512 + rr * 32 + cc] = v;       // raw partial tile (k_wreduce)
+            else if (n < N && k < K) {
                 G.C[(size_t)n * G.ldc + k] = v;
                 sq = fmaf(v, v, sq);
             }
@@ -830,6 +836,41 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     const float sq = block_sum(v * v, s_red);
     if (threadIdx.x == 0) part[blockIdx.x] = sq;
     MMG_WG_END();
+}
+
+// k_wreduce: output tiles whose rows k_wgrad split over several workgroups -- the first slice's block adds the raw partial
+// tiles in slice order, stores the gradient tile and its sum of squares (clip-norm partial).  grid = gemm tiles.
+__global__ __launch_bounds__(MMG_BLOCK) void k_wreduce(const JobTable* __restrict__ jt, const float* __restrict__ wpart, float* __restrict__ part) {
+    __shared__ float s_red[8];
+    const int nwg = jt->gemm_tiles, xq = nwg >> 3, xr = nwg & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;      // same order as k_wgrad
+    const int lane = threadIdx.x & 63;
+    const int j = __popcll(__ballot(jt->g_begin[lane] <= tile)) - 1;
+    const GemmJob& G = jt->g[j];
+    const int ns = G.nsplit;
+    if (ns <= 1) return;
+    const int lts = tile - G.tile_begin, sp = lts % ns, lt = lts / ns;
+    if (sp != 0) return;
+    const int tn = lt / G.tiles_k, tk = lt - tn * G.tiles_k;
+    const int n0 = tn * 16, k0 = tk * 32;
+    float sq = 0.f;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const int rr = threadIdx.x >> 4, cc = (threadIdx.x & 15) + 16 * h2;
+        float v = 0.f;
+        for (int s0 = 0; s0 < ns; s0 += 8) {
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = wpart[(size_t)(tile + min(s0 + u, ns - 1)) * 512 + rr * 32 + cc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += (s0 + u < ns) ? p[u] : 0.f;
+        }
+        const int n = n0 + rr, k = k0 + cc;
+        if (n < G.N && k < G.K) { G.C[(size_t)n * G.ldc + k] = v; sq = fmaf(v, v, sq); }
+    }
+    sq = block_sum(sq, s_red);
+    if (threadIdx.x == 0) part[tile] = sq;
 }
 
 // ---------------------------------------------------------------------------------------------

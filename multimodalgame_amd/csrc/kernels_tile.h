@@ -936,6 +936,10 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
                 if (m < nb) tp.hstar[(size_t)(b0 + m) * R + r] = v;
             });
         __syncthreads();
+        for (int idx = tid; idx < MMG_TM * D; idx += NT) {                 // transposed copy: 16 samples of a class = one 64-byte line
+            const int m = idx & 15, d = idx >> 4;
+            if (m < nb) tp.dyT[(size_t)d * B + b0 + m] = s_dy[m * L.ldD + d];
+        }
         tgemm_nt_raw(s_hs, L.ldR, P.p[R_Y1_W], R + V, R, R, raw0, wave, nw);
         __syncthreads();
         {
@@ -1173,5 +1177,61 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_dhx(Dims dm, Tape tp, int nblk_dh
         for (int u = 0; u < 16; ++u) if (t0 + u <= ts) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
     reinterpret_cast<float4*>(tp.dhx + (size_t)b * dm.H)[h4] = acc;
+}
+}  // namespace mmg
+
+namespace mmg {
+// ---------------------------------------------------------------------------------------------
+// k_dC_tile: class-side reduction of the y head for many samples / classes (same outputs as k_dC, kernels_bwd.h):
+//   dC[d, r]  = w_y2[r] sum_b dy[b, d] 1[A*[b, r] + Cd[d, r] > 0]      Py2[d, r] = sum_b dy[b, d] relu(A*[b, r] + Cd[d, r])
+// grid (ceil(D / CPB), NSB): a workgroup owns CPB classes x all R units and one slice of the samples; lanes run along r
+// (A* rows coalesced), dy comes from its transposed copy dyT[d, b] (one 64-byte line per 16 samples, written by k_bwd_tile),
+// 32 samples in flight per thread.  NSB > 1: partial sums to part[slice], combined in fixed order by the last-launched
+// pass (blockIdx.y == 0 of a second launch with `combine` set) -- deterministic, no float atomics.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMG_BLOCK) void k_dC_tile(Dims dm, Params P, Tape tp, int nsb, int combine) {
+    const int R = dm.R, B = dm.B, D = dm.D;
+    const int RL = R < MMG_BLOCK ? R : MMG_BLOCK;                 // lanes along r
+    const int CPB = MMG_BLOCK / RL;                                // classes per workgroup
+    const int c = threadIdx.x / RL, rl = threadIdx.x - c * RL;
+    const int d = blockIdx.x * CPB + c;
+    if (c >= CPB || d >= D) return;
+    if (combine) {                                                 // sum the sample slices in order
+        for (int r = rl; r < R; r += RL) {
+            float a = 0.f, p = 0.f;
+            for (int s = 0; s < nsb; ++s) { a += tp.dCpart[((size_t)s * 2 * D + d) * R + r]; p += tp.dCpart[((size_t)s * 2 * D + D + d) * R + r]; }
+            tp.dC[(size_t)d * R + r] = a * P.p[R_Y2_W][r];
+            tp.Py2[(size_t)d * R + r] = p;
+        }
+        return;
+    }
+    const int slice = blockIdx.y, per = (B + nsb - 1) / nsb;
+    const int bb0 = slice * per, bb1 = min(B, bb0 + per);
+    const float* dyt = tp.dyT + (size_t)d * B;
+    for (int r = rl; r < R; r += RL) {
+        const float cv = tp.Cd[(size_t)d * R + r];
+        float dc0 = 0.f, dc1 = 0.f, py0 = 0.f, py1 = 0.f;
+        for (int b0 = bb0; b0 < bb1; b0 += 32) {
+            float yv[32], av[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int b = min(b0 + u, bb1 - 1);
+                yv[u] = dyt[b]; av[u] = tp.Astar[(size_t)b * R + r];
+            }
+#pragma unroll
+            for (int u = 0; u < 32; u += 2) {
+                const float p0 = av[u] + cv, p1 = av[u + 1] + cv;
+                if (b0 + u < bb1 && p0 > 0.f) { dc0 += yv[u]; py0 = fmaf(yv[u], p0, py0); }
+                if (b0 + u + 1 < bb1 && p1 > 0.f) { dc1 += yv[u + 1]; py1 = fmaf(yv[u + 1], p1, py1); }
+            }
+        }
+        if (nsb == 1) {
+            tp.dC[(size_t)d * R + r] = (dc0 + dc1) * P.p[R_Y2_W][r];
+            tp.Py2[(size_t)d * R + r] = py0 + py1;
+        } else {
+            tp.dCpart[((size_t)slice * 2 * D + d) * R + r] = dc0 + dc1;
+            tp.dCpart[((size_t)slice * 2 * D + D + d) * R + r] = py0 + py1;
+        }
+    }
 }
 }  // namespace mmg

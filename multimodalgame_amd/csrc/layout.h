@@ -152,12 +152,15 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(Astar, float, 0, 2, B, R, 1)       /* W_y1h h at t*                          */ \
     X(hstar, float, 0, 2, B, R, 1)       /* h at t*                                */ \
     X(dy, float, 0, 2, B, D, 1)          /* dNLL/d outp                            */ \
+    X(dyT, float, 0, 2, D, B, 1)         /* its transpose (k_dC_tile reads a class's column coalesced) */ \
+    X(dCpart, float, 0, 3, NDCS, 2 * D, R) /* per-sample-slice partials of dC | Py2 (k_dC_tile) */ \
     X(dysum, float, 0, 1, B, 1, 1)                                                 \
     X(dC, float, 0, 2, D, R, 1)          /* dL/d Cd                                */ \
     X(Py2, float, 0, 2, D, R, 1)         /* per-class partials of dL/d w_y2        */ \
     X(dbs, float, 0, 2, T, B, 1)                                                   \
     X(dbr, float, 0, 2, T, B, 1)                                                   \
     X(gnpart, float, 0, 1, 16384 + NPART, 1, 1)  /* squared grad-norm partials (k_wgrad blocks | k_gradnorm) */ \
+    X(wpart, float, 0, 1, NWP, 1, 1)     /* raw partial tiles of weight gradients whose rows are split over workgroups (k_wgrad / k_wreduce) */ \
     X(tables, uint8_t, 1, 1, 98304, 1, 1) /* GEMM / column-sum job descriptors      */
 
 // statistics vector (f64).  Per stream (0 = stop bits, 1 = receiver msgs, 2 = sender msgs) and
@@ -175,6 +178,13 @@ struct Tape {
 #undef X
 };
 
+// row slices per output tile of k_wgrad's (step, sample)-row jobs: with thousands of rows the few dozen output tiles of the
+// small receiver matrices would otherwise be a handful of long-running workgroups
+__host__ __device__ inline int wgrad_nsplit(int TB) { int n = TB / 2048; return TB >= 4096 ? (n > 16 ? 16 : n) : 1; }
+
+// sample slices of the class-side reduction (k_dC_tile): enough workgroups for the chip when there are few class blocks
+__host__ __device__ inline int dc_slices(int B) { return B >= 1024 ? 4 : 1; }
+
 struct TapeLayout {
     int n;
     mmg_tape_entry e[96];
@@ -186,8 +196,9 @@ inline TapeLayout tape_layout(const mmg_config& c) {
     L.n = 0;
     const int64_t B = c.batch, D = c.n_classes, F = c.feat_dim, H = c.h_dim, W = c.w_dim, R = c.rec_hidden,
                   V = c.wv_dim, K = c.bas_hidden, T = c.max_exchange, T1 = T + 1,
-                  NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64;
-    (void)F; (void)V; (void)NPB;
+                  NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B),
+                  NWP = wgrad_nsplit((int)(T * B)) > 1 ? (int64_t)wgrad_nsplit((int)(T * B)) * (param_layout(c).total + 512 * 64) : 4;
+    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \

@@ -128,8 +128,9 @@ static int build_jobs(mmg_handle* h) {
         GemmJob& g = jt.g[ng++];
         g.A = A; g.Bm = Bm; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.rows = rows; g.N = N; g.K = Kk;
         g.bmod = bmod; g.bsrc = bsrc; g.tile_begin = tiles; g.tiles_k = (Kk + 31) / 32;     // 16 x 32 outputs per block
-        g.vhid = nullptr; g.vw2 = nullptr; g.compact = (rows == TB) ? 1 : 0; g.pad = 0;
-        tiles += ((N + 15) / 16) * g.tiles_k;
+        g.vhid = nullptr; g.vw2 = nullptr; g.compact = (rows == TB) ? 1 : 0;
+        g.nsplit = (rows == TB) ? wgrad_nsplit(TB) : 1;
+        tiles += ((N + 15) / 16) * g.tiles_k * g.nsplit;
     };
     // dW = (dbeta * w2 * relu'(hid))^T . input  with the first factor formed on the fly
     auto gemm_virt = [&](const float* dbeta, const float* hid, const float* w2, const float* Bm, int ldb, int bmod,
@@ -557,7 +558,13 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
                 hipLaunchKernelGGL(k_bwd_conv<false>, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
         if (launch_check("k_bwd_conv")) return -1;
     }
-    if (!(fast_shape(h) && h->merge_roles)) {
+    if (tile_path(h)) {
+        Scope sc(h, st, "k_dC");
+        const int RL = d.R < MMG_BLOCK ? d.R : MMG_BLOCK, CPB = MMG_BLOCK / RL, nsb = dc_slices(d.B);
+        hipLaunchKernelGGL(k_dC_tile, dim3((d.D + CPB - 1) / CPB, nsb), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, nsb, 0);
+        if (nsb > 1) hipLaunchKernelGGL(k_dC_tile, dim3((d.D + CPB - 1) / CPB, 1), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, nsb, 1);
+        if (launch_check("k_dC_tile")) return -1;
+    } else if (!(fast_shape(h) && h->merge_roles)) {
         Scope sc(h, st, "k_dC");
         hipLaunchKernelGGL(k_dC, dim3(d.D), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
         if (launch_check("k_dC")) return -1;
@@ -567,12 +574,16 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         hipLaunchKernelGGL(k_wgrad, dim3(h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
                            (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
                            h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
-                           (const int*)(row_map ? h->tp.rcount : nullptr)
+                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart
 #ifdef MMG_TIMING
                            , h->tp.dbg2
 #endif
                            );
         if (launch_check("k_wgrad")) return -1;
+        if (wgrad_nsplit(d.T * d.B) > 1) {
+            hipLaunchKernelGGL(k_wreduce, dim3(h->jt.gemm_tiles), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt, (const float*)h->tp.wpart, h->tp.gnpart);
+            if (launch_check("k_wreduce")) return -1;
+        }
     }
     return 0;
 }
