@@ -237,3 +237,36 @@ def default_flags(argv=None):
         import numpy as np
         np.seterr(all="raise")
     FLAGS.glove_path = os.path.expanduser(FLAGS.glove_path)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reference switches whose code paths are OUTSIDE the accelerated hot path (SURVEY.md §2 "out of scope"): the flags parse
+# (so a reference command line is accepted or rejected for a stated reason), but asking for one of them raises instead of
+# silently computing something else.
+# ---------------------------------------------------------------------------------------------------------------------
+UNSUPPORTED = (
+    # (flag, predicate on its value, reference lines that read it)
+    ("desc_attn", lambda v: bool(v), "model.py:344-409 (description attention)"),
+    ("sender_mix", lambda v: v not in (None, "sum"), "model.py:201-214 (prod / mou mixing of h_x and h_w)"),
+    ("flipout_sen", lambda v: v is not None, "model.py:233-234, 554-568 (random bit flips of the sender message)"),
+    ("flipout_rec", lambda v: v is not None, "model.py:467-470, 554-568 (random bit flips of the receiver message)"),
+    ("ignore_receiver", lambda v: bool(v), "model.py:217-218 (sender ignores the receiver's message)"),
+    ("ignore_code", lambda v: bool(v), "model.py:219-221 (sender ignores its code input)"),
+    ("visual_attn", lambda v: bool(v), "model.py:114-191 (visual attention over layer4_2)"),
+    ("bit_flip", lambda v: bool(v), "model.py:813-824 (message corruption)"),
+)
+
+
+def check_supported(flags=None):
+    """Raise NotImplementedError naming every requested switch the MI355X path does not implement."""
+    fl = FLAGS if flags is None else flags
+    bad = []
+    for name, pred, where in UNSUPPORTED:
+        try:
+            v = getattr(fl, name)
+        except (AttributeError, KeyError, FlagsError):
+            continue
+        if pred(v):
+            bad.append("-%s=%s [reference: %s]" % (name, v, where))
+    if bad:
+        raise NotImplementedError("outside the accelerated exchange path (SURVEY.md §2): " + "; ".join(bad))

@@ -65,6 +65,7 @@ class Game(object):
 
     def __init__(self, sender, receiver, baseline_sen, baseline_rec, flags=None, device=None, seed=0):
         fl = flags if flags is not None else _flags.FLAGS
+        _flags.check_supported(fl)                    # -desc_attn, -sender_mix prod|mou, -flipout_*, -ignore_*, ... raise
         self.modules = dict(sender=sender, receiver=receiver, baseline_sen=baseline_sen, baseline_rec=baseline_rec)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.max_exchange = fl.max_exchange

@@ -1,7 +1,6 @@
 """Host utilities with the reference's names and formats (misc.py): checkpoint dict, FileLogger line
 format, description pipeline (CSV -> tokens -> GloVe -> CBOW), HDF5 batch feed, init, bit-flip mask."""
 import datetime
-import itertools
 import os
 import random
 import string
@@ -13,38 +12,32 @@ import torch
 from . import hdf5io
 
 
-# ------------------------------------------------------------------ checkpoint (misc.py:42-92)
-def recursively_set_device(inp, gpu):
-    if hasattr(inp, "keys"):
-        for k in inp.keys():
-            inp[k] = recursively_set_device(inp[k], gpu)
-    elif isinstance(inp, list):
-        return [recursively_set_device(ii, gpu) for ii in inp]
-    elif isinstance(inp, tuple):
-        return tuple(recursively_set_device(ii, gpu) for ii in inp)
-    elif hasattr(inp, "cpu"):
-        inp = inp.cuda() if gpu >= 0 else inp.cpu()
-    return inp
+# ------------------------------------------------------------------ checkpoint (file contract: misc.py:58-75)
+def _host_copy(tree):
+    """Detached CPU copies of every tensor of a (nested) state_dict; containers are rebuilt, scalars pass through."""
+    from torch.utils._pytree import tree_map
+    return tree_map(lambda leaf: leaf.detach().to("cpu", copy=True) if torch.is_tensor(leaf) else leaf, tree)
 
 
 def torch_save(filename, data, models_dict, optimizers_dict, gpu=-1):
-    """Same file layout as misc.py:58-69: {'data', 'optimizers', 'models'}, tensors on the CPU."""
-    models_to_save = {k: recursively_set_device({kk: vv.detach().clone() for kk, vv in v.state_dict().items()}, gpu=-1)
-                      for k, v in models_dict.items()}
-    optimizers_to_save = {k: recursively_set_device(v.state_dict(), gpu=-1) for k, v in optimizers_dict.items()}
-    torch.save({"data": data, "optimizers": optimizers_to_save, "models": models_to_save}, filename)
+    """One file, three keys -- 'data' (step / best accuracy), 'models', 'optimizers' -- each a name -> state_dict map with
+    CPU tensors: what the reference's checkpoints contain and what its torch_load expects."""
+    payload = {"data": data,
+               "optimizers": {name: _host_copy(opt.state_dict()) for name, opt in optimizers_dict.items()},
+               "models": {name: _host_copy(dict(mod.state_dict())) for name, mod in models_dict.items()}}
+    torch.save(payload, filename)
 
 
 def torch_load(filename, models_dict, optimizers_dict):
-    filename = os.path.expanduser(filename)
-    if not os.path.exists(filename):
-        raise Exception("File does not exist: " + filename)                # misc.py:81-82
-    checkpoint = torch.load(filename, map_location="cpu", weights_only=False)
-    for k, v in models_dict.items():
-        v.load_state_dict(checkpoint["models"][k])
-    for k, v in optimizers_dict.items():
-        v.load_state_dict(checkpoint["optimizers"][k])
-    return checkpoint["data"]
+    """Restore every module and optimizer in place from a checkpoint file and return its 'data' entry."""
+    path = os.path.expanduser(filename)
+    if not os.path.isfile(path):
+        raise Exception("File does not exist: " + path)
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    for kind, targets in (("models", models_dict), ("optimizers", optimizers_dict)):
+        for name, obj in targets.items():
+            obj.load_state_dict(ckpt[kind][name])
+    return ckpt["data"]
 
 
 # ------------------------------------------------------------------ logging (misc.py:95-190)
@@ -102,62 +95,76 @@ def word_tokenize(text):
     return out
 
 
+_PUNCT = frozenset(string.punctuation)
+
+
 def clean_desc(desc):
-    words = word_tokenize(desc.lower())
-    words = list(dict.fromkeys(words))                                       # remove duplicates (stable order)
-    words = [w for w in words if w not in STOPWORDS]
-    words = [w for w in words if w not in string.punctuation]
-    return words
+    """Distinct lower-cased tokens of a description, first-occurrence order, without stop words and punctuation marks
+    (the reference's filter chain, misc.py:220-226; it de-duplicates through set(), i.e. in hash order)."""
+    seen, kept = set(), []
+    for tok in word_tokenize(desc.lower()):
+        if tok in seen:
+            continue
+        seen.add(tok)
+        if tok not in STOPWORDS and tok not in _PUNCT:
+            kept.append(tok)
+    return kept
 
 
 def read_data(input_descr):
-    """misc.py:229-254: label_id,label,free text (text may contain commas)."""
-    descr, word_dict, dict_size, num_descr = {}, {}, 0, 0
-    label_id_to_idx, idx_to_label = {}, {}
+    """Descriptions CSV `label_id,label,free text` -> the five structures the reference returns (misc.py:229-254):
+    descr[row] = {name, desc}, word_dict[word] = {id} (ids from 1 in order of first appearance), the vocabulary size,
+    label_id -> row and row -> label.  The text field keeps its commas: the line is split at the first two only."""
+    descr, vocab, row_of_label, label_of_row = {}, {}, {}, {}
     with open(input_descr, "r") as f:
-        for i, line in enumerate(f):
-            line = line.strip()
-            parts = line.split(",")
-            label_id, label = parts[:2]
-            desc = clean_desc(line[len(label_id) + len(label) + 2:])
-            for w in desc:
-                if w not in word_dict:
-                    dict_size += 1
-                    word_dict[w] = {"id": dict_size}
-            descr[num_descr] = {"name": label, "desc": desc}
-            num_descr += 1
-            label_id_to_idx[int(label_id)] = i
-            idx_to_label[i] = label
-    return descr, word_dict, dict_size, label_id_to_idx, idx_to_label
+        for row, raw in enumerate(f):
+            label_id, label, text = raw.strip().split(",", 2)
+            tokens = clean_desc(text)
+            for tok in tokens:
+                vocab.setdefault(tok, {"id": len(vocab) + 1})
+            descr[row] = {"name": label, "desc": tokens}
+            row_of_label[int(label_id)] = row
+            label_of_row[row] = label
+    return descr, vocab, len(vocab), row_of_label, label_of_row
 
 
 def embed(word_dict, emb):
-    glove = {}
+    """Attach the GloVe row of every vocabulary word (`word v1 ... vV` per line, misc.py:306-320); words the file does not
+    contain get None.  Only the lines of vocabulary words are parsed."""
+    rows = {}
     with open(emb, "r") as f:
         for line in f:
-            word = line.strip().split(" ")
-            if word[0] in word_dict:
-                glove[word[0]] = torch.tensor([float(s) for s in word[1:]])
-    for k in word_dict:
-        word_dict[k]["emb"] = glove.get(k, None)
+            head, _, tail = line.rstrip("\n").partition(" ")
+            if head in word_dict and head not in rows:
+                rows[head] = torch.from_numpy(np.array(tail.split(), dtype=np.float32))
+    for word, entry in word_dict.items():
+        entry["emb"] = rows.get(word)
     return word_dict
 
 
 def cbow(descr, word_dict):
-    """Mean of the GloVe vectors found; missing words are zero rows and do not count (misc.py:324-340)."""
-    emb_size = next(len(v["emb"]) for v in word_dict.values() if v["emb"] is not None)
-    for mammal in descr:
-        num_w = 0
-        desc_set = torch.zeros(len(descr[mammal]["desc"]), emb_size)
-        for i_w, w in enumerate(descr[mammal]["desc"]):
-            if word_dict[w]["emb"] is not None:
-                desc_set[i_w] = word_dict[w]["emb"]
-                num_w += 1
-        desc_cbow = desc_set.sum(0)
-        if num_w > 0:
-            desc_cbow = desc_cbow / num_w
-        descr[mammal]["cbow"] = desc_cbow
-        descr[mammal]["set"] = desc_set
+    """Description vectors: descr[row]['set'] = one GloVe row per token (zeros for words GloVe lacks), descr[row]['cbow'] =
+    their sum divided by the number of FOUND words (misc.py:323-340).  Built from one [vocab + 1, V] table (row 0 = the
+    zero vector of missing words) and an index gather instead of a per-word Python loop."""
+    words = list(word_dict.keys())
+    known = [w for w in words if word_dict[w].get("emb") is not None]
+    if not known:
+        raise ValueError("no description word has an embedding")
+    dim = int(word_dict[known[0]]["emb"].numel())
+    table = torch.zeros(len(words) + 1, dim)
+    slot = {}
+    for k, w in enumerate(words, start=1):
+        slot[w] = k
+        if word_dict[w]["emb"] is not None:
+            table[k] = word_dict[w]["emb"]
+    found = torch.tensor([0.0] + [float(word_dict[w]["emb"] is not None) for w in words])
+    for entry in descr.values():
+        idx = torch.tensor([slot[w] for w in entry["desc"]], dtype=torch.long)
+        rows = table[idx] if idx.numel() else torch.zeros(0, dim)
+        n_found = float(found[idx].sum()) if idx.numel() else 0.0
+        total = rows.sum(0)
+        entry["set"] = rows
+        entry["cbow"] = total / n_found if n_found > 0 else total
     return descr
 
 
@@ -233,17 +240,14 @@ def write_synthetic_dataset(dirname, n_classes=30, per_class=100, feat_dim=512, 
 
 
 # ------------------------------------------------------------------ init + mask (misc.py:349-402)
-def xavier_normal(tensor, gain=1):
-    fan_out, fan_in = tensor.size(0), tensor.size(1)
-    std = gain * np.sqrt(2.0 / (fan_in + fan_out))
-    with torch.no_grad():
-        return tensor.normal_(0, std)
+from .agents import xavier_normal  # noqa: E402,F401  (one implementation: agents.py)
 
 
 def build_mask(region_str, size):
-    regions = [r.split(":") for r in region_str.split(",")]
-    regions = [[int(r[0])] if len(r) == 1 else list(range(int(r[0]), int(r[1]))) for r in regions]
-    index = torch.LongTensor(list(itertools.chain(*regions)))
+    """[size, 1] indicator of the positions named by a region string such as "0:4,7,10:12" (half-open ranges and single
+    positions; -corrupt_region, misc.py:388-402)."""
     mask = torch.zeros(size, 1)
-    mask[index] = 1
+    for piece in region_str.split(","):
+        lo, _, hi = piece.partition(":")
+        mask[int(lo):(int(hi) if hi else int(lo) + 1)] = 1
     return mask

@@ -69,6 +69,7 @@ def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels
 
 
 def run():
+    _flags.check_supported(FLAGS)                     # unsupported reference switches fail before anything is written
     os.makedirs(FLAGS.log_path, exist_ok=True)
     flogger = FileLogger(FLAGS.log_file)
     VisdomLogger(env=FLAGS.env, experiment_name=FLAGS.experiment_name, enabled=FLAGS.visdom)

@@ -86,10 +86,24 @@ def oracle_train_case(name, meta):
 
 SHIFT_INVARIANT = ("y", "outp")
 
+# north_star: "logits/loss within 1e-4 of the reference CPU path".  Forward quantities -- logits, log-probabilities,
+# probabilities, rewards, baseline scores and the six loss scalars -- are compared with an ABSOLUTE tolerance of 1e-4 and no
+# relative slack; only gradients / updated parameters / gradient norms (sums over up to 10^4 products) keep a relative term.
+FORWARD_ATOL = 1e-4
+GRAD_KEYS = (".g.", ".p.", "gradnorm")
 
-def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None, shift_invariant=False):
-    """Compare two packed dicts.  Bit/mask/count entries must match exactly; float entries
-    within atol + rtol*|want|.
+# max abs error per (case label, quantity) seen by compare_packed in this process; tests/conftest.py writes it to
+# tests/out/parity_maxerr.json at the end of a GPU session (a copy is committed under profiles/)
+MAXERR = {}
+
+
+def is_grad_key(k):
+    return any(t in k for t in GRAD_KEYS)
+
+
+def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None, shift_invariant=False, label=None):
+    """Compare two packed dicts.  Bit/mask/count entries must match exactly; forward float entries within
+    min(atol, 1e-4) ABSOLUTE (rtol = 0); gradient / parameter entries within atol + rtol*|want|.
 
     shift_invariant: compare the class logits (``y``, ``outp``) after removing each row's mean.
     dL/d(y2.bias) is identically zero (softmax is shift invariant), so what reaches the optimizer
@@ -122,10 +136,36 @@ def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None, s
                 problems.append("%s differs (exact) in %d places" % (k, int((a != b).sum())))
         else:
             err = np.abs(a.astype(np.float64) - b.astype(np.float64))
-            tol = atol + rtol * np.abs(b.astype(np.float64))
-            if a.size and not np.all(err <= tol):
-                problems.append("%s max err %.3e (tol %.1e)" % (k, float(err.max()), float(tol.flat[err.argmax()])))
+            if is_grad_key(k):
+                tol = atol + rtol * np.abs(b.astype(np.float64))
+            else:
+                tol = np.full(err.shape, min(atol, FORWARD_ATOL))
+            if a.size:
+                if label is not None:
+                    q = k.split(".", 1)[-1] if k.startswith("mb") else k
+                    key = "%s:%s" % (label, q)
+                    MAXERR[key] = max(MAXERR.get(key, 0.0), float(err.max()))
+                if not np.all(err <= tol):
+                    problems.append("%s max err %.3e (tol %.1e)" % (k, float(err.max()), float(tol.flat[err.argmax()])))
     return problems
+
+
+def relu_margin(eng):
+    """Smallest |pre-activation| of a ReLU unit that carries gradient in the engine's last minibatch: the y head's
+    A*[b, r] + Cd[d, r] over classes with |dy| > 0 and the baselines' hidden units that are just above zero.  A
+    gradient entry may disagree with the CPU oracle only through a mask flip of such a unit (d relu/dx is
+    discontinuous), so a test that excuses a gradient mismatch must find this margin below 1e-5."""
+    tp = eng.tape
+    A, Cd, dy = tp["Astar"].double().cpu(), tp["Cd"].double().cpu(), tp["dy"].double().cpu()
+    pre = (A[:, None, :] + Cd[None, :, :]).abs()
+    pre[(dy.abs() == 0)[:, :, None].expand_as(pre)] = float("inf")
+    m = float(pre.min())
+    for name in ("hid_s", "hid_r"):
+        h = tp[name].double().cpu()
+        pos = h[h > 0]
+        if pos.numel():
+            m = min(m, float(pos.min()))
+    return m
 
 
 # ----------------------------------------------------------------------------------------------

@@ -74,3 +74,31 @@ def test_integer_and_bool_roundtrip(n, b):
     F.define_flags()
     F.FLAGS(["x", "-save_after", str(n), "-debug" if b else "-nodebug"])
     assert F.FLAGS.save_after == n and F.FLAGS.debug is b
+
+
+@pytest.mark.parametrize("argv", [["-desc_attn"], ["-sender_mix", "prod"], ["-sender_mix", "mou"], ["-flipout_sen", "0.1"],
+                                  ["-flipout_rec", "0.05"], ["-ignore_receiver"], ["-ignore_code"], ["-visual_attn"],
+                                  ["-bit_flip"]])
+def test_unsupported_reference_switches_raise(argv):
+    """Flags the reference reads at model.py:201-221, 233-234, 344, 467-470, 813 parse but must not be silently ignored."""
+    F.FLAGS(["model.py"] + argv)
+    with pytest.raises(NotImplementedError) as e:
+        F.check_supported()
+    assert argv[0].lstrip("-") in str(e.value)
+
+
+def test_supported_command_line_passes_the_check():
+    F.FLAGS(README_ARGV)
+    F.default_flags(README_ARGV)
+    F.check_supported()
+
+
+def test_game_constructor_checks_flags():
+    """Game.__init__ is the choke point of every entry (exchange(), train_step, the CLI)."""
+    from multimodalgame_amd.game import Game
+
+    class Fl(object):
+        desc_attn, sender_mix, flipout_sen, flipout_rec = False, "sum", None, 0.1
+        ignore_receiver = ignore_code = visual_attn = bit_flip = False
+    with pytest.raises(NotImplementedError):
+        Game(None, None, None, None, flags=Fl())

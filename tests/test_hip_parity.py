@@ -10,7 +10,7 @@ from tests import common
 
 pytestmark = pytest.mark.gpu
 
-ATOL, RTOL = 1e-4, 1e-3     # absolute 1e-4 on O(1) quantities; relative slack for large-magnitude entries
+ATOL, RTOL = 1e-4, 1e-3     # forward quantities: 1e-4 absolute, no relative term (common.compare_packed); gradients: 1e-4 + 1e-3 |v|
 
 
 def _skip_keys(meta):
@@ -33,16 +33,21 @@ def test_train_case_vs_golden_and_oracle(name):
     on g3_continuous mb1, one unit, dy = -1/B), so two correct implementations can legitimately
     disagree there; an entry that matches neither pin is a real error."""
     z, meta = common.load_golden(name)
-    got, _ = common.hip_train_case(name, meta)
+    got, eng = common.hip_train_case(name, meta)
     want = common.oracle_train_case(name, meta)
-    pg = common.compare_packed(got, z, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta), shift_invariant=True)
-    po = common.compare_packed(got, want, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta), shift_invariant=True)
-    is_grad = lambda k: (".g." in k) or (".p." in k) or ("gradnorm" in k)
+    pg = common.compare_packed(got, z, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta), shift_invariant=True, label=name + "/golden")
+    po = common.compare_packed(got, want, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta), shift_invariant=True, label=name + "/oracle")
+    is_grad = common.is_grad_key
     hard = [p for p in pg + po if not is_grad(_key(p))]
     both = sorted(set(map(_key, pg)) & set(map(_key, po)))
-    assert not hard, "forward mismatch:\n" + "\n".join(hard[:25])
+    assert not hard, "forward mismatch (atol 1e-4, rtol 0):\n" + "\n".join(hard[:25])
     assert not both, "gradient entries matching neither golden nor oracle:\n" + "\n".join(
         [p for p in pg + po if _key(p) in both][:25])
+    excused = [p for p in pg + po if is_grad(_key(p))]
+    if excused and all(k.startswith("mb%d." % (meta["n_minibatches"] - 1)) for k in map(_key, excused)):
+        # entries that match only one of the two pins: demonstrably a ReLU unit on the threshold (checked on the last
+        # minibatch, whose tape the engine still holds)
+        assert common.relu_margin(eng) < 1e-5, "excused gradient mismatch without a near-zero ReLU unit:\n" + "\n".join(excused[:10])
 
 
 @pytest.mark.parametrize("name", ["g2_adaptive_c1", "g5_one_active", "g3_tiny_adam"])
