@@ -98,12 +98,13 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     if (MERGE_DC && (int)blockIdx.x >= n_stats + dm.B) {
         float* s_c = t_a; float* s_p = t_a + 256;
         if ((int)blockIdx.x == n_stats + dm.B && threadIdx.x < 64) build_row_map(dm, tp);   // while waiting: rows k_wgrad will reduce over
-        role_wait<8>(tp.sync, 1, (uint32_t)dm.B, (uint32_t)D);
+        role_wait<8>(tp.sync, 1, (uint32_t)dm.B, (uint32_t)dm.D);
         dC_class(dm, P, tp, (int)blockIdx.x - n_stats - dm.B, s_c, s_p);
         return;
     }
     const int b = blockIdx.x - n_stats, tid = threadIdx.x, lane = tid & 63;
     const int B = dm.B, T = dm.T;
+    const int Dr = dm.D;                                // classes of this run (<= D, the compile-time capacity)
     const bool binary = dm.use_binary != 0;
 #ifdef MMG_TIMING
 #define MMG_BSTAMP(slot) do { if (b == 0 && tid == 0) tp.dbg[128 + (slot)] = (long long)wall_clock64(); } while (0)
@@ -137,11 +138,11 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     float y1r[R / K4];                             // y1[:, :R] row k4 fragment (forward product A = y1h . h*)
 #pragma unroll
     for (int i = 0; i < R / K4; ++i) y1r[i] = P.p[R_Y1_W][(size_t)k4 * (R + V) + p4 * (R / K4) + i];
-    const float sm_mine = (tid < D) ? tp.sm[(size_t)b * D + tid] : 0.f;
+    const float sm_mine = (tid < Dr) ? tp.sm[(size_t)b * Dr + tid] : 0.f;
     const float w2_mine = (tid < R) ? P.p[R_Y2_W][tid] : 0.f;
     float cdcol[D];                                // Cd[:, tid] for tid < R
 #pragma unroll
-    for (int d = 0; d < D; ++d) cdcol[d] = (tid < R) ? tp.Cd[(size_t)d * R + tid] : 0.f;
+    for (int d = 0; d < D; ++d) cdcol[d] = (tid < R) ? tp.Cd[(size_t)min(d, Dr - 1) * R + tid] : 0.f;   // (dy is zero beyond Dr)
     // forward tape of this sample -> registers for ALL T steps (no dependence on tstar: every load of the prologue is
     // in flight at once; indices are clamped instead of guarded so the compiler keeps counted waits), LDS stores below
     constexpr int NW_ = TMAX * W / NT, NG_ = TMAX * R / NT, NU_ = TMAX * 4 * R / NT, NH_ = ((TMAX + 1) * R + NT - 1) / NT, NA_ = TMAX * H / NT;
@@ -182,14 +183,14 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     // ---- output step t*, the part that needs no loss coefficient: NLL seed dy, A* = y1[:, :R] h*, dA (and the release of
     // dy / A* to the class roles).  Done here, while the statistics roles are still working, instead of inside the
     // first reverse step.
-    const float dy_mine = (tid < D) ? (sm_mine - (tid == tgt ? 1.f : 0.f)) / (float)dm.Bg : 0.f;
+    const float dy_mine = (tid < Dr) ? (sm_mine - (tid == tgt ? 1.f : 0.f)) / (float)dm.Bg : 0.f;
     __syncthreads();                                    // the forward tape is staged (t_h)
     {
         const int t = tstar;
         if (tid < 64) {
-            if (lane < D) {                             // (MERGE_DC: write-through store, see the signal below)
-                if (MERGE_DC) __hip_atomic_store(&tp.dy[(size_t)b * D + lane], dy_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else tp.dy[(size_t)b * D + lane] = dy_mine;
+            if (lane < Dr) {                            // (MERGE_DC: write-through store, see the signal below)
+                if (MERGE_DC) __hip_atomic_store(&tp.dy[(size_t)b * Dr + lane], dy_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else tp.dy[(size_t)b * Dr + lane] = dy_mine;
             }
             if (lane < 32) s_dy[lane] = dy_mine;
             const float dsum = dpp_wave_sum(dy_mine);
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
         gemm_nt_tile((int)blockIdx.x - dm.B, tp.hx, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H);
         return;
     }
-    static_assert(FastDims<H, W, R, V, D>::ok && D <= 30 && V <= 200, "unsupported fast shape");
+    static_assert(FastDims<H, W, R, V, D>::ok && D <= 32 && V <= 200, "unsupported fast shape");
     __shared__ __attribute__((aligned(16))) float s_a[H];
     __shared__ __attribute__((aligned(16))) float s_c[W];
     __shared__ __attribute__((aligned(16))) float s_z[W];
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = dm.B, T = dm.T;
+    const int Dr = dm.D;                                // classes of this run (<= D, the compile-time capacity)
     const bool binary = dm.use_binary != 0, train = ar.train != 0;
     const bool inject = ar.u_s != nullptr;
     MMG_STAMP(0);
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     const int dy = tid / LY, kpy = tid % LY;
     float cd[4], w2[4];
     {
-        const float4 v = *reinterpret_cast<const float4*>(tp.Cd + (size_t)(dy < D ? dy : 0) * R + kpy * 4);
+        const float4 v = *reinterpret_cast<const float4*>(tp.Cd + (size_t)(dy < Dr ? dy : 0) * R + kpy * 4);
         cd[0] = v.x; cd[1] = v.y; cd[2] = v.z; cd[3] = v.w;
         const float4 u = *reinterpret_cast<const float4*>(P.p[R_Y2_W] + kpy * 4);
         w2[0] = u.x; w2[1] = u.y; w2[2] = u.z; w2[3] = u.w;
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     const int v7 = tid >> 1, h7 = tid & 1;
     float dcol[DH];
 #pragma unroll
-    for (int j = 0; j < DH; ++j) { const int d = h7 * DH + j; dcol[j] = (v7 < V && d < D) ? ar.desc[(size_t)d * V + v7] : 0.f; }
+    for (int j = 0; j < DH; ++j) { const int d = h7 * DH + j; dcol[j] = (v7 < V && d < Dr) ? ar.desc[(size_t)d * V + v7] : 0.f; }
     const float sig_cb = (tid < W) ? fsigmoid(P.p[S_CODE_BIAS][tid]) : 0.f;
     if (train && !inject) {                        // Philox draws of the whole conversation, while the weight loads are in flight
         for (int i = tid; i < T * W; i += NT) {
@@ -617,9 +619,9 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             acc = fmaf(w2[3], fmaxf(a4.w + cd[3], 0.f), acc);
             acc = dpp_group_sum<LY>(acc);
             if (kpy == 0) {
-                const float yv = (dy < D) ? acc + b2 : -3.0e38f;
+                const float yv = (dy < Dr) ? acc + b2 : -3.0e38f;
                 s_y[dy] = yv;
-                if (dy < D) tp.y[row * D + dy] = yv;
+                if (dy < Dr) tp.y[row * Dr + dy] = yv;
             }
         }
         const float m_t = s_misc[0], sbit = s_misc[3];
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 0));
             const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 16));
             const float mxx = fmaxf(m0, m1);                               // classes live in lanes 0..31 only
-            const float e = (lane < D) ? __expf(yv - mxx) : 0.f;
+            const float e = (lane < Dr) ? __expf(yv - mxx) : 0.f;
             const float rs = dpp_group_sum<16>(e);
             const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 0));
             const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 16));
@@ -727,17 +729,17 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     if (tid < 64) {
         const float o = (lane < 32) ? s_yout[lane] : -3.0e38f;
         const float mx = dpp_wave_max(o);
-        const float e = (lane < D) ? __expf(o - mx) : 0.f;
+        const float e = (lane < Dr) ? __expf(o - mx) : 0.f;
         const float lse = mx + flog(dpp_wave_sum(e));
         const int tgt = ar.target ? (int)ar.target[b] : -1;
         const float dt = (tgt >= 0) ? (__shfl(o, tgt, 64) - lse) : 0.f;
         const float ld = o - lse;
-        if (lane < D) {
-            tp.outp[(size_t)b * D + lane] = o;
-            tp.dist[(size_t)b * D + lane] = ld;
-            tp.sm[(size_t)b * D + lane] = __expf(ld);
+        if (lane < Dr) {
+            tp.outp[(size_t)b * Dr + lane] = o;
+            tp.dist[(size_t)b * Dr + lane] = ld;
+            tp.sm[(size_t)b * Dr + lane] = __expf(ld);
         }
-        const float above = dpp_wave_sum((lane < D && tgt >= 0 && ld > dt) ? 1.f : 0.f);
+        const float above = dpp_wave_sum((lane < Dr && tgt >= 0 && ld > dt) ? 1.f : 0.f);
         if (lane == 0) {
             tp.tstar[b] = tstar;
             tp.logs[b] = dt;

@@ -415,7 +415,7 @@ static int launch_baselines_fused(mmg_handle* h, hipStream_t st) {
 static bool fast_shape(const mmg_handle* h) {
     const Dims& d = h->dm;
     if (h->tile_ok && h->tile_force) return false;
-    return h->use_fast && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D == 30 && d.T <= 16;
+    return h->use_fast && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16;   // (D = 30: own instantiation, other D <= 32: capacity 32)
 }
 // every other shape: sample tiles on the matrix cores (kernels_tile.h); the per-sample generic kernels remain for
 // dimensions whose tile does not fit the LDS and for the agent-level entry points
@@ -477,7 +477,8 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
         base_ready = fast && bas && !run_all_steps && h->merge_roles;
         const int base_tiles = base_ready ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
         if (fast)
-            hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
+            if (d.D == 30) hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
+            else hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 32>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
         else
             if (h->conv_threads == 512)
                 hipLaunchKernelGGL(k_conversation<512>, dim3(d.B), dim3(512), h->conv_smem, st, h->dm, h->P, h->tp, ar);
@@ -546,11 +547,14 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         row_map = merge_dc && d.T * d.B <= 2048;         // class role 0 lists the live (step, sample) rows for k_wgrad
         if (fast && with_stats) {
             const int n_stats = (5 * d.T + 2 + 3) / 4;       // statistics roles: one (stream, step) pair per wave
-            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1);
+            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1);
+            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1);
         } else if (merge_dc)
-            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1);
+            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1);
+            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, true>), dim3(d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1);
         else if (fast)      // (a 512-thread variant of this kernel measured slower: 31.8 vs 28.8 us -- it is not issue-bound)
-            hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1);
+            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1);
+            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, false>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1);
         else
             if (d.B > 512)
                 hipLaunchKernelGGL(k_bwd_conv<true>, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);

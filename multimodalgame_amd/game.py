@@ -9,13 +9,22 @@ from .engine import Engine
 class FlatOptimizer(object):
     """Checkpoint-facing stand-in for the reference's four torch.optim objects (model.py:1110-1142):
     the update itself runs inside libmmg (k_gradnorm/k_opt); this class only converts the agent's slice
-    of the flat optimizer state to and from torch.optim's state_dict layout (misc.py:61-62, 89-90)."""
+    of the flat optimizer state to and from torch.optim's state_dict layout (misc.py:61-62, 89-90): state index i is
+    the i-th entry of module.parameters(), so a state_dict saved by torch.optim.RMSprop / Adam built on the reference's
+    modules loads here and vice versa (tests/test_cli_gpu.py::test_optimizer_state_roundtrip_with_torch_optim)."""
 
     def __init__(self, game, agent):
         self.game, self.agent = game, agent
 
     def _params(self):
-        return list(self.game.engine.params[self.agent].items())
+        """(name, view into the flat buffer) in torch.optim's numbering: the order of module.parameters(), i.e. of
+        named_parameters() -- direct nn.Parameters first (Sender: code_bias is index 0), then the sub-modules in
+        registration order -- NOT the engine's flat-buffer order."""
+        views = self.game.engine.params[self.agent]
+        mod = self.game.modules.get(self.agent)
+        if mod is None:
+            return list(views.items())
+        return [(name, views[name]) for name, _ in mod.named_parameters()]
 
     def state_dict(self):
         eng, kind = self.game.engine, self.game.cfg["optim_type"]

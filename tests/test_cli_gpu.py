@@ -76,3 +76,42 @@ def test_binary_only_message_dump(tmp_path):
     np.testing.assert_array_equal(np.round(comm["BinaryProb"]), comm["BinaryVec"])   # eval mode: round(p)  (model.py:229, 462)
     assert comm["ExampleId"][0] == b"d00.jpg" and (preds["Target"][:10 * 1] == 0).all()
     flags.FLAGS.Reset()
+
+
+@pytest.mark.parametrize("kind", ["RMSprop", "Adam"])
+def test_optimizer_state_roundtrip_with_torch_optim(kind):
+    """'optimizer_*' entries of a checkpoint are torch.optim state_dicts numbered like module.parameters() (Sender: code_bias
+    first): a state built by a real torch.optim object on the module loads into the flat engine state by NAME, and what
+    FlatOptimizer saves loads back into torch.optim."""
+    from multimodalgame_amd.agents import Baseline, Receiver, Sender
+    from multimodalgame_amd.game import Game
+
+    class Fl(object):
+        max_exchange, fixed_exchange, s_prob_prod = 3, False, True
+        entropy_s = entropy_sen = entropy_rec = None
+        first_rec, optim_type, learning_rate, top_k_train = 0.0, kind, 1e-3, 2
+    sender = Sender("avgpool_512", 16, 8, 4, 4, True)
+    receiver = Receiver(4, 8, 4, 1, 4, 1, True)
+    game = Game(sender, receiver, Baseline(12, 8, 4, 0), Baseline(12, 0, 4, 4), flags=Fl(), device="cuda:0")
+    eng = game.engine_for(8, 5)
+    names = [n for n, _ in sender.named_parameters()]
+    assert names[0] == "code_bias"
+    # a reference-style optimizer on CPU copies of the sender's parameters, one step with known gradients
+    ref_params = [torch.nn.Parameter(p.detach().cpu().clone()) for _, p in sender.named_parameters()]
+    opt = getattr(torch.optim, kind)(ref_params, lr=1e-3)
+    for i, p in enumerate(ref_params):
+        p.grad = torch.full_like(p, 0.01 * (i + 1))
+    opt.step()
+    fo = game.optimizers_dict()["optimizer_sen"]
+    fo.load_state_dict(opt.state_dict())
+    key = "square_avg" if kind == "RMSprop" else "exp_avg"
+    for i, n in enumerate(names):
+        view = eng.params["sender"][n]
+        off = view.storage_offset()
+        got = eng.opt_state[off:off + view.numel()].view(view.shape).cpu()
+        torch.testing.assert_close(got, opt.state_dict()["state"][i][key])
+    sd = fo.state_dict()
+    opt2 = getattr(torch.optim, kind)([torch.nn.Parameter(p.detach().cpu().clone()) for p in ref_params], lr=1e-3)
+    opt2.load_state_dict(sd)
+    for i in range(len(names)):
+        torch.testing.assert_close(opt2.state_dict()["state"][i][key], opt.state_dict()["state"][i][key])

@@ -138,3 +138,29 @@ def test_ragged_batches_fused_step_vs_oracle(batch):
     hard = [p for p in problems if not common.is_grad_key(p.split(" ")[0])]
     assert not hard, "\n".join(hard[:20])
     assert len(problems) <= 6, "\n".join(problems[:20])
+
+
+@pytest.mark.parametrize("n_classes", [5, 30, 32])
+def test_register_resident_path_class_counts(n_classes):
+    """The register-resident kernels cover every class count up to 32 at the BASELINE agent shape (D = 30 has its own
+    instantiation, the others run the capacity-32 one): fused training step vs the oracle, and the launch names show that
+    neither the tile path nor the per-sample generic kernels ran."""
+    batch = 16
+    meta = _meta(dict(C1, batch_size=batch, top_k_train=min(6, n_classes - 1)), n_classes, batch, 2)
+    got, eng = common.hip_train_case(None, meta, fused=True)
+    want = common.oracle_train_case(None, meta)
+    keep = ("losses", "n_steps", "hits", "logs", "outp", "dist", ".g.", ".p.", "gradnorm")
+    got = {k: v for k, v in got.items() if any(t in k for t in keep)}
+    want = {k: v for k, v in want.items() if any(t in k for t in keep)}
+    problems = common.compare_packed(got, want, atol=1e-4, rtol=1e-3, skip=("y2.bias",), shift_invariant=True, label="fastD%d" % n_classes)
+    hard = [p for p in problems if not common.is_grad_key(p.split(" ")[0])]
+    assert not hard, "\n".join(hard[:20])
+    assert len(problems) <= 6, "\n".join(problems[:20])
+    x, target, desc, _ = common.case_inputs(meta, 0)
+    dev = eng.device
+    eng.set_profiling(True)
+    eng.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(target).to(dev), torch.from_numpy(desc).to(dev), seed=1)
+    torch.cuda.synchronize()
+    names = [n for n, _ in eng.kernel_times()]
+    eng.set_profiling(False)
+    assert "k_conversation" in names and "k_conv_tile" not in names and "k_bwd_tile" not in names, names

@@ -88,8 +88,9 @@ def test_binary_vectors_match_reference(tmp_path):
         f.write("Target", z["target"].astype(np.int32))
         f.write("Location", z["example_ids"].astype("S50"))
     n_comm, n_pred = bv.extract_binary(F, dev, B, 0, False, sender, receiver, torch.from_numpy(desc).cuda(), int, torch.device("cuda:0"))
+    comm_t, preds_t = bv.record_types(fl.sender_out_dim, D)
     with hdf5io.File(F.binary_output, "r") as f:
-        comm, preds = f.read("Communication"), f.read("Predictions")
+        comm, preds = f.read_struct("Communication", comm_t), f.read_struct("Predictions", preds_t)
     assert len(comm) == len(z["comm_index"]) and len(preds) == len(z["pred_index"])
     np.testing.assert_array_equal(comm["Index"], z["comm_index"])
     np.testing.assert_array_equal(comm["AgentId"], z["comm_agent"])
