@@ -902,7 +902,12 @@ struct OptArgs {
 
 __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ jt, OptArgs oa, float* __restrict__ params,
                                                    const float* __restrict__ grads, float* __restrict__ state,
-                                                   const float* __restrict__ part, const uint32_t* __restrict__ counter) {
+                                                   const float* __restrict__ part, const uint32_t* __restrict__ counter,
+                                                   const uint32_t* __restrict__ sync) {
+    // An in-launch dependency wait of this minibatch timed out (device_utils.h: role_wait sets sync[MMG_SYNC_ERR]): the
+    // gradients may be built from stale data -- leave parameters and optimizer state untouched.  The word is sticky;
+    // mmg_train_step reports it on the next call.
+    if (__hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     // oa.from_wgrad: the squared-norm partials are the ones k_wgrad left per block (single GPU);
     // otherwise the MMG_GN_BLOCKS partials of k_gradnorm over the all-reduced gradient (data parallel).
     __shared__ float s_coef[4];

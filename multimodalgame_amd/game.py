@@ -28,7 +28,7 @@ class FlatOptimizer(object):
 
     def state_dict(self):
         eng, kind = self.game.engine, self.game.cfg["optim_type"]
-        step = int(eng.tape["counter"][1:3].max().item())
+        step = self.game.counters()[1]
         n = eng.n_params
         state = {}
         for i, (name, view) in enumerate(self._params()):
@@ -65,7 +65,8 @@ class FlatOptimizer(object):
                 eng.opt_state[off:off + view.numel()].copy_(st["exp_avg"].reshape(-1).to(eng.device))
                 eng.opt_state[n + off:n + off + view.numel()].copy_(st["exp_avg_sq"].reshape(-1).to(eng.device))
         if step:
-            eng.tape["counter"][1:3] = step
+            for e in self.game.engines.values():
+                e.tape["counter"][1:3] = step
 
 
 class Game(object):
@@ -181,8 +182,25 @@ class Game(object):
         B = data.size(0)
         eng = self.engine_for(B, desc.size(0))
         u = uniforms or (None, None, None)
+        # the Philox minibatch counter and the optimizer step (Adam bias correction) live in each engine's workspace: hand
+        # them over when the batch size / class count -- hence the engine -- changes between steps
+        last = getattr(self, "_train_engine", None)
+        if last is not None and last is not eng:
+            eng.tape["counter"].copy_(last.tape["counter"])
+        self._train_engine = eng
         eng.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed)
         return eng
+
+    def counters(self):
+        """[minibatch counter (Philox stream), optimizer step] of the engine that trained last (checkpointed by model.py)."""
+        eng = getattr(self, "_train_engine", None) or self.engine
+        c = eng.tape["counter"].cpu().tolist()
+        return [int(c[0]), int(max(c[1], c[2]))]
+
+    def set_counters(self, minibatch, step):
+        for eng in self.engines.values():
+            eng.tape["counter"][0] = int(minibatch)
+            eng.tape["counter"][1:3] = int(step)
 
     def losses(self, batch, n_classes):
         return self.engine_for(batch, n_classes).losses()

@@ -110,6 +110,8 @@ def run():
         data = torch_load(FLAGS.checkpoint, models_dict, optimizers_dict)
         flogger.Log("Loaded at step: {} and best dev acc: {}".format(data["step"], data["best_dev_acc"]))
         step, best_dev_acc = data["step"], data["best_dev_acc"]
+        if "mmg_minibatch_counter" in data:              # resume the sampling stream where the checkpoint left it
+            game.set_counters(data["mmg_minibatch_counter"], game.counters()[1])
 
     def do_eval():
         return eval_dev(FLAGS.dev_file, FLAGS.batch_size_dev, epoch, FLAGS.shuffle_dev, FLAGS.top_k_dev, game, desc_dev,
@@ -137,6 +139,7 @@ def run():
         return
 
     hits_ring = torch.zeros(max(FLAGS.log_interval, 1), device=device)
+    steps_run = 0                                    # minibatches of THIS process (a resumed run starts with an empty ring)
     while epoch < FLAGS.max_epoch:
         flogger.Log("Starting epoch: {}".format(epoch))
         if FLAGS.images != "mammal":
@@ -144,10 +147,11 @@ def run():
         for i_batch, batch in enumerate(load_hdf5(FLAGS.train_file, FLAGS.batch_size, epoch, FLAGS.shuffle_train,
                                                   map_labels=map_labels_train, feats=(FLAGS.img_feat,), device=device)):
             eng = game.train_step(batch[FLAGS.img_feat], batch["target"], desc_train)     # model.py:1240-1339
-            hits_ring[step % hits_ring.numel()] = eng.tape["losses"][7]
+            hits_ring[steps_run % hits_ring.numel()] = eng.tape["losses"][7]
+            steps_run += 1
             if step % FLAGS.log_interval == 0:                             # model.py:1342-1377
                 L = eng.losses()
-                n_seen = min(step + 1, hits_ring.numel())
+                n_seen = min(steps_run, hits_ring.numel())               # only the slots filled since this process started
                 avg_batch_acc = float(hits_ring[:n_seen].sum()) / float(FLAGS.batch_size) / n_seen
                 pre = "Epoch: {} Step: {} Batch: {} ".format(epoch, step, i_batch)
                 flogger.Log(pre + "Training Accuracy: {}".format(avg_batch_acc))
@@ -171,10 +175,10 @@ def run():
                 if step >= FLAGS.save_after and dev_acc > best_dev_acc:
                     best_dev_acc = dev_acc
                     flogger.Log("Checkpointing with best Development Accuracy: {}".format(best_dev_acc))
-                    torch_save(FLAGS.checkpoint + "_best", dict(step=step, best_dev_acc=best_dev_acc), models_dict, optimizers_dict)
+                    torch_save(FLAGS.checkpoint + "_best", dict(step=step, best_dev_acc=best_dev_acc, mmg_minibatch_counter=game.counters()[0]), models_dict, optimizers_dict)
             if step >= FLAGS.save_after and step % FLAGS.save_interval == 0:   # model.py:1579-1584
                 flogger.Log("Checkpointing.")
-                torch_save(FLAGS.checkpoint, dict(step=step, best_dev_acc=best_dev_acc), models_dict, optimizers_dict)
+                torch_save(FLAGS.checkpoint, dict(step=step, best_dev_acc=best_dev_acc, mmg_minibatch_counter=game.counters()[0]), models_dict, optimizers_dict)
             step += 1
             if FLAGS.max_steps and step >= FLAGS.max_steps:
                 flogger.Log("Finished training.")
