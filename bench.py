@@ -32,13 +32,14 @@ C2 = dict(n_classes=30, feat_dim=512, h_dim=256, w_dim=32, rec_hidden=64, wv_dim
           entropy_sen=0.01, entropy_rec=0.01, first_rec=0.0, optim_type="RMSprop", learning_rate=1e-4, top_k=6)
 PER_GPU_BATCH = 64
 # --workload: the other BASELINE.json configs (parity-test cases; the default and the reported metric is configs[1])
+STRONG_GLOBAL_BATCH = {"c3": 512, "c5": 2048}    # BASELINE.json configs[2] / configs[4]
 WORKLOADS = {
     "c2": (C2, 64, "configs[1]: Adaptive 30-class, batch 64 per GPU, max_exchange 10, rec_w_dim 32, img_h_dim 256, rec_hidden 64, "
                    "RMSprop; one bench step = one training minibatch"),
     "c3": (dict(C2, fixed_exchange=True), 64, "configs[2]: Fixed-exchange 30-class, global batch 512 = 64 per GPU on 8 GPUs, max_exchange 10"),
-    "c4": (dict(C2, w_dim=256, h_dim=1024), 64, "configs[3]: Adaptive 30-class, batch 64, rec_w_dim 256 / img_h_dim 1024 (generic kernels)"),
+    "c4": (dict(C2, w_dim=256, h_dim=1024), 64, "configs[3]: Adaptive 30-class, batch 64, rec_w_dim 256 / img_h_dim 1024 (sample-tile MFMA kernels, per-step sender launches)"),
     "c5": (dict(C2, use_binary=False, fixed_exchange=True, n_classes=1000), 256,
-           "configs[4]: 1000 classes, continuous messages, global batch 2048 = 256 per GPU on 8 GPUs (generic kernels)"),
+           "configs[4]: 1000 classes, continuous messages, global batch 2048 = 256 per GPU on 8 GPUs (sample-tile MFMA kernels)"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
@@ -54,20 +55,32 @@ def synthetic_dataset(n_samples, n_classes, feat_dim, wv_dim, seed=1234):
 
 
 def algorithmic_work(kernel, d, B, t_steps):
-    """Algorithmic (minimal) work of one launch of `kernel`: (bound, amount) with amount in bytes for
-    HBM-bound kernels and flops for MFMA-bound ones.  B samples, t_steps = exchange steps the launch
-    covers per sample on average.  Formulas: DESIGN.md §Kernels."""
+    """Algorithmic (minimal) work of ALL launches of `kernel` in one minibatch: (bound, amount) with amount in bytes for
+    HBM-bound kernels and flops for MFMA-bound ones.  B samples, t_steps = exchange steps a sample takes on average
+    (B * t_steps live (step, sample) rows).  Formulas: DESIGN.md §3."""
     F, H, W, R, V, K, D, T = (d[k] for k in ("feat_dim", "h_dim", "w_dim", "rec_hidden", "wv_dim", "bas_hidden",
                                              "n_classes", "max_exchange"))
     rows = B * t_steps
     p_sender = H * W + W * H + 2 * H + 2 * W
     p_recv = 3 * R * (W + R) + 6 * R + R * R + R + R * V + W * R + W + R * R + 2 * R + 2 + D * R + D * V
+    mac_recv = 3 * R * W + 3 * R * R + 2 * R * R + R + D * V + R * V + W * R      # products of one receiver step of one sample
     if kernel == "k_conversation":
         tape = rows * 4 * (H + 4 * W + 5 * R + R + D + V + 12)          # floats written per (step, sample)
         return "hbm", 4 * (p_sender + p_recv) + tape + 4 * B * H
     if kernel == "k_bwd_conv":
         tape = rows * 4 * (2 * H + 6 * W + 13 * R + 2 * K + D + V + 16)  # read fwd tape + write delta tape
         return "hbm", 4 * (p_sender + p_recv) + tape
+    if kernel == "k_conv_tile":               # sample-tile recurrence on the matrix cores (kernels_tile.h)
+        sender = 2 * H * W if H * W < 65536 else 0                      # large sender MLPs run in k_send_s1 / k_send_s2
+        return "mfma", 2 * rows * (mac_recv + sender)
+    if kernel == "k_send_s1":
+        return "mfma", 2 * rows * H * W
+    if kernel == "k_send_s2":
+        return "mfma", 2 * rows * W * H
+    if kernel == "k_bwd_tile":                # transposed receiver products of the reverse pass
+        return "mfma", 2 * rows * (W * R + 2 * R * R + 3 * R * R) + 2 * B * R * R
+    if kernel == "k_send_bwd":
+        return "mfma", 2 * rows * W * H
     if kernel == "k_wgrad":                   # reduces over the live (step, sample) rows only
         TB = rows
         fl = 2 * TB * (3 * R * W + 3 * R * R + R * R + R * V + W * R + R + H * W + W * H + K * (W + R) + K + K * (H + W) + K)
@@ -78,132 +91,163 @@ def algorithmic_work(kernel, d, B, t_steps):
     if kernel.startswith("k_prep"):           # h_x GEMM + Cd
         return "mfma", 2 * B * H * F + 2 * D * R * V
     if kernel == "k_opt":                     # read w, g, state; write w, state
-        p_total = ((H * F + H) + (H * W + H) + W + (W * H + W)                                   # sender        148 032
-                   + 3 * R * (W + R) + 6 * R + (R * R + R) + R * V + (W * R + W) + (R * (R + V) + R) + 2 * (R + 1)   # receiver 42 146
-                   + (K * (W + R) + K + K + 1) + (K * (H + W) + K + K + 1))                        # baselines     194 002
+        p_total = ((H * F + H) + (H * W + H) + W + (W * H + W)
+                   + 3 * R * (W + R) + 6 * R + (R * R + R) + R * V + (W * R + W) + (R * (R + V) + R) + 2 * (R + 1)
+                   + (K * (W + R) + K + K + 1) + (K * (H + W) + K + K + 1))
         return "hbm", 4 * 5 * p_total
     if kernel == "k_stats":
         return "hbm", 5 * T * B * 16
-    if kernel.startswith("k_gemm_nt"):
-        return "mfma", 2 * B * H * F if "h_x)" in kernel and "bas" not in kernel else 2 * B * K * H
+    if kernel == "k_dC":
+        return "hbm", 4 * (B * D + B * R + 2 * D * R)
     return "hbm", 0
 
 
-def run_gpu(args, rank, world, local_rank):
-    from multimodalgame_amd.engine import Engine
-    from multimodalgame_amd.dist import DataParallel
-    import torch.distributed as dist
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (ranks may share a GPU in the gloo smoke test)
-    torch.cuda.set_device(dev)
-    CFG, B, _ = WORKLOADS[args.workload]
-    Bg = B * world
-    eng = Engine(device=dev, batch=B, global_batch=Bg, batch_offset=rank * B, **CFG)
-    # random-init agents (reference init: Xavier-normal weights, zero biases, N(0,1) code_bias;
-    # baselines torch-default uniform) from a fixed seed -- identical on every rank
-    from multimodalgame_amd.agents import init_state_dicts
-    eng.load_state_dicts(init_state_dicts(eng, seed=0))
-    n_steps_total = args.steps + args.warmup
-    feats, target, desc = synthetic_dataset(max(100 * CFG["n_classes"], 4 * Bg), CFG["n_classes"], CFG["feat_dim"], CFG["wv_dim"])
-    # minibatches of the epoch loop, resident in HBM before the timed region (misc.py:257-302 order:
-    # seeded shuffle, sorted indices inside a batch, drop-last)
+MIN_TIMED_SECONDS = 0.25       # the timed region is repeated until it lasts at least this long
+
+
+def build_batches(CFG, Bg, B, rank, n, dev):
+    """Minibatches of the epoch loop resident in HBM (misc.py:257-302 order: seeded shuffle, sorted indices inside a batch)."""
     import random
+    feats, target, desc = synthetic_dataset(max(100 * CFG["n_classes"], 4 * Bg), CFG["n_classes"], CFG["feat_dim"], CFG["wv_dim"])
     order = list(range(feats.shape[0]))
     random.seed(11)
     random.shuffle(order)
     nb = feats.shape[0] // Bg
     xs, ts = [], []
-    for i in range(n_steps_total):
+    for i in range(n):
         idx = sorted(order[(i % nb) * Bg:(i % nb + 1) * Bg])[rank * B:(rank + 1) * B]
         xs.append(feats[idx]); ts.append(target[idx])
-    xs = torch.from_numpy(np.stack(xs)).to(dev)
-    ts = torch.from_numpy(np.stack(ts)).to(dev)
-    desc_d = torch.from_numpy(desc).to(dev)
+    return torch.from_numpy(np.stack(xs)).to(dev), torch.from_numpy(np.stack(ts)).to(dev), torch.from_numpy(desc).to(dev)
+
+
+def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=False, want_roofline=True):
+    """Times `steps` training minibatches of one workload (repeated until MIN_TIMED_SECONDS); returns a dict."""
+    from multimodalgame_amd.engine import Engine
+    from multimodalgame_amd.dist import DataParallel
+    from multimodalgame_amd.agents import init_state_dicts
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (ranks may share a GPU in the gloo smoke test)
+    torch.cuda.set_device(dev)
+    CFG, B_weak, label = WORKLOADS[workload]
+    if strong:
+        Bg = STRONG_GLOBAL_BATCH[workload]
+        assert Bg % world == 0, "global batch %d does not divide over %d ranks" % (Bg, world)
+        B = Bg // world
+    else:
+        B, Bg = B_weak, B_weak * world
+    eng = Engine(device=dev, batch=B, global_batch=Bg, batch_offset=rank * B, **CFG)
+    # random-init agents (reference init: Xavier-normal weights, zero biases, N(0,1) code_bias; baselines torch-default
+    # uniform) from a fixed seed -- identical on every rank
+    eng.load_state_dicts(init_state_dicts(eng, seed=0))
+    n_cycle = min(steps + warmup, 64)
+    xs, ts, desc_d = build_batches(CFG, Bg, B, rank, n_cycle, dev)
     dp = DataParallel(eng)
 
     def one(i):
+        k = i % n_cycle
         if world > 1:
-            dp.train_step(xs[i], ts[i], desc_d, seed=args.seed)
+            dp.train_step(xs[k], ts[k], desc_d, seed=seed)
         else:
-            eng.train_step(xs[i], ts[i], desc_d, seed=args.seed)
+            eng.train_step(xs[k], ts[k], desc_d, seed=seed)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         one(i)
     sync()
     totals_before = eng.tape["totals"].cpu().numpy().copy()   # device-side running sums (semantic exchange steps, ..., sample-steps)
-    steps_before = float(totals_before[0])
+    # EXACTLY `steps` minibatches per pass; passes are repeated (all inside one timed region, same count on every rank)
+    # until the region lasts MIN_TIMED_SECONDS: a 20-step run of a 75 us minibatch is 1.5 ms, too short for any sampler
+    passes, done, elapsed = 1, 0, 0.0
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps_total):
-        one(i)
-    sync()
-    elapsed = time.perf_counter() - t0
+    while True:
+        for i in range(steps):
+            one(warmup + done + i)
+        done += steps
+        sync()
+        elapsed = time.perf_counter() - t0
+        more = torch.tensor([1.0 if elapsed < MIN_TIMED_SECONDS else 0.0], device=dev)
+        if world > 1:
+            dist.all_reduce(more, op=dist.ReduceOp.MAX)
+        if more.item() == 0.0 or passes >= 4096:
+            break
+        passes += 1
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     totals_after = eng.tape["totals"].cpu().numpy()
-    ex_steps = float(totals_after[0]) - steps_before
-    run_gpu.sample_steps = float(totals_after[3] - totals_before[3])   # sum_t n_active,t over the GLOBAL minibatches
-    eng.check_sync()                                      # no in-launch dependency wait may have timed out
-
-    # per-kernel launch durations of the same workload, HIP events on the launch stream (rank 0)
-    roof = None
+    ex_steps = float(totals_after[0] - totals_before[0])
+    sample_steps = float(totals_after[3] - totals_before[3])        # sum_t n_active,t over the GLOBAL minibatches
+    eng.check_sync()                                                # no in-launch dependency wait may have timed out
+    res = dict(workload=workload, label=label, B=B, Bg=Bg, elapsed=elapsed, minibatches=done, ex_steps=ex_steps,
+               sample_steps=sample_steps, cfg=CFG, roofline=None)
+    if not want_roofline:
+        return res
+    # per-kernel durations of the same workload, HIP events on the launch stream (rank 0); per-step launches of one kernel
+    # are summed per minibatch
     kern_ms = {}
-    reps = min(20, args.steps)
+    reps = min(20, steps)
     for i in range(reps):                    # every rank runs these steps (collectives!); only rank 0 records timings
         if rank == 0:
             eng.set_profiling(True)
-        if world > 1:
-            dp.train_step(xs[args.warmup + i], ts[args.warmup + i], desc_d, seed=args.seed)
-        else:
-            eng.train_step(xs[args.warmup + i], ts[args.warmup + i], desc_d, seed=args.seed)
+        one(warmup + i)
         torch.cuda.synchronize(dev)
         if rank == 0:
-            for name, ms in eng.kernel_times():
+            per = {}
+            for name, ms in eng.kernel_times(max_kernels=512):
+                per[name] = per.get(name, 0.0) + ms
+            for name, ms in per.items():
                 kern_ms.setdefault(name, []).append(ms)
     if rank == 0:
         eng.set_profiling(False)
         avg = {k: float(np.mean(v)) for k, v in kern_ms.items()}
         dom = max(avg, key=avg.get)
-        # average steps a sample takes (early exit): take it from the tape of the last minibatch
-        tstar = eng.tape["tstar"].float().mean().item() + 1.0
-        bound, amount = algorithmic_work(dom, CFG, B, tstar)     # tstar = live steps per sample (B * tstar live rows)
+        tstar = eng.tape["tstar"].float().mean().item() + 1.0      # live steps per sample (B * tstar live rows)
+        bound, amount = algorithmic_work(dom, CFG, B, tstar)
         secs = avg[dom] * 1e-3
         if bound == "hbm":
             achieved, peak, unit = amount / secs / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             achieved, peak, unit = amount / secs / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-        # HBM traffic of that kernel from the committed PMC summary (counters need their own rocprofv3 passes and
-        # cannot be collected inside this run): profiles/*_pmc_hbm_traffic.json, per-dispatch FETCH_SIZE/WRITE_SIZE
-        traffic = None
+        # HBM traffic of that kernel from the committed PMC summary of THIS workload (counters need their own rocprofv3
+        # passes and cannot be collected inside this run): per-dispatch FETCH_SIZE / WRITE_SIZE
+        traffic, traffic_source = None, None
         try:
             import glob
-            pmc = json.load(open(sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_hbm_traffic.json")))[-1]))["kernels"]
-            key = {"k_conversation": "k_conversation_fast2", "k_bwd_conv": "k_bwd_conv_fast", "k_baselines": "k_baselines2"}.get(dom, dom)
-            traffic = pmc[key]["traffic_bytes_corrected"] if key in pmc else None
+            files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_config%s_pmc_hbm_traffic.json" % {"c2": "2", "c3": "3", "c4": "4", "c5": "5"}[workload])))
+            if files:
+                pmc = json.load(open(files[-1]))["kernels"]
+                key = {"c2:k_conversation": "k_conversation_fast2", "c3:k_conversation": "k_conversation_fast2",
+                       "c2:k_bwd_conv": "k_bwd_conv_fast", "c3:k_bwd_conv": "k_bwd_conv_fast",
+                       "c2:k_baselines": "k_baselines3"}.get("%s:%s" % (workload, dom), dom)
+                if key in pmc:
+                    traffic = pmc[key]["traffic_bytes_corrected"]
+                    traffic_source = "%s (per dispatch, committed file; not measured in this run)" % os.path.relpath(files[-1], REPO)
         except Exception:
             traffic = None
-        per_kernel = {}                          # the same figure for every launch of the minibatch (HIP-event durations)
+        per_kernel = {}
         for k, ms in avg.items():
             bk, amt = algorithmic_work(k, CFG, B, tstar)
             if amt:
                 a_k = amt / (ms * 1e-3) / (1e9 if bk == "hbm" else 1e12)
                 per_kernel[k] = dict(bound=bk, achieved=round(a_k, 3), unit="GB/s" if bk == "hbm" else "TFLOP/s",
                                      frac=round(a_k / (HBM_PEAK_GBS if bk == "hbm" else MFMA_F32_PEAK_TFLOPS), 5))
-        roof = dict(bound=bound, kernel=dom, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                    traffic=traffic, launch_us=avg[dom] * 1e3,
-                    kernels_us={k: round(v * 1e3, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
-                    per_kernel=per_kernel)
-    return elapsed, ex_steps, roof
+        res["roofline"] = dict(bound=bound, kernel=dom, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                               traffic=traffic, traffic_source=traffic_source, launch_us=avg[dom] * 1e3,
+                               note="launch_us / kernels_us: HIP-event time of ALL launches of the kernel in one minibatch",
+                               kernels_us={k: round(v * 1e3, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
+                               per_kernel=per_kernel)
+    del eng
+    return res
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The CPU oracle (literal restatement of the reference, oracle/cpu_ref.py) timed on this host:
-    same config, same synthetic data, RMSprop, data loading excluded."""
+def cpu_baseline(seconds_budget=24.0):
+    """The CPU oracle (literal restatement of the reference, oracle/cpu_ref.py) timed on this host: same config, same
+    synthetic data, RMSprop, data loading excluded.  Thread counts {1, 4, 8, 16, all} are tried and the best is reported."""
     from oracle import cpu_ref
     fl = cpu_ref.Flags(use_binary=True, fixed_exchange=False, max_exchange=10, batch_size=64, learning_rate=1e-4,
                        entropy_s=0.08, entropy_sen=0.01, entropy_rec=0.01, img_feat_dim=512, img_h_dim=256,
@@ -211,10 +255,12 @@ def cpu_baseline(seconds_budget=20.0):
                        top_k_train=6)
     feats, target, desc = synthetic_dataset(3000, 30, 512, 100)
     desc_t = torch.from_numpy(desc)
+    ncpu = os.cpu_count() or 1
+    all_threads = torch.get_num_threads()
+    counts = sorted(set([c for c in (1, 4, 8, 16) if c <= ncpu] + [all_threads]))
     out = {}
-    for label, threads in (("all", None), ("one", 1)):
-        if threads:
-            torch.set_num_threads(threads)
+    for threads in counts:
+        torch.set_num_threads(threads)
         torch.manual_seed(0)
         np.random.seed(0)
         models = cpu_ref.build_agents(fl)
@@ -228,15 +274,15 @@ def cpu_baseline(seconds_budget=20.0):
             dt = time.perf_counter() - t0
             if i >= 3:
                 steps += res["n_steps"]; n_mb += 1; t_used += dt
-                if t_used > seconds_budget / 2:
+                if t_used > seconds_budget / len(counts):
                     break
-        out[label] = dict(steps_per_s=steps / t_used, minibatches=n_mb, seconds=t_used, threads=torch.get_num_threads())
+        out[threads] = dict(steps_per_s=steps / t_used, minibatches=n_mb, seconds=t_used, threads=threads)
+    torch.set_num_threads(all_threads)
     best = max(out.values(), key=lambda v: v["steps_per_s"])
     return dict(value=best["steps_per_s"], unit="exchange-steps/s", cores=best["threads"], kind="port",
-                sample="%d minibatches of config 1 (B=64) in %.1f s on %d thread(s); single-thread: %.1f steps/s; "
-                       "all-thread (%d): %.1f steps/s; host has %d logical CPUs" % (
-                           best["minibatches"], best["seconds"], best["threads"], out["one"]["steps_per_s"],
-                           out["all"]["threads"], out["all"]["steps_per_s"], os.cpu_count()))
+                sample="%d minibatches of config 1 (B=64) in %.1f s on %d thread(s); sweep %s exchange-steps/s; host has %d logical CPUs" % (
+                    best["minibatches"], best["seconds"], best["threads"],
+                    ", ".join("%d thr: %.1f" % (k, v["steps_per_s"]) for k, v in sorted(out.items())), ncpu))
 
 
 def main():
@@ -246,9 +292,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short c3 / c4 / c5 runs of the default invocation")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 = BASELINE.json's metric config (default); c3/c4/c5 = the other listed configs, for reference")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="strong (c3 / c5 only): the GLOBAL minibatch is fixed (512 / 2048 samples) and sharded over the ranks; "
+                         "value = global-batch exchange steps per second (SURVEY.md 8d)")
     args = ap.parse_args()
+    if args.scaling == "strong" and args.workload not in STRONG_GLOBAL_BATCH:
+        ap.error("--scaling strong needs --workload c3 or c5 (the configs BASELINE.json defines with a global batch)")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -257,24 +309,41 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm; MMG_BENCH_BACKEND=gloo only exists to smoke-test this code path on a 1-GPU box
         dist.init_process_group(os.environ.get("MMG_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    elapsed, ex_steps, roof = run_gpu(args, rank, world, local_rank)
+    strong = args.scaling == "strong"
+    r = run_workload(args.workload, args.steps, args.warmup, args.seed, rank, world, local_rank, strong=strong)
     if rank == 0:
+        per_mb = r["elapsed"] / r["minibatches"]
+        unit_batch = r["Bg"] if strong else WORKLOADS[args.workload][1]
+        # weak: one unit = an exchange step of one per-GPU-sized batch, a global minibatch of B*N samples advances N of them;
+        # strong: one unit = an exchange step of the fixed global batch
+        value = (1.0 if strong else world) * r["ex_steps"] / r["elapsed"]
         line = {
             "metric": ("exchange-steps/sec (whole node), 30-class Adaptive max_exchange=10 bs=64" if args.workload == "c2" else
                        "exchange-steps/sec (whole node) of reference workload %s -- NOT BASELINE.json's metric" % args.workload),
-            "value": world * ex_steps / elapsed, "unit": "exchange-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload][2],
-                       "global_batch": WORKLOADS[args.workload][1] * world, "parallelism": "dp%d" % world,
-                       "exchange_steps_per_minibatch": ex_steps / args.steps, "sampling": "in-kernel Philox4x32-10",
-                       "minibatches_per_s": world * args.steps / elapsed,          # 64-sample batches
-                       "sample_steps_per_s": run_gpu.sample_steps / elapsed,       # sum_t n_active,t per second, whole job
-                       "unit_definition": "one exchange step (model.py:801 loop iteration) of one %d-sample batch; a global "
-                                          "minibatch of %d*N samples advances N of them per iteration" % (
-                                              WORKLOADS[args.workload][1], WORKLOADS[args.workload][1])},
-            "roofline": roof,
+            "value": value, "unit": "exchange-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * per_mb, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": r["label"], "global_batch": r["Bg"], "per_gpu_batch": r["B"], "parallelism": "dp%d" % world,
+                       "exchange_steps_per_minibatch": r["ex_steps"] / r["minibatches"], "sampling": "in-kernel Philox4x32-10",
+                       "timed_minibatches": r["minibatches"], "timed_seconds": r["elapsed"],
+                       "minibatches_per_s": (1.0 if strong else world) * r["minibatches"] / r["elapsed"],
+                       "sample_steps_per_s": r["sample_steps"] / r["elapsed"],       # sum_t n_active,t per second, whole job
+                       "unit_definition": "one exchange step (model.py:801 loop iteration) of one %d-sample batch%s" % (
+                           unit_batch, " (the fixed global minibatch, sharded over the ranks)" if strong else
+                           "; a global minibatch of %d*N samples advances N of them per iteration" % unit_batch)},
+            "roofline": r["roofline"],
         }
+        if world == 1 and args.workload == "c2" and not args.no_other_configs:
+            # the other BASELINE.json configs on this GPU (short runs; parity-test cases, not the metric)
+            other = {}
+            for w in ("c3", "c4", "c5"):
+                o = run_workload(w, 30, 5, args.seed, 0, 1, local_rank)
+                rf = o["roofline"] or {}
+                other[w] = dict(workload=o["label"], batch=o["B"], ms_per_minibatch=1e3 * o["elapsed"] / o["minibatches"],
+                                exchange_steps_per_s=o["ex_steps"] / o["elapsed"],
+                                roofline={k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_us", "traffic", "traffic_source")},
+                                kernels_us=rf.get("kernels_us"))
+            line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

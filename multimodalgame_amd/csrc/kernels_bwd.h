@@ -903,7 +903,11 @@ struct OptArgs {
 __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ jt, OptArgs oa, float* __restrict__ params,
                                                    const float* __restrict__ grads, float* __restrict__ state,
                                                    const float* __restrict__ part, const uint32_t* __restrict__ counter,
-                                                   const uint32_t* __restrict__ sync) {
+                                                   const uint32_t* __restrict__ sync, uint32_t* __restrict__ err_host) {
+    // the dependency-error word goes to a pinned HOST word (device-mapped) with a posted store: the host reads it before the
+    // next minibatch without any stream operation or synchronisation
+    if (err_host && blockIdx.x == 0 && threadIdx.x == 0)
+        *err_host = __hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // An in-launch dependency wait of this minibatch timed out (device_utils.h: role_wait sets sync[MMG_SYNC_ERR]): the
     // gradients may be built from stale data -- leave parameters and optimizer state untouched.  The word is sticky;
     // mmg_train_step reports it on the next call.

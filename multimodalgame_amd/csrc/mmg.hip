@@ -54,7 +54,8 @@ struct mmg_handle {
     int tile_bwd_smem, send_bwd_smem;
     std::vector<KernelTimer> timers;
     size_t timers_used;
-    uint32_t* h_err;           // pinned host copy of sync[MMG_SYNC_ERR], refreshed asynchronously at the end of every mmg_train_step
+    uint32_t* h_err;           // pinned host copy of sync[MMG_SYNC_ERR], written by k_opt of every step (posted store to mapped host memory)
+    uint32_t* d_err;           // its device-side address
 };
 
 extern "C" const char* mmg_last_error(void) { return g_err; }
@@ -270,7 +271,11 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->d_jt = reinterpret_cast<JobTable*>(h->tp.tables);
     h->profiling = false; h->timers_used = 0; h->scores_in_parts = false;
     h->h_err = nullptr;
-    if (hipHostMalloc((void**)&h->h_err, sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) *h->h_err = 0u; else h->h_err = nullptr;
+    h->d_err = nullptr;
+    if (hipHostMalloc((void**)&h->h_err, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+        *h->h_err = 0u;
+        if (hipHostGetDevicePointer((void**)&h->d_err, h->h_err, 0) != hipSuccess) h->d_err = nullptr;
+    } else h->h_err = nullptr;
     h->use_fast = !getenv("MMG_NO_FAST"); h->merge_roles = !getenv("MMG_NO_MERGE");
     // few samples and large sender matrices or class tables: 512-thread variant of the generic conversation kernel
     h->conv_threads = (h->dm.B <= 256 && ((int64_t)h->dm.H * h->dm.W >= 65536 || (int64_t)h->dm.D * (h->dm.R + h->dm.V) >= 65536)) ? 512 : 256;
@@ -622,7 +627,7 @@ static int clip_step_impl(mmg_handle* h, hipStream_t st, bool from_wgrad) {
     {
         Scope sc(h, st, "k_opt");
         hipLaunchKernelGGL(k_opt, dim3(blocks), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt, oa, h->params,
-                           (const float*)h->grads, h->opt_state, (const float*)part, (const uint32_t*)h->tp.counter, (const uint32_t*)h->tp.sync);
+                           (const float*)h->grads, h->opt_state, (const float*)part, (const uint32_t*)h->tp.counter, (const uint32_t*)h->tp.sync, h->d_err);
         if (launch_check("k_opt")) return -1;
     }
     return 0;
@@ -638,8 +643,8 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
     if (!h) return fail("NULL handle");
     if (h->cfg.global_batch != h->cfg.batch) return fail("mmg_train_step is single-GPU; with several ranks all-reduce between the phases");
     if (!d_target) return fail("target must not be NULL");
-    // state of the dependency-error word as of an EARLIER step (a 4-byte asynchronous device-to-host copy into pinned
-    // memory, read here without any synchronisation): a timed-out role_wait never trains on silently -- k_opt already
+    // state of the dependency-error word as of an EARLIER step (k_opt posts it to a pinned, device-mapped host word;
+    // read here without any synchronisation): a timed-out role_wait never trains on silently -- k_opt already
     // skipped that update, and every later call fails
     if (h->h_err && *(volatile uint32_t*)h->h_err != 0u)
         return fail("in-launch dependency %u timed out on the device in an earlier minibatch (workgroup roles out of order?); "
@@ -648,9 +653,7 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
     const bool merged = merge_stats(h);
     if (!merged && mmg_loss_stats(h, stream)) return -1;
     if (backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, merged)) return -1;
-    if (clip_step_impl(h, (hipStream_t)stream, true)) return -1;
-    if (h->h_err) HIP_OK(hipMemcpyAsync(h->h_err, h->tp.sync + MMG_SYNC_ERR, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    return 0;
+    return clip_step_impl(h, (hipStream_t)stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------

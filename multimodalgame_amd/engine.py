@@ -154,10 +154,10 @@ class Engine(object):
     def set_profiling(self, on):
         _lib.check(self.lib.mmg_set_profiling(self.handle, int(bool(on))))
 
-    def kernel_times(self, max_kernels=64):
-        names = C.create_string_buffer(4096)
+    def kernel_times(self, max_kernels=512):
+        names = C.create_string_buffer(16384)
         ms = (C.c_float * max_kernels)()
-        n = self.lib.mmg_get_kernel_times(self.handle, names, 4096, ms, max_kernels)
+        n = self.lib.mmg_get_kernel_times(self.handle, names, 16384, ms, max_kernels)
         if n < 0:
             raise _lib.MmgError(self.lib.mmg_last_error().decode())
         nm = names.value.decode().split(";")[:n]

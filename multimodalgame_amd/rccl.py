@@ -32,23 +32,21 @@ def _load():
     return lib
 
 
-class RcclComm(object):
-    """One communicator over all ranks of `group`; all_reduce(tensor) sums in place on the current stream."""
+def _agree(ok, device, group):
+    """Collective MIN of a per-rank success flag over torch.distributed: every rank learns whether ALL succeeded."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        flag = flag.to(device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
 
-    def __init__(self, device, group=None):
-        self.lib = _load()
-        self.device = torch.device(device)
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-        uid = _UniqueId()
-        if self.rank == 0:
-            self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        on_gpu = dist.get_backend(group) == "nccl"
-        buf = torch.frombuffer(bytearray(bytes(uid.internal)), dtype=torch.uint8).clone()
-        if on_gpu:
-            buf = buf.to(self.device)
-        dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        C.memmove(C.addressof(uid), bytes(buf.cpu().numpy().tobytes()), 128)
+
+class RcclComm(object):
+    """One communicator over all ranks of `group`; all_reduce(tensor) sums in place on the current stream.
+    Construct through try_create(): the set-up is a sequence of collective stages with an agreement after each."""
+
+    def __init__(self, lib, device, rank, world, uid):
+        self.lib, self.device, self.rank, self.world = lib, torch.device(device), rank, world
         self.comm = C.c_void_p()
         with torch.cuda.device(self.device):
             self._check(self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
@@ -70,26 +68,53 @@ class RcclComm(object):
 
 
 def try_create(device, group=None):
-    """Collective: every rank of `group` calls it.  Returns an RcclComm on all ranks or None on all ranks."""
-    comm, ok = None, 1
+    """Collective: every rank of `group` calls it.  Returns an RcclComm on ALL ranks or None on ALL ranks.
+
+    Every stage that can fail locally is followed by an agreement (MIN all-reduce of a success flag through
+    torch.distributed), and a rank only enters the next RCCL call when all ranks passed the previous stage -- so a rank-local
+    failure (library not loadable, ncclGetUniqueId error, init error reported by RCCL, wrong self-check sum) never leaves
+    the other ranks blocked in a collective this rank will not join:
+      1. load librccl + (rank 0) ncclGetUniqueId           -> agree
+      2. broadcast of the 128-byte id (always executed)     -> ncclCommInitRank on every rank -> agree
+      3. f32 AND f64 self-check all-reduces, both unconditionally, result compared afterwards -> agree
+    Residual risk: ncclCommInitRank itself is a blocking rendezvous -- if a rank dies inside it the others wait for RCCL's own
+    bootstrap timeout (NCCL_SOCKET / bootstrap settings); MMG_DP_DIRECT_RCCL=0 selects torch.distributed outright."""
+    device = torch.device(device)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lib, uid, ok = None, _UniqueId(), True
     try:
-        comm = RcclComm(device, group)
-        # self-check before trusting it with gradients: f32 and f64 sums over the ranks on the current stream
-        for dt in (torch.float32, torch.float64):
-            probe = torch.full((257,), float(comm.rank + 1), dtype=dt, device=comm.device)
-            comm.all_reduce(probe)
-            torch.cuda.synchronize(comm.device)
-            want = comm.world * (comm.world + 1) / 2.0
-            if not bool((probe == want).all().item()):
-                raise RuntimeError("direct RCCL all-reduce self-check failed")
-    except Exception:                                   # noqa: BLE001 -- any failure means "use torch.distributed"
-        ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32)
+        lib = _load()
+        if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+            ok = False
+    except Exception:                                   # noqa: BLE001
+        ok = False
+    if not _agree(ok, device, group):
+        return None
+    buf = torch.frombuffer(bytearray(bytes(uid.internal)), dtype=torch.uint8).clone()
     if dist.get_backend(group) == "nccl":
-        flag = flag.to(device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 0:
+        buf = buf.to(device)
+    dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    C.memmove(C.addressof(uid), bytes(buf.cpu().numpy().tobytes()), 128)
+    comm = None
+    try:
+        comm = RcclComm(lib, device, rank, world, uid)
+    except Exception:                                   # noqa: BLE001
+        ok = False
+    if not _agree(ok, device, group):
         if comm is not None:
             comm.close()
+        return None
+    # self-check before trusting it with gradients: both probes run on every rank, verdict afterwards
+    want = world * (world + 1) / 2.0
+    try:
+        probes = [torch.full((257,), float(rank + 1), dtype=dt, device=device) for dt in (torch.float32, torch.float64)]
+        for p in probes:
+            comm.all_reduce(p)
+        torch.cuda.synchronize(device)
+        ok = all(bool((p == want).all().item()) for p in probes)
+    except Exception:                                   # noqa: BLE001
+        ok = False
+    if not _agree(ok, device, group):
+        comm.close()
         return None
     return comm

@@ -106,3 +106,46 @@ def test_rccl_collectives_on_engine_buffers(direct, tmp_path):
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
         if k != "receiver.y2.bias":
             np.testing.assert_allclose(got[k], fused[k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def _rccl2_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from multimodalgame_amd import rccl
+    from multimodalgame_amd.dist import DataParallel
+    dev = torch.device("cuda", rank)
+    comm = rccl.try_create(dev)                      # ncclCommInitRank with the by-value 128-byte id through ctypes, world = 2
+    assert comm is not None and comm.world == 2
+    for dt in (torch.float32, torch.float64):
+        t = torch.arange(1000, dtype=dt, device=dev) * (rank + 1)
+        comm.all_reduce(t)
+        torch.cuda.synchronize(dev)
+        assert bool((t == torch.arange(1000, dtype=dt, device=dev) * 3).all())
+    comm.close()
+    z, meta = common.load_golden(NAME)
+    B = meta["batch"] // world
+    eng = common.make_engine(meta, batch=B, global_batch=meta["batch"], batch_offset=rank * B, device=dev)
+    dp = DataParallel(eng)
+    assert dp.comm is not None
+    out = _run(eng, dp, meta, rank * B, B, True)
+    np.savez(os.path.join(out_dir, "nccl_rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: multi-rank RCCL (ncclCommInitRank with world > 1, "
+                    "f32 / f64 ncclAllReduce over xGMI) cannot execute on a one-GPU box")
+def test_two_rank_rccl_data_parallel(tmp_path):
+    """World size 2 on two GPUs through multimodalgame_amd.rccl: the direct communicator's all-reduces and a sharded
+    training step equal to the single-GPU step on the whole batch."""
+    world = 2
+    mp.spawn(_rccl2_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z, meta = common.load_golden(NAME)
+    want = _run(common.make_engine(meta), None, meta, 0, meta["batch"], True)
+    r0, r1 = np.load(tmp_path / "nccl_rank0.npz"), np.load(tmp_path / "nccl_rank1.npz")
+    for k, v in want.items():
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg="ranks diverged: " + k)
+        if k != "receiver.y2.bias":
+            np.testing.assert_allclose(r0[k], v, rtol=2e-4, atol=2e-6, err_msg=k)
