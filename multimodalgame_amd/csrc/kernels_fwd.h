@@ -72,6 +72,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         }
         const bool first = (int)blockIdx.x == dm.D;
         if (first && tid < dm.T + 2) tp.alive[tid] = (tid == 0) ? 1 : 0;     // per-step live-tile counts (kernels_tile.h)
+        if (first) for (int i = tid; i < 4 * 64; i += blockDim.x) tp.pflags[(size_t)i * 64] = 0u;   // role counters of k_conv_persist
         if (first && tid == 0) {
             tp.counter[0] += 1u;                    // minibatch counter: the Philox stream of this conversation
             if (tp.counter[2] > tp.counter[1]) tp.counter[1] = tp.counter[2];   // optimizer step bumped by k_opt
@@ -201,6 +202,7 @@ struct ConvArgs {
     float* h_state;            // receiver GRU state in/out           [B,R]
     float* sprod_state;        // receiver running stop product       [B]
     int sprod_first;
+    int persist, ns1, ns2;     // kernels_tile.h, k_conv_persist: sender roles per sample tile (0: not persistent)
 };
 
 struct ConvSmem {

@@ -244,8 +244,41 @@ struct F2 { float x, y; };
 #else
 #define MMG_TSTAMP(slot) do {} while (0)
 #endif
+// ---- counters between the roles of k_conv_persist: monotonic (zeroed by k_prep), one per 256-byte block.
+// kind 0: g published by the receiver role of a tile (value = steps done), 1: sender-hidden slices a_t (NS1 per step),
+// 2: message columns + GRU-input partials (NS2 per step), 3: the tile's conversation is over.
+__device__ __forceinline__ uint32_t* pf_ctr(const Tape& tp, int kind, int tile) { return tp.pflags + ((size_t)kind * 64 + tile) * 64; }
+// producer: everything the consumers read was written with agent-scope (write-through) stores
+__device__ __forceinline__ void pf_signal(uint32_t* ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// consumer: returns false when the tile's conversation ended instead (done counter set); bounded spin -> error word
+__device__ __forceinline__ bool pf_wait(uint32_t* ctr, uint32_t target, uint32_t* done, uint32_t* sync_err) {
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        int ok = -1, spins = 0;
+        while (ok < 0) {
+            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) ok = 1;
+            else if (done && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = 0;
+            else {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(sync_err + MMG_SYNC_ERR, 100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; }
+            }
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const bool r = s_ok != 0;
+    __syncthreads();                                    // (s_ok may be rewritten by the next wait)
+    return r;
+}
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int NT>
-__global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, ConvArgs ar) {
+__device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile_idx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     MMG_TSTAMP(0);
 #ifdef MMG_TIMING
@@ -254,8 +287,9 @@ __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, Co
     constexpr int nw = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
-    const int b0 = blockIdx.x * MMG_TM, nb = min(MMG_TM, B - b0);
+    const int b0 = tile_idx * MMG_TM, nb = min(MMG_TM, B - b0);
     const bool do_sen = (ar.phases & 1) != 0;
+    const bool persist = ar.persist != 0;              // receiver role of k_conv_persist: sender roles run beside it in this launch
     const bool binary = dm.use_binary != 0, train = ar.train != 0;
     const bool may_stop = !ar.run_all && !dm.fixed && train;          // a finished tile stops computing
     const TileLds L = tile_lds(dm, nw, do_sen);
@@ -351,11 +385,11 @@ __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, Co
                 if (do_sen && t > 0) add(s_c, L.ldW, P.p[S_CODE_W], W, H, W, rawS, 0);
                 add(s_h, L.ldR, P.p[R_WHH], R, 3 * R, R, raw1, 0); break;
             case 1: if (do_sen) add(s_a, L.ldH, P.p[S_BIN_W], H, W, H, raw0, 0); break;                 // sender logits, model.py:218
-            case 2: add(s_z, L.ldW, P.p[R_WIH], W, 3 * R, W, raw0, 0); break;                           // GRU input side, model.py:340
+            case 2: if (!persist) add(s_z, L.ldW, P.p[R_WIH], W, 3 * R, W, raw0, 0); break;              // GRU input side, model.py:340 (persist: partials of the sender roles)
             case 3: add(s_h, L.ldR, P.p[R_Y1_W], R + V, R, R, raw0, 0); add(s_h, L.ldR, P.p[R_WH_W], R, R, R, raw1, 0); break;   // A (App. A.2), w_h h
             case 5: add(s_y, L.ldD, ar.desc, V, V, D, raw0, 1); break;                                  // softmax . desc, model.py:442-449
             case 6: add(s_dbar, L.ldV, P.p[R_WD_W], V, R, V, raw0, 0); break;                           // w_d dbar, model.py:452
-            case 7: add(s_g, L.ldR, P.p[R_W_W], R, W, R, raw0, 0); break;                               // receiver message logits, model.py:454
+            case 7: if (!persist) add(s_g, L.ldR, P.p[R_W_W], R, W, R, raw0, 0); break;                  // receiver message logits, model.py:454 (persist: in the sender roles)
             default: break;
             }
             for (int j = 0; j < nj; ++j) {
@@ -457,6 +491,25 @@ __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, Co
                         if (misc[TL_LIVE + m] != 0.f) tp.z[(rowb + b) * W + n] = zz;
                     }
                 } else {
+                    if (persist) {
+                        // the message of this step and the GRU's input-side product arrive from the sender roles of the tile:
+                        // gi = sum over the roles' column slices of z_slice W_ih[:, slice]^T, added in role order
+                        pf_wait(pf_ctr(tp, 2, tile_idx), (uint32_t)(ar.ns2 * (t + 1)), nullptr, tp.sync);
+                        const int kp = tile_kparts((3 * R + 15) >> 4, nw);
+                        for (int idx = tid; idx < MMG_TM * 3 * R; idx += NT) {
+                            const int m = idx / (3 * R), n = idx - m * 3 * R;
+                            const size_t o = (size_t)min(b0 + m, B - 1) * 3 * R + n;
+                            float p8[8], acc = 0.f;
+                            for (int k0 = 0; k0 < ar.ns2; k0 += 8) {
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) p8[u] = tp.gip[(size_t)min(k0 + u, ar.ns2 - 1) * B * 3 * R + o];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) acc += (k0 + u < ar.ns2) ? p8[u] : 0.f;
+                            }
+                            raw0[m * L.ld3R + n] = acc;
+                            for (int q = 1; q < kp; ++q) raw0[(q * MMG_TM + m) * L.ld3R + n] = 0.f;
+                        }
+                    }
                     batched_for<NT, 8>(MMG_TM * W, [&](int idx) {
                             const int m = idx / W, n = idx - m * W;
                             const size_t o = (rowb + min(b0 + m, B - 1)) * W + n;
@@ -501,6 +554,7 @@ __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, Co
                     misc[TL_MT + m] = m_next;
                     if (misc[TL_LIVE + m] != 0.f) tp.mask[(size_t)(t + 1) * B + b0 + m] = (uint8_t)(m_next != 0.f);
                     misc[TL_LIVE2 + m] = (misc[TL_LIVE + m] != 0.f && (!may_stop || m_next != 0.f)) ? 1.f : 0.f;
+                    if (persist && m < nb) st_wt(&tp.mstate[b0 + m], m_next);        // the sender roles store live rows only, too
                 }
             } else if (ph == 4) {
                 // ===== class logits  y[m][d] = b_y2 + sum_r w_y2[r] relu(A[m][r] + Cd[d][r])     (model.py:432-433)
@@ -630,9 +684,11 @@ __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, Co
                     const int m = idx / R, n = idx - m * R;
                     const float gv = ftanh(s_gw[m * L.ldR + n] + raw_sum(raw0, L.ldR, kp, m, n));
                     s_g[m * L.ldR + n] = gv;
-                    if (misc[TL_LIVE2 + m] != 0.f) tp.g[(rowb + b0 + m) * R + n] = gv;
+                    if (persist) { if (m < nb) st_wt(&tp.g[(rowb + b0 + m) * R + n], gv); }     // read by the sender roles (all rows)
+                    else if (misc[TL_LIVE2 + m] != 0.f) tp.g[(rowb + b0 + m) * R + n] = gv;
                 }
-            } else {                                                     // receiver message (model.py:454-475)
+                if (persist) pf_signal(pf_ctr(tp, 0, tile_idx));            // g_t (and the stop masks) are out: the sender roles go on
+            } else if (!persist) {                                       // receiver message (model.py:454-475)
                 const float* s_bw = smem + L.bw;
                 const int kp = tile_kparts((W + 15) >> 4, nw);
                 for (int idx = tid; idx < MMG_TM * W; idx += NT) {
@@ -672,6 +728,7 @@ __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, Co
 #ifdef MMG_TIMING
     if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[5] = (long long)clock64();
 #endif
+    if (persist && threadIdx.x == 0) __hip_atomic_store(pf_ctr(tp, 3, tile_idx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // conversation over
     // ---- state hand-over to the next launch of this conversation
     if (tid < nb) {
         tp.tstar[b0 + tid] = (int)misc[TL_TSTAR + tid];
@@ -726,6 +783,207 @@ __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, Co
             tp.hit[b] = (tgt >= 0 && above < (float)dm.top_k) ? 1 : 0;
         }
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, ConvArgs ar) {
+    conv_tile_body<NT>(dm, P, tp, ar, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_persist: the whole conversation of the "large sender, few samples" regime (BASELINE config 4: H*W = 262 144, four
+// sample tiles) as ONE launch of co-resident workgroup roles that hand their results on through memory + counters
+// (pf_signal / pf_wait), instead of three launches per exchange step.  Per tile of 16 samples:
+//   receiver role (1)   conv_tile_body with persist set: GRU, heads, class logits, description mixture, g_t     -> counter 0
+//   S1 roles (H / 64)   every role recomputes the tile's message w_{t-1} = sample(sigmoid(g W_w^T + b)) (64 KB of weights,
+//                       bit-identical in all of them: Philox / injected uniforms are indexed by element) and then ITS
+//                       64-unit slice of a_t = tanh(h_x + w W_c^T + b)                                            -> counter 1
+//   S2 roles (W / 32)   32 message bits z_t = sample(sigmoid(a W_b^T + b)) and the partial GRU input product
+//                       z_slice W_ih[:, slice]^T, which the receiver role adds up in role order                   -> counter 2
+// So the 2 MB of sender weights are streamed by 24 CUs per tile instead of one, W_ih and W_w leave the receiver role (its
+// per-step weights drop from 388 KB to 125 KB), and nothing returns to the host between steps.
+// All roles must be resident together (host: tiles * (1 + NS1 + NS2) <= 240 workgroups of 512 threads); every wait is
+// bounded (error word).  Tape rows follow the live-row contract of k_conv_tile.
+// ---------------------------------------------------------------------------------------------
+struct SRoleLds { int g, w, pw, a, zs, raw, vec, live, total; };
+__host__ __device__ inline SRoleLds srole_lds(const Dims& d, int nw) {
+    SRoleLds L; int o = 0;
+    auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };
+    L.g = take(MMG_TM * ld16(d.R)); L.w = take(MMG_TM * ld16(d.W)); L.pw = take(MMG_TM * ld16(d.W));
+    L.a = take(MMG_TM * ld16(d.H)); L.zs = take(MMG_TM * ld16(32));
+    int r = tile_raw_floats(d.W, nw);
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    r = mx(r, tile_raw_floats(64, nw)); r = mx(r, tile_raw_floats(32, nw)); r = mx(r, tile_raw_floats(3 * d.R, nw));
+    L.raw = take(r); L.vec = take(ld16(d.W) + 2 * 64 + 2 * 32 + 16); L.live = take(16);
+    L.total = o;
+    return L;
+}
+
+template <int NT>
+__device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int j) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int nw = NT / 64;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, T = dm.T;
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0), n0 = j * 64;
+    const bool binary = dm.use_binary != 0, train = ar.train != 0;
+    const bool may_stop = !ar.run_all && !dm.fixed && train;
+    const SRoleLds L = srole_lds(dm, nw);
+    const int ldR = ld16(R), ldW = ld16(W);
+    float* s_g = smem + L.g; float* s_w = smem + L.w; float* s_pw = smem + L.pw; float* raw = smem + L.raw;
+    float* s_bw = smem + L.vec; float* s_bc = s_bw + ldW; float* s_hw0 = s_bc + 64; float* s_live = smem + L.live;
+    for (int i = tid; i < L.total; i += NT) smem[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < W; i += NT) s_bw[i] = P.p[R_W_B][i];
+    if (tid < 64) { s_bc[tid] = P.p[S_CODE_B][n0 + tid]; s_hw0[tid] = tp.hw0[n0 + tid]; }
+    if (tid < MMG_TM) s_live[tid] = tid < nb ? 1.f : 0.f;
+    float hxr[2];                                                       // h_x[b, n0 .. n0+63] of the tile: 1024 values on 512 threads
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int idx = tid + u * NT, m = idx >> 6, n = idx & 63; hxr[u] = tp.hx[(size_t)min(b0 + m, B - 1) * H + n0 + n]; }
+    const uint32_t mb_counter = tp.counter[0];
+    uint32_t* cG = pf_ctr(tp, 0, tile); uint32_t* cA = pf_ctr(tp, 1, tile); uint32_t* done = pf_ctr(tp, 3, tile);
+    __syncthreads();
+    for (int t = 0; t <= T; ++t) {
+        const size_t rowb = (size_t)t * B;
+        if (t >= 1) {
+            // ---- the receiver's message of step t-1 (model.py:454-475), recomputed identically by every S1 role of the tile
+            if (!pf_wait(cG, (uint32_t)t, done, tp.sync)) return;
+            const size_t rowp = (size_t)(t - 1) * B;
+            batched_for<NT, 2>(MMG_TM * R, [&](int idx) { const int m = idx / R, r = idx - m * R; return tp.g[(rowp + min(b0 + m, B - 1)) * R + r]; },
+                               [&](int idx, float v) { const int m = idx / R, r = idx - m * R; s_g[m * ldR + r] = v; });
+            if (tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
+            __syncthreads();
+            tgemm_nt_raw(s_g, ldR, P.p[R_W_W], R, W, R, raw, wave, nw);
+            __syncthreads();
+            {
+                const int kp = tile_kparts((W + 15) >> 4, nw);
+                for (int idx = tid; idx < MMG_TM * W; idx += NT) {
+                    const int m = idx / W, n = idx - m * W, b = min(b0 + m, B - 1);
+                    const float lw = raw_sum(raw, ldW, kp, m, n) + s_bw[n];
+                    float wv = lw, pp = 0.f;
+                    if (binary) {
+                        pp = fsigmoid(lw);
+                        if (train) {
+                            const float u = ar.u_w ? ar.u_w[(rowp + b) * W + n]
+                                                   : philox_uniform(ar.seed, (uint32_t)(((t - 1) * dm.Bg + dm.boff + b) * W + n), mb_counter, 2u);
+                            wv = (u < pp) ? 1.f : 0.f;                                      // model.py:460
+                        } else wv = rintf(pp);                                              // model.py:462
+                        if (j == 0 && s_live[m] != 0.f) tp.pw[(rowp + b) * W + n] = pp;
+                    }
+                    s_w[m * ldW + n] = wv; s_pw[m * ldW + n] = pp;
+                    if (j == 0 && s_live[m] != 0.f) tp.w[(rowp + b) * W + n] = wv;
+                }
+            }
+            __syncthreads();
+            if (j == 0 && binary && tid < 256) {
+                const int m = tid >> 4, l16 = tid & 15;
+                float lpv = 0.f, nev = 0.f;
+                for (int q = l16; q < W; q += 16) {
+                    const float p = s_pw[m * ldW + q], wv = s_w[m * ldW + q];
+                    const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                    lpv += wv * l1 + (1.f - wv) * l0; nev += p * l1 + (1.f - p) * l0;
+                }
+                lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
+                if (l16 == 0 && s_live[m] != 0.f) { tp.lp_w[rowp + b0 + m] = lpv; tp.ne_w[rowp + b0 + m] = nev; }
+            }
+            if (t == T) return;
+            // ---- this role's 64 units of the sender hidden state (model.py:195-216)
+            tgemm_nt_raw(s_w, ldW, P.p[S_CODE_W] + (size_t)n0 * W, W, 64, W, raw, wave, nw);
+            __syncthreads();
+        }
+        {
+            const int kp = tile_kparts(4, nw), ldr = ld16(64);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + u * NT, m = idx >> 6, n = idx & 63;
+                const float hw = (t == 0) ? s_hw0[n] : raw_sum(raw, ldr, kp, m, n) + s_bc[n];
+                if (m < nb) st_wt(&tp.a[(rowb + b0 + m) * H + n0 + n], ftanh(hxr[u] + hw));      // every valid row: the S2 roles multiply whole tiles
+            }
+            if (j == 0) for (int idx = tid; idx < nb * W; idx += NT) {
+                const int m = idx / W, q = idx - m * W;
+                if (s_live[m] == 0.f) continue;
+                const float cv = (t == 0) ? dm.first_rec : s_w[m * ldW + q];
+                tp.zr[(rowb + b0 + m) * W + q] = cv;                                            // z_r of baseline_sen, model.py:836
+                tp.c[(rowb + b0 + m) * W + q] = (t == 0) ? fsigmoid(P.p[S_CODE_BIAS][q]) : cv;
+            }
+        }
+        pf_signal(cA);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void s2_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int k) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int nw = NT / 64;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, T = dm.T;
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0), n0 = k * 32;
+    const bool binary = dm.use_binary != 0, train = ar.train != 0;
+    const bool may_stop = !ar.run_all && !dm.fixed && train;
+    const SRoleLds L = srole_lds(dm, nw);
+    const int ldH = ld16(H), ldZ = ld16(32), ld3R = ld16(3 * R);
+    float* s_a = smem + L.a; float* s_zs = smem + L.zs; float* raw = smem + L.raw;
+    float* s_bb = smem + L.vec; float* s_live = smem + L.live;
+    for (int i = tid; i < L.total; i += NT) smem[i] = 0.f;
+    __syncthreads();
+    if (tid < 32) s_bb[tid] = P.p[S_BIN_B][n0 + tid];
+    if (tid < MMG_TM) s_live[tid] = tid < nb ? 1.f : 0.f;
+    const uint32_t mb_counter = tp.counter[0];
+    uint32_t* cA = pf_ctr(tp, 1, tile); uint32_t* cZ = pf_ctr(tp, 2, tile); uint32_t* done = pf_ctr(tp, 3, tile);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const size_t rowb = (size_t)t * B;
+        if (!pf_wait(cA, (uint32_t)(ar.ns1 * (t + 1)), done, tp.sync)) return;
+        const int H4 = H >> 2;
+        batched_for<NT, 8>(MMG_TM * H4, [&](int idx) { const int m = idx / H4, q = idx - m * H4; return reinterpret_cast<const float4*>(tp.a + (rowb + min(b0 + m, B - 1)) * H)[q]; },
+                           [&](int idx, float4 v) { const int m = idx / H4, q = idx - m * H4; *reinterpret_cast<float4*>(s_a + m * ldH + 4 * q) = v; });
+        if (t >= 1 && tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
+        __syncthreads();
+        tgemm_nt_raw(s_a, ldH, P.p[S_BIN_W] + (size_t)n0 * H, H, 32, H, raw, wave, nw);          // 32 message logits, model.py:218
+        __syncthreads();
+        {
+            const int kp = tile_kparts(2, nw);
+            for (int idx = tid; idx < MMG_TM * 32; idx += NT) {
+                const int m = idx >> 5, n = idx & 31, b = min(b0 + m, B - 1);
+                const float lz = raw_sum(raw, ldZ, kp, m, n) + s_bb[n];
+                float zz = lz, pp = 0.f;
+                if (binary) {
+                    pp = fsigmoid(lz);
+                    if (train) {
+                        const float u = ar.u_z ? ar.u_z[(rowb + b) * W + n0 + n]
+                                               : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + dm.boff + b) * W + n0 + n), mb_counter, 0u);
+                        zz = (u < pp) ? 1.f : 0.f;                                          // model.py:227
+                    } else zz = rintf(pp);                                                  // model.py:229
+                }
+                s_zs[m * ldZ + n] = zz;
+                if (m < nb && s_live[m] != 0.f) {                                           // (read back by the receiver role: write-through)
+                    st_wt(&tp.z[(rowb + b) * W + n0 + n], zz);
+                    if (binary) st_wt(&tp.pz[(rowb + b) * W + n0 + n], pp);
+                }
+            }
+        }
+        __syncthreads();
+        tgemm_nt_raw(s_zs, ldZ, P.p[R_WIH] + n0, W, 3 * R, 32, raw, wave, nw);                  // z_slice W_ih[:, slice]^T
+        __syncthreads();
+        {
+            const int kp = tile_kparts((3 * R + 15) >> 4, nw);
+            for (int idx = tid; idx < MMG_TM * 3 * R; idx += NT) {
+                const int m = idx / (3 * R), n = idx - m * 3 * R;
+                if (m < nb) st_wt(&tp.gip[((size_t)k * B + b0 + m) * 3 * R + n], raw_sum(raw, ld3R, kp, m, n));
+            }
+        }
+        pf_signal(cZ);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles) {
+    const int blk = blockIdx.x;
+    if (blk < tiles) { conv_tile_body<NT>(dm, P, tp, ar, blk); return; }
+    const int r = blk - tiles;
+    if (r < tiles * ar.ns2) { s2_role<NT>(dm, P, tp, ar, r / ar.ns2, r % ar.ns2); return; }
+    const int q = r - tiles * ar.ns2;
+    s1_role<NT>(dm, P, tp, ar, q / ar.ns1, q % ar.ns1);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -52,6 +52,8 @@ struct mmg_handle {
     bool tile_ext;             // the sender MLP of a step runs as its own chip-wide launches (k_send_s1 / k_send_s2)
     int tile_nt, tile_smem;    // threads per tile workgroup, dynamic LDS bytes
     int tile_bwd_smem, send_bwd_smem;
+    bool tile_persist;         // the whole conversation as one launch of co-resident roles (k_conv_persist)
+    int persist_ns1, persist_ns2, persist_smem;
     std::vector<KernelTimer> timers;
     size_t timers_used;
     uint32_t* h_err;           // pinned host copy of sync[MMG_SYNC_ERR], written by k_opt of every step (posted store to mapped host memory)
@@ -307,6 +309,16 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         const bool aligned = !(d.H & 3) && !(d.W & 3) && !(d.R & 3) && !(d.V & 3);
         h->tile_ok = aligned && h->tile_smem <= 160 * 1024 && !getenv("MMG_NO_TILE");
         h->tile_force = getenv("MMG_TILE") != nullptr;
+        // per-step sender products as ROLES of one persistent launch when all of them fit on the chip together
+        h->persist_ns1 = d.H / 64; h->persist_ns2 = d.W / 32;
+        h->tile_persist = h->tile_ok && h->tile_ext && !(d.H % 64) && !(d.W % 32) && tiles <= 64 &&
+                          tiles * (1 + h->persist_ns1 + h->persist_ns2) <= 240 && !getenv("MMG_NO_PERSIST");
+        if (h->tile_persist) {
+            const int a = tile_lds(d, 512 / 64, false).total * 4, b = srole_lds(d, 512 / 64).total * 4;
+            h->persist_smem = a > b ? a : b;
+            if (h->persist_smem > 160 * 1024) h->tile_persist = false;
+            else if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_persist<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->persist_smem);
+        }
         h->tile_bwd_smem = bwd_tile_lds(d, 512 / 64).total * 4;
         h->send_bwd_smem = (MMG_TM * ld16(d.W) + 7 * 64 + 16 + tile_raw_floats_nn(256, MMG_BLOCK / 64)) * 4;
         if (h->tile_bwd_smem > 160 * 1024) h->tile_ok = false;
@@ -443,6 +455,12 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
         ar.phases = 3; ar.t_begin = 0; ar.t_end = d.T;
         conv(ar);
         return launch_check("k_conv_tile");
+    }
+    if (h->tile_persist) {
+        Scope sc(h, st, "k_conv_persist");
+        ar.phases = 2; ar.t_begin = 0; ar.t_end = d.T; ar.persist = 1; ar.ns1 = h->persist_ns1; ar.ns2 = h->persist_ns2;
+        hipLaunchKernelGGL(k_conv_persist<512>, dim3(tiles * (1 + ar.ns1 + ar.ns2)), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles);
+        return launch_check("k_conv_persist");
     }
     const int skip = (!ar.run_all && !d.fixed && ar.train) ? 1 : 0;
     for (int t = 0; t < d.T; ++t) {

@@ -32,11 +32,11 @@ for i in range(T.N_TRAIN_MB):
         print(i + 1, curve[-1], "%.0fs" % (time.time() - t0), flush=True)
 for m in models.values():
     m.eval()
-xdev, tdev = draw(T.N_DEV)
+xdev, tdev = T.dev_set(draw)
 h = 0
 for i in range(0, T.N_DEV, T.B):
     h += cpu_ref.eval_batch(models, torch.from_numpy(xdev[i:i + T.B]), torch.from_numpy(tdev[i:i + T.B]), torch.from_numpy(desc), fl)["hits"]
-out = dict(n_train_minibatches=T.N_TRAIN_MB, n_dev=T.N_DEV, oracle_dev_top6_percent=100.0 * h / T.N_DEV,
+out = dict(n_train_minibatches=T.N_TRAIN_MB, n_dev=T.N_DEV, dev_relabel=T.DEV_RELABEL, oracle_dev_top6_percent=100.0 * h / T.N_DEV,
            oracle_train_top6_percent_per_250=curve, flags=T.FLAGS, torch=torch.__version__, numpy=np.__version__)
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "accuracy_oracle.json"), "w"), indent=1)
 print(out)
