@@ -108,6 +108,58 @@ __device__ __forceinline__ void tgemm_nt_raw(const float* A, int lda, const floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// Register-resident weight fragments for loops that multiply by the SAME matrix every step (the persistent roles): a wave's
+// work item (n-tile, k-part) of tgemm_nt is fixed, so its weight fragment -- one float4 per k-group -- is loaded once and
+// kept in MAXKG registers; the per-step product then has no global load at all.  Item numbering and staging layout are
+// tgemm_nt_body's (item `it` = tn * kparts + kp), so products from fragments and from memory are interchangeable.
+// ---------------------------------------------------------------------------------------------
+template <int MAXKG>
+struct WFrag { float4 b[MAXKG]; int tn, kp, g0, n; };       // n = k-groups held (0: no item)
+
+template <int MAXKG>
+__device__ __forceinline__ void wfrag_load(WFrag<MAXKG>& f, const float* __restrict__ Wm, int ldw, int N, int K, int it, int nw) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int ntiles = (N + 15) >> 4, kparts = tile_kparts(ntiles, nw);
+    const int kgroups = (K + 15) >> 4, per = (kgroups + kparts - 1) / kparts;
+    const bool has = it < ntiles * kparts;
+    f.tn = (has ? it : 0) / kparts; f.kp = (has ? it : 0) - f.tn * kparts;
+    f.g0 = f.kp * per;
+    f.n = has ? min(kgroups, f.g0 + per) - f.g0 : 0;
+    const float* w0 = Wm + (size_t)min(f.tn * 16 + i, N - 1) * ldw;
+#pragma unroll
+    for (int u = 0; u < MAXKG; ++u) f.b[u] = ldrow4c<true>(w0, min(f.g0 + u, kgroups - 1) * 16 + q * 4, K);
+}
+// raw[kp][m][tile columns] = A[16, K-part] . fragment   (A: LDS tile, zero padded)
+template <int MAXKG>
+__device__ __forceinline__ void wfrag_mma(const WFrag<MAXKG>& f, const float* A, int lda, float* raw, int ldr) {
+    if (f.n == 0) return;
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const float* arow = A + i * lda + q * 4 + f.g0 * 16;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < MAXKG; u += 2) {
+        if (u < f.n) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + u * 16);
+            acc0 = mfma16(a.x, f.b[u].x, acc0); acc0 = mfma16(a.y, f.b[u].y, acc0);
+            acc0 = mfma16(a.z, f.b[u].z, acc0); acc0 = mfma16(a.w, f.b[u].w, acc0);
+        }
+        if (u + 1 < MAXKG && u + 1 < f.n) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + (u + 1) * 16);
+            acc1 = mfma16(a.x, f.b[u + 1].x, acc1); acc1 = mfma16(a.y, f.b[u + 1].y, acc1);
+            acc1 = mfma16(a.z, f.b[u + 1].z, acc1); acc1 = mfma16(a.w, f.b[u + 1].w, acc1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) raw[((f.kp * MMG_TM) + q * 4 + r) * ldr + f.tn * 16 + i] = acc0[r] + acc1[r];
+}
+// does one pass of the waves (items `wave` and optionally `wave + nw`) cover the product, with <= MAXKG k-groups per item?
+__device__ __forceinline__ bool wfrag_fits(int N, int K, int nw, int maxkg, int items_per_wave) {
+    const int ntiles = (N + 15) >> 4, kparts = tile_kparts(ntiles, nw);
+    const int kgroups = (K + 15) >> 4, per = (kgroups + kparts - 1) / kparts;
+    return ntiles * kparts <= items_per_wave * nw && per <= maxkg;
+}
+
+// ---------------------------------------------------------------------------------------------
 // raw[kp][m][n] = sum_{k in part kp} A[m][k] * Bm[k*ldb + n]        ("NN": n contiguous -- desc [D, V]; transposed weight
 // products of the backward pass, dX = dY . W with W the PyTorch [out,in] matrix).  Work items (group of 64 columns, k-part).
 // Lane (i, q) reads float4 Bm[k][g*64 + 4i ..] for its four k = kg + 4q + c and feeds four n-tiles: accumulator j holds
@@ -240,6 +292,11 @@ struct F2 { float x, y; };
 // per-sample kernels store.
 // ---------------------------------------------------------------------------------------------
 #ifdef MMG_TIMING
+#define MMG_RSTAMP(cond, slot) do { if ((cond) && threadIdx.x == 0) tp.dbg[(slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define MMG_RSTAMP(cond, slot) do {} while (0)
+#endif
+#ifdef MMG_TIMING
 #define MMG_TSTAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[(slot)] = (long long)wall_clock64(); } while (0)
 #else
 #define MMG_TSTAMP(slot) do {} while (0)
@@ -277,7 +334,7 @@ __device__ __forceinline__ bool pf_wait(uint32_t* ctr, uint32_t target, uint32_t
 }
 __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int NT>
+template <int NT, bool PERSIST>
 __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile_idx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     MMG_TSTAMP(0);
@@ -288,8 +345,8 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
     const int b0 = tile_idx * MMG_TM, nb = min(MMG_TM, B - b0);
-    const bool do_sen = (ar.phases & 1) != 0;
-    const bool persist = ar.persist != 0;              // receiver role of k_conv_persist: sender roles run beside it in this launch
+    constexpr bool persist = PERSIST;                   // receiver role of k_conv_persist: sender roles run beside it in this launch
+    const bool do_sen = !PERSIST && (ar.phases & 1) != 0;
     const bool binary = dm.use_binary != 0, train = ar.train != 0;
     const bool may_stop = !ar.run_all && !dm.fixed && train;          // a finished tile stops computing
     const TileLds L = tile_lds(dm, nw, do_sen);
@@ -354,6 +411,14 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
         if (!any) return;
     }
 
+    // receiver role of the persistent launch: the weights of its small per-step products as register fragments (wfrag_*)
+    WFrag<2> fA, fGw; WFrag<4> fWd, fHh0, fHh1;
+    fA.n = fGw.n = fWd.n = fHh0.n = fHh1.n = 0;
+    const bool res_heads = PERSIST && wfrag_fits(R, R, nw, 2, 1), res_wd = PERSIST && wfrag_fits(R, V, nw, 4, 1);
+    const bool res_hh = PERSIST && wfrag_fits(3 * R, R, nw, 4, 2);
+    if (res_heads) { wfrag_load<2>(fA, P.p[R_Y1_W], R + V, R, R, wave, nw); wfrag_load<2>(fGw, P.p[R_WH_W], R, R, R, wave, nw); }
+    if (res_wd) wfrag_load<4>(fWd, P.p[R_WD_W], V, R, V, wave, nw);
+    if (res_hh) { wfrag_load<4>(fHh0, P.p[R_WHH], R, 3 * R, R, wave, nw); wfrag_load<4>(fHh1, P.p[R_WHH], R, 3 * R, R, wave + nw, nw); }
     int t = t0;
     bool finished = false;
     MMG_TSTAMP(1);
@@ -383,12 +448,20 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
             switch (ph) {
             case 0:   // sender hidden (model.py:195-216) and the GRU's hidden-side product (independent of z)
                 if (do_sen && t > 0) add(s_c, L.ldW, P.p[S_CODE_W], W, H, W, rawS, 0);
-                add(s_h, L.ldR, P.p[R_WHH], R, 3 * R, R, raw1, 0); break;
+                if (res_hh) { wfrag_mma<4>(fHh0, s_h, L.ldR, raw1, L.ld3R); wfrag_mma<4>(fHh1, s_h, L.ldR, raw1, L.ld3R); }
+                else add(s_h, L.ldR, P.p[R_WHH], R, 3 * R, R, raw1, 0);
+                break;
             case 1: if (do_sen) add(s_a, L.ldH, P.p[S_BIN_W], H, W, H, raw0, 0); break;                 // sender logits, model.py:218
             case 2: if (!persist) add(s_z, L.ldW, P.p[R_WIH], W, 3 * R, W, raw0, 0); break;              // GRU input side, model.py:340 (persist: partials of the sender roles)
-            case 3: add(s_h, L.ldR, P.p[R_Y1_W], R + V, R, R, raw0, 0); add(s_h, L.ldR, P.p[R_WH_W], R, R, R, raw1, 0); break;   // A (App. A.2), w_h h
+            case 3:                                                                                     // A (App. A.2), w_h h
+                if (res_heads) { wfrag_mma<2>(fA, s_h, L.ldR, raw0, L.ldR); wfrag_mma<2>(fGw, s_h, L.ldR, raw1, L.ldR); }
+                else { add(s_h, L.ldR, P.p[R_Y1_W], R + V, R, R, raw0, 0); add(s_h, L.ldR, P.p[R_WH_W], R, R, R, raw1, 0); }
+                break;
             case 5: add(s_y, L.ldD, ar.desc, V, V, D, raw0, 1); break;                                  // softmax . desc, model.py:442-449
-            case 6: add(s_dbar, L.ldV, P.p[R_WD_W], V, R, V, raw0, 0); break;                           // w_d dbar, model.py:452
+            case 6:                                                                                     // w_d dbar, model.py:452
+                if (res_wd) wfrag_mma<4>(fWd, s_dbar, L.ldV, raw0, L.ldR);
+                else add(s_dbar, L.ldV, P.p[R_WD_W], V, R, V, raw0, 0);
+                break;
             case 7: if (!persist) add(s_g, L.ldR, P.p[R_W_W], R, W, R, raw0, 0); break;                  // receiver message logits, model.py:454 (persist: in the sender roles)
             default: break;
             }
@@ -494,7 +567,9 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                     if (persist) {
                         // the message of this step and the GRU's input-side product arrive from the sender roles of the tile:
                         // gi = sum over the roles' column slices of z_slice W_ih[:, slice]^T, added in role order
+                        MMG_RSTAMP(tile_idx == 0 && t == 3, 220);
                         pf_wait(pf_ctr(tp, 2, tile_idx), (uint32_t)(ar.ns2 * (t + 1)), nullptr, tp.sync);
+                        MMG_RSTAMP(tile_idx == 0 && t == 3, 221);
                         const int kp = tile_kparts((3 * R + 15) >> 4, nw);
                         for (int idx = tid; idx < MMG_TM * 3 * R; idx += NT) {
                             const int m = idx / (3 * R), n = idx - m * 3 * R;
@@ -687,6 +762,7 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                     if (persist) { if (m < nb) st_wt(&tp.g[(rowb + b0 + m) * R + n], gv); }     // read by the sender roles (all rows)
                     else if (misc[TL_LIVE2 + m] != 0.f) tp.g[(rowb + b0 + m) * R + n] = gv;
                 }
+                MMG_RSTAMP(persist && tile_idx == 0 && t == 2, 222);
                 if (persist) pf_signal(pf_ctr(tp, 0, tile_idx));            // g_t (and the stop masks) are out: the sender roles go on
             } else if (!persist) {                                       // receiver message (model.py:454-475)
                 const float* s_bw = smem + L.bw;
@@ -787,7 +863,7 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, ConvArgs ar) {
-    conv_tile_body<NT>(dm, P, tp, ar, (int)blockIdx.x);
+    conv_tile_body<NT, false>(dm, P, tp, ar, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -842,56 +918,66 @@ __device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const T
     for (int u = 0; u < 2; ++u) { const int idx = tid + u * NT, m = idx >> 6, n = idx & 63; hxr[u] = tp.hx[(size_t)min(b0 + m, B - 1) * H + n0 + n]; }
     const uint32_t mb_counter = tp.counter[0];
     uint32_t* cG = pf_ctr(tp, 0, tile); uint32_t* cA = pf_ctr(tp, 1, tile); uint32_t* done = pf_ctr(tp, 3, tile);
+    // both weight matrices of this role as register fragments, loaded once (W_w: two items of 4 k-groups per wave, the W_c
+    // slice: one item of 8): the step loop then reads no weight from memory.  Larger shapes keep streaming them.
+    const bool res_w = wfrag_fits(W, R, nw, 4, 2), res_c = wfrag_fits(64, W, nw, 8, 1);
+    WFrag<4> fw0, fw1; WFrag<8> fc;
+    fw0.n = fw1.n = fc.n = 0;
+    if (res_w) { wfrag_load<4>(fw0, P.p[R_W_W], R, W, R, wave, nw); wfrag_load<4>(fw1, P.p[R_W_W], R, W, R, wave + nw, nw); }
+    if (res_c) wfrag_load<8>(fc, P.p[S_CODE_W] + (size_t)n0 * W, W, 64, W, wave, nw);
     __syncthreads();
+    constexpr int UW = 8;                                               // message elements per thread (host: 16 * W <= UW * NT)
     for (int t = 0; t <= T; ++t) {
-        const size_t rowb = (size_t)t * B;
+        const size_t rowb = (size_t)t * B, rowp = (size_t)(t > 0 ? t - 1 : 0) * B;
         if (t >= 1) {
-            // ---- the receiver's message of step t-1 (model.py:454-475), recomputed identically by every S1 role of the tile
+            // ---- the receiver's message of step t-1 (model.py:454-475), recomputed identically by every S1 role of the tile.
+            // The uniforms of its Bernoulli draws do not depend on anything this step computes: drawn BEFORE the wait.
+            float uw[UW];
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+                const int idx = min(tid + u * NT, MMG_TM * W - 1), m = idx / W, n = idx - m * W, b = min(b0 + m, B - 1);
+                uw[u] = !(binary && train) ? 0.f
+                        : ar.u_w ? ar.u_w[(rowp + b) * W + n]
+                                 : philox_uniform(ar.seed, (uint32_t)(((t - 1) * dm.Bg + dm.boff + b) * W + n), mb_counter, 2u);
+            }
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 200);
             if (!pf_wait(cG, (uint32_t)t, done, tp.sync)) return;
-            const size_t rowp = (size_t)(t - 1) * B;
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201);
             batched_for<NT, 2>(MMG_TM * R, [&](int idx) { const int m = idx / R, r = idx - m * R; return tp.g[(rowp + min(b0 + m, B - 1)) * R + r]; },
                                [&](int idx, float v) { const int m = idx / R, r = idx - m * R; s_g[m * ldR + r] = v; });
             if (tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
             __syncthreads();
-            tgemm_nt_raw(s_g, ldR, P.p[R_W_W], R, W, R, raw, wave, nw);
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 202);
+            if (res_w) { wfrag_mma<4>(fw0, s_g, ldR, raw, ldW); wfrag_mma<4>(fw1, s_g, ldR, raw, ldW); }
+            else tgemm_nt_raw(s_g, ldR, P.p[R_W_W], R, W, R, raw, wave, nw);
             __syncthreads();
             {
                 const int kp = tile_kparts((W + 15) >> 4, nw);
-                for (int idx = tid; idx < MMG_TM * W; idx += NT) {
-                    const int m = idx / W, n = idx - m * W, b = min(b0 + m, B - 1);
-                    const float lw = raw_sum(raw, ldW, kp, m, n) + s_bw[n];
-                    float wv = lw, pp = 0.f;
-                    if (binary) {
-                        pp = fsigmoid(lw);
-                        if (train) {
-                            const float u = ar.u_w ? ar.u_w[(rowp + b) * W + n]
-                                                   : philox_uniform(ar.seed, (uint32_t)(((t - 1) * dm.Bg + dm.boff + b) * W + n), mb_counter, 2u);
-                            wv = (u < pp) ? 1.f : 0.f;                                      // model.py:460
-                        } else wv = rintf(pp);                                              // model.py:462
-                        if (j == 0 && s_live[m] != 0.f) tp.pw[(rowp + b) * W + n] = pp;
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const int idx = tid + u * NT;
+                    if (idx < MMG_TM * W) {
+                        const int m = idx / W, n = idx - m * W;
+                        const float lw = raw_sum(raw, ldW, kp, m, n) + s_bw[n];
+                        float wv = lw, pp = 0.f;
+                        if (binary) {
+                            pp = fsigmoid(lw);
+                            wv = train ? ((uw[u] < pp) ? 1.f : 0.f) : rintf(pp);            // model.py:460 / 462
+                        }
+                        s_w[m * ldW + n] = wv; s_pw[m * ldW + n] = pp;
                     }
-                    s_w[m * ldW + n] = wv; s_pw[m * ldW + n] = pp;
-                    if (j == 0 && s_live[m] != 0.f) tp.w[(rowp + b) * W + n] = wv;
                 }
             }
             __syncthreads();
-            if (j == 0 && binary && tid < 256) {
-                const int m = tid >> 4, l16 = tid & 15;
-                float lpv = 0.f, nev = 0.f;
-                for (int q = l16; q < W; q += 16) {
-                    const float p = s_pw[m * ldW + q], wv = s_w[m * ldW + q];
-                    const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                    lpv += wv * l1 + (1.f - wv) * l0; nev += p * l1 + (1.f - p) * l0;
-                }
-                lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
-                if (l16 == 0 && s_live[m] != 0.f) { tp.lp_w[rowp + b0 + m] = lpv; tp.ne_w[rowp + b0 + m] = nev; }
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 203);
+            if (t < T) {
+                // ---- this role's 64 units of the sender hidden state (model.py:195-216)
+                if (res_c) wfrag_mma<8>(fc, s_w, ldW, raw, ld16(64));
+                else tgemm_nt_raw(s_w, ldW, P.p[S_CODE_W] + (size_t)n0 * W, W, 64, W, raw, wave, nw);
+                __syncthreads();
             }
-            if (t == T) return;
-            // ---- this role's 64 units of the sender hidden state (model.py:195-216)
-            tgemm_nt_raw(s_w, ldW, P.p[S_CODE_W] + (size_t)n0 * W, W, 64, W, raw, wave, nw);
-            __syncthreads();
         }
-        {
+        if (t < T) {
             const int kp = tile_kparts(4, nw), ldr = ld16(64);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -899,15 +985,41 @@ __device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const T
                 const float hw = (t == 0) ? s_hw0[n] : raw_sum(raw, ldr, kp, m, n) + s_bc[n];
                 if (m < nb) st_wt(&tp.a[(rowb + b0 + m) * H + n0 + n], ftanh(hxr[u] + hw));      // every valid row: the S2 roles multiply whole tiles
             }
-            if (j == 0) for (int idx = tid; idx < nb * W; idx += NT) {
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 204);
+            pf_signal(cA);
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 205);
+        }
+        // ---- off the critical path (the S2 roles are running): role 0 of the tile records the message and its statistics
+        if (j == 0) {
+            if (t >= 1) {
+                for (int idx = tid; idx < nb * W; idx += NT) {
+                    const int m = idx / W, n = idx - m * W;
+                    if (s_live[m] == 0.f) continue;
+                    tp.w[(rowp + b0 + m) * W + n] = s_w[m * ldW + n];
+                    if (binary) tp.pw[(rowp + b0 + m) * W + n] = s_pw[m * ldW + n];
+                }
+                if (binary && tid < 256) {
+                    const int m = tid >> 4, l16 = tid & 15;
+                    float lpv = 0.f, nev = 0.f;
+                    for (int q = l16; q < W; q += 16) {
+                        const float p = s_pw[m * ldW + q], wv = s_w[m * ldW + q];
+                        const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                        lpv += wv * l1 + (1.f - wv) * l0; nev += p * l1 + (1.f - p) * l0;
+                    }
+                    lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
+                    if (l16 == 0 && s_live[m] != 0.f) { tp.lp_w[rowp + b0 + m] = lpv; tp.ne_w[rowp + b0 + m] = nev; }
+                }
+            }
+            if (t < T) for (int idx = tid; idx < nb * W; idx += NT) {
                 const int m = idx / W, q = idx - m * W;
                 if (s_live[m] == 0.f) continue;
                 const float cv = (t == 0) ? dm.first_rec : s_w[m * ldW + q];
                 tp.zr[(rowb + b0 + m) * W + q] = cv;                                            // z_r of baseline_sen, model.py:836
                 tp.c[(rowb + b0 + m) * W + q] = (t == 0) ? fsigmoid(P.p[S_CODE_BIAS][q]) : cv;
             }
+            __syncthreads();                                                                    // s_w / s_pw are rewritten next step
         }
-        pf_signal(cA);
+        if (t == T) return;
     }
 }
 
@@ -930,16 +1042,26 @@ __device__ __forceinline__ void s2_role(const Dims& dm, const Params& P, const T
     if (tid < MMG_TM) s_live[tid] = tid < nb ? 1.f : 0.f;
     const uint32_t mb_counter = tp.counter[0];
     uint32_t* cA = pf_ctr(tp, 1, tile); uint32_t* cZ = pf_ctr(tp, 2, tile); uint32_t* done = pf_ctr(tp, 3, tile);
+    // register-resident weights (see s1_role): 32 rows of W_b (one item of 16 k-groups per wave) and the W_ih column slice
+    const bool res_b = wfrag_fits(32, H, nw, 16, 1), res_i = wfrag_fits(3 * R, 32, nw, 2, 2);
+    WFrag<16> fb; WFrag<2> fi0, fi1;
+    fb.n = fi0.n = fi1.n = 0;
+    if (res_b) wfrag_load<16>(fb, P.p[S_BIN_W] + (size_t)n0 * H, H, 32, H, wave, nw);
+    if (res_i) { wfrag_load<2>(fi0, P.p[R_WIH] + n0, W, 3 * R, 32, wave, nw); wfrag_load<2>(fi1, P.p[R_WIH] + n0, W, 3 * R, 32, wave + nw, nw); }
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const size_t rowb = (size_t)t * B;
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 210);
         if (!pf_wait(cA, (uint32_t)(ar.ns1 * (t + 1)), done, tp.sync)) return;
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 211);
         const int H4 = H >> 2;
         batched_for<NT, 8>(MMG_TM * H4, [&](int idx) { const int m = idx / H4, q = idx - m * H4; return reinterpret_cast<const float4*>(tp.a + (rowb + min(b0 + m, B - 1)) * H)[q]; },
                            [&](int idx, float4 v) { const int m = idx / H4, q = idx - m * H4; *reinterpret_cast<float4*>(s_a + m * ldH + 4 * q) = v; });
         if (t >= 1 && tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
         __syncthreads();
-        tgemm_nt_raw(s_a, ldH, P.p[S_BIN_W] + (size_t)n0 * H, H, 32, H, raw, wave, nw);          // 32 message logits, model.py:218
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 212);
+        if (res_b) wfrag_mma<16>(fb, s_a, ldH, raw, ldZ);                                        // 32 message logits, model.py:218
+        else tgemm_nt_raw(s_a, ldH, P.p[S_BIN_W] + (size_t)n0 * H, H, 32, H, raw, wave, nw);
         __syncthreads();
         {
             const int kp = tile_kparts(2, nw);
@@ -963,7 +1085,9 @@ __device__ __forceinline__ void s2_role(const Dims& dm, const Params& P, const T
             }
         }
         __syncthreads();
-        tgemm_nt_raw(s_zs, ldZ, P.p[R_WIH] + n0, W, 3 * R, 32, raw, wave, nw);                  // z_slice W_ih[:, slice]^T
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 213);
+        if (res_i) { wfrag_mma<2>(fi0, s_zs, ldZ, raw, ld3R); wfrag_mma<2>(fi1, s_zs, ldZ, raw, ld3R); }   // z_slice W_ih[:, slice]^T
+        else tgemm_nt_raw(s_zs, ldZ, P.p[R_WIH] + n0, W, 3 * R, 32, raw, wave, nw);
         __syncthreads();
         {
             const int kp = tile_kparts((3 * R + 15) >> 4, nw);
@@ -972,14 +1096,16 @@ __device__ __forceinline__ void s2_role(const Dims& dm, const Params& P, const T
                 if (m < nb) st_wt(&tp.gip[((size_t)k * B + b0 + m) * 3 * R + n], raw_sum(raw, ld3R, kp, m, n));
             }
         }
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 214);
         pf_signal(cZ);
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 215);
     }
 }
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles) {
     const int blk = blockIdx.x;
-    if (blk < tiles) { conv_tile_body<NT>(dm, P, tp, ar, blk); return; }
+    if (blk < tiles) { conv_tile_body<NT, true>(dm, P, tp, ar, blk); return; }
     const int r = blk - tiles;
     if (r < tiles * ar.ns2) { s2_role<NT>(dm, P, tp, ar, r / ar.ns2, r % ar.ns2); return; }
     const int q = r - tiles * ar.ns2;

@@ -312,7 +312,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         // per-step sender products as ROLES of one persistent launch when all of them fit on the chip together
         h->persist_ns1 = d.H / 64; h->persist_ns2 = d.W / 32;
         h->tile_persist = h->tile_ok && h->tile_ext && !(d.H % 64) && !(d.W % 32) && tiles <= 64 &&
-                          tiles * (1 + h->persist_ns1 + h->persist_ns2) <= 240 && !getenv("MMG_NO_PERSIST");
+                          tiles * (1 + h->persist_ns1 + h->persist_ns2) <= 240 && MMG_TM * d.W <= 8 * 512 && !getenv("MMG_NO_PERSIST");
         if (h->tile_persist) {
             const int a = tile_lds(d, 512 / 64, false).total * 4, b = srole_lds(d, 512 / 64).total * 4;
             h->persist_smem = a > b ? a : b;

@@ -32,3 +32,11 @@ for st in range(10):
         if dbg[base + k] < dbg[base + k - 1]: break
         parts.append("%s %.2f" % (names[k - 1], (dbg[base + k] - dbg[base + k - 1]) * tick / 1e3))
     print("step %d: " % st + " | ".join(parts))
+
+if dbg[200]:
+    us = lambda a, b: (dbg[b] - dbg[a]) * tick / 1e3
+    print("R  signal g(2) at 0; S1: wait-start %.2f -> wait done %.2f | g load %.2f | w gemm+epi+lp %.2f | a gemm+epi %.2f | signal %.2f" % (
+        us(222, 200), us(222, 201), us(201, 202), us(202, 203), us(203, 204), us(204, 205)))
+    print("S2: wait-start %.2f -> wait done %.2f (S1 signal at %.2f) | a load %.2f | z gemm+epi %.2f | gi gemm+store %.2f | signal %.2f (at %.2f)" % (
+        us(222, 210), us(222, 211), us(222, 205), us(211, 212), us(212, 213), us(213, 214), us(214, 215), us(222, 215)))
+    print("R: wait-start %.2f -> wait done %.2f" % (us(222, 220), us(222, 221)))
