@@ -292,7 +292,7 @@ struct F2 { float x, y; };
 // per-sample kernels store.
 // ---------------------------------------------------------------------------------------------
 #ifdef MMG_TIMING
-#define MMG_RSTAMP(cond, slot) do { if ((cond) && threadIdx.x == 0) tp.dbg[(slot)] = (long long)wall_clock64(); } while (0)
+#define MMG_RSTAMP(cond, slot) do { if ((cond) && threadIdx.x == 0) { if ((slot) < 256) tp.dbg[(slot)] = (long long)wall_clock64(); else tp.dbg2[(slot) - 256] = (long long)wall_clock64(); } } while (0)
 #else
 #define MMG_RSTAMP(cond, slot) do {} while (0)
 #endif
@@ -1237,7 +1237,9 @@ namespace mmg {
 // The sender's backward is not recurrent (its input is detached) and runs over all (step, sample) rows in k_send_bwd.
 // Rows of steps a sample never took are zero-filled when zero_dead != 0 (no live-row list for k_wgrad), else untouched.
 // ---------------------------------------------------------------------------------------------
-struct BwdLds { int dh, dlw, dgp, dgh, dAm, dA, A, hs, dy, ws, w2, coef, raw0, raw1, misc, total; int ldW, ldR, ld3R, ldD; };
+struct BwdLds { int dh, dlw, dgp, dgh, dAm, dA, A, hs, dy, ws, w2, coef, raw0, raw1, misc, total;
+                int whh, wh, wy1, ww;          // LDS copies of W_hh / w_h / y1[:, :R] / W_w in [K][N + 4] layout (-1: streamed from L2)
+                int ldW, ldR, ld3R, ldD; };
 __host__ __device__ inline BwdLds bwd_tile_lds(const Dims& d, int nw) {
     BwdLds L;
     L.ldW = ld16(d.W); L.ldR = ld16(d.R); L.ld3R = ld16(3 * d.R); L.ldD = ((d.D + 31) & ~31) + 4;      // (dA streams classes 32 at a time)
@@ -1245,10 +1247,20 @@ __host__ __device__ inline BwdLds bwd_tile_lds(const Dims& d, int nw) {
     auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };
     L.dh = take(MMG_TM * L.ldR); L.dlw = take(MMG_TM * L.ldW); L.dgp = take(MMG_TM * L.ldR); L.dgh = take(MMG_TM * L.ld3R);
     L.dAm = take(MMG_TM * L.ldR); L.dA = take(MMG_TM * L.ldR); L.A = take(MMG_TM * L.ldR); L.hs = take(MMG_TM * L.ldR);
-    L.dy = take(MMG_TM * L.ldD); L.ws = take(L.ldR); L.w2 = take(L.ldR); L.coef = take(7 * 64);
+    L.ws = take(L.ldR); L.w2 = take(L.ldR); L.coef = take(7 * 64);
     const int r = tile_raw_floats_nn(d.R, nw) > tile_raw_floats(d.R, nw) ? tile_raw_floats_nn(d.R, nw) : tile_raw_floats(d.R, nw);
     L.raw0 = take(r); L.raw1 = take(r);
     L.misc = take(128);
+    // the dy tile (output-step prelude only) shares its space with the copy of W_hh used by the time loop; the other
+    // matrices are cached while the 160 KB last (the transposed products then read no weight from L2)
+    const int stride = d.R + 4, budget = 160 * 256 - 64;
+    const int dysz = MMG_TM * L.ldD, hhsz = 3 * d.R * stride;
+    L.whh = -1; L.wh = -1; L.wy1 = -1; L.ww = -1;
+    const bool hh = o + (dysz > hhsz ? dysz : hhsz) <= budget;
+    L.dy = take(hh ? (dysz > hhsz ? dysz : hhsz) : dysz);
+    if (hh) L.whh = L.dy;
+    if (o + 2 * d.R * stride <= budget) { L.wh = take(d.R * stride); L.wy1 = take(d.R * stride); }
+    if (d.use_binary && o + d.W * stride <= budget) L.ww = take(d.W * stride);
     L.total = o;
     return L;
 }
@@ -1257,9 +1269,11 @@ __host__ __device__ inline BwdLds bwd_tile_lds(const Dims& d, int nw) {
 #define BL_DLS 32
 #define BL_LIVE 48
 
-template <int NT>
+// UWP / URP: forward-tape values a thread prefetches per step: 16 * W <= UWP * NT, 16 * R <= URP * NT (host picks the smallest instantiation)
+template <int NT, int UWP, int URP>
 __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int zero_dead, int make_map) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    MMG_RSTAMP(blockIdx.x == 0, 224);
     constexpr int nw = NT / 64;
     const int B = dm.B, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
     const int b0 = blockIdx.x * MMG_TM, nb = min(MMG_TM, B - b0);
@@ -1282,6 +1296,7 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
         for (int r = tid; r < R; r += NT) { s_ws[r] = P.p[R_S_W][r]; s_w2[r] = P.p[R_Y2_W][r]; }
     }
     loss_coefficients(dm, tp.stats, lc, nullptr, nullptr);                  // (ends with a barrier)
+    MMG_RSTAMP(blockIdx.x == 0, 225);
     int tmax = 0;
     for (int m = 0; m < nb; ++m) tmax = max(tmax, (int)misc[BL_TSTAR + m]);
     const int wave = threadIdx.x >> 6;
@@ -1320,6 +1335,7 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
                 if (m < nb) tp.hstar[(size_t)(b0 + m) * R + r] = v;
             });
         __syncthreads();
+        MMG_RSTAMP(blockIdx.x == 0, 226);
         for (int idx = tid; idx < MMG_TM * D; idx += NT) {                 // transposed copy: 16 samples of a class = one 64-byte line
             const int m = idx & 15, d = idx >> 4;
             if (m < nb) tp.dyT[(size_t)d * B + b0 + m] = s_dy[m * L.ldD + d];
@@ -1336,112 +1352,191 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
             }
         }
         __syncthreads();
-        // dA[m][r] = w2[r] sum_d dy[m][d] 1[A*[m][r] + Cd[d][r] > 0]: one (sample, r) pair per thread pass, consecutive lanes on
-        // consecutive r (class rows read coalesced, 32 of them in flight), the sample's dy row broadcast from LDS
-        for (int idx = tid; idx < MMG_TM * R; idx += NT) {
-            const int m = idx / R, r1 = idx - m * R;
-            const float a = s_A[m * L.ldR + r1];
-            const float* dyr = s_dy + m * L.ldD;
-            float acc0 = 0.f, acc1 = 0.f;
-            for (int d0 = 0; d0 < D; d0 += 32) {
-                float cv[32];
+        MMG_RSTAMP(blockIdx.x == 0, 227);
+        // dA[m][r] = w2[r] sum_d dy[m][d] 1[A*[m][r] + Cd[d][r] > 0].  Thread (r, class slice): lanes along r (class rows read
+        // coalesced), the classes split over the NT / RL thread groups, all 16 samples of the tile in registers -- every class
+        // row is read once per tile and 32 of them are in flight per thread; the slices are then added through LDS.
+        {
+            const int RL = (R < NT) ? R : NT, NSL = NT / RL;                // lanes along r, class slices
+            const int sl = tid / RL, r1 = tid - sl * RL;
+            const int per = (((D + NSL - 1) / NSL) + 3) & ~3, d_lo = min(D, sl * per), d_hi = min(D, d_lo + per);
+            float* part = raw0;                                             // [NSL][16][RL] partials (raw0 | raw1 are contiguous)
+            for (int rb = 0; rb < R; rb += RL) {
+                const int r = rb + r1;
+                float acc[MMG_TM], av[MMG_TM];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) cv[u] = tp.Cd[(size_t)min(d0 + u, D - 1) * R + r1];
+                for (int m = 0; m < MMG_TM; ++m) { acc[m] = 0.f; av[m] = s_A[m * L.ldR + min(r, R - 1)]; }
+                if (sl < NSL && r < R) {
+                    for (int d0 = d_lo; d0 < d_hi; d0 += 32) {
+                        float cv[32];
 #pragma unroll
-                for (int u = 0; u < 32; u += 2) {                          // (dy is zero beyond D: the LDS tile is zero padded)
-                    acc0 += (a + cv[u] > 0.f) ? dyr[d0 + u] : 0.f;
-                    acc1 += (a + cv[u + 1] > 0.f) ? dyr[d0 + u + 1] : 0.f;
+                        for (int u = 0; u < 32; ++u) cv[u] = tp.Cd[(size_t)min(d0 + u, d_hi - 1) * R + r];
+                        // (beyond d_hi the clamped class row repeats; its dy factor is masked to zero)
+#pragma unroll 2
+                        for (int u = 0; u < 32; u += 4) {
+#pragma unroll
+                            for (int m = 0; m < MMG_TM; ++m) {
+                                const float* dp = s_dy + m * L.ldD + d0 + u;      // d0 is a multiple of 4 only if d_lo is: scalar reads otherwise
+                                const float y0 = (d0 + u < d_hi) ? dp[0] : 0.f, y1 = (d0 + u + 1 < d_hi) ? dp[1] : 0.f;
+                                const float y2 = (d0 + u + 2 < d_hi) ? dp[2] : 0.f, y3 = (d0 + u + 3 < d_hi) ? dp[3] : 0.f;
+                                acc[m] += (av[m] + cv[u] > 0.f) ? y0 : 0.f; acc[m] += (av[m] + cv[u + 1] > 0.f) ? y1 : 0.f;
+                                acc[m] += (av[m] + cv[u + 2] > 0.f) ? y2 : 0.f; acc[m] += (av[m] + cv[u + 3] > 0.f) ? y3 : 0.f;
+                            }
+                        }
+                    }
                 }
+                // combine the class slices: NSL * 16 * RL floats through LDS in chunks that fit the two staging areas
+                const int cap = (2 * (L.raw1 - L.raw0)) / (MMG_TM * RL);        // slices per pass
+                for (int s0 = 0; s0 < NSL; s0 += cap) {
+                    __syncthreads();
+                    if (sl >= s0 && sl < s0 + cap && sl < NSL) {
+#pragma unroll
+                        for (int m = 0; m < MMG_TM; ++m) part[((sl - s0) * MMG_TM + m) * RL + r1] = acc[m];
+                    }
+                    __syncthreads();
+                    for (int idx = tid; idx < MMG_TM * RL; idx += NT) {
+                        const int m = idx / RL, rr = idx - m * RL;
+                        if (rb + rr < R) {
+                            float v = (s0 == 0) ? 0.f : s_dA[m * L.ldR + rb + rr];
+                            for (int q = 0; q < min(cap, NSL - s0); ++q) v += part[(q * MMG_TM + m) * RL + rr];
+                            s_dA[m * L.ldR + rb + rr] = v;
+                        }
+                    }
+                }
+                __syncthreads();
             }
-            const float v = (acc0 + acc1) * s_w2[r1];
-            s_dA[m * L.ldR + r1] = v;
-            if (m < nb) tp.dA[(size_t)(b0 + m) * R + r1] = v;
+            for (int idx = tid; idx < MMG_TM * R; idx += NT) {
+                const int m = idx / R, r = idx - m * R;
+                const float v = s_dA[m * L.ldR + r] * s_w2[r];
+                s_dA[m * L.ldR + r] = v;
+                if (m < nb) tp.dA[(size_t)(b0 + m) * R + r] = v;
+            }
         }
         __syncthreads();
     }
 
+    MMG_RSTAMP(blockIdx.x == 0, 228);
+    // ---------------- weight cache: [K][N + 4] copies of the matrices of the transposed products (dy is dead now)
+    {
+        const int tid = threadIdx.x, stride = R + 4;
+        auto cache = [&](int off, const float* src, int rows, int ld) {
+            if (off < 0) return;
+            const int n4 = R >> 2;
+            batched_for<NT, 8>(rows * n4, [&](int idx) { const int k = idx / n4, q = idx - k * n4; return *reinterpret_cast<const float4*>(src + (size_t)k * ld + 4 * q); },
+                               [&](int idx, float4 v) { const int k = idx / n4, q = idx - k * n4; *reinterpret_cast<float4*>(smem + off + k * stride + 4 * q) = v; });
+        };
+        cache(L.whh, P.p[R_WHH], 3 * R, R); cache(L.wh, P.p[R_WH_W], R, R); cache(L.wy1, P.p[R_Y1_W], R, R + V); cache(L.ww, P.p[R_W_W], W, R);
+        (void)tid;
+        __syncthreads();
+    }
+    MMG_RSTAMP(blockIdx.x == 0, 229);
     // ---------------- reverse time
-    struct Job { const float* A; const float* Wm; float* raw; int lda, ldw, N, K; };
+    struct Job { const float* A; const float* Wm; float* raw; int lda, ldw, N, K, lds; };
     for (int t = zero_dead ? T - 1 : tmax; t >= 0; --t) {
         const size_t rowb = (size_t)t * B;
+        // ---- this step's forward tape, ONE round trip for all phases: message bits and probabilities, g, GRU gates, h_{t-1}
+        float fw[UWP], fpw[UWP], fg[URP], fru[URP][4], fh[URP], fsc[4];
+        {
+            const int tid0 = threadIdx.x;
+#pragma unroll
+            for (int u = 0; u < UWP; ++u) {
+                const int idx = min(tid0 + u * NT, MMG_TM * W - 1), m = idx / W, j = idx - m * W;
+                const size_t o = (rowb + min(b0 + m, B - 1)) * W + j;
+                fw[u] = binary ? tp.w[o] : 0.f; fpw[u] = binary ? tp.pw[o] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < URP; ++u) {
+                const int idx = min(tid0 + u * NT, MMG_TM * R - 1), m = idx / R, i = idx - m * R, b = min(b0 + m, B - 1);
+                const float* gr = tp.gru + (rowb + b) * 4 * R;
+                fg[u] = binary ? tp.g[(rowb + b) * R + i] : 0.f;
+                fru[u][0] = gr[i]; fru[u][1] = gr[R + i]; fru[u][2] = gr[2 * R + i]; fru[u][3] = gr[3 * R + i];
+                fh[u] = tp.h[(rowb + b) * R + i];
+            }
+            const size_t ob = rowb + min(b0 + min(tid0, MMG_TM - 1), B - 1);
+            fsc[0] = binary ? tp.br[ob] : 0.f; fsc[1] = binary ? tp.bs[ob] : 0.f;
+            fsc[2] = (binary && !dm.fixed) ? tp.s[ob] : 0.f; fsc[3] = (binary && !dm.fixed) ? tp.ps[ob] : 0.5f;
+        }
         for (int ph = 0; ph < 4; ++ph) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
+            MMG_RSTAMP(blockIdx.x == 0 && t < 4, 232 + 4 * t + ph);
             // ---------------- epilogue of the previous product / seeds
             if (ph == 0) {
-                if (tid < MMG_TM) misc[BL_LIVE + tid] = ((float)t <= misc[BL_TSTAR + tid]) ? 1.f : 0.f;
-                // seeds of the receiver-message stream (active while m_{t+1} == 1, i.e. t < t*) and of the stop bit
-                if (binary) {
-                    batched_for<NT, 8>(MMG_TM * W, [&](int idx) {
-                            const int m = idx / W, j = idx - m * W;
-                            const size_t o = (rowb + min(b0 + m, B - 1)) * W + j;
-                            return F2{tp.w[o], tp.pw[o]};
-                        }, [&](int idx, F2 v) {
-                            const int m = idx / W, j = idx - m * W;
-                            const bool act = (float)t < misc[BL_TSTAR + m];
-                            float sv = 0.f;
-                            if (act) {
-                                const float wh = (misc[BL_L + m] - tp.br[rowb + b0 + m]) * lc.cw[T + t];
-                                sv = bit_seed_fast(v.x, v.y, wh, lc.ce[T + t]);
-                            }
-                            s_dlw[m * L.ldW + j] = sv;
-                            if (m < nb && (act || zero_dead || (float)t <= misc[BL_TSTAR + m])) tp.dlw[(rowb + b0 + m) * W + j] = sv;
-                        });
-                    if (tid < MMG_TM) {
-                        const int m = tid;
-                        const bool live = (float)t <= misc[BL_TSTAR + m];
-                        float dls = 0.f, dbs = 0.f, dbr = 0.f;
-                        if (live) {
-                            const float Lr = misc[BL_L + m], brv = tp.br[rowb + b0 + m], bsv = tp.bs[rowb + b0 + m];
-                            if (!dm.fixed) dls = bit_seed_fast(tp.s[rowb + b0 + m], tp.ps[rowb + b0 + m], (Lr - brv) * lc.cw[t], lc.ce[t]);
-                            dbs = lc.cb[t] * (bsv - Lr); dbr = lc.cb[t] * (brv - Lr);      // MSE seeds, model.py:971-988
-                        }
-                        misc[BL_DLS + m] = dls;
-                        if (m < nb && (live || zero_dead)) { tp.dls[rowb + b0 + m] = dls; tp.dbs[rowb + b0 + m] = dbs; tp.dbr[rowb + b0 + m] = dbr; }
+                if (tid < MMG_TM) {
+                    const int m = tid;
+                    const bool live = (float)t <= misc[BL_TSTAR + m];
+                    misc[BL_LIVE + m] = live ? 1.f : 0.f;
+                    float dls = 0.f, dbs = 0.f, dbr = 0.f;
+                    if (binary && live) {
+                        const float Lr = misc[BL_L + m];
+                        if (!dm.fixed) dls = bit_seed_fast(fsc[2], fsc[3], (Lr - fsc[0]) * lc.cw[t], lc.ce[t]);
+                        dbs = lc.cb[t] * (fsc[1] - Lr); dbr = lc.cb[t] * (fsc[0] - Lr);      // MSE seeds, model.py:971-988
                     }
+                    misc[BL_DLS + m] = dls;
+                    misc[64 + m] = fsc[0];                                     // baseline_rec score of the row (message seeds below)
+                    if (binary && m < nb && (live || zero_dead)) { tp.dls[rowb + b0 + m] = dls; tp.dbs[rowb + b0 + m] = dbs; tp.dbr[rowb + b0 + m] = dbr; }
                 }
                 for (int idx = tid; idx < MMG_TM * R; idx += NT) {          // dA enters at the sample's output step
                     const int m = idx / R, r = idx - m * R;
                     s_dAm[m * L.ldR + r] = ((float)t == misc[BL_TSTAR + m]) ? s_dA[m * L.ldR + r] : 0.f;
                 }
+                __syncthreads();
+                // seeds of the receiver-message stream (active while m_{t+1} == 1, i.e. t < t*)
+                if (binary) {
+#pragma unroll
+                    for (int u = 0; u < UWP; ++u) {
+                        const int idx = tid + u * NT;
+                        if (idx < MMG_TM * W) {
+                            const int m = idx / W, j = idx - m * W;
+                            const bool act = (float)t < misc[BL_TSTAR + m];
+                            float sv = 0.f;
+                            if (act) sv = bit_seed_fast(fw[u], fpw[u], (misc[BL_L + m] - misc[64 + m]) * lc.cw[T + t], lc.ce[T + t]);
+                            s_dlw[m * L.ldW + j] = sv;
+                            if (m < nb && (zero_dead || (float)t <= misc[BL_TSTAR + m])) tp.dlw[(rowb + b0 + m) * W + j] = sv;
+                        }
+                    }
+                }
             } else if (ph == 1) {
                 if (binary) {                                                // dgpre = (dlw W_w) (1 - g^2)
                     const int kp = tile_kparts((R + 63) >> 6, nw);
-                    batched_for<NT, 4>(MMG_TM * R, [&](int idx) { const int m = idx / R, r = idx - m * R; return tp.g[(rowb + min(b0 + m, B - 1)) * R + r]; },
-                        [&](int idx, float g) {
+#pragma unroll
+                    for (int u = 0; u < URP; ++u) {
+                        const int idx = tid + u * NT;
+                        if (idx < MMG_TM * R) {
                             const int m = idx / R, r = idx - m * R;
                             const bool act = (float)t < misc[BL_TSTAR + m];
-                            const float v = act ? raw_sum(raw0, L.ldR, kp, m, r) * (1.f - g * g) : 0.f;
+                            const float v = act ? raw_sum(raw0, L.ldR, kp, m, r) * (1.f - fg[u] * fg[u]) : 0.f;
                             s_dgp[m * L.ldR + r] = v;
                             if (m < nb && (zero_dead || (float)t <= misc[BL_TSTAR + m])) tp.dgpre[(rowb + b0 + m) * R + r] = v;
-                        });
+                        }
+                    }
                 }
             } else if (ph == 2) {
                 // dh += dgpre W_h + dA W_y1h + dls w_s ; GRU cell backward (model.py:340)
                 const int kp = tile_kparts((R + 63) >> 6, nw);
-                struct G5 { float rr, uu, nn, ghn, hp; };
-                batched_for<NT, 2>(MMG_TM * R, [&](int idx) {
-                        const int m = idx / R, i = idx - m * R, b = min(b0 + m, B - 1);
-                        const float* gr = tp.gru + (rowb + b) * 4 * R;
-                        return G5{gr[i], gr[R + i], gr[2 * R + i], gr[3 * R + i], tp.h[(rowb + b) * R + i]};
-                    }, [&](int idx, G5 gq) {
+#pragma unroll
+                for (int u = 0; u < URP; ++u) {
+                    const int idx = tid + u * NT;
+                    if (idx < MMG_TM * R) {
                         const int m = idx / R, i = idx - m * R;
                         const bool live = misc[BL_LIVE + m] != 0.f;
+                        const float rr = fru[u][0], uu = fru[u][1], nn = fru[u][2], ghn = fru[u][3];
                         float dh = s_dh[m * L.ldR + i] + raw_sum(raw1, L.ldR, kp, m, i) + misc[BL_DLS + m] * s_ws[i];
                         if (binary) dh += raw_sum(raw0, L.ldR, kp, m, i);
                         if (!live) dh = 0.f;
-                        const float dn = dh * (1.f - gq.uu), du = dh * (gq.hp - gq.nn);
-                        const float dnp = dn * (1.f - gq.nn * gq.nn), dup = du * gq.uu * (1.f - gq.uu);
-                        const float drp = dnp * gq.ghn * gq.rr * (1.f - gq.rr);
+                        const float dn = dh * (1.f - uu), du = dh * (fh[u] - nn);
+                        const float dnp = dn * (1.f - nn * nn), dup = du * uu * (1.f - uu);
+                        const float drp = dnp * ghn * rr * (1.f - rr);
                         float* dg = s_dgh + m * L.ld3R;
-                        dg[i] = drp; dg[R + i] = dup; dg[2 * R + i] = dnp * gq.rr;
-                        s_dh[m * L.ldR + i] = dh * gq.uu;
+                        dg[i] = drp; dg[R + i] = dup; dg[2 * R + i] = dnp * rr;
+                        s_dh[m * L.ldR + i] = dh * uu;
                         if (m < nb && (live || zero_dead)) {
                             float* gi = tp.dgi + (rowb + b0 + m) * 3 * R; float* gh = tp.dgh + (rowb + b0 + m) * 3 * R;
                             gi[i] = drp; gi[R + i] = dup; gi[2 * R + i] = dnp;
-                            gh[i] = drp; gh[R + i] = dup; gh[2 * R + i] = dnp * gq.rr;
+                            gh[i] = drp; gh[R + i] = dup; gh[2 * R + i] = dnp * rr;
                         }
-                    });
+                    }
+                }
             } else {
                 const int kp = tile_kparts((R + 63) >> 6, nw);
                 for (int idx = tid; idx < MMG_TM * R; idx += NT) {          // dh_{t-1} = dh u + dgh W_hh
@@ -1450,29 +1545,34 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
                 }
             }
             __syncthreads();
-            // ---------------- products feeding the next phase
+            // ---------------- products feeding the next phase (weights from their LDS copies where cached)
             Job j0, j1;
             int nj = 0;
-            auto add = [&](const float* A, int lda, const float* Wm, int ldw, int N, int K, float* raw) {
+            auto add = [&](const float* A, int lda, int cached, const float* Wm, int ldw, int N, int K, float* raw) {
                 Job& J = nj ? j1 : j0;
-                J.A = A; J.lda = lda; J.Wm = Wm; J.ldw = ldw; J.N = N; J.K = K; J.raw = raw; ++nj;
+                J.A = A; J.lda = lda; J.N = N; J.K = K; J.raw = raw; J.lds = cached >= 0;
+                J.Wm = cached >= 0 ? smem + cached : Wm; J.ldw = cached >= 0 ? R + 4 : ldw; ++nj;
             };
-            if (ph == 0) { if (binary) add(s_dlw, L.ldW, P.p[R_W_W], R, R, W, raw0); }
-            else if (ph == 1) { if (binary) add(s_dgp, L.ldR, P.p[R_WH_W], R, R, R, raw0); add(s_dAm, L.ldR, P.p[R_Y1_W], R + V, R, R, raw1); }
-            else if (ph == 2) add(s_dgh, L.ld3R, P.p[R_WHH], R, R, 3 * R, raw0);
+            if (ph == 0) { if (binary) add(s_dlw, L.ldW, L.ww, P.p[R_W_W], R, R, W, raw0); }
+            else if (ph == 1) { if (binary) add(s_dgp, L.ldR, L.wh, P.p[R_WH_W], R, R, R, raw0); add(s_dAm, L.ldR, L.wy1, P.p[R_Y1_W], R + V, R, R, raw1); }
+            else if (ph == 2) add(s_dgh, L.ld3R, L.whh, P.p[R_WHH], R, R, 3 * R, raw0);
             for (int j = 0; j < nj; ++j) {
-                const float* jA = j ? j1.A : j0.A; const float* jW = j ? j1.Wm : j0.Wm; float* jr = j ? j1.raw : j0.raw;
-                tgemm_nn_raw(jA, j ? j1.lda : j0.lda, jW, j ? j1.ldw : j0.ldw, j ? j1.N : j0.N, j ? j1.K : j0.K, jr, wave, nw);
+                const float* jA = j ? j1.A : j0.A; float* jr = j ? j1.raw : j0.raw;
+                const int jlda = j ? j1.lda : j0.lda, jldw = j ? j1.ldw : j0.ldw, jN = j ? j1.N : j0.N, jK = j ? j1.K : j0.K;
+                if (j ? j1.lds : j0.lds) {
+                    const int off = (int)((j ? j1.Wm : j0.Wm) - smem);        // (an LDS address: its own copy of the product code, ds_read operands)
+                    tgemm_nn_raw(jA, jlda, smem + off, jldw, jN, jK, jr, wave, nw);
+                } else tgemm_nn_raw(jA, jlda, j ? j1.Wm : j0.Wm, jldw, jN, jK, jr, wave, nw);
             }
             __syncthreads();
         }
     }
+    MMG_RSTAMP(blockIdx.x == 0, 230);
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_send_bwd: sender backward over (step, sample) rows (binary mode): dlz = REINFORCE/entropy seed of the sender's bits,
-// dpre = (dlz W_b) (1 - a^2).  grid (ceil(rows/16), ceil(H/64/nw')): a workgroup owns 16 rows and a band of 64-column
-// groups of H; rows come from the live-row list (rmap) or are all T*B rows (dead rows zero-filled).
+// dpre = (dlz W_b) (1 - a^2).  grid (ceil(rows/16), ceil(H/64)): a workgroup owns 16 rows and 64 columns of H; rows come from the live-row list (rmap) or are all T*B rows (dead rows zero-filled).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape tp, const int* __restrict__ rmap, const int* __restrict__ rcount) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1505,8 +1605,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape 
             if (blockIdx.y == 0) tp.dlz[(size_t)row * W + j] = sv;
         });
     __syncthreads();
-    // band of column groups handled by this workgroup: nw groups of 64 columns
-    const int n0 = blockIdx.y * 64 * nw, Nb = min(64 * nw, H - n0);
+    // this workgroup's 64 columns of H; its four waves split K (one batch of weight rows in flight per wave)
+    const int n0 = blockIdx.y * 64, Nb = min(64, H - n0);
     tgemm_nn_raw(s_dlz, ldW, P.p[S_BIN_W] + n0, H, Nb, W, raw, wave, nw);
     __syncthreads();
     const int ldr = ld16(Nb), kp = tile_kparts((Nb + 63) >> 6, nw);
@@ -1616,6 +1716,101 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_dC_tile(Dims dm, Params P, Tape t
             tp.dCpart[((size_t)slice * 2 * D + d) * R + r] = dc0 + dc1;
             tp.dCpart[((size_t)slice * 2 * D + D + d) * R + r] = py0 + py1;
         }
+    }
+}
+}  // namespace mmg
+
+namespace mmg {
+// acc += X[16 rows, K] . Wt[16 cols, K]^T for one MFMA tile; lane (i, q) owns row i of both operands (k contiguous),
+// 8 k-groups (16 float4 loads) in flight; columns beyond K are clamped on both sides and masked on X.
+template <bool VEC>
+__device__ __forceinline__ void seg_mfma_batched(f32x4& acc, const float* __restrict__ xrow, const float* __restrict__ wrow, int K, int q) {
+    const int kgroups = (K + 15) >> 4;
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int g0 = 0; g0 < kgroups; g0 += 8) {
+        float4 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(g0 + u, kgroups - 1) * 16 + q * 4;
+            a[u] = ldrow4c<VEC>(xrow, k, K); b[u] = ldrow4c<VEC>(wrow, k, K);
+            if (k + 3 >= K) {
+                a[u].x = (k < K) ? a[u].x : 0.f; a[u].y = (k + 1 < K) ? a[u].y : 0.f;
+                a[u].z = (k + 2 < K) ? a[u].z : 0.f; a[u].w = (k + 3 < K) ? a[u].w : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            if (g0 + u < kgroups) {
+                acc = mfma16(a[u].x, b[u].x, acc); acc = mfma16(a[u].y, b[u].y, acc);
+                acc = mfma16(a[u].z, b[u].z, acc); acc = mfma16(a[u].w, b[u].w, acc);
+            }
+            if (g0 + u + 1 < kgroups) {
+                acc1 = mfma16(a[u + 1].x, b[u + 1].x, acc1); acc1 = mfma16(a[u + 1].y, b[u + 1].y, acc1);
+                acc1 = mfma16(a[u + 1].z, b[u + 1].z, acc1); acc1 = mfma16(a[u + 1].w, b[u + 1].w, acc1);
+            }
+        }
+    }
+    acc += acc1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_baselines4: k_baselines3 (kernels_fwd.h: both baselines over the LIVE (step, sample) rows only, one MFMA pass per
+// 16 rows x 64 hidden units, no time loop) for any message / state width: the operand rows are streamed with batched float4
+// loads instead of living in four register fragments.  Needs B <= 64, W / R / H multiples of 4 and tape.basehx
+// (h_x . linear1.weight[:, :H]^T of baseline_sen, a k_gemm_nt launch).  grid (ceil(T*B/16), ceil(K/64), 2).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMG_BLOCK) void k_baselines4(Dims dm, Params P, Tape tp) {
+    __shared__ int s_rid[16];
+    __shared__ float s_part[4][16];
+    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, K = dm.K, T = dm.T;
+    const int which = blockIdx.z, lo = blockIdx.x * 16, byi = blockIdx.y, npb = gridDim.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int ts = tp.tstar[min(lane, B - 1)];
+    const int n = (byi * 4 + wave) * 16 + i;
+    const bool nv = n < K;
+    const float* W1 = which ? P.p[BS_L1_W] : P.p[BR_L1_W];
+    const int ldw = which ? H + W : W + R;
+    const float* wrow = W1 + (size_t)(nv ? n : 0) * ldw;
+    const float bias = nv ? (which ? P.p[BS_L1_B][n] : P.p[BR_L1_B][n]) : 0.f;
+    const float w2 = nv ? (which ? P.p[BS_L2_W][n] : P.p[BR_L2_W][n]) : 0.f;
+    if (wave == 0) {                                     // entries [lo, lo + 16) of the live-row list
+        if (lane < 16) s_rid[lane] = -1;
+        int base = 0;
+        for (int t = 0; t < T && base < lo + 16; ++t) {
+            const bool act = (lane < B) && (t <= ts);
+            const unsigned long long m = __ballot(act);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (act && pos >= lo && pos < lo + 16) s_rid[pos - lo] = t * B + lane;
+            base += __popcll(m);
+        }
+    }
+    __syncthreads();
+    if (s_rid[0] < 0) return;                            // window beyond the live rows
+    const int rid = s_rid[i];
+    const size_t rr = (size_t)(rid >= 0 ? rid : s_rid[0]);      // (padding rows repeat a live row; their results are dropped)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int orow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        orow[r] = s_rid[q * 4 + r];
+        if (which) acc[r] = (orow[r] >= 0) ? tp.basehx[(size_t)(orow[r] % B) * K + min(n, K - 1)] : 0.f;
+    }
+    seg_mfma_batched<true>(acc, (which ? tp.zr : tp.z) + rr * W, wrow + (which ? H : 0), W, q);
+    if (!which) seg_mfma_batched<true>(acc, tp.h + (rr + B) * R, wrow + W, R, q);
+    float* hid = which ? tp.hid_s : tp.hid_r;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = fmaxf(acc[r] + bias, 0.f);                                // model.py:514
+        if (orow[r] >= 0 && nv) hid[(size_t)orow[r] * K + n] = v; else v = 0.f;
+        v = dpp_group_sum<16>(v * w2);
+        if (i == 0) s_part[wave][q * 4 + r] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && s_rid[threadIdx.x] >= 0) {
+        float* part = which ? tp.bs_part : tp.br_part;
+        part[(size_t)s_rid[threadIdx.x] * npb + byi] =
+            (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
     }
 }
 }  // namespace mmg

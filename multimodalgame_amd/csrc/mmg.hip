@@ -320,10 +320,14 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
             else if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_persist<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->persist_smem);
         }
         h->tile_bwd_smem = bwd_tile_lds(d, 512 / 64).total * 4;
-        h->send_bwd_smem = (MMG_TM * ld16(d.W) + 7 * 64 + 16 + tile_raw_floats_nn(256, MMG_BLOCK / 64)) * 4;
-        if (h->tile_bwd_smem > 160 * 1024) h->tile_ok = false;
+        h->send_bwd_smem = (MMG_TM * ld16(d.W) + 7 * 64 + 16 + tile_raw_floats_nn(64, MMG_BLOCK / 64)) * 4;
+        if (h->tile_bwd_smem > 160 * 1024 || d.W > 256 || d.R > 128) h->tile_ok = false;     // (k_bwd_tile keeps a step's forward tape in 8 + 4 registers per thread)
         if (h->tile_ok && e == hipSuccess && h->tile_bwd_smem > 48 * 1024)
-            e = hipFuncSetAttribute((const void*)k_bwd_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
+        {
+            e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
+        }
         if (h->tile_ok && e == hipSuccess && h->send_bwd_smem > 48 * 1024)
             e = hipFuncSetAttribute((const void*)k_send_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, h->send_bwd_smem);
         if (h->tile_ok && h->tile_smem > 48 * 1024) {
@@ -520,7 +524,13 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
         } else {
             Scope sc(h, st, "k_baselines");
             const bool live_rows = base_ready && d.B <= 64;      // k_baselines3: live (step, sample) rows only
-            if (live_rows) {
+            if (tile_path(h) && d.B <= 64 && !(d.H & 3)) {
+                // any message / state width: basehx as a GEMM launch, then one MFMA pass over the live rows (kernels_tile.h)
+                const int bt = ((d.B + 15) / 16) * ((d.K + 15) / 16);
+                hipLaunchKernelGGL(k_gemm_nt, dim3(bt), dim3(MMG_BLOCK), 0, st, (const float*)h->tp.hx, d.H, (const float*)h->P.p[BS_L1_W], d.H + d.W,
+                                   (const float*)nullptr, h->tp.basehx, d.K, d.B, d.K, d.H);
+                hipLaunchKernelGGL(k_baselines4, dim3((d.T * d.B + 15) / 16, (d.K + 63) / 64, 2), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
+            } else if (live_rows) {
                 hipLaunchKernelGGL(k_baselines3, dim3((d.T * d.B + 15) / 16, (d.K + 63) / 64, 2), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
             } else {
                 // grid.z = 2 baselines x 2 step ranges: 128 workgroups at config 1 instead of 64
@@ -556,12 +566,17 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         const int tiles = (d.B + MMG_TM - 1) / MMG_TM;
         {
             Scope sc(h, st, "k_bwd_tile");
-            hipLaunchKernelGGL(k_bwd_tile<512>, dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+            if (d.W <= 32 && d.R <= 64)
+                hipLaunchKernelGGL((k_bwd_tile<512, 1, 2>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+            else if (d.R <= 64)
+                hipLaunchKernelGGL((k_bwd_tile<512, 8, 2>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+            else
+                hipLaunchKernelGGL((k_bwd_tile<512, 8, 4>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             if (launch_check("k_bwd_tile")) return -1;
         }
         if (d.use_binary) {
             Scope sc(h, st, "k_send_bwd");
-            hipLaunchKernelGGL(k_send_bwd, dim3((d.T * d.B + MMG_TM - 1) / MMG_TM, (d.H + 255) / 256), dim3(MMG_BLOCK), h->send_bwd_smem, st,
+            hipLaunchKernelGGL(k_send_bwd, dim3((d.T * d.B + MMG_TM - 1) / MMG_TM, (d.H + 63) / 64), dim3(MMG_BLOCK), h->send_bwd_smem, st,
                                h->dm, h->P, h->tp, (const int*)(row_map ? h->tp.rmap : nullptr), (const int*)(row_map ? h->tp.rcount : nullptr));
             const int nblk = (d.B * (d.H / 4) + MMG_BLOCK - 1) / MMG_BLOCK;
             hipLaunchKernelGGL(k_dhx, dim3(nblk + (d.H / 4 + 63) / 64), dim3(MMG_BLOCK), 0, st, h->dm, h->tp, nblk);

@@ -40,3 +40,13 @@ if dbg[200]:
     print("S2: wait-start %.2f -> wait done %.2f (S1 signal at %.2f) | a load %.2f | z gemm+epi %.2f | gi gemm+store %.2f | signal %.2f (at %.2f)" % (
         us(222, 210), us(222, 211), us(222, 205), us(211, 212), us(212, 213), us(213, 214), us(214, 215), us(222, 215)))
     print("R: wait-start %.2f -> wait done %.2f" % (us(222, 220), us(222, 221)))
+
+if dbg[224]:
+    us = lambda a, b: (dbg[b] - dbg[a]) * tick / 1e3
+    print("k_bwd_tile: init+coef %.2f | dy+h* %.2f | dyT+A* %.2f | dA %.2f | weight cache %.2f | loop %.2f" % (
+        us(224, 225), us(225, 226), us(226, 227), us(227, 228), us(228, 229), us(229, 230)))
+    for t in range(3, -1, -1):
+        b = 232 + 4 * t
+        if dbg[b] and dbg[b + 3] > dbg[b]:
+            nxt = dbg[232 + 4 * (t - 1)] if t > 0 else dbg[230]
+            print("  bwd step %d: ph0 %.2f ph1 %.2f ph2 %.2f ph3+prefetch %.2f" % (t, us(b, b + 1), us(b + 1, b + 2), us(b + 2, b + 3), (nxt - dbg[b + 3]) * tick / 1e3))
