@@ -660,42 +660,60 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                         if (misc[TL_LIVE + m] != 0.f) tp.y[(rowb + b0 + m) * D + d] = yv;
                     }
                 } else {
-                    // many classes: a thread owns a class and keeps its 16 samples' partial sums in registers; the class row is
-                    // read ONCE for the whole tile (negated transposed copy CdT[r][d]: consecutive lanes, consecutive addresses)
-                    for (int d0 = 0; d0 < D; d0 += NT) {
-                        const int d = d0 + tid;
-                        const int dc = min(d, D - 1);
-                        const float cyd = tp.cy[dc];
-                        float acc[MMG_TM];
+                    // many classes: 4 samples x 4 classes per thread in registers (a 4 x 4 x 4 block per step of the r loop: 48 VALU
+                    // operations per five 16-byte operand reads), lanes along the class groups: the NEGATED transposed class
+                    // table CdT[r][d] is read ONCE per tile with coalesced float4 loads (next r-chunk in flight), the A rows come
+                    // from LDS.  relu(A + c) = max(A, -c) + c; the sum_r w2[r] c[r] part is the per-class constant cy.
+                    const bool dvec = (D & 3) == 0;
+                    const int mg = tid & 3, DG = (D + 3) >> 2;
+                    for (int dg0 = 0; dg0 < DG; dg0 += NT / 4) {
+                        const int dg = dg0 + (tid >> 2), d0 = min(dg, DG - 1) * 4;
+                        auto ldc = [&](int r) -> float4 {
+                            const float* row = tp.CdT + (size_t)min(r, R - 1) * D;
+                            if (dvec) return *reinterpret_cast<const float4*>(row + d0);
+                            float4 v; v.x = row[min(d0, D - 1)]; v.y = row[min(d0 + 1, D - 1)]; v.z = row[min(d0 + 2, D - 1)]; v.w = row[min(d0 + 3, D - 1)];
+                            return v;
+                        };
+                        float acc[4][4];
 #pragma unroll
-                        for (int m = 0; m < MMG_TM; ++m) acc[m] = 0.f;
-                        float cv[16], cn[16];
+                        for (int a = 0; a < 4; ++a) { acc[a][0] = acc[a][1] = acc[a][2] = acc[a][3] = 0.f; }
+                        float4 cv[4], cn[4];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) cv[u] = tp.CdT[(size_t)min(u, R - 1) * D + dc];
+                        for (int u = 0; u < 4; ++u) cv[u] = ldc(u);
 #pragma unroll 1
-                        for (int r0 = 0; r0 < R; r0 += 16) {           // chunk r0 in registers, chunk r0 + 16 in flight
+                        for (int r0 = 0; r0 < R; r0 += 4) {
 #pragma unroll
-                            for (int u = 0; u < 16; ++u) cn[u] = tp.CdT[(size_t)min(r0 + 16 + u, R - 1) * D + dc];
+                            for (int u = 0; u < 4; ++u) cn[u] = ldc(r0 + 4 + u);
+                            const float4 wq = *reinterpret_cast<const float4*>(s_w2 + r0);            // zero beyond R
 #pragma unroll
-                            for (int u = 0; u < 16; u += 4) {
-                                const float4 wq = *reinterpret_cast<const float4*>(s_w2 + r0 + u);           // zero beyond R
-#pragma unroll
-                                for (int m = 0; m < MMG_TM; ++m) {
-                                    const float4 av = *reinterpret_cast<const float4*>(s_A + m * L.ldR + r0 + u);    // LDS broadcast
-                                    // relu(A + c) = max(A, -c) + c: CdT holds -c, the sum_r w2[r] c[r] part is the per-class constant cy
-                                    acc[m] = fmaf(wq.x, fmaxf(av.x, cv[u]), acc[m]); acc[m] = fmaf(wq.y, fmaxf(av.y, cv[u + 1]), acc[m]);
-                                    acc[m] = fmaf(wq.z, fmaxf(av.z, cv[u + 2]), acc[m]); acc[m] = fmaf(wq.w, fmaxf(av.w, cv[u + 3]), acc[m]);
-                                }
+                            for (int a = 0; a < 4; ++a) {
+                                const float4 av = *reinterpret_cast<const float4*>(s_A + (4 * mg + a) * L.ldR + r0);
+                                acc[a][0] = fmaf(wq.x, fmaxf(av.x, cv[0].x), acc[a][0]); acc[a][1] = fmaf(wq.x, fmaxf(av.x, cv[0].y), acc[a][1]);
+                                acc[a][2] = fmaf(wq.x, fmaxf(av.x, cv[0].z), acc[a][2]); acc[a][3] = fmaf(wq.x, fmaxf(av.x, cv[0].w), acc[a][3]);
+                                acc[a][0] = fmaf(wq.y, fmaxf(av.y, cv[1].x), acc[a][0]); acc[a][1] = fmaf(wq.y, fmaxf(av.y, cv[1].y), acc[a][1]);
+                                acc[a][2] = fmaf(wq.y, fmaxf(av.y, cv[1].z), acc[a][2]); acc[a][3] = fmaf(wq.y, fmaxf(av.y, cv[1].w), acc[a][3]);
+                                acc[a][0] = fmaf(wq.z, fmaxf(av.z, cv[2].x), acc[a][0]); acc[a][1] = fmaf(wq.z, fmaxf(av.z, cv[2].y), acc[a][1]);
+                                acc[a][2] = fmaf(wq.z, fmaxf(av.z, cv[2].z), acc[a][2]); acc[a][3] = fmaf(wq.z, fmaxf(av.z, cv[2].w), acc[a][3]);
+                                acc[a][0] = fmaf(wq.w, fmaxf(av.w, cv[3].x), acc[a][0]); acc[a][1] = fmaf(wq.w, fmaxf(av.w, cv[3].y), acc[a][1]);
+                                acc[a][2] = fmaf(wq.w, fmaxf(av.w, cv[3].z), acc[a][2]); acc[a][3] = fmaf(wq.w, fmaxf(av.w, cv[3].w), acc[a][3]);
                             }
 #pragma unroll
-                            for (int u = 0; u < 16; ++u) cv[u] = cn[u];
+                            for (int u = 0; u < 4; ++u) cv[u] = cn[u];
                         }
-                        if (d < D) {
+                        if (dg < DG) {
+                            const float4 cy4 = dvec ? *reinterpret_cast<const float4*>(tp.cy + d0)
+                                                    : make_float4(tp.cy[min(d0, D - 1)], tp.cy[min(d0 + 1, D - 1)], tp.cy[min(d0 + 2, D - 1)], tp.cy[min(d0 + 3, D - 1)]);
 #pragma unroll
-                            for (int m = 0; m < MMG_TM; ++m) {
-                                const float yv = acc[m] + cyd;
-                                s_y[m * L.ldD + d] = yv;
-                                if (misc[TL_LIVE + m] != 0.f) tp.y[(rowb + b0 + m) * D + d] = yv;
+                            for (int a = 0; a < 4; ++a) {
+                                const int m = 4 * mg + a;
+                                const float y4[4] = {acc[a][0] + cy4.x, acc[a][1] + cy4.y, acc[a][2] + cy4.z, acc[a][3] + cy4.w};
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    if (d0 + c < D) {
+                                        s_y[m * L.ldD + d0 + c] = y4[c];
+                                        if (misc[TL_LIVE + m] != 0.f) tp.y[(rowb + b0 + m) * D + d0 + c] = y4[c];
+                                    }
+                                }
                             }
                         }
                     }

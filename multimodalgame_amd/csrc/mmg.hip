@@ -143,19 +143,26 @@ static int build_jobs(mmg_handle* h) {
         jt.g[ng - 1].vhid = hid; jt.g[ng - 1].vw2 = w2;
     };
     int cblocks = 0, nc = 0;
+    // bias gradient = column sums of a (step, sample)-row tape.  With thousands of rows the 16-column blocks of a column job
+    // are a handful of latency-bound workgroups: run it through the row-split GEMM pipeline instead, as delta^T . ones (K = 1)
+    const bool bias_as_gemm = wgrad_nsplit(TB) > 1;
     auto col = [&](const float* src, int ld, int rows, int cols, float* dst, const float* scale) {
         ColJob& c = jt.c[nc++];
         c.src = src; c.dst = dst; c.scale = scale; c.ld = ld; c.rows = rows; c.cols = cols; c.blk_begin = cblocks;
         c.vbeta = nullptr; c.vw2 = nullptr; c.wrow = nullptr; c.compact = (rows == TB) ? 1 : 0; c.special = 0;
         cblocks += (cols + 15) / 16;
     };
+    auto bias = [&](const float* src, int ld, int cols, float* dst) {        // plain column sums over the (step, sample) rows
+        if (bias_as_gemm) gemm(src, ld, tp.ones, 0, 0, SRC_STATIC, dst, 1, TB, cols, 1);
+        else col(src, ld, TB, cols, dst, nullptr);
+    };
     const Params& P = h->P;
     const bool bin = d.use_binary;
     // ---- receiver ----
     gemm(tp.dgi, 3 * R, tp.z, W, 0, SRC_STATIC, G.p[R_WIH], W, TB, 3 * R, W);          // rnn.weight_ih
     gemm(tp.dgh, 3 * R, tp.h, R, 0, SRC_STATIC, G.p[R_WHH], R, TB, 3 * R, R);          // rnn.weight_hh (h before the step)
-    col(tp.dgi, 3 * R, TB, 3 * R, G.p[R_BIH], nullptr);
-    col(tp.dgh, 3 * R, TB, 3 * R, G.p[R_BHH], nullptr);
+    bias(tp.dgi, 3 * R, 3 * R, G.p[R_BIH]);
+    bias(tp.dgh, 3 * R, 3 * R, G.p[R_BHH]);
     gemm(tp.dA, R, tp.hstar, R, 0, SRC_STATIC, G.p[R_Y1_W], R + V, B, R, R);           // y1.weight[:, :R]
     gemm(tp.dC, R, tp.descc, V, 0, SRC_STATIC, G.p[R_Y1_W] + R, R + V, D, R, V);      // y1.weight[:, R:]
     col(tp.dC, R, D, R, G.p[R_Y1_B], nullptr);
@@ -163,10 +170,10 @@ static int build_jobs(mmg_handle* h) {
     col(tp.dysum, 1, B, 1, G.p[R_Y2_B], nullptr);
     if (bin) {
         gemm(tp.dgpre, R, tp.h + (size_t)B * R, R, 0, SRC_STATIC, G.p[R_WH_W], R, TB, R, R);   // w_h (h after the step)
-        col(tp.dgpre, R, TB, R, G.p[R_WH_B], nullptr);
+        bias(tp.dgpre, R, R, G.p[R_WH_B]);
         gemm(tp.dgpre, R, tp.dbar, V, 0, SRC_STATIC, G.p[R_WD_W], V, TB, R, V);        // w_d
         gemm(tp.dlw, W, tp.g, R, 0, SRC_STATIC, G.p[R_W_W], R, TB, W, R);              // w
-        col(tp.dlw, W, TB, W, G.p[R_W_B], nullptr);
+        bias(tp.dlw, W, W, G.p[R_W_B]);
         col(tp.h + (size_t)B * R, R, TB, R, G.p[R_S_W], nullptr);                      // s.weight = dls^T . h_after
         jt.c[nc - 1].wrow = tp.dls;
         col(tp.dls, 1, TB, 1, G.p[R_S_B], nullptr);
@@ -174,7 +181,7 @@ static int build_jobs(mmg_handle* h) {
         gemm(tp.dhx, H, nullptr, F, 0, SRC_X, G.p[S_IMG_W], F, B, H, F);               // image_layer (sum over steps first)
         col(tp.dhx, H, B, H, G.p[S_IMG_B], nullptr);
         gemm(tp.dpre, H, tp.c, W, 0, SRC_STATIC, G.p[S_CODE_W], W, TB, H, W);          // code_layer
-        col(tp.dpre, H, TB, H, G.p[S_CODE_B], nullptr);
+        bias(tp.dpre, H, H, G.p[S_CODE_B]);
         if (tile_path(h)) {
             // code_bias: dsig[j] * sum_h code_layer.weight[h, j] * u0[h], u0 = sum_b dpre[t = 0, b, :] (k_dhx): a row-weighted
             // column sum over the weight matrix itself
@@ -189,7 +196,7 @@ static int build_jobs(mmg_handle* h) {
             col(tp.dc0, W, B, W, G.p[S_CODE_BIAS], tp.dsig);                           // code_bias
         }
         gemm(tp.dlz, W, tp.a, H, 0, SRC_STATIC, G.p[S_BIN_W], H, TB, W, H);            // binary_layer
-        col(tp.dlz, W, TB, W, G.p[S_BIN_B], nullptr);
+        bias(tp.dlz, W, W, G.p[S_BIN_B]);
         // ---- baseline_rec: input [z || h_after] ----
         gemm_virt(tp.dbr, tp.hid_r, P.p[BR_L2_W], tp.z, W, 0, G.p[BR_L1_W], W + R, TB, K, W);
         gemm_virt(tp.dbr, tp.hid_r, P.p[BR_L2_W], tp.h + (size_t)B * R, R, 0, G.p[BR_L1_W] + W, W + R, TB, K, R);
@@ -346,6 +353,11 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     if (e == hipSuccess) e = hipMemset(d_grads, 0, sizeof(float) * h->pl.total);
     if (e != hipSuccess) { fail("device init failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
     if (build_jobs(h)) { delete h; return nullptr; }
+    {
+        std::vector<float> one(256, 1.0f);
+        e = hipMemcpy(h->tp.ones, one.data(), sizeof(float) * one.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { fail("constant upload failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
+    }
     e = hipMemcpy(h->d_jt, &h->jt, sizeof(JobTable), hipMemcpyHostToDevice);
     if (e != hipSuccess) { fail("job table upload failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
     return h;
