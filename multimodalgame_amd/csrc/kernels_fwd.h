@@ -203,6 +203,7 @@ struct ConvArgs {
     float* sprod_state;        // receiver running stop product       [B]
     int sprod_first;
     int persist, ns1, ns2;     // kernels_tile.h, k_conv_persist: sender roles per sample tile (0: not persistent)
+    int nhelp, per;            // kernels_tile.h, k_conv_split: class helpers per sample tile, classes per slice
 };
 
 struct ConvSmem {

@@ -24,6 +24,8 @@
 namespace mmg {
 
 #define MMG_TM 16                                   // samples per tile = MFMA M
+// agent-scope (write-through) store: payload another workgroup of the same launch reads after a counter hand-off
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __host__ __device__ inline int ld16(int n) { return ((n + 15) & ~15) + 4; }      // LDS row stride of a [16][n] activation tile
 
 // 4 consecutive floats of a weight row, BRANCH-FREE (a branch around a load makes hipcc wait vmcnt(0) at the join: one
@@ -236,6 +238,139 @@ __device__ __forceinline__ void batched_for(int total, Ld ld, Use use) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Many-class y head of one tile over the class slice [d_lo, d_lo + Dl)   (model.py:432-433):
+//   y[m][d] = b_y2 + sum_r w_y2[r] relu(A[m][r] + Cd[d][r]) = cy[d] + sum_r w_y2[r] max(A[m][r], -Cd[d][r])
+// 4 samples x 4 classes per thread in registers (a 4 x 4 x 4 block per step of the r loop: 48 VALU operations per five
+// 16-byte operand reads), lanes along the class groups: the NEGATED transposed class table CdT[r][d] is read once per
+// tile with coalesced float4 loads (next r-chunk in flight), the A rows come from LDS.  Logits go to s_y[m][d - d_lo] and,
+// per row flag, to tape.y (live rows) and tape.outp (the row's output step).  d_lo and Dl are multiples of 4 (or Dl ends at D).
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void class_logits(const Dims& dm, const Tape& tp, const float* s_A, int ldR, const float* s_w2, float* s_y, int ldY,
+                                             int d_lo, int Dl, size_t rowb, int b0, const float* live, const float* take, int tid, float b2v) {
+    const int D = dm.D, R = dm.R;
+    if (Dl * MMG_TM <= 4 * NT) {
+        // a narrow slice (class helpers of a 16-tile batch hold ~70 classes): the 4 x 4 blocks would occupy a fraction of the
+        // workgroup, each walking R in 16 dependent round trips.  One (class, sample) pair per thread pass instead, the
+        // class's whole row Cd[d, 0..63] in flight at once (relu form, as the few-class path of the tile kernel).
+        for (int idx = tid; idx < Dl * MMG_TM; idx += NT) {
+            const int l = idx >> 4, m = idx & 15, d = d_lo + l;
+            const float* crow = tp.Cd + (size_t)d * R;
+            const float* arow = s_A + m * ldR;
+            float a0 = 0.f, a1 = 0.f;
+            for (int r0 = 0; r0 < R; r0 += 64) {
+                float4 cq[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) cq[u] = ldrow4c<true>(crow, r0 + 4 * u, R);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int r = r0 + 4 * u;
+                    if (r < R) {                                                            // (w2 is zero beyond R)
+                        const float4 av = *reinterpret_cast<const float4*>(arow + r);
+                        const float4 wq = *reinterpret_cast<const float4*>(s_w2 + r);
+                        a0 = fmaf(wq.x, fmaxf(av.x + cq[u].x, 0.f), a0); a1 = fmaf(wq.y, fmaxf(av.y + cq[u].y, 0.f), a1);
+                        a0 = fmaf(wq.z, fmaxf(av.z + cq[u].z, 0.f), a0); a1 = fmaf(wq.w, fmaxf(av.w + cq[u].w, 0.f), a1);
+                    }
+                }
+            }
+            const float yv = (a0 + a1) + b2v;
+            s_y[m * ldY + l] = yv;
+            if (live[m] != 0.f) tp.y[(rowb + b0 + m) * D + d] = yv;
+            if (take[m] != 0.f) st_wt(&tp.outp[(size_t)(b0 + m) * D + d], yv);
+        }
+        for (int idx = tid; idx < MMG_TM * (ldY - Dl); idx += NT) s_y[(idx / (ldY - Dl)) * ldY + Dl + idx % (ldY - Dl)] = 0.f;
+        return;
+    }
+    const bool dvec = ((D & 3) == 0) && ((d_lo & 3) == 0);
+    const int mg = tid & 3, DG = (Dl + 3) >> 2;
+    for (int dg0 = 0; dg0 < DG; dg0 += NT / 4) {
+        const int dg = dg0 + (tid >> 2), l0 = min(dg, DG - 1) * 4, d0 = d_lo + l0;
+        auto ldc = [&](int r) -> float4 {
+            const float* row = tp.CdT + (size_t)min(r, R - 1) * D;
+            if (dvec) return *reinterpret_cast<const float4*>(row + d0);
+            float4 v; v.x = row[min(d0, D - 1)]; v.y = row[min(d0 + 1, D - 1)]; v.z = row[min(d0 + 2, D - 1)]; v.w = row[min(d0 + 3, D - 1)];
+            return v;
+        };
+        float acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { acc[a][0] = acc[a][1] = acc[a][2] = acc[a][3] = 0.f; }
+        float4 cv[4], cn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cv[u] = ldc(u);
+#pragma unroll 1
+        for (int r0 = 0; r0 < R; r0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cn[u] = ldc(r0 + 4 + u);
+            const float4 wq = *reinterpret_cast<const float4*>(s_w2 + r0);            // zero beyond R
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float4 av = *reinterpret_cast<const float4*>(s_A + (4 * mg + a) * ldR + r0);
+                acc[a][0] = fmaf(wq.x, fmaxf(av.x, cv[0].x), acc[a][0]); acc[a][1] = fmaf(wq.x, fmaxf(av.x, cv[0].y), acc[a][1]);
+                acc[a][2] = fmaf(wq.x, fmaxf(av.x, cv[0].z), acc[a][2]); acc[a][3] = fmaf(wq.x, fmaxf(av.x, cv[0].w), acc[a][3]);
+                acc[a][0] = fmaf(wq.y, fmaxf(av.y, cv[1].x), acc[a][0]); acc[a][1] = fmaf(wq.y, fmaxf(av.y, cv[1].y), acc[a][1]);
+                acc[a][2] = fmaf(wq.y, fmaxf(av.y, cv[1].z), acc[a][2]); acc[a][3] = fmaf(wq.y, fmaxf(av.y, cv[1].w), acc[a][3]);
+                acc[a][0] = fmaf(wq.z, fmaxf(av.z, cv[2].x), acc[a][0]); acc[a][1] = fmaf(wq.z, fmaxf(av.z, cv[2].y), acc[a][1]);
+                acc[a][2] = fmaf(wq.z, fmaxf(av.z, cv[2].z), acc[a][2]); acc[a][3] = fmaf(wq.z, fmaxf(av.z, cv[2].w), acc[a][3]);
+                acc[a][0] = fmaf(wq.w, fmaxf(av.w, cv[3].x), acc[a][0]); acc[a][1] = fmaf(wq.w, fmaxf(av.w, cv[3].y), acc[a][1]);
+                acc[a][2] = fmaf(wq.w, fmaxf(av.w, cv[3].z), acc[a][2]); acc[a][3] = fmaf(wq.w, fmaxf(av.w, cv[3].w), acc[a][3]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cv[u] = cn[u];
+        }
+        if (dg < DG) {
+            const float4 cy4 = dvec ? *reinterpret_cast<const float4*>(tp.cy + d0)
+                                    : make_float4(tp.cy[min(d0, D - 1)], tp.cy[min(d0 + 1, D - 1)], tp.cy[min(d0 + 2, D - 1)], tp.cy[min(d0 + 3, D - 1)]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int m = 4 * mg + a;
+                const float y4[4] = {acc[a][0] + cy4.x, acc[a][1] + cy4.y, acc[a][2] + cy4.z, acc[a][3] + cy4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (l0 + c < Dl) {
+                        s_y[m * ldY + l0 + c] = y4[c];
+                        if (live[m] != 0.f) tp.y[(rowb + b0 + m) * D + d0 + c] = y4[c];
+                        if (take[m] != 0.f) st_wt(&tp.outp[(size_t)(b0 + m) * D + d0 + c], y4[c]);    // model.py:1261-1264 (write-through: a helper's slice is read back by the tile's owner)
+                    }
+                }
+            }
+        }
+    }
+    for (int idx = tid; idx < MMG_TM * (ldY - Dl); idx += NT) s_y[(idx / (ldY - Dl)) * ldY + Dl + idx % (ldY - Dl)] = 0.f;   // K padding of the mixture product
+}
+
+// softmax NUMERATORS of the slice in place, e = exp(y - slice max); stat[m] = slice max, stat[16 + m] = sum of e.
+// (the mixture product runs on the numerators; normalisation -- and the combination of slices -- follows it)
+template <int NT>
+__device__ __forceinline__ void class_softmax_num(float* s_y, int ldY, int Dl, float* stat, int wave, int lane) {
+    constexpr int nw = NT / 64;
+    for (int m = wave; m < MMG_TM; m += nw) {
+        float* yr = s_y + m * ldY;
+        float mx = -3.0e38f;
+        for (int d0 = lane; d0 < Dl; d0 += 64 * 8) {                          // 8 LDS reads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = yr[min(d0 + 64 * u, Dl - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mx = fmaxf(mx, v[u]);
+        }
+        mx = dpp_wave_max(mx);
+        float se = 0.f;
+        for (int d0 = lane; d0 < Dl; d0 += 64 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = yr[min(d0 + 64 * u, Dl - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float e = __expf(v[u] - mx);
+                if (d0 + 64 * u < Dl) { yr[d0 + 64 * u] = e; se += e; }
+            }
+        }
+        se = dpp_wave_sum(se);
+        if (lane == 0) { stat[m] = mx; stat[MMG_TM + m] = se; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS plan of the forward tile kernel (float offsets); host and device compute it from the dimensions
 // ---------------------------------------------------------------------------------------------
 struct TileLds {
@@ -243,9 +378,10 @@ struct TileLds {
     int bc, hw0, bb, sc, bih, bhh, bh, bw, ws, w2;          // per-column vectors (biases, N = 1 weights), zero padded
     int ldH, ldW, ldR, ld3R, ldD, ldV;
 };
-__host__ __device__ inline TileLds tile_lds(const Dims& d, int nw, bool with_sender) {
+// per: classes this workgroup holds logits for (D, or its slice of them when class helpers share the tile: k_conv_split)
+__host__ __device__ inline TileLds tile_lds(const Dims& d, int nw, bool with_sender, int per = 0) {
     TileLds L;
-    L.ldH = ld16(d.H); L.ldW = ld16(d.W); L.ldR = ld16(d.R); L.ld3R = ld16(3 * d.R); L.ldD = ld16(d.D); L.ldV = ld16(d.V);
+    L.ldH = ld16(d.H); L.ldW = ld16(d.W); L.ldR = ld16(d.R); L.ld3R = ld16(3 * d.R); L.ldD = ld16(per > 0 ? per : d.D); L.ldV = ld16(d.V);
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };
     L.c = take(MMG_TM * L.ldW); L.z = take(MMG_TM * L.ldW); L.pz = take(MMG_TM * L.ldW);
@@ -266,7 +402,7 @@ __host__ __device__ inline TileLds tile_lds(const Dims& d, int nw, bool with_sen
     r0 = mx(r0, tile_raw_floats(d.W, nw)); r0 = mx(r0, tile_raw_floats(d.R, nw)); r0 = mx(r0, tile_raw_floats_nn(d.V, nw));
     L.raw0 = take(r0);
     L.raw1 = take(mx(tile_raw_floats(3 * d.R, nw), tile_raw_floats(d.R, nw)));
-    L.misc = take(256);
+    L.misc = take(448);
     L.total = o;
     return L;
 }
@@ -279,6 +415,8 @@ __host__ __device__ inline TileLds tile_lds(const Dims& d, int nw, bool with_sen
 #define TL_SBIT 48
 #define TL_TAKE 64
 #define TL_LIVE 96                                   // [96,112): row is stored this step (valid sample, still in conversation)
+#define TL_STAT 128                                   // [128,160): slice max | slice sum of the softmax numerators (many-class path)
+#define TL_FAC 160                                    // [160,416): combination weights of up to 16 class slices
 #define TL_LIVE2 112                                 // [112,128): ... and its conversation goes on after this step (message rows)
 
 struct F2 { float x, y; };
@@ -332,9 +470,8 @@ __device__ __forceinline__ bool pf_wait(uint32_t* ctr, uint32_t target, uint32_t
     __syncthreads();                                    // (s_ok may be rewritten by the next wait)
     return r;
 }
-__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int NT, bool PERSIST>
+template <int NT, bool PERSIST, bool SPLIT = false>
 __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile_idx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     MMG_TSTAMP(0);
@@ -349,7 +486,9 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
     const bool do_sen = !PERSIST && (ar.phases & 1) != 0;
     const bool binary = dm.use_binary != 0, train = ar.train != 0;
     const bool may_stop = !ar.run_all && !dm.fixed && train;          // a finished tile stops computing
-    const TileLds L = tile_lds(dm, nw, do_sen);
+    const bool bigD = D * MMG_TM > 8 * NT;             // many classes: register-tiled y head, slices, normalisation after the mixture product
+    const int Dl = SPLIT ? min(ar.per, D) : D;          // classes of this workgroup's slice [0, Dl) (class helpers take the rest)
+    const TileLds L = tile_lds(dm, nw, do_sen, SPLIT ? ar.per : 0);
     float* s_a = smem + L.a; float* s_c = smem + L.c; float* s_z = smem + L.z; float* s_pz = smem + L.pz;
     float* s_h = smem + L.h; float* s_gh = smem + L.gh; float* s_A = smem + L.A; float* s_gw = smem + L.gw; float* s_g = smem + L.g;
     float* s_y = smem + L.y; float* s_dbar = smem + L.dbar; float* raw0 = smem + L.raw0; float* raw1 = smem + L.raw1;
@@ -421,6 +560,7 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
     if (res_hh) { wfrag_load<4>(fHh0, P.p[R_WHH], R, 3 * R, R, wave, nw); wfrag_load<4>(fHh1, P.p[R_WHH], R, 3 * R, R, wave + nw, nw); }
     int t = t0;
     bool finished = false;
+    int published = 0;                                                  // class-split: steps whose A tile went out to the helpers
     MMG_TSTAMP(1);
     // A step is eight phases: [products of the phase] barrier [epilogue of the phase] barrier.  The product code exists ONCE
     // (a loop over the phase's job list) -- inlined at every call site the kernel was 125 KB of code, twice the instruction
@@ -457,7 +597,7 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                 if (res_heads) { wfrag_mma<2>(fA, s_h, L.ldR, raw0, L.ldR); wfrag_mma<2>(fGw, s_h, L.ldR, raw1, L.ldR); }
                 else { add(s_h, L.ldR, P.p[R_Y1_W], R + V, R, R, raw0, 0); add(s_h, L.ldR, P.p[R_WH_W], R, R, R, raw1, 0); }
                 break;
-            case 5: add(s_y, L.ldD, ar.desc, V, V, D, raw0, 1); break;                                  // softmax . desc, model.py:442-449
+            case 5: add(s_y, L.ldD, ar.desc, V, V, bigD ? Dl : D, raw0, 1); break;                      // softmax . desc, model.py:442-449 (bigD: numerators of the slice)
             case 6:                                                                                     // w_d dbar, model.py:452
                 if (res_wd) wfrag_mma<4>(fWd, s_dbar, L.ldV, raw0, L.ldR);
                 else add(s_dbar, L.ldV, P.p[R_WD_W], V, R, V, raw0, 0);
@@ -660,114 +800,86 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                         if (misc[TL_LIVE + m] != 0.f) tp.y[(rowb + b0 + m) * D + d] = yv;
                     }
                 } else {
-                    // many classes: 4 samples x 4 classes per thread in registers (a 4 x 4 x 4 block per step of the r loop: 48 VALU
-                    // operations per five 16-byte operand reads), lanes along the class groups: the NEGATED transposed class
-                    // table CdT[r][d] is read ONCE per tile with coalesced float4 loads (next r-chunk in flight), the A rows come
-                    // from LDS.  relu(A + c) = max(A, -c) + c; the sum_r w2[r] c[r] part is the per-class constant cy.
-                    const bool dvec = (D & 3) == 0;
-                    const int mg = tid & 3, DG = (D + 3) >> 2;
-                    for (int dg0 = 0; dg0 < DG; dg0 += NT / 4) {
-                        const int dg = dg0 + (tid >> 2), d0 = min(dg, DG - 1) * 4;
-                        auto ldc = [&](int r) -> float4 {
-                            const float* row = tp.CdT + (size_t)min(r, R - 1) * D;
-                            if (dvec) return *reinterpret_cast<const float4*>(row + d0);
-                            float4 v; v.x = row[min(d0, D - 1)]; v.y = row[min(d0 + 1, D - 1)]; v.z = row[min(d0 + 2, D - 1)]; v.w = row[min(d0 + 3, D - 1)];
-                            return v;
-                        };
-                        float acc[4][4];
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) { acc[a][0] = acc[a][1] = acc[a][2] = acc[a][3] = 0.f; }
-                        float4 cv[4], cn[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) cv[u] = ldc(u);
-#pragma unroll 1
-                        for (int r0 = 0; r0 < R; r0 += 4) {
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) cn[u] = ldc(r0 + 4 + u);
-                            const float4 wq = *reinterpret_cast<const float4*>(s_w2 + r0);            // zero beyond R
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) {
-                                const float4 av = *reinterpret_cast<const float4*>(s_A + (4 * mg + a) * L.ldR + r0);
-                                acc[a][0] = fmaf(wq.x, fmaxf(av.x, cv[0].x), acc[a][0]); acc[a][1] = fmaf(wq.x, fmaxf(av.x, cv[0].y), acc[a][1]);
-                                acc[a][2] = fmaf(wq.x, fmaxf(av.x, cv[0].z), acc[a][2]); acc[a][3] = fmaf(wq.x, fmaxf(av.x, cv[0].w), acc[a][3]);
-                                acc[a][0] = fmaf(wq.y, fmaxf(av.y, cv[1].x), acc[a][0]); acc[a][1] = fmaf(wq.y, fmaxf(av.y, cv[1].y), acc[a][1]);
-                                acc[a][2] = fmaf(wq.y, fmaxf(av.y, cv[1].z), acc[a][2]); acc[a][3] = fmaf(wq.y, fmaxf(av.y, cv[1].w), acc[a][3]);
-                                acc[a][0] = fmaf(wq.z, fmaxf(av.z, cv[2].x), acc[a][0]); acc[a][1] = fmaf(wq.z, fmaxf(av.z, cv[2].y), acc[a][1]);
-                                acc[a][2] = fmaf(wq.z, fmaxf(av.z, cv[2].z), acc[a][2]); acc[a][3] = fmaf(wq.z, fmaxf(av.z, cv[2].w), acc[a][3]);
-                                acc[a][0] = fmaf(wq.w, fmaxf(av.w, cv[3].x), acc[a][0]); acc[a][1] = fmaf(wq.w, fmaxf(av.w, cv[3].y), acc[a][1]);
-                                acc[a][2] = fmaf(wq.w, fmaxf(av.w, cv[3].z), acc[a][2]); acc[a][3] = fmaf(wq.w, fmaxf(av.w, cv[3].w), acc[a][3]);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) cv[u] = cn[u];
-                        }
-                        if (dg < DG) {
-                            const float4 cy4 = dvec ? *reinterpret_cast<const float4*>(tp.cy + d0)
-                                                    : make_float4(tp.cy[min(d0, D - 1)], tp.cy[min(d0 + 1, D - 1)], tp.cy[min(d0 + 2, D - 1)], tp.cy[min(d0 + 3, D - 1)]);
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) {
-                                const int m = 4 * mg + a;
-                                const float y4[4] = {acc[a][0] + cy4.x, acc[a][1] + cy4.y, acc[a][2] + cy4.z, acc[a][3] + cy4.w};
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    if (d0 + c < D) {
-                                        s_y[m * L.ldD + d0 + c] = y4[c];
-                                        if (misc[TL_LIVE + m] != 0.f) tp.y[(rowb + b0 + m) * D + d0 + c] = y4[c];
-                                    }
-                                }
-                            }
-                        }
+                    if (SPLIT) {
+                        // A tile and row flags for the class helpers of this tile, then the owner's own slice
+                        float* pub = tp.Apub + (size_t)tile_idx * (MMG_TM * R + 32);
+                        for (int idx = tid; idx < MMG_TM * R; idx += NT) st_wt(pub + idx, s_A[(idx / R) * L.ldR + idx % R]);
+                        if (tid < MMG_TM) { st_wt(pub + MMG_TM * R + tid, misc[TL_LIVE + tid]); st_wt(pub + MMG_TM * R + 16 + tid, misc[TL_TAKE + tid]); }
+                        pf_signal(pf_ctr(tp, 0, tile_idx));
+                        ++published;
                     }
+                    class_logits<NT>(dm, tp, s_A, L.ldR, s_w2, s_y, L.ldD, 0, Dl, rowb, b0, misc + TL_LIVE, misc + TL_TAKE, tid, b2);
                 }
-                for (int idx = tid; idx < MMG_TM * (L.ldD - D); idx += NT) s_y[(idx / (L.ldD - D)) * L.ldD + D + idx % (L.ldD - D)] = 0.f;   // K padding of the mixture product
+                if (!bigD) for (int idx = tid; idx < MMG_TM * (L.ldD - D); idx += NT) s_y[(idx / (L.ldD - D)) * L.ldD + D + idx % (L.ldD - D)] = 0.f;   // K padding of the mixture product
                 __syncthreads();
                 // output step of a sample: its logits go to tape.outp (model.py:1261-1264); the tile may be done
                 alive = false;
                 for (int m = 0; m < nb; ++m) alive = alive || (misc[TL_MT + m] != 0.f);
-                for (int m = 0; m < nb; ++m) {
+                if (!bigD) for (int m = 0; m < nb; ++m) {
                     if (misc[TL_TAKE + m] != 0.f)
                         for (int d = tid; d < D; d += NT) tp.outp[(size_t)(b0 + m) * D + d] = s_y[m * L.ldD + d];
                 }
                 if (tid == 0 && t + 1 < T && alive) atomicAdd(&tp.alive[t + 1], 1);
                 if (may_stop && !alive) break;
                 __syncthreads();                                        // the selected rows are copied before the softmax overwrites them
+                if (bigD) class_softmax_num<NT>(s_y, L.ldD, Dl, misc + TL_STAT, wave, lane);
+                else {
                 // softmax(y) (detached, model.py:441): wave per sample row, in place
                 for (int m = wave; m < MMG_TM; m += nw) {
                     float* yr = s_y + m * L.ldD;
                     float mx = -3.0e38f;
-                    for (int d0 = lane; d0 < D; d0 += 64 * 8) {          // 8 LDS reads in flight per lane
-                        float v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = yr[min(d0 + 64 * u, D - 1)];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) mx = fmaxf(mx, v[u]);
-                    }
+                    for (int d = lane; d < D; d += 64) mx = fmaxf(mx, yr[d]);
                     mx = dpp_wave_max(mx);
                     float se = 0.f;
-                    for (int d0 = lane; d0 < D; d0 += 64 * 8) {
-                        float v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = yr[min(d0 + 64 * u, D - 1)];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const float e = __expf(v[u] - mx);
-                            if (d0 + 64 * u < D) { yr[d0 + 64 * u] = e; se += e; }
-                        }
-                    }
+                    for (int d = lane; d < D; d += 64) { const float e = __expf(yr[d] - mx); yr[d] = e; se += e; }
                     se = dpp_wave_sum(se);
                     const float inv = __builtin_amdgcn_rcpf(se);
-                    for (int d0 = lane; d0 < D; d0 += 64 * 8) {
-                        float v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = yr[min(d0 + 64 * u, D - 1)];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) if (d0 + 64 * u < D) yr[d0 + 64 * u] = v[u] * inv;
-                    }
+                    for (int d = lane; d < D; d += 64) yr[d] *= inv;
+                }
                 }
             } else if (ph == 5) {                                        // description mixture
                 const int kp = tile_kparts((V + 63) >> 6, nw);
+                float* fac = misc + TL_FAC;                                  // [slot][16]: weight of each slice's partial, already divided by the total
+                if (bigD) {
+                    if (SPLIT) pf_wait(pf_ctr(tp, 2, tile_idx), (uint32_t)(ar.nhelp * (t + 1)), nullptr, tp.sync);
+                    if (tid < MMG_TM) {
+                        // slices are combined like a streaming softmax: weights exp(max_h - M) / sum_h s_h exp(max_h - M)
+                        const int m = tid;
+                        const float* cp = tp.cpart + ((size_t)tile_idx * (SPLIT ? ar.nhelp : 1) * MMG_TM + m) * (V + 2);
+                        float mh[16], sh[16];
+                        float M = misc[TL_STAT + m];
+#pragma unroll
+                        for (int q = 0; q < 15; ++q) {
+                            const bool on = SPLIT && q < ar.nhelp;
+                            mh[q] = on ? cp[(size_t)q * MMG_TM * (V + 2) + V] : -3.0e38f;
+                            sh[q] = on ? cp[(size_t)q * MMG_TM * (V + 2) + V + 1] : 0.f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 15; ++q) M = fmaxf(M, mh[q]);
+                        float S = misc[TL_STAT + MMG_TM + m] * __expf(misc[TL_STAT + m] - M);
+#pragma unroll
+                        for (int q = 0; q < 15; ++q) S += sh[q] * __expf(mh[q] - M);
+                        const float inv = 1.0f / S;
+                        fac[m] = __expf(misc[TL_STAT + m] - M) * inv;
+#pragma unroll
+                        for (int q = 0; q < 15; ++q) fac[(q + 1) * MMG_TM + m] = (SPLIT && q < ar.nhelp) ? __expf(mh[q] - M) * inv : 0.f;
+                    }
+                    __syncthreads();
+                }
                 for (int idx = tid; idx < MMG_TM * V; idx += NT) {
                     const int m = idx / V, v = idx - m * V;
-                    const float dv = raw_sum(raw0, L.ldV, kp, m, v);
+                    float dv = raw_sum(raw0, L.ldV, kp, m, v);
+                    if (bigD) {
+                        dv *= fac[m];
+                        if (SPLIT) {
+                            const float* cp = tp.cpart + ((size_t)tile_idx * ar.nhelp * MMG_TM + m) * (V + 2) + v;
+                            float pv[15];
+#pragma unroll
+                            for (int q = 0; q < 15; ++q) pv[q] = cp[(size_t)min(q, ar.nhelp - 1) * MMG_TM * (V + 2)];
+#pragma unroll
+                            for (int q = 0; q < 15; ++q) dv = fmaf(pv[q], fac[(q + 1) * MMG_TM + m], dv);     // (weights beyond nhelp are zero)
+                        }
+                    }
                     s_dbar[m * L.ldV + v] = dv;
                     if (misc[TL_LIVE2 + m] != 0.f) tp.dbar[(rowb + b0 + m) * V + v] = dv;
                 }
@@ -822,7 +934,9 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
 #ifdef MMG_TIMING
     if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[5] = (long long)clock64();
 #endif
-    if (persist && threadIdx.x == 0) __hip_atomic_store(pf_ctr(tp, 3, tile_idx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // conversation over
+    if (SPLIT && published > 0)                                         // the helpers' slices of the selected logits are in tape.outp
+        pf_wait(pf_ctr(tp, 2, tile_idx), (uint32_t)(ar.nhelp * published), nullptr, tp.sync);
+    if ((persist || SPLIT) && threadIdx.x == 0) __hip_atomic_store(pf_ctr(tp, 3, tile_idx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // conversation over
     // ---- state hand-over to the next launch of this conversation
     if (tid < nb) {
         tp.tstar[b0 + tid] = (int)misc[TL_TSTAR + tid];
@@ -882,6 +996,79 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_conv_tile(Dims dm, Params P, Tape tp, ConvArgs ar) {
     conv_tile_body<NT, false>(dm, P, tp, ar, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_split: many classes, fewer sample tiles than CUs (BASELINE config 5: 1000 classes; 16 tiles per GPU in the 8-GPU
+// sharding, 128 on one GPU).  The class-dependent part of a step -- logits over D classes (VALU) and the description mixture
+// (softmax . desc) -- is the bulk of the step and is independent per class: the workgroups the tiles leave idle become
+// CLASS HELPERS.  Per step the tile's owner publishes its A tile (4 KB) and row flags, owner and helpers each take a slice of
+// the classes (logits -> tape, slice max / sum of the softmax numerators, unnormalised mixture partial), the helpers publish
+// 16 x (V + 2) floats, and the owner combines the slices like a streaming softmax.  Same counters as k_conv_persist.
+// ---------------------------------------------------------------------------------------------
+struct HelperLds { int A, w2, y, raw, flags, total; };
+__host__ __device__ inline HelperLds helper_lds(const Dims& d, int nw, int per) {
+    HelperLds L; int o = 0;
+    auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };
+    L.A = take(MMG_TM * ld16(d.R)); L.w2 = take(ld16(d.R)); L.y = take(MMG_TM * ld16(per)); L.raw = take(tile_raw_floats_nn(d.V, nw)); L.flags = take(64);
+    L.total = o;
+    return L;
+}
+
+template <int NT>
+__device__ __forceinline__ void class_helper_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int hidx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int nw = NT / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int B = dm.B, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
+    const int b0 = tile * MMG_TM;
+    const int d_lo = min(D, (hidx + 1) * ar.per), Dl = min(ar.per, D - d_lo);
+    const HelperLds L = helper_lds(dm, nw, ar.per);
+    const int ldR = ld16(R), ldY = ld16(ar.per), ldV = ld16(V);
+    float* s_A = smem + L.A; float* s_w2 = smem + L.w2; float* s_y = smem + L.y; float* raw = smem + L.raw; float* flags = smem + L.flags;
+    for (int i = tid; i < L.total; i += NT) smem[i] = 0.f;
+    __syncthreads();
+    for (int r = tid; r < R; r += NT) s_w2[r] = P.p[R_Y2_W][r];
+    const float b2h = P.p[R_Y2_B][0];
+    uint32_t* cA = pf_ctr(tp, 0, tile); uint32_t* cY = pf_ctr(tp, 2, tile); uint32_t* done = pf_ctr(tp, 3, tile);
+    const float* pub = tp.Apub + (size_t)tile * (MMG_TM * R + 32);
+    float* out = tp.cpart + ((size_t)tile * ar.nhelp + hidx) * MMG_TM * (V + 2);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const size_t rowb = (size_t)t * B;
+        if (!pf_wait(cA, (uint32_t)(t + 1), done, tp.sync)) return;
+        batched_for<NT, 2>(MMG_TM * R + 32, [&](int idx) { return pub[idx]; },
+                           [&](int idx, float v) { if (idx < MMG_TM * R) s_A[(idx / R) * ldR + idx % R] = v; else flags[idx - MMG_TM * R] = v; });
+        __syncthreads();
+        if (Dl > 0) {
+            class_logits<NT>(dm, tp, s_A, ldR, s_w2, s_y, ldY, d_lo, Dl, rowb, b0, flags, flags + 16, tid, b2h);
+            __syncthreads();
+            class_softmax_num<NT>(s_y, ldY, Dl, flags + 32, wave, lane);
+            __syncthreads();
+            tgemm_nn_raw(s_y, ldY, ar.desc + (size_t)d_lo * V, V, V, Dl, raw, wave, nw);
+            __syncthreads();
+        }
+        {
+            const int kp = tile_kparts((V + 63) >> 6, nw);
+            for (int idx = tid; idx < MMG_TM * (V + 2); idx += NT) {
+                const int m = idx / (V + 2), v = idx - m * (V + 2);
+                float val;
+                if (v < V) val = Dl > 0 ? raw_sum(raw, ldV, kp, m, v) : 0.f;
+                else if (v == V) val = Dl > 0 ? flags[32 + m] : -3.0e38f;
+                else val = Dl > 0 ? flags[48 + m] : 0.f;
+                st_wt(out + idx, val);
+            }
+        }
+        pf_signal(cY);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_conv_split(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles) {
+    const int blk = blockIdx.x;
+    if (blk < tiles) { conv_tile_body<NT, false, true>(dm, P, tp, ar, blk); return; }
+    const int r = blk - tiles;
+    class_helper_role<NT>(dm, P, tp, ar, r / ar.nhelp, r % ar.nhelp);
 }
 
 // ---------------------------------------------------------------------------------------------

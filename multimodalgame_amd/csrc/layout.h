@@ -90,6 +90,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(CdT, float, 0, 2, R, D, 1)         /* -Cd transposed: class index contiguous (kernels_tile.h, many-class y head) */ \
     X(cy, float, 0, 1, D, 1, 1)          /* b_y2 + sum_r w_y2[r] Cd[d][r]                                              */ \
     X(mstate, float, 0, 1, B, 1, 1)      /* running stop mask m_t between the per-step launches of one conversation */ \
+    X(Apub, float, 0, 2, NTILE, 16 * R + 32, 1)  /* k_conv_split: A tile + row flags published by a tile's owner role       */ \
+    X(cpart, float, 0, 3, NTILE * NHLP, 16, V + 2) /* k_conv_split: per helper: unnormalised mixture partial | slice max | slice sum */ \
     X(gip, float, 0, 3, NS2P, B, 3 * R)  /* per-sender-role partials of the GRU input product (k_conv_persist)           */ \
     X(pflags, uint32_t, 2, 1, 4 * 64 * 64, 1, 1) /* k_conv_persist: per (kind, sample tile) counters, one per 256-byte block */ \
     X(alive, int32_t, 2, 1, T + 2, 1, 1) /* [t]: sample tiles with a live sample when step t starts (kernels_tile.h)  */ \
@@ -185,6 +187,10 @@ struct Tape {
 // small receiver matrices would otherwise be a handful of long-running workgroups
 __host__ __device__ inline int wgrad_nsplit(int TB) { int n = TB / 2048; return TB >= 4096 ? (n > 16 ? 16 : n) : 1; }
 
+// class helpers per sample tile of the many-class forward (k_conv_split): every CU the sample tiles leave idle takes a
+// slice of the classes; 0: no split
+__host__ __device__ inline int split_helpers(int B) { const int tiles = (B + 15) / 16; int nh = 224 / tiles - 1; return nh > 15 ? 15 : (nh < 0 ? 0 : nh); }   // (all roles must be co-resident: margin below the 256 CUs)
+
 // sample slices of the class-side reduction (k_dC_tile): enough workgroups for the chip when there are few class blocks
 __host__ __device__ inline int dc_slices(int B) { return B >= 1024 ? 4 : 1; }
 
@@ -199,9 +205,9 @@ inline TapeLayout tape_layout(const mmg_config& c) {
     L.n = 0;
     const int64_t B = c.batch, D = c.n_classes, F = c.feat_dim, H = c.h_dim, W = c.w_dim, R = c.rec_hidden,
                   V = c.wv_dim, K = c.bas_hidden, T = c.max_exchange, T1 = T + 1,
-                  NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B), NS2P = (W + 31) / 32,
+                  NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B), NS2P = (W + 31) / 32, NTILE = (B + 15) / 16, NHLP = split_helpers((int)B) > 0 ? split_helpers((int)B) : 1,
                   NWP = wgrad_nsplit((int)(T * B)) > 1 ? (int64_t)wgrad_nsplit((int)(T * B)) * (param_layout(c).total + 512 * 64) : 4;
-    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P;
+    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \

@@ -53,6 +53,8 @@ struct mmg_handle {
     int tile_nt, tile_smem;    // threads per tile workgroup, dynamic LDS bytes
     int tile_bwd_smem, send_bwd_smem;
     bool tile_persist;         // the whole conversation as one launch of co-resident roles (k_conv_persist)
+    bool tile_split;           // many classes: idle CUs as class helpers of the sample tiles (k_conv_split)
+    int split_nh, split_per, split_smem;
     int persist_ns1, persist_ns2, persist_smem;
     std::vector<KernelTimer> timers;
     size_t timers_used;
@@ -316,6 +318,17 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         const bool aligned = !(d.H & 3) && !(d.W & 3) && !(d.R & 3) && !(d.V & 3);
         h->tile_ok = aligned && h->tile_smem <= 160 * 1024 && !getenv("MMG_NO_TILE");
         h->tile_force = getenv("MMG_TILE") != nullptr;
+        // many classes and fewer sample tiles than CUs: class helpers (k_conv_split)
+        h->split_nh = split_helpers(d.B);
+        h->split_per = (((d.D + h->split_nh) / (h->split_nh + 1)) + 3) & ~3;
+        h->tile_split = h->tile_ok && !h->tile_ext && d.D * MMG_TM > 8 * 512 && h->split_nh >= 1 && tiles * (1 + h->split_nh) <= 224 &&
+                        !getenv("MMG_NO_SPLIT");
+        if (h->tile_split) {
+            const int a = tile_lds(d, 512 / 64, true, h->split_per).total * 4, b = helper_lds(d, 512 / 64, h->split_per).total * 4;
+            h->split_smem = a > b ? a : b;
+            if (h->split_smem > 160 * 1024) h->tile_split = false;
+            else if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_split<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->split_smem);
+        }
         // per-step sender products as ROLES of one persistent launch when all of them fit on the chip together
         h->persist_ns1 = d.H / 64; h->persist_ns2 = d.W / 32;
         h->tile_persist = h->tile_ok && h->tile_ext && !(d.H % 64) && !(d.W % 32) && tiles <= 64 &&
@@ -466,6 +479,12 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
         else if (h->tile_nt == 512) hipLaunchKernelGGL(k_conv_tile<512>, dim3(tiles), dim3(512), h->tile_smem, st, h->dm, h->P, h->tp, a);
         else hipLaunchKernelGGL(k_conv_tile<256>, dim3(tiles), dim3(256), h->tile_smem, st, h->dm, h->P, h->tp, a);
     };
+    if (h->tile_split) {
+        Scope sc(h, st, "k_conv_split");
+        ar.phases = 3; ar.t_begin = 0; ar.t_end = d.T; ar.nhelp = h->split_nh; ar.per = h->split_per;
+        hipLaunchKernelGGL(k_conv_split<512>, dim3(tiles * (1 + ar.nhelp)), dim3(512), h->split_smem, st, h->dm, h->P, h->tp, ar, tiles);
+        return launch_check("k_conv_split");
+    }
     if (!h->tile_ext) {
         Scope sc(h, st, "k_conv_tile");
         ar.phases = 3; ar.t_begin = 0; ar.t_end = d.T;
