@@ -37,7 +37,7 @@ WORKLOADS = {
     "c2": (C2, 64, "configs[1]: Adaptive 30-class, batch 64 per GPU, max_exchange 10, rec_w_dim 32, img_h_dim 256, rec_hidden 64, "
                    "RMSprop; one bench step = one training minibatch"),
     "c3": (dict(C2, fixed_exchange=True), 64, "configs[2]: Fixed-exchange 30-class, global batch 512 = 64 per GPU on 8 GPUs, max_exchange 10"),
-    "c4": (dict(C2, w_dim=256, h_dim=1024), 64, "configs[3]: Adaptive 30-class, batch 64, rec_w_dim 256 / img_h_dim 1024 (sample-tile MFMA kernels, per-step sender launches)"),
+    "c4": (dict(C2, w_dim=256, h_dim=1024), 64, "configs[3]: Adaptive 30-class, batch 64, rec_w_dim 256 / img_h_dim 1024 (sample-tile MFMA kernels, co-resident receiver / sender roles in one launch)"),
     "c5": (dict(C2, use_binary=False, fixed_exchange=True, n_classes=1000), 256,
            "configs[4]: 1000 classes, continuous messages, global batch 2048 = 256 per GPU on 8 GPUs (sample-tile MFMA kernels)"),
 }
@@ -73,6 +73,8 @@ def algorithmic_work(kernel, d, B, t_steps):
     if kernel == "k_conv_tile":               # sample-tile recurrence on the matrix cores (kernels_tile.h)
         sender = 2 * H * W if H * W < 65536 else 0                      # large sender MLPs run in k_send_s1 / k_send_s2
         return "mfma", 2 * rows * (mac_recv + sender)
+    if kernel in ("k_conv_persist", "k_conv_split"):   # all roles of the conversation in one launch: receiver + whole sender
+        return "mfma", 2 * rows * (mac_recv + 2 * H * W)
     if kernel == "k_send_s1":
         return "mfma", 2 * rows * H * W
     if kernel == "k_send_s2":
