@@ -39,7 +39,7 @@ WORKLOADS = {
     "c3": (dict(C2, fixed_exchange=True), 64, "configs[2]: Fixed-exchange 30-class, global batch 512 = 64 per GPU on 8 GPUs, max_exchange 10"),
     "c4": (dict(C2, w_dim=256, h_dim=1024), 64, "configs[3]: Adaptive 30-class, batch 64, rec_w_dim 256 / img_h_dim 1024 (sample-tile MFMA kernels, co-resident receiver / sender roles in one launch)"),
     "c5": (dict(C2, use_binary=False, fixed_exchange=True, n_classes=1000), 256,
-           "configs[4]: 1000 classes, continuous messages, global batch 2048 = 256 per GPU on 8 GPUs (sample-tile MFMA kernels)"),
+           "configs[4]: 1000 classes, continuous messages, global batch 2048 = 256 per GPU on 8 GPUs (256 samples per GPU: one workgroup per sample; the sample-tile MFMA kernels take over from 1024 samples per GPU, --scaling strong at N=1)"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak

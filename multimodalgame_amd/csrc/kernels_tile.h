@@ -479,14 +479,14 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
     if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[4] = (long long)clock64();
 #endif
     constexpr int nw = NT / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: work-item bookkeeping of the products lives in scalar registers)
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
     const int b0 = tile_idx * MMG_TM, nb = min(MMG_TM, B - b0);
     constexpr bool persist = PERSIST;                   // receiver role of k_conv_persist: sender roles run beside it in this launch
     const bool do_sen = !PERSIST && (ar.phases & 1) != 0;
     const bool binary = dm.use_binary != 0, train = ar.train != 0;
     const bool may_stop = !ar.run_all && !dm.fixed && train;          // a finished tile stops computing
-    const bool bigD = D * MMG_TM > 8 * NT;             // many classes: register-tiled y head, slices, normalisation after the mixture product
+    const bool bigD = !PERSIST && D * MMG_TM > 8 * NT;             // many classes: register-tiled y head, slices, normalisation after the mixture product
     const int Dl = SPLIT ? min(ar.per, D) : D;          // classes of this workgroup's slice [0, Dl) (class helpers take the rest)
     const TileLds L = tile_lds(dm, nw, do_sen, SPLIT ? ar.per : 0);
     float* s_a = smem + L.a; float* s_c = smem + L.c; float* s_z = smem + L.z; float* s_pz = smem + L.pz;
@@ -611,6 +611,7 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                 if ((j ? j1.nn : j0.nn)) tgemm_nn_raw(jA, jlda, jW, jldw, jN, jK, jr, wave, nw);
                 else tgemm_nt_raw(jA, jlda, jW, jldw, jN, jK, jr, wave, nw);
             }
+            MMG_TSTAMP(16 + 16 * (t - t0) + ph);
             if (ph == 2 && binary && tid < 256) {                        // log-likelihood / neg-entropy of the sender's bits, model.py:908-922
                 const int m = tid >> 4, l16 = tid & 15;
                 float lpv = 0.f, nev = 0.f;
@@ -1134,6 +1135,8 @@ __device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const T
     constexpr int UW = 8;                                               // message elements per thread (host: 16 * W <= UW * NT)
     for (int t = 0; t <= T; ++t) {
         const size_t rowb = (size_t)t * B, rowp = (size_t)(t > 0 ? t - 1 : 0) * B;
+        int tid = threadIdx.x;                                          // (opaque per step: keeps the index arithmetic of the
+        asm volatile("" : "+v"(tid));                                   //  epilogues from being hoisted out of the step loop)
         if (t >= 1) {
             // ---- the receiver's message of step t-1 (model.py:454-475), recomputed identically by every S1 role of the tile.
             // The uniforms of its Bernoulli draws do not depend on anything this step computes: drawn BEFORE the wait.
@@ -1450,22 +1453,19 @@ __host__ __device__ inline BwdLds bwd_tile_lds(const Dims& d, int nw) {
     L.ldW = ld16(d.W); L.ldR = ld16(d.R); L.ld3R = ld16(3 * d.R); L.ldD = ((d.D + 31) & ~31) + 4;      // (dA streams classes 32 at a time)
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };
-    L.dh = take(MMG_TM * L.ldR); L.dlw = take(MMG_TM * L.ldW); L.dgp = take(MMG_TM * L.ldR); L.dgh = take(MMG_TM * L.ld3R);
+    L.dh = take(MMG_TM * L.ldR); L.dlw = -1; L.dgp = -1; L.dgh = take(MMG_TM * L.ld3R);
     L.dAm = take(MMG_TM * L.ldR); L.dA = take(MMG_TM * L.ldR); L.A = take(MMG_TM * L.ldR); L.hs = take(MMG_TM * L.ldR);
-    L.ws = take(L.ldR); L.w2 = take(L.ldR); L.coef = take(7 * 64);
+    L.ws = take(L.ldR); L.w2 = take(L.ldR); L.coef = -1;
     const int r = tile_raw_floats_nn(d.R, nw) > tile_raw_floats(d.R, nw) ? tile_raw_floats_nn(d.R, nw) : tile_raw_floats(d.R, nw);
     L.raw0 = take(r); L.raw1 = take(r);
     L.misc = take(128);
-    // the dy tile (output-step prelude only) shares its space with the copy of W_hh used by the time loop; the other
-    // matrices are cached while the 160 KB last (the transposed products then read no weight from L2)
+    // the dy tile (output-step prelude only) shares its space with the [K][N + 4] copy of W_hh the time loop multiplies by
     const int stride = d.R + 4, budget = 160 * 256 - 64;
     const int dysz = MMG_TM * L.ldD, hhsz = 3 * d.R * stride;
     L.whh = -1; L.wh = -1; L.wy1 = -1; L.ww = -1;
     const bool hh = o + (dysz > hhsz ? dysz : hhsz) <= budget;
     L.dy = take(hh ? (dysz > hhsz ? dysz : hhsz) : dysz);
     if (hh) L.whh = L.dy;
-    if (o + 2 * d.R * stride <= budget) { L.wh = take(d.R * stride); L.wy1 = take(d.R * stride); }
-    if (d.use_binary && o + d.W * stride <= budget) L.ww = take(d.W * stride);
     L.total = o;
     return L;
 }
@@ -1474,8 +1474,8 @@ __host__ __device__ inline BwdLds bwd_tile_lds(const Dims& d, int nw) {
 #define BL_DLS 32
 #define BL_LIVE 48
 
-// UWP / URP: forward-tape values a thread prefetches per step: 16 * W <= UWP * NT, 16 * R <= URP * NT (host picks the smallest instantiation)
-template <int NT, int UWP, int URP>
+// URP: forward-tape values a thread prefetches per step: 16 * R <= URP * NT (host picks the smallest instantiation)
+template <int NT, int URP>
 __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int zero_dead, int make_map) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     MMG_RSTAMP(blockIdx.x == 0, 224);
@@ -1484,10 +1484,9 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
     const int b0 = blockIdx.x * MMG_TM, nb = min(MMG_TM, B - b0);
     const bool binary = dm.use_binary != 0;
     const BwdLds L = bwd_tile_lds(dm, nw);
-    float* s_dh = smem + L.dh; float* s_dlw = smem + L.dlw; float* s_dgp = smem + L.dgp; float* s_dgh = smem + L.dgh;
+    float* s_dh = smem + L.dh; float* s_dgh = smem + L.dgh;
     float* s_dAm = smem + L.dAm; float* s_dA = smem + L.dA; float* s_A = smem + L.A; float* s_hs = smem + L.hs; float* s_dy = smem + L.dy;
     float* s_ws = smem + L.ws; float* s_w2 = smem + L.w2; float* raw0 = smem + L.raw0; float* raw1 = smem + L.raw1; float* misc = smem + L.misc;
-    LossCoef lc; lc.cw = smem + L.coef; lc.ce = lc.cw + 3 * T; lc.cb = lc.cw + 6 * T;
     {
         const int tid = threadIdx.x;
         for (int i = tid; i < L.total; i += NT) smem[i] = 0.f;
@@ -1500,7 +1499,7 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
         }
         for (int r = tid; r < R; r += NT) { s_ws[r] = P.p[R_S_W][r]; s_w2[r] = P.p[R_Y2_W][r]; }
     }
-    loss_coefficients(dm, tp.stats, lc, nullptr, nullptr);                  // (ends with a barrier)
+    __syncthreads();
     MMG_RSTAMP(blockIdx.x == 0, 225);
     int tmax = 0;
     for (int m = 0; m < nb; ++m) tmax = max(tmax, (int)misc[BL_TSTAR + m]);
@@ -1621,158 +1620,170 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
     }
 
     MMG_RSTAMP(blockIdx.x == 0, 228);
-    // ---------------- weight cache: [K][N + 4] copies of the matrices of the transposed products (dy is dead now)
+    // ---------------- dAy = dA W_y1h: enters dh once, at the sample's output step (one product per tile, not one per step)
     {
-        const int tid = threadIdx.x, stride = R + 4;
-        auto cache = [&](int off, const float* src, int rows, int ld) {
-            if (off < 0) return;
-            const int n4 = R >> 2;
-            batched_for<NT, 8>(rows * n4, [&](int idx) { const int k = idx / n4, q = idx - k * n4; return *reinterpret_cast<const float4*>(src + (size_t)k * ld + 4 * q); },
-                               [&](int idx, float4 v) { const int k = idx / n4, q = idx - k * n4; *reinterpret_cast<float4*>(smem + off + k * stride + 4 * q) = v; });
-        };
-        cache(L.whh, P.p[R_WHH], 3 * R, R); cache(L.wh, P.p[R_WH_W], R, R); cache(L.wy1, P.p[R_Y1_W], R, R + V); cache(L.ww, P.p[R_W_W], W, R);
-        (void)tid;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        tgemm_nn_raw(s_dA, L.ldR, P.p[R_Y1_W], R + V, R, R, raw0, wave, nw);
+        __syncthreads();
+        const int kp = tile_kparts((R + 63) >> 6, nw);
+        for (int idx = tid; idx < MMG_TM * R; idx += NT) {
+            const int m = idx / R, i = idx - m * R;
+            s_dAm[m * L.ldR + i] = raw_sum(raw0, L.ldR, kp, m, i);
+        }
+        __syncthreads();
+    }
+    // ---------------- W_hh in [K][N + 4] layout in LDS (the dy tile is dead now): the loop's only product reads no weight from L2
+    if (L.whh >= 0) {
+        const int stride = R + 4, n4 = R >> 2;
+        batched_for<NT, 8>(3 * R * n4, [&](int idx) { const int k = idx / n4, q = idx - k * n4; return *reinterpret_cast<const float4*>(P.p[R_WHH] + (size_t)k * R + 4 * q); },
+                           [&](int idx, float4 v) { const int k = idx / n4, q = idx - k * n4; *reinterpret_cast<float4*>(smem + L.whh + k * stride + 4 * q) = v; });
         __syncthreads();
     }
     MMG_RSTAMP(blockIdx.x == 0, 229);
-    // ---------------- reverse time
-    struct Job { const float* A; const float* Wm; float* raw; int lda, ldw, N, K, lds; };
+    // ---------------- reverse time.  Everything that does not depend on the carried dh was formed for all (step, sample)
+    // rows by k_bwd_pre (dhin = dgpre W_h + dls w_s); a step is: [dh, GRU cell backward] barrier [dgh W_hh] barrier.
+    bool have_prod = false;                                             // raw0 holds dgh_{t+1} W_hh
     for (int t = zero_dead ? T - 1 : tmax; t >= 0; --t) {
         const size_t rowb = (size_t)t * B;
-        // ---- this step's forward tape, ONE round trip for all phases: message bits and probabilities, g, GRU gates, h_{t-1}
-        float fw[UWP], fpw[UWP], fg[URP], fru[URP][4], fh[URP], fsc[4];
-        {
-            const int tid0 = threadIdx.x;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        MMG_RSTAMP(blockIdx.x == 0 && t < 4, 232 + 4 * t);
+        // ---- this step's forward tape (GRU gates, h_{t-1}) and dhin, ONE round trip
+        float fru[URP][4], fh[URP], fin[URP];
 #pragma unroll
-            for (int u = 0; u < UWP; ++u) {
-                const int idx = min(tid0 + u * NT, MMG_TM * W - 1), m = idx / W, j = idx - m * W;
-                const size_t o = (rowb + min(b0 + m, B - 1)) * W + j;
-                fw[u] = binary ? tp.w[o] : 0.f; fpw[u] = binary ? tp.pw[o] : 0.f;
-            }
+        for (int u = 0; u < URP; ++u) {
+            const int idx = min(tid + u * NT, MMG_TM * R - 1), m = idx / R, i = idx - m * R, b = min(b0 + m, B - 1);
+            const float* gr = tp.gru + (rowb + b) * 4 * R;
+            fru[u][0] = gr[i]; fru[u][1] = gr[R + i]; fru[u][2] = gr[2 * R + i]; fru[u][3] = gr[3 * R + i];
+            fh[u] = tp.h[(rowb + b) * R + i];
+            fin[u] = binary ? tp.dhin[(rowb + b) * R + i] : 0.f;
+        }
+        {
+            // dh_t = dh_{t+1} u_{t+1} + dgh_{t+1} W_hh + dhin_t (+ dAy at the output step); GRU cell backward (model.py:340)
+            const int kp = tile_kparts((R + 63) >> 6, nw);
 #pragma unroll
             for (int u = 0; u < URP; ++u) {
-                const int idx = min(tid0 + u * NT, MMG_TM * R - 1), m = idx / R, i = idx - m * R, b = min(b0 + m, B - 1);
-                const float* gr = tp.gru + (rowb + b) * 4 * R;
-                fg[u] = binary ? tp.g[(rowb + b) * R + i] : 0.f;
-                fru[u][0] = gr[i]; fru[u][1] = gr[R + i]; fru[u][2] = gr[2 * R + i]; fru[u][3] = gr[3 * R + i];
-                fh[u] = tp.h[(rowb + b) * R + i];
-            }
-            const size_t ob = rowb + min(b0 + min(tid0, MMG_TM - 1), B - 1);
-            fsc[0] = binary ? tp.br[ob] : 0.f; fsc[1] = binary ? tp.bs[ob] : 0.f;
-            fsc[2] = (binary && !dm.fixed) ? tp.s[ob] : 0.f; fsc[3] = (binary && !dm.fixed) ? tp.ps[ob] : 0.5f;
-        }
-        for (int ph = 0; ph < 4; ++ph) {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            MMG_RSTAMP(blockIdx.x == 0 && t < 4, 232 + 4 * t + ph);
-            // ---------------- epilogue of the previous product / seeds
-            if (ph == 0) {
-                if (tid < MMG_TM) {
-                    const int m = tid;
-                    const bool live = (float)t <= misc[BL_TSTAR + m];
-                    misc[BL_LIVE + m] = live ? 1.f : 0.f;
-                    float dls = 0.f, dbs = 0.f, dbr = 0.f;
-                    if (binary && live) {
-                        const float Lr = misc[BL_L + m];
-                        if (!dm.fixed) dls = bit_seed_fast(fsc[2], fsc[3], (Lr - fsc[0]) * lc.cw[t], lc.ce[t]);
-                        dbs = lc.cb[t] * (fsc[1] - Lr); dbr = lc.cb[t] * (fsc[0] - Lr);      // MSE seeds, model.py:971-988
-                    }
-                    misc[BL_DLS + m] = dls;
-                    misc[64 + m] = fsc[0];                                     // baseline_rec score of the row (message seeds below)
-                    if (binary && m < nb && (live || zero_dead)) { tp.dls[rowb + b0 + m] = dls; tp.dbs[rowb + b0 + m] = dbs; tp.dbr[rowb + b0 + m] = dbr; }
-                }
-                for (int idx = tid; idx < MMG_TM * R; idx += NT) {          // dA enters at the sample's output step
-                    const int m = idx / R, r = idx - m * R;
-                    s_dAm[m * L.ldR + r] = ((float)t == misc[BL_TSTAR + m]) ? s_dA[m * L.ldR + r] : 0.f;
-                }
-                __syncthreads();
-                // seeds of the receiver-message stream (active while m_{t+1} == 1, i.e. t < t*)
-                if (binary) {
-#pragma unroll
-                    for (int u = 0; u < UWP; ++u) {
-                        const int idx = tid + u * NT;
-                        if (idx < MMG_TM * W) {
-                            const int m = idx / W, j = idx - m * W;
-                            const bool act = (float)t < misc[BL_TSTAR + m];
-                            float sv = 0.f;
-                            if (act) sv = bit_seed_fast(fw[u], fpw[u], (misc[BL_L + m] - misc[64 + m]) * lc.cw[T + t], lc.ce[T + t]);
-                            s_dlw[m * L.ldW + j] = sv;
-                            if (m < nb && (zero_dead || (float)t <= misc[BL_TSTAR + m])) tp.dlw[(rowb + b0 + m) * W + j] = sv;
-                        }
-                    }
-                }
-            } else if (ph == 1) {
-                if (binary) {                                                // dgpre = (dlw W_w) (1 - g^2)
-                    const int kp = tile_kparts((R + 63) >> 6, nw);
-#pragma unroll
-                    for (int u = 0; u < URP; ++u) {
-                        const int idx = tid + u * NT;
-                        if (idx < MMG_TM * R) {
-                            const int m = idx / R, r = idx - m * R;
-                            const bool act = (float)t < misc[BL_TSTAR + m];
-                            const float v = act ? raw_sum(raw0, L.ldR, kp, m, r) * (1.f - fg[u] * fg[u]) : 0.f;
-                            s_dgp[m * L.ldR + r] = v;
-                            if (m < nb && (zero_dead || (float)t <= misc[BL_TSTAR + m])) tp.dgpre[(rowb + b0 + m) * R + r] = v;
-                        }
-                    }
-                }
-            } else if (ph == 2) {
-                // dh += dgpre W_h + dA W_y1h + dls w_s ; GRU cell backward (model.py:340)
-                const int kp = tile_kparts((R + 63) >> 6, nw);
-#pragma unroll
-                for (int u = 0; u < URP; ++u) {
-                    const int idx = tid + u * NT;
-                    if (idx < MMG_TM * R) {
-                        const int m = idx / R, i = idx - m * R;
-                        const bool live = misc[BL_LIVE + m] != 0.f;
-                        const float rr = fru[u][0], uu = fru[u][1], nn = fru[u][2], ghn = fru[u][3];
-                        float dh = s_dh[m * L.ldR + i] + raw_sum(raw1, L.ldR, kp, m, i) + misc[BL_DLS + m] * s_ws[i];
-                        if (binary) dh += raw_sum(raw0, L.ldR, kp, m, i);
-                        if (!live) dh = 0.f;
-                        const float dn = dh * (1.f - uu), du = dh * (fh[u] - nn);
-                        const float dnp = dn * (1.f - nn * nn), dup = du * uu * (1.f - uu);
-                        const float drp = dnp * ghn * rr * (1.f - rr);
-                        float* dg = s_dgh + m * L.ld3R;
-                        dg[i] = drp; dg[R + i] = dup; dg[2 * R + i] = dnp * rr;
-                        s_dh[m * L.ldR + i] = dh * uu;
-                        if (m < nb && (live || zero_dead)) {
-                            float* gi = tp.dgi + (rowb + b0 + m) * 3 * R; float* gh = tp.dgh + (rowb + b0 + m) * 3 * R;
-                            gi[i] = drp; gi[R + i] = dup; gi[2 * R + i] = dnp;
-                            gh[i] = drp; gh[R + i] = dup; gh[2 * R + i] = dnp * rr;
-                        }
-                    }
-                }
-            } else {
-                const int kp = tile_kparts((R + 63) >> 6, nw);
-                for (int idx = tid; idx < MMG_TM * R; idx += NT) {          // dh_{t-1} = dh u + dgh W_hh
+                const int idx = tid + u * NT;
+                if (idx < MMG_TM * R) {
                     const int m = idx / R, i = idx - m * R;
-                    s_dh[m * L.ldR + i] += raw_sum(raw0, L.ldR, kp, m, i);
+                    const float ts = misc[BL_TSTAR + m];
+                    const bool live = (float)t <= ts;
+                    const float rr = fru[u][0], uu = fru[u][1], nn = fru[u][2], ghn = fru[u][3];
+                    float dh = s_dh[m * L.ldR + i] + (have_prod ? raw_sum(raw0, L.ldR, kp, m, i) : 0.f);
+                    dh += ((float)t == ts) ? s_dAm[m * L.ldR + i] : 0.f;
+                    dh += (binary && live) ? fin[u] : 0.f;              // (rows of steps a sample never took hold no dhin)
+                    if (!live) dh = 0.f;
+                    const float dn = dh * (1.f - uu), du = dh * (fh[u] - nn);
+                    const float dnp = dn * (1.f - nn * nn), dup = du * uu * (1.f - uu);
+                    const float drp = dnp * ghn * rr * (1.f - rr);
+                    float* dg = s_dgh + m * L.ld3R;
+                    dg[i] = live ? drp : 0.f; dg[R + i] = live ? dup : 0.f; dg[2 * R + i] = live ? dnp * rr : 0.f;
+                    s_dh[m * L.ldR + i] = live ? dh * uu : 0.f;
+                    if (m < nb && (live || zero_dead)) {
+                        float* gi = tp.dgi + (rowb + b0 + m) * 3 * R; float* gh = tp.dgh + (rowb + b0 + m) * 3 * R;
+                        gi[i] = live ? drp : 0.f; gi[R + i] = live ? dup : 0.f; gi[2 * R + i] = live ? dnp : 0.f;
+                        gh[i] = live ? drp : 0.f; gh[R + i] = live ? dup : 0.f; gh[2 * R + i] = live ? dnp * rr : 0.f;
+                    }
                 }
             }
-            __syncthreads();
-            // ---------------- products feeding the next phase (weights from their LDS copies where cached)
-            Job j0, j1;
-            int nj = 0;
-            auto add = [&](const float* A, int lda, int cached, const float* Wm, int ldw, int N, int K, float* raw) {
-                Job& J = nj ? j1 : j0;
-                J.A = A; J.lda = lda; J.N = N; J.K = K; J.raw = raw; J.lds = cached >= 0;
-                J.Wm = cached >= 0 ? smem + cached : Wm; J.ldw = cached >= 0 ? R + 4 : ldw; ++nj;
-            };
-            if (ph == 0) { if (binary) add(s_dlw, L.ldW, L.ww, P.p[R_W_W], R, R, W, raw0); }
-            else if (ph == 1) { if (binary) add(s_dgp, L.ldR, L.wh, P.p[R_WH_W], R, R, R, raw0); add(s_dAm, L.ldR, L.wy1, P.p[R_Y1_W], R + V, R, R, raw1); }
-            else if (ph == 2) add(s_dgh, L.ld3R, L.whh, P.p[R_WHH], R, R, 3 * R, raw0);
-            for (int j = 0; j < nj; ++j) {
-                const float* jA = j ? j1.A : j0.A; float* jr = j ? j1.raw : j0.raw;
-                const int jlda = j ? j1.lda : j0.lda, jldw = j ? j1.ldw : j0.ldw, jN = j ? j1.N : j0.N, jK = j ? j1.K : j0.K;
-                if (j ? j1.lds : j0.lds) {
-                    const int off = (int)((j ? j1.Wm : j0.Wm) - smem);        // (an LDS address: its own copy of the product code, ds_read operands)
-                    tgemm_nn_raw(jA, jlda, smem + off, jldw, jN, jK, jr, wave, nw);
-                } else tgemm_nn_raw(jA, jlda, j ? j1.Wm : j0.Wm, jldw, jN, jK, jr, wave, nw);
-            }
+        }
+        __syncthreads();
+        MMG_RSTAMP(blockIdx.x == 0 && t < 4, 232 + 4 * t + 1);
+        if (t > 0) {                                                    // dh_{t-1} receives dgh W_hh
+            if (L.whh >= 0) tgemm_nn_raw(s_dgh, L.ld3R, smem + L.whh, R + 4, R, 3 * R, raw0, wave, nw);
+            else tgemm_nn_raw(s_dgh, L.ld3R, P.p[R_WHH], R, R, 3 * R, raw0, wave, nw);
+            have_prod = true;
             __syncthreads();
         }
     }
     MMG_RSTAMP(blockIdx.x == 0, 230);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bwd_pre (binary mode): the part of the receiver's BPTT that does NOT depend on the carried dh, for all (step, sample)
+// rows at once instead of inside the reverse-time loop of k_bwd_tile -- REINFORCE / entropy seeds of the stop bit and the
+// receiver's message (App. A.4), MSE seeds of the baselines (model.py:971-988), dgpre = (dlw W_w)(1 - g^2) and
+//   dhin = dgpre W_h + dls w_s        (what step t adds to dh besides the recurrence and the output-step term)
+// grid = T x ceil(B/16): a workgroup owns 16 samples of one step.  Rows of steps a sample never took: skipped (live-row
+// contract) or zero-filled (zero_dead).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int bwd_pre_lds_floats(const Dims& d) {
+    return MMG_TM * ld16(d.W) + MMG_TM * ld16(d.R) + tile_raw_floats_nn(d.R, MMG_BLOCK / 64) + 7 * 64 + 64 + ld16(d.R);
+}
+__global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre(Dims dm, Params P, Tape tp, int zero_dead) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = MMG_BLOCK, nw = NT / 64;
+    const int B = dm.B, W = dm.W, R = dm.R, T = dm.T;
+    const int ldW = ld16(W), ldR = ld16(R);
+    const int tiles = (B + MMG_TM - 1) / MMG_TM;
+    const int t = (int)blockIdx.x / tiles, b0 = ((int)blockIdx.x - t * tiles) * MMG_TM, nb = min(MMG_TM, B - b0);
+    float* s_dlw = smem; float* s_dgp = s_dlw + MMG_TM * ldW; float* raw = s_dgp + MMG_TM * ldR;
+    float* s_coef = raw + tile_raw_floats_nn(R, nw); float* misc = s_coef + 7 * 64; float* s_ws = misc + 64;
+    // misc: [0,16) t*   [16,32) reward L   [32,48) baseline_rec score of the row   [48,64) dls
+    LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const size_t rowb = (size_t)t * B;
+    for (int i = tid; i < MMG_TM * (ldW + ldR); i += NT) smem[i] = 0.f;
+    if (tid < MMG_TM) {
+        const int b = min(b0 + tid, B - 1);
+        misc[tid] = (tid < nb) ? (float)tp.tstar[b] : -1.f;
+        misc[16 + tid] = tp.logs[b];
+    }
+    for (int r = tid; r < ldR; r += NT) s_ws[r] = r < R ? P.p[R_S_W][r] : 0.f;
+    loss_coefficients(dm, tp.stats, lc, nullptr, nullptr);                  // (ends with a barrier)
+    bool any = false;
+    for (int m = 0; m < nb; ++m) any = any || ((float)t <= misc[m]);
+    if (!any && !zero_dead) return;
+    if (tid < MMG_TM) {
+        const int m = tid;
+        const bool live = (float)t <= misc[m];
+        const size_t ob = rowb + min(b0 + m, B - 1);
+        const float br = tp.br[ob], bs = tp.bs[ob];
+        const float sb = dm.fixed ? 0.f : tp.s[ob], ps = dm.fixed ? 0.5f : tp.ps[ob];
+        float dls = 0.f, dbs = 0.f, dbr = 0.f;
+        if (live) {
+            const float Lr = misc[16 + m];
+            if (!dm.fixed) dls = bit_seed_fast(sb, ps, (Lr - br) * lc.cw[t], lc.ce[t]);
+            dbs = lc.cb[t] * (bs - Lr); dbr = lc.cb[t] * (br - Lr);              // MSE seeds, model.py:971-988
+        }
+        misc[32 + m] = br; misc[48 + m] = dls;
+        if (m < nb && (live || zero_dead)) { tp.dls[rowb + b0 + m] = dls; tp.dbs[rowb + b0 + m] = dbs; tp.dbr[rowb + b0 + m] = dbr; }
+    }
+    __syncthreads();
+    // seeds of the receiver-message stream (active while m_{t+1} == 1, i.e. t < t*)
+    batched_for<NT, 4>(MMG_TM * W, [&](int idx) {
+            const int m = idx / W, j = idx - m * W;
+            const size_t o = (rowb + min(b0 + m, B - 1)) * W + j;
+            return F2{tp.w[o], tp.pw[o]};
+        }, [&](int idx, F2 v) {
+            const int m = idx / W, j = idx - m * W;
+            const bool act = (float)t < misc[m];
+            const float sv = act ? bit_seed_fast(v.x, v.y, (misc[16 + m] - misc[32 + m]) * lc.cw[T + t], lc.ce[T + t]) : 0.f;
+            s_dlw[m * ldW + j] = sv;
+            if (m < nb && (zero_dead || (float)t <= misc[m])) tp.dlw[(rowb + b0 + m) * W + j] = sv;
+        });
+    __syncthreads();
+    tgemm_nn_raw(s_dlw, ldW, P.p[R_W_W], R, R, W, raw, wave, nw);            // dg = dlw W_w
+    __syncthreads();
+    const int kp = tile_kparts((R + 63) >> 6, nw);
+    batched_for<NT, 4>(MMG_TM * R, [&](int idx) {
+            const int m = idx / R, r = idx - m * R;
+            return tp.g[(rowb + min(b0 + m, B - 1)) * R + r];
+        }, [&](int idx, float g) {
+            const int m = idx / R, r = idx - m * R;
+            const bool act = (float)t < misc[m];
+            const float v = act ? raw_sum(raw, ldR, kp, m, r) * (1.f - g * g) : 0.f;
+            s_dgp[m * ldR + r] = v;
+            if (m < nb && (zero_dead || (float)t <= misc[m])) tp.dgpre[(rowb + b0 + m) * R + r] = v;
+        });
+    __syncthreads();
+    tgemm_nn_raw(s_dgp, ldR, P.p[R_WH_W], R, R, R, raw, wave, nw);            // dgpre W_h
+    __syncthreads();
+    for (int idx = tid; idx < MMG_TM * R; idx += NT) {
+        const int m = idx / R, i = idx - m * R;
+        if (m < nb && (float)t <= misc[m]) tp.dhin[(rowb + b0 + m) * R + i] = raw_sum(raw, ldR, kp, m, i) + misc[48 + m] * s_ws[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

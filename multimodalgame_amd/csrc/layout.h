@@ -150,6 +150,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(dls, float, 0, 2, T, B, 1)         /* dL/d stop logit                        */ \
     X(dlw, float, 0, 3, T, B, W)         /* dL/d receiver message logits           */ \
     X(dgpre, float, 0, 3, T, B, R)       /* dL/d pre-tanh of h_w                   */ \
+    X(dhin, float, 0, 3, T, B, R)        /* dgpre W_h + dls w_s: what a step adds to dh besides the recurrence (k_bwd_pre) */ \
     X(dgi, float, 0, 3, T, B, 3 * R)     /* dL/d GRU input-side gate pre-acts      */ \
     X(dgh, float, 0, 3, T, B, 3 * R)     /* dL/d GRU hidden-side gate pre-acts     */ \
     X(dA, float, 0, 2, B, R, 1)          /* dL/d (W_y1h h) at t*                   */ \

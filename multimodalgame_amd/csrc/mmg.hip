@@ -318,6 +318,10 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         const bool aligned = !(d.H & 3) && !(d.W & 3) && !(d.R & 3) && !(d.V & 3);
         h->tile_ok = aligned && h->tile_smem <= 160 * 1024 && !getenv("MMG_NO_TILE");
         h->tile_force = getenv("MMG_TILE") != nullptr;
+        // many classes, small agents, fewer than 64 tiles: a workgroup per SAMPLE fills the chip (256 samples = 256 CUs) and
+        // beats 16 tiles + class helpers (measured at D = 1000, B = 256: 557 us against 1 010 us per minibatch; B = 2048:
+        // 2 091 against 1 189) -- the tile kernels take over from 1024 samples (MMG_TILE=1: always)
+        if (h->tile_ok && !h->tile_force && !h->tile_ext && d.D * MMG_TM > 8 * 512 && d.B < 1024) h->tile_ok = false;
         // many classes and fewer sample tiles than CUs: class helpers (k_conv_split)
         h->split_nh = split_helpers(d.B);
         h->split_per = (((d.D + h->split_nh) / (h->split_nh + 1)) + 3) & ~3;
@@ -341,13 +345,14 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         }
         h->tile_bwd_smem = bwd_tile_lds(d, 512 / 64).total * 4;
         h->send_bwd_smem = (MMG_TM * ld16(d.W) + 7 * 64 + 16 + tile_raw_floats_nn(64, MMG_BLOCK / 64)) * 4;
-        if (h->tile_bwd_smem > 160 * 1024 || d.W > 256 || d.R > 128) h->tile_ok = false;     // (k_bwd_tile keeps a step's forward tape in 8 + 4 registers per thread)
+        if (h->tile_bwd_smem > 160 * 1024 || d.W > 256 || d.R > 128) h->tile_ok = false;     // (k_bwd_tile keeps a step's GRU tape in 4 registers per thread per 32 hidden units)
         if (h->tile_ok && e == hipSuccess && h->tile_bwd_smem > 48 * 1024)
         {
-            e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
+            e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
         }
+        if (h->tile_ok && e == hipSuccess && bwd_pre_lds_floats(d) * 4 > 48 * 1024)
+            e = hipFuncSetAttribute((const void*)k_bwd_pre, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_pre_lds_floats(d) * 4);
         if (h->tile_ok && e == hipSuccess && h->send_bwd_smem > 48 * 1024)
             e = hipFuncSetAttribute((const void*)k_send_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, h->send_bwd_smem);
         if (h->tile_ok && h->tile_smem > 48 * 1024) {
@@ -597,12 +602,13 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         const int tiles = (d.B + MMG_TM - 1) / MMG_TM;
         {
             Scope sc(h, st, "k_bwd_tile");
-            if (d.W <= 32 && d.R <= 64)
-                hipLaunchKernelGGL((k_bwd_tile<512, 1, 2>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
-            else if (d.R <= 64)
-                hipLaunchKernelGGL((k_bwd_tile<512, 8, 2>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+            // the dh-independent part of the receiver's BPTT (seeds, dgpre, dhin) for all (step, sample) rows, then the recurrence
+            if (d.use_binary)
+                hipLaunchKernelGGL(k_bwd_pre, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
+            if (d.R <= 64)
+                hipLaunchKernelGGL((k_bwd_tile<512, 2>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             else
-                hipLaunchKernelGGL((k_bwd_tile<512, 8, 4>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+                hipLaunchKernelGGL((k_bwd_tile<512, 4>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             if (launch_check("k_bwd_tile")) return -1;
         }
         if (d.use_binary) {

@@ -30,7 +30,9 @@ for st in range(10):
     for k in range(1, 8):
         if dbg[base + k] == 0: break
         if dbg[base + k] < dbg[base + k - 1]: break
-        parts.append("%s %.2f" % (names[k - 1], (dbg[base + k] - dbg[base + k - 1]) * tick / 1e3))
+        mid = dbg[base + 8 + k - 1]          # after the products of the phase, before its barrier
+        parts.append("%s %.2f (prod %.2f)" % (names[k - 1], (dbg[base + k] - dbg[base + k - 1]) * tick / 1e3,
+                                             (mid - dbg[base + k - 1]) * tick / 1e3 if mid else -1.0))
     print("step %d: " % st + " | ".join(parts))
 
 if dbg[200]:
@@ -43,10 +45,10 @@ if dbg[200]:
 
 if dbg[224]:
     us = lambda a, b: (dbg[b] - dbg[a]) * tick / 1e3
-    print("k_bwd_tile: init+coef %.2f | dy+h* %.2f | dyT+A* %.2f | dA %.2f | weight cache %.2f | loop %.2f" % (
+    print("k_bwd_tile: init %.2f | dy+h* %.2f | dyT+A* %.2f | dA %.2f | dAy + W_hh cache %.2f | loop %.2f" % (
         us(224, 225), us(225, 226), us(226, 227), us(227, 228), us(228, 229), us(229, 230)))
     for t in range(3, -1, -1):
         b = 232 + 4 * t
-        if dbg[b] and dbg[b + 3] > dbg[b]:
+        if dbg[b] and dbg[b + 1] > dbg[b]:
             nxt = dbg[232 + 4 * (t - 1)] if t > 0 else dbg[230]
-            print("  bwd step %d: ph0 %.2f ph1 %.2f ph2 %.2f ph3+prefetch %.2f" % (t, us(b, b + 1), us(b + 1, b + 2), us(b + 2, b + 3), (nxt - dbg[b + 3]) * tick / 1e3))
+            print("  bwd step %d: prefetch + cell backward %.2f | dgh W_hh %.2f" % (t, us(b, b + 1), (nxt - dbg[b + 1]) * tick / 1e3))

@@ -45,9 +45,14 @@ def test_config4_shape_vs_oracle():
     _compare(_meta(C4, 30, 64, 2), skip=("y2.bias",), label="config4")
 
 
-def test_config5_flavour_vs_oracle():
-    """1000 classes, continuous messages, Fixed (configs[4]) at a batch the oracle can afford."""
-    _compare(_meta(C5, 1000, 128, 2), skip=("y2.bias", ".bs", ".br"), label="config5")
+@pytest.mark.parametrize("kernels", ["default", "tile"])
+def test_config5_flavour_vs_oracle(kernels, monkeypatch):
+    """1000 classes, continuous messages, Fixed (configs[4]) at a batch the oracle can afford.  At this size the library
+    picks the per-sample kernels; "tile" forces the sample-tile kernels with class helpers (k_conv_split) the full-size
+    configuration runs on."""
+    if kernels == "tile":
+        monkeypatch.setenv("MMG_TILE", "1")
+    _compare(_meta(C5, 1000, 128, 2), skip=("y2.bias", ".bs", ".br"), label="config5-" + kernels)
 
 
 def test_config5_full_size_properties():
