@@ -67,7 +67,8 @@ namespace mmg {
 // ---------------------------------------------------------------------------------------------
 // k_bwd_conv_fast: reverse-time pass of one sample with the TRANSPOSED weight fragments the
 // recurrence needs resident in registers (w^T: 8, w_h^T: 16, W_hh^T: 48, binary_layer^T: 32 per lane).
-// Same math, tape contract and zero-filling as k_bwd_conv (kernels_bwd.h); 5 barriers per step.
+// Same math, tape contract and zero-filling as k_bwd_conv (kernels_bwd.h).  The dh-independent work of all steps runs in
+// three sweeps before the recurrence; a reverse step is two phases (cell backward | W_hh^T dgh).
 // ---------------------------------------------------------------------------------------------
 // MERGED: the grid starts with `n_stats` one-wave statistics roles (k_stats' pairs); the sample roles load their
 // weights and forward tape while those run and wait for them right before the loss coefficients (device_utils.h).
@@ -82,14 +83,16 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     constexpr int TMAX = 16;
     static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
     __shared__ float s_coef[7 * 64];
-    __shared__ __attribute__((aligned(16))) float s_dh[R], s_dhs[R], s_dlw[W], s_dlz[W], s_dgpre[R], s_dgh[3 * R];
+    __shared__ __attribute__((aligned(16))) float s_dh[R], s_dgh[3 * R];
     __shared__ __attribute__((aligned(16))) float s_dy[32], s_A[R], s_dA[R];
-    __shared__ float s_misc[8];
+    __shared__ float s_dls[TMAX], s_cf[4 * TMAX], s_dAy[R];
+    __shared__ __attribute__((aligned(16))) float s_dhin[TMAX * R];
     // forward tape of this sample, loaded once: the time loop then issues stores only (a load inside it
     // would make its s_waitcnt vmcnt drain all outstanding delta-tape stores, ~1-2 us per wait on gfx950)
-    __shared__ float t_w[TMAX * W], t_pw[TMAX * W], t_z[TMAX * W], t_pz[TMAX * W], t_g[TMAX * R];
+    __shared__ __attribute__((aligned(16))) float t_msg[4 * TMAX * W], t_g[TMAX * R];     // t_w | t_pw | t_z | t_pz
+    float* t_w = t_msg; float* t_pw = t_msg + TMAX * W; float* t_z = t_msg + 2 * TMAX * W; float* t_pz = t_msg + 3 * TMAX * W;
+    static_assert(2 * TMAX * W == TMAX * R, "a pair of message arrays holds one [16][R] tile");
     __shared__ float t_gru[TMAX * 4 * R], t_h[(TMAX + 1) * R], t_a[TMAX * H];
-    __shared__ float t_bs[TMAX], t_br[TMAX], t_s[TMAX], t_ps[TMAX];
     if (MERGED && (int)blockIdx.x < n_stats) {          // four pairs per workgroup (one per wave): few releasing workgroups
         stats_pairs<true>(dm, P, tp, 1, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
         role_signal_wt(tp.sync, 0);
@@ -121,17 +124,24 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     const float L = tp.logs[b];
     // transposed fragments: output unit k4 = tid/4, reduction slice p4 = tid%4 (n = p4 + 4*i)
     const int k4 = tid / K4, p4 = tid % K4;
-    float wwT[W / K4], whT[R / K4], whhT[3 * R / K4];
-#pragma unroll
-    for (int i = 0; i < W / K4; ++i) wwT[i] = P.p[R_W_W][(size_t)(p4 * (W / K4) + i) * R + k4];
-#pragma unroll
-    for (int i = 0; i < R / K4; ++i) whT[i] = P.p[R_WH_W][(size_t)(p4 * (R / K4) + i) * R + k4];
+    float whhT[3 * R / K4];
 #pragma unroll
     for (int i = 0; i < 3 * R / K4; ++i) whhT[i] = P.p[R_WHH][(size_t)(p4 * (3 * R / K4) + i) * R + k4];
     const float wsk = P.p[R_S_W][k4];
-    float wbT[W];                                  // binary_layer column tid: W_b[j][tid]
+    // the three dh-independent transposed products run for all steps at once on the matrix cores ([16 steps, K] x [K, N],
+    // v_mfma_f32_16x16x4_f32): B fragments, lane (i = lane & 15, q = lane >> 4) holds Wm[4 ks + q][n0 + i] per k-step ks.
+    // W_w^T: wave w owns units 16 w ..; W_h^T likewise; binary_layer^T: wave w owns columns 64 w .. 64 w + 63 (4 n-tiles).
+    static_assert(R == 64 && H == 256 && NT == 256, "one n-tile of the R-wide products and four of the H-wide product per wave");
+    const int wv = tid >> 6, fi = lane & 15, fq = lane >> 4;
+    float wwF[W / 4], whF[R / 4], wbF[4][W / 4];
 #pragma unroll
-    for (int j = 0; j < W; ++j) wbT[j] = P.p[S_BIN_W][(size_t)j * H + tid];
+    for (int ks = 0; ks < W / 4; ++ks) wwF[ks] = P.p[R_W_W][(size_t)(4 * ks + fq) * R + 16 * wv + fi];
+#pragma unroll
+    for (int ks = 0; ks < R / 4; ++ks) whF[ks] = P.p[R_WH_W][(size_t)(4 * ks + fq) * R + 16 * wv + fi];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < W / 4; ++ks) wbF[nt][ks] = P.p[S_BIN_W][(size_t)(4 * ks + fq) * H + 64 * wv + 16 * nt + fi];
     float y1T[R / K4];                             // y1[:, :R]^T fragment (output step only)
 #pragma unroll
     for (int i = 0; i < R / K4; ++i) y1T[i] = P.p[R_Y1_W][(size_t)(p4 * (R / K4) + i) * (R + V) + k4];
@@ -179,7 +189,6 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     for (int u = 0; u < NH_; ++u) { const int i = tid + NT * u; if (i < (TMAX + 1) * R) t_h[i] = rh_[u]; }
 #pragma unroll
     for (int u = 0; u < NA_; ++u) t_a[tid + NT * u] = ra_[u];
-    if (tid < TMAX) { t_s[tid] = rs_; t_ps[tid] = rps_; }
     // ---- output step t*, the part that needs no loss coefficient: NLL seed dy, A* = y1[:, :R] h*, dA (and the release of
     // dy / A* to the class roles).  Done here, while the statistics roles are still working, instead of inside the
     // first reverse step.
@@ -224,18 +233,110 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             __hip_atomic_fetch_add(tp.sync + MMG_SYNC_ARR(1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // ---- everything that does not depend on the carried dh, for ALL steps of the sample at once, and BEFORE the batch
+    // statistics are needed.  A Bernoulli seed is linear in its two loss coefficients (App. A.4):
+    //   seed = wh S1 + ce S2,   S1 = -(q / pe - (1 - q) / qe) p (1 - p),   S2 = (log pe + p / pe - log qe - (1 - p) / qe) p (1 - p)
+    // and so is everything downstream of it.  The sweeps below run on the two BASIS vectors of every step while the
+    // statistics roles of this launch are still reducing: dgpre = (dlw W_w)(1 - g^2), the sender's dpre = (dlz W_b)(1 - a^2)
+    // and dgpre W_h as [16 steps, K] x [K, N] products on the matrix cores.  After the wait a step's gradients are two
+    // multiply-adds of its bases with (wh_t, ce_t).
+    MMG_BSTAMP(8);
+    auto seed_basis = [](float q, float pr, float& S1, float& S2) {
+        const float pe = pr + MMG_EPS, qe = 1.f - pr + MMG_EPS;
+        const float rp = __builtin_amdgcn_rcpf(pe), rq = __builtin_amdgcn_rcpf(qe), pq = pr * (1.f - pr);
+        S1 = -(q * rp - (1.f - q) * rq) * pq;
+        S2 = (flog(pe) + pr * rp - flog(qe) - (1.f - pr) * rq) * pq;
+    };
+    constexpr int NS_ = TMAX * W / NT;
+    float s1w[NS_], s2w[NS_], s1z[NS_], s2z[NS_];
+#pragma unroll
+    for (int u = 0; u < NS_; ++u) {
+        const int i = tid + NT * u, t = i / W;
+        float a1, a2, b1, b2;
+        seed_basis(t_w[i], t_pw[i], a1, a2);
+        seed_basis(t_z[i], t_pz[i], b1, b2);
+        if (!(binary && t < tstar)) { a1 = 0.f; a2 = 0.f; }                  // receiver message: active while m_{t+1} == 1
+        if (!(binary && t <= tstar)) { b1 = 0.f; b2 = 0.f; }
+        s1w[u] = a1; s2w[u] = a2; s1z[u] = b1; s2z[u] = b2;
+        t_w[i] = a1; t_pw[i] = a2; t_z[i] = b1; t_pz[i] = b2;                // (same thread, same element: in place)
+    }
+    __syncthreads();
+    MMG_BSTAMP(9);
+    // D fragments: lane holds rows t = 4 fq + r of column fi of its n-tile
+    f32x4 g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f}, p1[4], p2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { p1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; p2[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < W / 4; ++ks) {
+        const int o = fi * W + 4 * ks + fq;
+        const float aw1 = t_w[o], aw2 = t_pw[o], az1 = t_z[o], az2 = t_pz[o];
+        g1 = mfma16(aw1, wwF[ks], g1); g2 = mfma16(aw2, wwF[ks], g2);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { p1[nt] = mfma16(az1, wbF[nt][ks], p1[nt]); p2[nt] = mfma16(az2, wbF[nt][ks], p2[nt]); }
+    }
+    const int unit = 16 * wv + fi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float g = t_g[(4 * fq + r) * R + unit];
+        g1[r] *= (1.f - g * g); g2[r] *= (1.f - g * g);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = t_a[(4 * fq + r) * H + 64 * wv + 16 * nt + fi];
+            p1[nt][r] *= (1.f - a * a); p2[nt][r] *= (1.f - a * a);
+        }
+    // W_y1h^T dA enters dh at the output step only (unit k4, reduction slice p4)
+    {
+        float accy = 0.f;
+#pragma unroll
+        for (int i = 0; i < R / K4; ++i) accy = fmaf(y1T[i], s_dA[p4 * (R / K4) + i], accy);
+        accy = lane_group_sum<K4>(accy);
+        if (p4 == 0) s_dAy[k4] = accy;
+    }
+    __syncthreads();                                    // every wave has read the seed bases: their space is reused
+    float* s_G2 = t_msg;                                // [16][R] over t_w | t_pw
+    float* s_H2 = t_msg + 2 * TMAX * W;                 // [16][R] over t_z | t_pz
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { t_g[(4 * fq + r) * R + unit] = g1[r]; s_G2[(4 * fq + r) * R + unit] = g2[r]; }
+    __syncthreads();
+    MMG_BSTAMP(10);
+    {
+        f32x4 h1 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < R / 4; ++ks) {
+            h1 = mfma16(t_g[fi * R + 4 * ks + fq], whF[ks], h1);
+            h2 = mfma16(s_G2[fi * R + 4 * ks + fq], whF[ks], h2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s_dhin[(4 * fq + r) * R + unit] = h1[r]; s_H2[(4 * fq + r) * R + unit] = h2[r]; }
+    }
+    MMG_BSTAMP(11);
     if (MERGED) {                                       // the statistics roles of this launch publish stats, bs, br
         role_wait(tp.sync, 0, (uint32_t)n_stats, (uint32_t)B);
         creg = coef_load(dm, tp.stats);
         rbs_ = tp.bs[so]; rbr_ = tp.br[so];
         coef_compute(dm, creg, lc);
     }
-    if (tid < TMAX) { t_bs[tid] = rbs_; t_br[tid] = rbr_; }
     MMG_BSTAMP(2);
-    const float* cw_s = lc.cw, *cw_r = lc.cw + T, *cw_z = lc.cw + 2 * T;
-    const float* ce_s = lc.ce, *ce_r = lc.ce + T, *ce_z = lc.ce + 2 * T;
+    if (tid < TMAX) {
+        // per-step scalars of the three streams (model.py:908-922): wh = (L - baseline) cw, ce; stop-bit and MSE seeds
+        const int t = min(tid, Tm1);
+        const bool on = binary && tid <= tstar;
+        s_cf[tid] = on ? (L - rbr_) * lc.cw[T + t] : 0.f;          s_cf[TMAX + tid] = on ? lc.ce[T + t] : 0.f;          // receiver message
+        s_cf[2 * TMAX + tid] = on ? (L - rbs_) * lc.cw[2 * T + t] : 0.f; s_cf[3 * TMAX + tid] = on ? lc.ce[2 * T + t] : 0.f;   // sender message
+        float dls = 0.f;
+        if (on && !dm.fixed) dls = bit_seed_fast(rs_, rps_, (L - rbr_) * lc.cw[t], lc.ce[t]);
+        s_dls[tid] = dls;
+        if (tid <= tstar) {
+            const size_t row = (size_t)tid * B + b;
+            tp.dls[row] = dls;
+            tp.dbs[row] = binary ? lc.cb[t] * (rbs_ - L) : 0.f;                  // MSE seeds (model.py:971-988)
+            tp.dbr[row] = binary ? lc.cb[t] * (rbr_ - L) : 0.f;
+        }
+    }
     if (tid < R) s_dh[tid] = 0.f;
-    float dhx_acc = 0.f;
 
     // ---- zero the gradient tapes of steps this sample never took -- unless k_wgrad reduces over the live rows only
     // (build_row_map) and never looks at them: ~1.7 MB of stores per minibatch at config 2
@@ -249,75 +350,53 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     }
     __syncthreads();
     MMG_BSTAMP(3);
+    // ---- the gradient tapes of the live steps: bases x coefficients (stores only; the recurrence below does not wait for them)
+    {
+        const float* c1r = s_cf, *c2r = s_cf + TMAX, *c1z = s_cf + 2 * TMAX, *c2z = s_cf + 3 * TMAX;
+#pragma unroll
+        for (int u = 0; u < NS_; ++u) {
+            const int i = tid + NT * u, t = i / W, j = i - t * W;
+            if (t <= tstar) {
+                const size_t row = (size_t)t * B + b;
+                tp.dlw[row * W + j] = fmaf(c1r[t], s1w[u], c2r[t] * s2w[u]);
+                tp.dlz[row * W + j] = fmaf(c1z[t], s1z[u], c2z[t] * s2z[u]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 4 * fq + r;
+            if (t <= tstar) tp.dgpre[((size_t)t * B + b) * R + unit] = fmaf(c1r[t], g1[r], c2r[t] * g2[r]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int hcol = 64 * wv + 16 * nt + fi;
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 4 * fq + r;
+                if (t <= tstar) {
+                    const float v = fmaf(c1z[t], p1[nt][r], c2z[t] * p2[nt][r]);
+                    tp.dpre[((size_t)t * B + b) * H + hcol] = v;
+                    part += v;
+                }
+            }
+            part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);       // the four row groups of the column
+            if (fq == 0) tp.dhx[(size_t)b * H + hcol] = part;
+        }
+    }
 
+    // ---- the recurrence: two phases per step
+    auto step_in = [&](int t) {                                        // what step t adds to dh besides the recurrence
+        float v = fmaf(s_cf[t], s_dhin[t * R + k4], s_cf[TMAX + t] * s_H2[t * R + k4]) + wsk * s_dls[t];
+        if (t == tstar) v += s_dAy[k4];
+        return v;
+    };
     for (int t = tstar; t >= 0; --t) {
         const size_t row = (size_t)t * B + b;
-        const bool act_next = binary && (t < tstar);
-        MMG_BSTAMP(8 + 6 * t);
-        // ===== (1) gradient seeds of both message heads, of the stop bit and of the baselines
-        if (tid < W) {
-            float v = 0.f;
-            if (act_next) v = bit_seed_fast(t_w[t * W + tid], t_pw[t * W + tid], (L - t_br[t]) * cw_r[t], ce_r[t]);
-            s_dlw[tid] = v; tp.dlw[row * W + tid] = v;
-        } else if (tid >= 64 && tid < 64 + W) {
-            const int j = tid - 64;
-            float v = 0.f;
-            if (binary) v = bit_seed_fast(t_z[t * W + j], t_pz[t * W + j], (L - t_bs[t]) * cw_z[t], ce_z[t]);
-            s_dlz[j] = v; tp.dlz[row * W + j] = v;
-        } else if (tid == 128) {
-            float v = 0.f;
-            if (binary && !dm.fixed) v = bit_seed_fast(t_s[t], t_ps[t], (L - t_br[t]) * cw_s[t], ce_s[t]);
-            s_misc[0] = v; tp.dls[row] = v;
-        } else if (tid == 192) {                                            // MSE seeds (model.py:971-988)
-            tp.dbs[row] = binary ? lc.cb[t] * (t_bs[t] - L) : 0.f;
-            tp.dbr[row] = binary ? lc.cb[t] * (t_br[t] - L) : 0.f;
-        }
-        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 1);                              // b1
-        // ===== (2) dg = W_w^T dlw -> dgpre ; sender: da = W_b^T dlz -> dpre
+        MMG_BSTAMP(16 + 2 * t);
         {
-            float acc = 0.f;
-            if (act_next) {
-#pragma unroll
-                for (int i = 0; i < W / K4; ++i) acc = fmaf(wwT[i], s_dlw[p4 * (W / K4) + i], acc);
-            }
-            acc = lane_group_sum<K4>(acc);
-            if (p4 == 0) {
-                const float g = t_g[t * R + k4];
-                const float v = act_next ? acc * (1.f - g * g) : 0.f;
-                s_dgpre[k4] = v; tp.dgpre[row * R + k4] = v;
-            }
-        }
-        {
-            float v = 0.f;
-            if (binary) {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-                for (int j = 0; j < W; j += 4) {
-                    a0 = fmaf(wbT[j], s_dlz[j], a0); a1 = fmaf(wbT[j + 1], s_dlz[j + 1], a1);
-                    a2 = fmaf(wbT[j + 2], s_dlz[j + 2], a2); a3 = fmaf(wbT[j + 3], s_dlz[j + 3], a3);
-                }
-                const float a = t_a[t * H + tid];
-                v = ((a0 + a1) + (a2 + a3)) * (1.f - a * a);
-            }
-            tp.dpre[row * H + tid] = v;
-            dhx_acc += v;
-        }
-        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 2);                              // b2
-        // ===== (3) dh += W_h^T dgpre + w_s dls (+ W_y1h^T dA at the output step)
-        {
-            float acc = 0.f;
-            if (act_next) {
-#pragma unroll
-                for (int i = 0; i < R / K4; ++i) acc = fmaf(whT[i], s_dgpre[p4 * (R / K4) + i], acc);
-            }
-            if (t == tstar) {
-#pragma unroll
-                for (int i = 0; i < R / K4; ++i) acc = fmaf(y1T[i], s_dA[p4 * (R / K4) + i], acc);
-            }
-            acc = lane_group_sum<K4>(acc);
-            // ===== (4) GRU cell backward, in the same phase: after the group sum all K4 lanes of unit k4 hold its dh,
-            // each forms the gate gradients and lane p4 stores the p4-th of them (no barrier between (3) and (4))
-            const float dh = s_dh[k4] + acc + wsk * s_misc[0];
+            // ===== (4) GRU cell backward: all K4 lanes of unit k4 form the gate gradients, lane p4 stores the p4-th of them
+            const float dh = s_dh[k4] + step_in(t);
             const float* gr = t_gru + t * 4 * R;
             const float rr = gr[k4], uu = gr[R + k4], nn = gr[2 * R + k4], ghn = gr[3 * R + k4];
             const float hp = t_h[t * R + k4];
@@ -329,10 +408,9 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             if (p4 == 0)      { gi[k4] = drp; gh[k4] = drp; s_dgh[k4] = drp; }
             else if (p4 == 1) { gi[R + k4] = dup; gh[R + k4] = dup; s_dgh[R + k4] = dup; }
             else if (p4 == 2) { gi[2 * R + k4] = dnp; gh[2 * R + k4] = dnp * rr; s_dgh[2 * R + k4] = dnp * rr; }
-            else              { s_dh[k4] = dh * uu; }
         }
-        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 4);                              // b4
-        // ===== (5) dh_{t-1} = dh * u + W_hh^T dgh
+        __syncthreads(); MMG_BSTAMP(16 + 2 * t + 1);
+        // ===== (5) dh_{t-1} = dh * u + W_hh^T dgh      (lane p4 == 3 of the unit re-forms dh * u: s_dh is rewritten here only)
         {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -342,12 +420,14 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
                 a2 = fmaf(whhT[i + 2], dv.z, a2); a3 = fmaf(whhT[i + 3], dv.w, a3);
             }
             const float acc = lane_group_sum<K4>((a0 + a1) + (a2 + a3));
-            if (p4 == 0) s_dh[k4] += acc;
+            if (p4 == 0) {
+                const float dh = s_dh[k4] + step_in(t);
+                s_dh[k4] = __fmul_rn(dh, t_gru[t * 4 * R + R + k4]) + acc;
+            }
         }
-        __syncthreads(); MMG_BSTAMP(8 + 6 * t + 5);                              // b5
+        __syncthreads();
     }
     MMG_BSTAMP(4);
-    tp.dhx[(size_t)b * H + tid] = dhx_acc;
     // (code_bias: k_wgrad's special column job forms dsig * W_c^T (sum_b dpre_0) once, instead of W_c^T dpre_0 per sample here)
 }
 

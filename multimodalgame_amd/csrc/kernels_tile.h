@@ -1311,8 +1311,18 @@ __device__ __forceinline__ void s2_role(const Dims& dm, const Params& P, const T
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles) {
+__global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles, int xcd_map) {
     const int blk = blockIdx.x;
+    if (xcd_map) {
+        // at most 8 tiles: workgroup i runs on XCD i % 8, so tile x takes the workgroups with i % 8 == x -- all roles of a
+        // tile share one L2 and their hand-offs (payload + counter) never leave it.  grid = 8 x roles per tile.
+        const int tile = blk & 7, slot = blk >> 3;
+        if (tile >= tiles) return;
+        if (slot == 0) conv_tile_body<NT, true>(dm, P, tp, ar, tile);
+        else if (slot <= ar.ns2) s2_role<NT>(dm, P, tp, ar, tile, slot - 1);
+        else s1_role<NT>(dm, P, tp, ar, tile, slot - 1 - ar.ns2);
+        return;
+    }
     if (blk < tiles) { conv_tile_body<NT, true>(dm, P, tp, ar, blk); return; }
     const int r = blk - tiles;
     if (r < tiles * ar.ns2) { s2_role<NT>(dm, P, tp, ar, r / ar.ns2, r % ar.ns2); return; }

@@ -499,7 +499,13 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
     if (h->tile_persist) {
         Scope sc(h, st, "k_conv_persist");
         ar.phases = 2; ar.t_begin = 0; ar.t_end = d.T; ar.persist = 1; ar.ns1 = h->persist_ns1; ar.ns2 = h->persist_ns2;
-        hipLaunchKernelGGL(k_conv_persist<512>, dim3(tiles * (1 + ar.ns1 + ar.ns2)), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles);
+        // optional: one tile per XCD (32 CUs each hold the tile's roles)
+        const int roles = 1 + ar.ns1 + ar.ns2;
+        // (measured at config 4: 575 us per minibatch against 527 with plain role order -- the 25 roles of a tile then share
+        //  ONE L2 for their weight and payload reads, and a load that follows a write-through store in the same L2 took 5-8 us
+        //  instead of 2.3; off unless MMG_XCD_MAP=1)
+        const int xcd_map = (tiles <= 8 && roles <= 30 && getenv("MMG_XCD_MAP")) ? 1 : 0;
+        hipLaunchKernelGGL(k_conv_persist<512>, dim3(xcd_map ? 8 * roles : tiles * roles), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, xcd_map);
         return launch_check("k_conv_persist");
     }
     const int skip = (!ar.run_all && !d.fixed && ar.train) ? 1 : 0;

@@ -35,16 +35,14 @@ wall_us = (dbg[3] - dbg[0]) * tick / 1e3
 print("kernel body %.2f us, shader cycles %d -> shader clock %.0f MHz" % (wall_us, dbg[5] - dbg[4], (dbg[5] - dbg[4]) / wall_us))
 
 bd = dbg[128:]
-print("== k_bwd_conv_fast (sample 0): tape preload %.2f us | loss coefficients %.2f us | weights+zero-fill %.2f us | loop %.2f us" % (
-    (bd[1]-bd[0])*tick/1e3, (bd[2]-bd[1])*tick/1e3, (bd[3]-bd[2])*tick/1e3, (bd[4]-bd[3])*tick/1e3))
-for st in range(int(eng.tape["tstar"][0]), -1, -1):
-    base = 8 + 6 * st
-    prev = bd[base]; parts = []
-    for k in range(1, 6):
-        cur = bd[base + k]
-        if cur < prev: break
-        parts.append("(%d) %.2f" % (k, (cur - prev) * tick / 1e3)); prev = cur
-    print("bwd step %d: total %.2f us | " % (st, (prev - bd[base]) * tick / 1e3) + " ".join(parts))
+u = lambda a, b: (bd[b] - bd[a]) * tick / 1e3
+print("== k_bwd_conv_fast (sample 0): tape preload %.2f us | staging + output step %.2f | seed bases %.2f | dgpre / dpre bases (MFMA) %.2f | dgpre W_h bases (MFMA) %.2f | wait for the statistics roles + coefficients %.2f | per-step scalars %.2f | tape stores + recurrence %.2f" % (
+    u(0, 1), u(1, 8), u(8, 9), u(9, 10), u(10, 11), u(11, 2), u(2, 3), u(3, 4)))
+ts0 = int(eng.tape["tstar"][0])
+for st in range(ts0, -1, -1):
+    base = 16 + 2 * st
+    nxt = bd[16 + 2 * (st - 1)] if st > 0 else bd[4]
+    print("bwd step %d: cell backward %.2f us | W_hh^T dgh %.2f us" % (st, (bd[base + 1] - bd[base]) * tick / 1e3, (nxt - bd[base + 1]) * tick / 1e3))
 
 for which, nm in ((0, "baseline_rec"), (1, "baseline_sen")):
     d2 = dbg[64 + 32 * which:]
