@@ -202,6 +202,7 @@ struct ConvArgs {
     float* h_state;            // receiver GRU state in/out           [B,R]
     float* sprod_state;        // receiver running stop product       [B]
     int sprod_first;
+    int rsample;               // k_conv_persist: one receiver role per SAMPLE (register-resident weights) instead of one per tile
     int persist, ns1, ns2;     // kernels_tile.h, k_conv_persist: sender roles per sample tile (0: not persistent)
     int nhelp, per;            // kernels_tile.h, k_conv_split: class helpers per sample tile, classes per slice
 };

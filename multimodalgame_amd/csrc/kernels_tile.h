@@ -455,8 +455,8 @@ __device__ __forceinline__ bool pf_wait(uint32_t* ctr, uint32_t target, uint32_t
     if (threadIdx.x == 0) {
         int ok = -1, spins = 0;
         while (ok < 0) {
-            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) ok = 1;
-            else if (done && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = 0;
+            if (done && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = 0;
+            else if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) ok = 1;
             else {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(sync_err + MMG_SYNC_ERR, 100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; }
@@ -1149,7 +1149,7 @@ __device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const T
                                  : philox_uniform(ar.seed, (uint32_t)(((t - 1) * dm.Bg + dm.boff + b) * W + n), mb_counter, 2u);
             }
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 200);
-            if (!pf_wait(cG, (uint32_t)t, done, tp.sync)) return;
+            if (!pf_wait(cG, (uint32_t)(ar.rsample ? nb * t : t), done, tp.sync)) return;      // (per-sample receiver roles: one count per sample)
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201);
             batched_for<NT, 2>(MMG_TM * R, [&](int idx) { const int m = idx / R, r = idx - m * R; return tp.g[(rowp + min(b0 + m, B - 1)) * R + r]; },
                                [&](int idx, float v) { const int m = idx / R, r = idx - m * R; s_g[m * ldR + r] = v; });
@@ -1310,9 +1310,274 @@ __device__ __forceinline__ void s2_role(const Dims& dm, const Params& P, const T
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// rs_role: the receiver of ONE sample as a role of k_conv_persist (agents with a large sender but the receiver shape of
+// BASELINE configs 1-4: R = 64, V = 100, D <= 32).  A 16-sample tile role walks through eight barrier-separated phases of
+// [16, K] x [K, N] products per step (~20 us); one workgroup per sample with every receiver weight in registers (the
+// lane layouts of k_conversation_fast2, kernels_fast.h) does the same step in ~3 us, and 64 of them fit beside the sender
+// roles.  The GRU's input-side product arrives as the S2 roles' partials (W_ih never enters this role); g_t goes out with
+// write-through stores and one count per sample on the tile's g counter.  A sample that stops adds the counts of the steps
+// it will not take, the last one of a tile raises the tile's done flag.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int R, int V, int D>
+__device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int b) {
+    static_assert(NT == 512 && R == 64 && D <= 32 && V <= 200, "receiver shape of the register-resident kernels");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_h = smem; float* s_gi = s_h + R; float* s_gh = s_gi + 3 * R; float* s_A = s_gh + 3 * R;
+    float* s_y = s_A + R; float* s_yout = s_y + 32; float* s_dbar = s_yout + 32; float* s_pi = s_dbar + 208;   // [8][32]
+    float* s_misc = s_pi + 256; float* s_us = s_misc + 8; float* s_lpz = s_us + 16;                             // [2][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = dm.B, T = dm.T, W = dm.W, Dr = dm.D;
+    const int tile = b / MMG_TM, nb_tile = min(MMG_TM, B - tile * MMG_TM);
+    const bool binary = dm.use_binary != 0, train = ar.train != 0;
+    const bool may_stop = !ar.run_all && !dm.fixed && train;
+    const uint32_t mb_counter = tp.counter[0];
+    const uint32_t gb = (uint32_t)(dm.boff + b);
+    if (train && tid < T) s_us[tid] = ar.u_s ? ar.u_s[(size_t)tid * B + b] : philox_uniform(ar.seed, (uint32_t)(tid * dm.Bg + gb), mb_counter, 1u);
+    // ---- weights -> registers (once)
+    // GRU hidden side: row n3 = tid/2 (< 3R), half h3
+    const int n3 = tid >> 1, h3 = tid & 1;
+    const bool gru_lane = n3 < 3 * R;
+    const int nr = gru_lane ? n3 : 0;
+    constexpr int J3H = R / 8;
+    float whh[4 * J3H];
+#pragma unroll
+    for (int j = 0; j < J3H; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(P.p[R_WHH] + (size_t)nr * R + (h3 + 2 * j) * 4);
+        whh[4 * j] = v.x; whh[4 * j + 1] = v.y; whh[4 * j + 2] = v.z; whh[4 * j + 3] = v.w;
+    }
+    const float bih = P.p[R_BIH][nr], bhh = P.p[R_BHH][nr];
+    // y1[:, :R], w_h, w_d: 8 lanes per row
+    constexpr int L4 = NT / R, J4 = R / (4 * L4);
+    const int n4 = tid / L4, kp4 = tid % L4;
+    float wy1[4 * J4], wh[4 * J4];
+#pragma unroll
+    for (int j = 0; j < J4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(P.p[R_Y1_W] + (size_t)n4 * (R + V) + kp4 * 4 + 4 * L4 * j);
+        wy1[4 * j] = v.x; wy1[4 * j + 1] = v.y; wy1[4 * j + 2] = v.z; wy1[4 * j + 3] = v.w;
+        const float4 u = *reinterpret_cast<const float4*>(P.p[R_WH_W] + (size_t)n4 * R + kp4 * 4 + 4 * L4 * j);
+        wh[4 * j] = u.x; wh[4 * j + 1] = u.y; wh[4 * j + 2] = u.z; wh[4 * j + 3] = u.w;
+    }
+    const float bh = P.p[R_WH_B][n4];
+    constexpr int JD = (V + L4 - 1) / L4;
+    float wd[JD];
+#pragma unroll
+    for (int j = 0; j < JD; ++j) { const int k = kp4 + L4 * j; wd[j] = P.p[R_WD_W][(size_t)n4 * V + min(k, V - 1)]; if (k >= V) wd[j] = 0.f; }
+    const float ws = P.p[R_S_W][lane];
+    const float bs = P.p[R_S_B][0];
+    // y head: 16 lanes per class
+    constexpr int LY = 16;
+    const int dy = tid / LY, kpy = tid % LY;
+    float cd[4], w2[4];
+    {
+        const float4 v = *reinterpret_cast<const float4*>(tp.Cd + (size_t)(dy < Dr ? dy : 0) * R + kpy * 4);
+        cd[0] = v.x; cd[1] = v.y; cd[2] = v.z; cd[3] = v.w;
+        const float4 u = *reinterpret_cast<const float4*>(P.p[R_Y2_W] + kpy * 4);
+        w2[0] = u.x; w2[1] = u.y; w2[2] = u.z; w2[3] = u.w;
+    }
+    const float b2 = P.p[R_Y2_B][0];
+    // description column v7 = tid/2 (< V), half h7 covers classes h7*DH .. h7*DH + DH-1
+    constexpr int DH = (D + 1) / 2;
+    const int v7 = tid >> 1, h7 = tid & 1;
+    float dcol[DH];
+#pragma unroll
+    for (int j = 0; j < DH; ++j) { const int d = h7 * DH + j; dcol[j] = ar.desc[(size_t)min(d, Dr - 1) * V + min(v7, V - 1)]; if (!(v7 < V && d < Dr)) dcol[j] = 0.f; }
+
+    if (tid < R) { s_h[tid] = 0.f; tp.h[(size_t)b * R + tid] = 0.f; }
+    if (tid == 0) { s_misc[0] = 1.f; s_misc[1] = -1.f; s_misc[2] = 1.f; tp.mask[b] = 1; }
+    __syncthreads();
+    uint32_t* cG = pf_ctr(tp, 0, tile); uint32_t* cZ = pf_ctr(tp, 2, tile); uint32_t* done = pf_ctr(tp, 3, tile);
+    const int ns2 = ar.ns2;
+    float stop_p = 0.5f, stop_bit = 0.f;
+    int signalled = 0;
+    int t = 0;
+    for (; t < T; ++t) {
+        const size_t row = (size_t)t * B + b;
+        const float ghv = bhh + dpp_group_sum<2>(dot4<J3H>(whh, s_h + h3 * 4, 8));      // hidden-side product: before the wait
+        // ===== the sender roles' message of this step: its GRU input-side product arrives as ns2 partials
+        if (!pf_wait(cZ, (uint32_t)(ns2 * (t + 1)), nullptr, tp.sync)) return;
+        {
+            float p4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p4[u] = tp.gip[((size_t)min(h3 + 2 * u, ns2 - 1) * B + b) * 3 * R + nr];
+            float zz = 0.f, pp = 0.5f;
+            if (binary && tid < W) { zz = tp.z[row * W + tid]; pp = tp.pz[row * W + tid]; }
+            float gp = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gp += (h3 + 2 * u < ns2) ? p4[u] : 0.f;
+            const float giv = bih + dpp_group_sum<2>(gp);
+            if (gru_lane && h3 == 0) { s_gi[n3] = giv; s_gh[n3] = ghv; }
+            if (binary && wave < 4) {                                      // log-likelihood / neg-entropy of the sender's bits, model.py:908-922
+                float lpv = 0.f, nev = 0.f;
+                if (tid < W) {
+                    const float l1 = flog(pp + MMG_EPS), l0 = flog(1.f - pp + MMG_EPS);
+                    lpv = zz * l1 + (1.f - zz) * l0; nev = pp * l1 + (1.f - pp) * l0;
+                }
+                lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
+                if (lane == 0) { s_lpz[wave] = lpv; s_lpz[8 + wave] = nev; }
+            }
+        }
+        __syncthreads();
+        // ===== GRU state update
+        if (tid < R) {
+            const float rr = fsigmoid(s_gi[tid] + s_gh[tid]);
+            const float uu = fsigmoid(s_gi[R + tid] + s_gh[R + tid]);
+            const float ghn = s_gh[2 * R + tid];
+            const float nn = ftanh(s_gi[2 * R + tid] + rr * ghn);
+            const float hv = nn + uu * (s_h[tid] - nn);
+            float* gr = tp.gru + row * 4 * R;
+            gr[tid] = rr; gr[R + tid] = uu; gr[2 * R + tid] = nn; gr[3 * R + tid] = ghn;
+            tp.h[((size_t)(t + 1) * B + b) * R + tid] = hv;
+            s_h[tid] = hv;
+        } else if (binary && tid == R) {
+            const int nwz = (W + 63) >> 6;
+            float a = 0.f, c = 0.f;
+            for (int q = 0; q < nwz; ++q) { a += s_lpz[q]; c += s_lpz[8 + q]; }
+            tp.lp_z[row] = a; tp.ne_z[row] = c;
+        }
+        __syncthreads();
+        // ===== heads on h
+        float gpre_h;
+        {
+            const float accA = dpp_group_sum<L4>(dot4<J4>(wy1, s_h + kp4 * 4, 4 * L4));
+            const float accH = dpp_group_sum<L4>(dot4<J4>(wh, s_h + kp4 * 4, 4 * L4));
+            if (kp4 == 0) s_A[n4] = accA;
+            gpre_h = accH + bh;
+        }
+        if (wave == 7) {
+            const float sv = dpp_wave_sum(ws * s_h[lane]);
+            if (lane == 0) {
+                const float p = fsigmoid(sv + bs);
+                float sbit;
+                if (train) sbit = (s_us[t] < p) ? 1.f : 0.f;
+                else {
+                    const float prod = dm.s_prob_prod ? s_misc[2] * p : p;
+                    s_misc[2] = prod;
+                    sbit = rintf(prod);
+                }
+                s_misc[3] = sbit;
+                tp.s[row] = sbit; tp.ps[row] = p;
+                stop_p = p; stop_bit = sbit;
+            }
+        }
+        __syncthreads();
+        // ===== class logits
+        {
+            const float4 a4 = *reinterpret_cast<const float4*>(s_A + kpy * 4);
+            float acc = w2[0] * fmaxf(a4.x + cd[0], 0.f);
+            acc = fmaf(w2[1], fmaxf(a4.y + cd[1], 0.f), acc);
+            acc = fmaf(w2[2], fmaxf(a4.z + cd[2], 0.f), acc);
+            acc = fmaf(w2[3], fmaxf(a4.w + cd[3], 0.f), acc);
+            acc = dpp_group_sum<LY>(acc);
+            if (kpy == 0) {
+                const float yv = (dy < Dr) ? acc + b2 : -3.0e38f;
+                s_y[dy] = yv;
+                if (dy < Dr) tp.y[row * Dr + dy] = yv;
+            }
+        }
+        const float m_t = s_misc[0], sbit = s_misc[3];
+        const float m_next = fminf(m_t, sbit);
+        const bool first_stop = (m_next == 0.f) && (s_misc[1] < 0.f);
+        const bool take_out = dm.fixed ? (t == T - 1) : (first_stop || ((t == T - 1) && (s_misc[1] < 0.f)));
+        __syncthreads();
+        if (take_out && tid < 32) s_yout[tid] = s_y[tid];
+        if (tid == 0) {
+            tp.mask[(size_t)(t + 1) * B + b] = (uint8_t)(m_next != 0.f);
+            if (take_out) s_misc[1] = (float)t;
+            s_misc[0] = m_next;
+            st_wt(&tp.mstate[b], m_next);                                  // the sender roles store live rows only
+        }
+        if (wave == 7 && lane == 0) {
+            const float l1 = flog(stop_p + MMG_EPS), l0 = flog(1.f - stop_p + MMG_EPS);
+            tp.lp_s[row] = stop_bit * l1 + (1.f - stop_bit) * l0;
+            tp.ne_s[row] = stop_p * l1 + (1.f - stop_p) * l0;
+        }
+        if (may_stop && m_next == 0.f) { ++t; __syncthreads(); break; }
+        // ===== softmax (per wave) -> wave-private LDS -> description mixture (2 lanes per column)
+        {
+            const float yv = (lane < 32) ? s_y[lane] : -3.0e38f;
+            float mx = fmaxf(yv, dpp_f<MMG_DPP_QUAD_1032>(yv)); mx = fmaxf(mx, dpp_f<MMG_DPP_QUAD_2301>(mx));
+            mx = fmaxf(mx, dpp_f<MMG_DPP_ROW_HALF_MIRROR>(mx)); mx = fmaxf(mx, dpp_f<MMG_DPP_ROW_MIRROR>(mx));
+            const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 0));
+            const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 16));
+            const float mxx = fmaxf(m0, m1);
+            const float e = (lane < Dr) ? __expf(yv - mxx) : 0.f;
+            const float rs = dpp_group_sum<16>(e);
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 0));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 16));
+            const float inv = __builtin_amdgcn_rcpf(s0 + s1);
+            float* pi = s_pi + wave * 32;
+            if (lane < 32) pi[lane] = e * inv;
+            __builtin_amdgcn_wave_barrier();
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int j = 0; j + 2 < DH; j += 3) {
+                q0 = fmaf(pi[h7 * DH + j], dcol[j], q0);
+                q1 = fmaf(pi[h7 * DH + j + 1], dcol[j + 1], q1);
+                q2 = fmaf(pi[h7 * DH + j + 2], dcol[j + 2], q2);
+            }
+#pragma unroll
+            for (int j = DH - DH % 3; j < DH; ++j) q0 = fmaf(pi[min(h7 * DH + j, 31)], dcol[j], q0);
+            const float acc = dpp_group_sum<2>((q0 + q1) + q2);
+            if (h7 == 0 && v7 < V) { s_dbar[v7] = acc; tp.dbar[row * V + v7] = acc; }
+        }
+        __syncthreads();
+        // ===== h_w = tanh(w_h h + b_h + w_d dbar) -> the sender roles
+        {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int j = 0; j + 3 < JD; j += 4) {
+                a0 = fmaf(wd[j], s_dbar[min(kp4 + L4 * j, V - 1)], a0); a1 = fmaf(wd[j + 1], s_dbar[min(kp4 + L4 * (j + 1), V - 1)], a1);
+                a2 = fmaf(wd[j + 2], s_dbar[min(kp4 + L4 * (j + 2), V - 1)], a2); a3 = fmaf(wd[j + 3], s_dbar[min(kp4 + L4 * (j + 3), V - 1)], a3);
+            }
+#pragma unroll
+            for (int j = JD & ~3; j < JD; ++j) a0 = fmaf(wd[j], s_dbar[min(kp4 + L4 * j, V - 1)], a0);
+            const float acc = dpp_group_sum<L4>((a0 + a1) + (a2 + a3));
+            if (kp4 == 0) st_wt(&tp.g[row * R + n4], ftanh(gpre_h + acc));
+        }
+        pf_signal(cG);
+        ++signalled;
+    }
+    __syncthreads();
+    // the counts of the steps this sample does not take; the tile's last sample ends the sender roles
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the final stop mask is out before the counts move)
+        if (signalled < T) __hip_atomic_fetch_add(cG, (uint32_t)(T - signalled), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t fin = __hip_atomic_fetch_add(done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)fin == nb_tile - 1) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- output selection / reward / top-k (model.py:1264-1275, 1333-1339)
+    const int tstar = dm.fixed ? (T - 1) : (int)s_misc[1];
+    if (tid < 64) {
+        const float o = (lane < 32) ? s_yout[lane] : -3.0e38f;
+        const float mx = dpp_wave_max(o);
+        const float e = (lane < Dr) ? __expf(o - mx) : 0.f;
+        const float lse = mx + flog(dpp_wave_sum(e));
+        const int tgt = ar.target ? (int)ar.target[b] : -1;
+        const float dt = (tgt >= 0) ? (__shfl(o, tgt, 64) - lse) : 0.f;
+        const float ld = o - lse;
+        if (lane < Dr) {
+            tp.outp[(size_t)b * Dr + lane] = o;
+            tp.dist[(size_t)b * Dr + lane] = ld;
+            tp.sm[(size_t)b * Dr + lane] = __expf(ld);
+        }
+        const float above = dpp_wave_sum((lane < Dr && tgt >= 0 && ld > dt) ? 1.f : 0.f);
+        if (lane == 0) {
+            tp.tstar[b] = tstar;
+            tp.sprod[b] = s_misc[2];
+            tp.logs[b] = dt;
+            tp.hit[b] = (tgt >= 0 && above < (float)dm.top_k) ? 1 : 0;
+        }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles, int xcd_map) {
-    const int blk = blockIdx.x;
+    int blk = blockIdx.x;
+    if (ar.rsample) {                                   // one receiver role per sample, then the sender roles of the tiles
+        if (blk < dm.B) { if (dm.D == 30) rs_role<NT, 64, 100, 30>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32>(dm, P, tp, ar, blk); return; }
+        blk += tiles - dm.B;                            // (the tile-role slots [0, tiles) stay empty)
+    }
     if (xcd_map) {
         // at most 8 tiles: workgroup i runs on XCD i % 8, so tile x takes the workgroups with i % 8 == x -- all roles of a
         // tile share one L2 and their hand-offs (payload + counter) never leave it.  grid = 8 x roles per tile.
@@ -1577,9 +1842,12 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
             float* part = raw0;                                             // [NSL][16][RL] partials (raw0 | raw1 are contiguous)
             for (int rb = 0; rb < R; rb += RL) {
                 const int r = rb + r1;
+                // indicator 1[A + c > 0] as ONE instruction: clamp((c + A) * 2^100) to [0, 1] (a fused multiply-add with the
+                // clamp output modifier) -- exactly 0 or 1 unless 0 < |A + c| < 2^-100, which a sum of two O(1) floats never is
+                constexpr float BIG = 1.2676506e30f;                            // 2^100
                 float acc[MMG_TM], av[MMG_TM];
 #pragma unroll
-                for (int m = 0; m < MMG_TM; ++m) { acc[m] = 0.f; av[m] = s_A[m * L.ldR + min(r, R - 1)]; }
+                for (int m = 0; m < MMG_TM; ++m) { acc[m] = 0.f; av[m] = s_A[m * L.ldR + min(r, R - 1)] * BIG; }
                 if (sl < NSL && r < R) {
                     for (int d0 = d_lo; d0 < d_hi; d0 += 32) {
                         float cv[32];
@@ -1593,8 +1861,10 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
                                 const float* dp = s_dy + m * L.ldD + d0 + u;      // d0 is a multiple of 4 only if d_lo is: scalar reads otherwise
                                 const float y0 = (d0 + u < d_hi) ? dp[0] : 0.f, y1 = (d0 + u + 1 < d_hi) ? dp[1] : 0.f;
                                 const float y2 = (d0 + u + 2 < d_hi) ? dp[2] : 0.f, y3 = (d0 + u + 3 < d_hi) ? dp[3] : 0.f;
-                                acc[m] += (av[m] + cv[u] > 0.f) ? y0 : 0.f; acc[m] += (av[m] + cv[u + 1] > 0.f) ? y1 : 0.f;
-                                acc[m] += (av[m] + cv[u + 2] > 0.f) ? y2 : 0.f; acc[m] += (av[m] + cv[u + 3] > 0.f) ? y3 : 0.f;
+                                acc[m] = fmaf(__builtin_amdgcn_fmed3f(fmaf(cv[u], BIG, av[m]), 0.f, 1.f), y0, acc[m]);
+                                acc[m] = fmaf(__builtin_amdgcn_fmed3f(fmaf(cv[u + 1], BIG, av[m]), 0.f, 1.f), y1, acc[m]);
+                                acc[m] = fmaf(__builtin_amdgcn_fmed3f(fmaf(cv[u + 2], BIG, av[m]), 0.f, 1.f), y2, acc[m]);
+                                acc[m] = fmaf(__builtin_amdgcn_fmed3f(fmaf(cv[u + 3], BIG, av[m]), 0.f, 1.f), y3, acc[m]);
                             }
                         }
                     }

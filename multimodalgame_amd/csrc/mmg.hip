@@ -500,6 +500,12 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
         Scope sc(h, st, "k_conv_persist");
         ar.phases = 2; ar.t_begin = 0; ar.t_end = d.T; ar.persist = 1; ar.ns1 = h->persist_ns1; ar.ns2 = h->persist_ns2;
         // optional: one tile per XCD (32 CUs each hold the tile's roles)
+        // receiver shape of the register-resident kernels: one receiver role per SAMPLE (rs_role) beside the tiles' sender roles
+        ar.rsample = (d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && d.B + tiles * (ar.ns1 + ar.ns2) <= 240 && !getenv("MMG_NO_RSAMPLE")) ? 1 : 0;
+        if (ar.rsample) {
+            hipLaunchKernelGGL(k_conv_persist<512>, dim3(d.B + tiles * (ar.ns1 + ar.ns2)), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
+            return launch_check("k_conv_persist");
+        }
         const int roles = 1 + ar.ns1 + ar.ns2;
         // (measured at config 4: 575 us per minibatch against 527 with plain role order -- the 25 roles of a tile then share
         //  ONE L2 for their weight and payload reads, and a load that follows a write-through store in the same L2 took 5-8 us
