@@ -2217,6 +2217,134 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_dC_tile(Dims dm, Params P, Tape t
 }  // namespace mmg
 
 namespace mmg {
+// ---------------------------------------------------------------------------------------------
+// k_bwd_sample: the receiver's reverse-time pass of ONE sample per workgroup for the receiver shape of the register-resident
+// kernels (R = 64, V = 100, D <= 32) with ANY message / sender width -- the sample-tile path's counterpart of rs_role.
+// Everything that depends on the message width was formed for all (step, sample) rows by k_bwd_pre (dhin) and the sender's
+// backward runs in k_send_bwd, so what is left is k_bwd_conv_fast's output step (dy, A*, dA) and its two-phase recurrence
+// with W_hh^T in registers: ~0.65 us per step instead of ~3 us per step of a 16-sample tile (k_bwd_tile), on B CUs instead
+// of B / 16.  Same tape contract as k_bwd_tile (zero_dead / live rows; block 0 builds the live-row list).
+// ---------------------------------------------------------------------------------------------
+template <int R, int V, int D>
+__global__ __launch_bounds__(256, 1) void k_bwd_sample(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int zero_dead, int make_map) {
+    constexpr int NT = 256, K4 = NT / R, TMAX = 16;
+    static_assert(R == 64 && D <= 32 && K4 == 4, "receiver shape of the register-resident kernels");
+    __shared__ __attribute__((aligned(16))) float s_dh[R], s_dgh[3 * R], s_dy[32], s_A[R], s_dA[R], s_dAy[R];
+    __shared__ __attribute__((aligned(16))) float s_dhin[TMAX * R], t_gru[TMAX * 4 * R], t_h[(TMAX + 1) * R];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int B = dm.B, T = dm.T, Dr = dm.D;
+    const bool binary = dm.use_binary != 0;
+    if (b >= B) {                                                            // extra workgroup: live (step, sample) rows for k_wgrad / k_send_bwd
+        if (make_map && tid < 64) build_row_map(dm, tp);
+        return;
+    }
+    const int tstar = tp.tstar[b];
+    const int tgt = (int)target[b];
+    const int k4 = tid / K4, p4 = tid % K4;
+    float whhT[3 * R / K4], y1T[R / K4], y1r[R / K4];
+#pragma unroll
+    for (int i = 0; i < 3 * R / K4; ++i) whhT[i] = P.p[R_WHH][(size_t)(p4 * (3 * R / K4) + i) * R + k4];
+#pragma unroll
+    for (int i = 0; i < R / K4; ++i) y1T[i] = P.p[R_Y1_W][(size_t)(p4 * (R / K4) + i) * (R + V) + k4];
+#pragma unroll
+    for (int i = 0; i < R / K4; ++i) y1r[i] = P.p[R_Y1_W][(size_t)k4 * (R + V) + p4 * (R / K4) + i];
+    const float sm_mine = (tid < Dr) ? tp.sm[(size_t)b * Dr + tid] : 0.f;
+    const float w2_mine = (tid < R) ? P.p[R_Y2_W][tid] : 0.f;
+    float cdcol[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) cdcol[d] = (tid < R) ? tp.Cd[(size_t)min(d, Dr - 1) * R + tid] : 0.f;   // (dy is zero beyond Dr)
+    // this sample's GRU tape, h and dhin for ALL steps in one round trip (clamped, not guarded)
+    constexpr int NU_ = TMAX * 4 * R / NT, NH_ = ((TMAX + 1) * R + NT - 1) / NT, NI_ = TMAX * R / NT;
+    float ru_[NU_], rh_[NH_], ri_[NI_];
+    const int Tm1 = T - 1;
+#pragma unroll
+    for (int u = 0; u < NU_; ++u) { const int i = tid + NT * u, t = min(i / (4 * R), min(tstar, Tm1)), j = i % (4 * R); ru_[u] = tp.gru[((size_t)t * B + b) * 4 * R + j]; }
+#pragma unroll
+    for (int u = 0; u < NH_; ++u) { const int i = tid + NT * u, t = min(i / R, min(tstar + 1, T)), j = i % R; rh_[u] = tp.h[((size_t)t * B + b) * R + j]; }
+#pragma unroll
+    for (int u = 0; u < NI_; ++u) { const int i = tid + NT * u, t = min(i / R, min(tstar, Tm1)), j = i % R; ri_[u] = binary ? tp.dhin[((size_t)t * B + b) * R + j] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < NU_; ++u) t_gru[tid + NT * u] = ru_[u];
+#pragma unroll
+    for (int u = 0; u < NH_; ++u) { const int i = tid + NT * u; if (i < (TMAX + 1) * R) t_h[i] = rh_[u]; }
+#pragma unroll
+    for (int u = 0; u < NI_; ++u) s_dhin[tid + NT * u] = ri_[u];
+    const float dy_mine = (tid < Dr) ? (sm_mine - (tid == tgt ? 1.f : 0.f)) / (float)dm.Bg : 0.f;
+    if (tid < R) s_dh[tid] = 0.f;
+    __syncthreads();
+    // ---- output step t* (model.py:1264-1275): dy, A* = y1[:, :R] h*, dA, dAy = W_y1h^T dA
+    {
+        const int t = tstar;
+        if (tid < 64) {
+            if (lane < Dr) { tp.dy[(size_t)b * Dr + lane] = dy_mine; tp.dyT[(size_t)lane * B + b] = dy_mine; }
+            if (lane < 32) s_dy[lane] = dy_mine;
+            const float dsum = dpp_wave_sum(dy_mine);
+            if (lane == 0) tp.dysum[b] = dsum;
+        } else if (tid < 64 + R) {
+            tp.hstar[(size_t)b * R + tid - 64] = t_h[(t + 1) * R + tid - 64];
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < R / K4; ++i) acc = fmaf(y1r[i], t_h[(t + 1) * R + p4 * (R / K4) + i], acc);
+        acc = lane_group_sum<K4>(acc);
+        if (p4 == 0) s_A[k4] = acc;
+        __syncthreads();
+        if (tid < R) {
+            const float a = s_A[tid];
+            float dacc = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) dacc += (a + cdcol[d] > 0.f) ? s_dy[d] : 0.f;
+            const float v = dacc * w2_mine;
+            s_dA[tid] = v; tp.dA[(size_t)b * R + tid] = v; tp.Astar[(size_t)b * R + tid] = a;
+        }
+        __syncthreads();
+        float accy = 0.f;
+#pragma unroll
+        for (int i = 0; i < R / K4; ++i) accy = fmaf(y1T[i], s_dA[p4 * (R / K4) + i], accy);
+        accy = lane_group_sum<K4>(accy);
+        if (p4 == 0) s_dAy[k4] = accy;
+    }
+    // rows of steps this sample never took (only when k_wgrad has no live-row list)
+    for (int t = zero_dead ? tstar + 1 : T; t < T; ++t) {
+        const size_t row = (size_t)t * B + b;
+        if (tid < 3 * R) { tp.dgi[row * 3 * R + tid] = 0.f; tp.dgh[row * 3 * R + tid] = 0.f; }
+    }
+    __syncthreads();
+    // ---- the recurrence: [cell backward] barrier [W_hh^T dgh] barrier
+    for (int t = tstar; t >= 0; --t) {
+        const size_t row = (size_t)t * B + b;
+        const float din = s_dhin[t * R + k4] + ((t == tstar) ? s_dAy[k4] : 0.f);
+        {
+            const float dh = s_dh[k4] + din;
+            const float* gr = t_gru + t * 4 * R;
+            const float rr = gr[k4], uu = gr[R + k4], nn = gr[2 * R + k4], ghn = gr[3 * R + k4];
+            const float hp = t_h[t * R + k4];
+            const float dn = dh * (1.f - uu), du = dh * (hp - nn);
+            const float dnp = dn * (1.f - nn * nn), dup = du * uu * (1.f - uu);
+            const float drp = dnp * ghn * rr * (1.f - rr);
+            float* gi = tp.dgi + row * 3 * R; float* gh = tp.dgh + row * 3 * R;
+            if (p4 == 0)      { gi[k4] = drp; gh[k4] = drp; s_dgh[k4] = drp; }
+            else if (p4 == 1) { gi[R + k4] = dup; gh[R + k4] = dup; s_dgh[R + k4] = dup; }
+            else if (p4 == 2) { gi[2 * R + k4] = dnp; gh[2 * R + k4] = dnp * rr; s_dgh[2 * R + k4] = dnp * rr; }
+        }
+        __syncthreads();
+        {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3 * R / K4; i += 4) {
+                const float4 dv = *reinterpret_cast<const float4*>(s_dgh + p4 * (3 * R / K4) + i);
+                a0 = fmaf(whhT[i], dv.x, a0); a1 = fmaf(whhT[i + 1], dv.y, a1);
+                a2 = fmaf(whhT[i + 2], dv.z, a2); a3 = fmaf(whhT[i + 3], dv.w, a3);
+            }
+            const float acc = lane_group_sum<K4>((a0 + a1) + (a2 + a3));
+            if (p4 == 0) s_dh[k4] = __fmul_rn(s_dh[k4] + din, t_gru[t * 4 * R + R + k4]) + acc;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace mmg
+
+namespace mmg {
 // acc += X[16 rows, K] . Wt[16 cols, K]^T for one MFMA tile; lane (i, q) owns row i of both operands (k contiguous),
 // 8 k-groups (16 float4 loads) in flight; columns beyond K are clamped on both sides and masked on X.
 template <bool VEC>

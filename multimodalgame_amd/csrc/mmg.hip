@@ -617,7 +617,11 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             // the dh-independent part of the receiver's BPTT (seeds, dgpre, dhin) for all (step, sample) rows, then the recurrence
             if (d.use_binary)
                 hipLaunchKernelGGL(k_bwd_pre, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
-            if (d.R <= 64)
+            if (d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && !getenv("MMG_NO_RSAMPLE")) {
+                // receiver shape of the register-resident kernels: one workgroup per sample (+ one for the live-row list)
+                if (d.D == 30) hipLaunchKernelGGL((k_bwd_sample<64, 100, 30>), dim3(d.B + 1), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+                else hipLaunchKernelGGL((k_bwd_sample<64, 100, 32>), dim3(d.B + 1), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+            } else if (d.R <= 64)
                 hipLaunchKernelGGL((k_bwd_tile<512, 2>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             else
                 hipLaunchKernelGGL((k_bwd_tile<512, 4>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
