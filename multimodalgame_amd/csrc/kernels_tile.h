@@ -1126,7 +1126,8 @@ __device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const T
     uint32_t* cG = pf_ctr(tp, 0, tile); uint32_t* cA = pf_ctr(tp, 1, tile); uint32_t* done = pf_ctr(tp, 3, tile);
     // both weight matrices of this role as register fragments, loaded once (W_w: two items of 4 k-groups per wave, the W_c
     // slice: one item of 8): the step loop then reads no weight from memory.  Larger shapes keep streaming them.
-    const bool res_w = wfrag_fits(W, R, nw, 4, 2), res_c = wfrag_fits(64, W, nw, 8, 1);
+    const bool msg_in = ar.rsample == 2;                                // the receiver roles publish the message, not g
+    const bool res_w = !msg_in && wfrag_fits(W, R, nw, 4, 2), res_c = wfrag_fits(64, W, nw, 8, 1);
     WFrag<4> fw0, fw1; WFrag<8> fc;
     fw0.n = fw1.n = fc.n = 0;
     if (res_w) { wfrag_load<4>(fw0, P.p[R_W_W], R, W, R, wave, nw); wfrag_load<4>(fw1, P.p[R_W_W], R, W, R, wave + nw, nw); }
@@ -1144,22 +1145,29 @@ __device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const T
 #pragma unroll
             for (int u = 0; u < UW; ++u) {
                 const int idx = min(tid + u * NT, MMG_TM * W - 1), m = idx / W, n = idx - m * W, b = min(b0 + m, B - 1);
-                uw[u] = !(binary && train) ? 0.f
+                uw[u] = (!(binary && train) || msg_in) ? 0.f
                         : ar.u_w ? ar.u_w[(rowp + b) * W + n]
                                  : philox_uniform(ar.seed, (uint32_t)(((t - 1) * dm.Bg + dm.boff + b) * W + n), mb_counter, 2u);
             }
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 200);
             if (!pf_wait(cG, (uint32_t)(ar.rsample ? nb * t : t), done, tp.sync)) return;      // (per-sample receiver roles: one count per sample)
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201);
+            if (msg_in) {
+                // (per-sample receiver roles that form the message themselves: it arrives ready)
+                batched_for<NT, 8>(MMG_TM * W, [&](int idx) { const int m = idx / W, n = idx - m * W; return tp.w[(rowp + min(b0 + m, B - 1)) * W + n]; },
+                                   [&](int idx, float v) { const int m = idx / W, n = idx - m * W; s_w[m * ldW + n] = v; });
+            } else
             batched_for<NT, 2>(MMG_TM * R, [&](int idx) { const int m = idx / R, r = idx - m * R; return tp.g[(rowp + min(b0 + m, B - 1)) * R + r]; },
                                [&](int idx, float v) { const int m = idx / R, r = idx - m * R; s_g[m * ldR + r] = v; });
             if (tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
             __syncthreads();
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 202);
+            if (!msg_in) {
             if (res_w) { wfrag_mma<4>(fw0, s_g, ldR, raw, ldW); wfrag_mma<4>(fw1, s_g, ldR, raw, ldW); }
             else tgemm_nt_raw(s_g, ldR, P.p[R_W_W], R, W, R, raw, wave, nw);
             __syncthreads();
-            {
+            }
+            if (!msg_in) {
                 const int kp = tile_kparts((W + 15) >> 4, nw);
 #pragma unroll
                 for (int u = 0; u < UW; ++u) {
@@ -1176,7 +1184,7 @@ __device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const T
                     }
                 }
             }
-            __syncthreads();
+            if (!msg_in) __syncthreads();
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 203);
             if (t < T) {
                 // ---- this role's 64 units of the sender hidden state (model.py:195-216)
@@ -1198,7 +1206,7 @@ __device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const T
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 205);
         }
         // ---- off the critical path (the S2 roles are running): role 0 of the tile records the message and its statistics
-        if (j == 0) {
+        if (j == 0 && !msg_in) {
             if (t >= 1) {
                 for (int idx = tid; idx < nb * W; idx += NT) {
                     const int m = idx / W, n = idx - m * W;
@@ -1319,13 +1327,17 @@ __device__ __forceinline__ void s2_role(const Dims& dm, const Params& P, const T
 // write-through stores and one count per sample on the tile's g counter.  A sample that stops adds the counts of the steps
 // it will not take, the last one of a tile raises the tile's done flag.
 // ---------------------------------------------------------------------------------------------
-template <int NT, int R, int V, int D>
+// MW = 256: the role also forms the receiver's message w_t = Bernoulli(sigmoid(W_w g_t + b_w)) (2 lanes per message bit, W_w in
+// registers) and publishes IT instead of g_t: the S1 roles then start from the message (no redundant 16-fold recompute of
+// it, one product less on the per-step chain).  MW = 0: other widths, g_t goes out and the S1 roles form the message.
+template <int NT, int R, int V, int D, int MW>
 __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int b) {
-    static_assert(NT == 512 && R == 64 && D <= 32 && V <= 200, "receiver shape of the register-resident kernels");
+    static_assert(NT == 512 && R == 64 && D <= 32 && V <= 200 && (MW == 0 || MW == 256), "receiver shape of the register-resident kernels");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_h = smem; float* s_gi = s_h + R; float* s_gh = s_gi + 3 * R; float* s_A = s_gh + 3 * R;
     float* s_y = s_A + R; float* s_yout = s_y + 32; float* s_dbar = s_yout + 32; float* s_pi = s_dbar + 208;   // [8][32]
     float* s_misc = s_pi + 256; float* s_us = s_misc + 8; float* s_lpz = s_us + 16;                             // [2][8]
+    float* s_g = s_lpz + 16; float* s_c = s_g + R; float* s_lpw = s_c + 256;                                      // message path (MW): g, last message, [2][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = dm.B, T = dm.T, W = dm.W, Dr = dm.D;
     const int tile = b / MMG_TM, nb_tile = min(MMG_TM, B - tile * MMG_TM);
@@ -1383,6 +1395,21 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
 #pragma unroll
     for (int j = 0; j < DH; ++j) { const int d = h7 * DH + j; dcol[j] = ar.desc[(size_t)min(d, Dr - 1) * V + min(v7, V - 1)]; if (!(v7 < V && d < Dr)) dcol[j] = 0.f; }
 
+    // message head (MW): row nw = tid/2 of W_w, half hw (the GRU lanes' k pattern)
+    const int nw = tid >> 1, hw = tid & 1;
+    float ww[MW ? 4 * J3H : 1];
+    float bw = 0.f, sig_cb = 0.f;
+    if (MW) {
+#pragma unroll
+        for (int j = 0; j < (MW ? J3H : 0); ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(P.p[R_W_W] + (size_t)nw * R + (hw + 2 * j) * 4);
+            ww[4 * j] = v.x; ww[4 * j + 1] = v.y; ww[4 * j + 2] = v.z; ww[4 * j + 3] = v.w;
+        }
+        bw = P.p[R_W_B][nw];
+        sig_cb = fsigmoid(P.p[S_CODE_BIAS][nw]);
+        if (hw == 0) s_c[nw] = dm.first_rec;                               // model.py:786
+    }
+
     if (tid < R) { s_h[tid] = 0.f; tp.h[(size_t)b * R + tid] = 0.f; }
     if (tid == 0) { s_misc[0] = 1.f; s_misc[1] = -1.f; s_misc[2] = 1.f; tp.mask[b] = 1; }
     __syncthreads();
@@ -1394,6 +1421,15 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
     for (; t < T; ++t) {
         const size_t row = (size_t)t * B + b;
         const float ghv = bhh + dpp_group_sum<2>(dot4<J3H>(whh, s_h + h3 * 4, 8));      // hidden-side product: before the wait
+        float uwv = 0.f;
+        if (MW) {
+            if (hw == 0) {                                                 // the sender's input of this step (tape only), model.py:836
+                const float cv = s_c[nw];
+                tp.zr[row * W + nw] = cv;
+                tp.c[row * W + nw] = (t == 0) ? sig_cb : cv;
+            }
+            if (binary && train) uwv = ar.u_w ? ar.u_w[row * W + nw] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + gb) * W + nw), mb_counter, 2u);
+        }
         // ===== the sender roles' message of this step: its GRU input-side product arrives as ns2 partials
         if (!pf_wait(cZ, (uint32_t)(ns2 * (t + 1)), nullptr, tp.sync)) return;
         {
@@ -1533,10 +1569,42 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
 #pragma unroll
             for (int j = JD & ~3; j < JD; ++j) a0 = fmaf(wd[j], s_dbar[min(kp4 + L4 * j, V - 1)], a0);
             const float acc = dpp_group_sum<L4>((a0 + a1) + (a2 + a3));
-            if (kp4 == 0) st_wt(&tp.g[row * R + n4], ftanh(gpre_h + acc));
+            if (kp4 == 0) {
+                const float gv = ftanh(gpre_h + acc);
+                if (MW) { s_g[n4] = gv; tp.g[row * R + n4] = gv; }
+                else st_wt(&tp.g[row * R + n4], gv);
+            }
+        }
+        if (MW) {
+            __syncthreads();
+            // ===== receiver message (model.py:454-475) -> the S1 roles
+            const float acc = dpp_group_sum<2>(dot4<J3H>(ww, s_g + hw * 4, 8));
+            float lpv = 0.f, nev = 0.f;
+            if (hw == 0) {
+                const float lw = acc + bw;
+                float wv = lw, pp = 0.f;
+                if (binary) {
+                    pp = fsigmoid(lw);
+                    wv = train ? ((uwv < pp) ? 1.f : 0.f) : rintf(pp);
+                    tp.pw[row * W + nw] = pp;
+                    const float l1 = flog(pp + MMG_EPS), l0 = flog(1.f - pp + MMG_EPS);
+                    lpv = wv * l1 + (1.f - wv) * l0; nev = pp * l1 + (1.f - pp) * l0;
+                }
+                s_c[nw] = wv;
+                st_wt(&tp.w[row * W + nw], wv);
+            }
+            if (binary) {
+                lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
+                if (lane == 0) { s_lpw[wave] = lpv; s_lpw[8 + wave] = nev; }
+            }
         }
         pf_signal(cG);
         ++signalled;
+        if (MW && binary && tid == 0) {                                    // (after the signal's barrier: off the sender roles' path)
+            float a = 0.f, c = 0.f;
+            for (int q = 0; q < 8; ++q) { a += s_lpw[q]; c += s_lpw[8 + q]; }
+            tp.lp_w[row] = a; tp.ne_w[row] = c;
+        }
     }
     __syncthreads();
     // the counts of the steps this sample does not take; the tile's last sample ends the sender roles
@@ -1575,7 +1643,11 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles, int xcd_map) {
     int blk = blockIdx.x;
     if (ar.rsample) {                                   // one receiver role per sample, then the sender roles of the tiles
-        if (blk < dm.B) { if (dm.D == 30) rs_role<NT, 64, 100, 30>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32>(dm, P, tp, ar, blk); return; }
+        if (blk < dm.B) {
+            if (ar.rsample == 2) { if (dm.D == 30) rs_role<NT, 64, 100, 30, 256>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32, 256>(dm, P, tp, ar, blk); }
+            else { if (dm.D == 30) rs_role<NT, 64, 100, 30, 0>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32, 0>(dm, P, tp, ar, blk); }
+            return;
+        }
         blk += tiles - dm.B;                            // (the tile-role slots [0, tiles) stay empty)
     }
     if (xcd_map) {
