@@ -1431,7 +1431,9 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
             if (binary && train) uwv = ar.u_w ? ar.u_w[row * W + nw] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + gb) * W + nw), mb_counter, 2u);
         }
         // ===== the sender roles' message of this step: its GRU input-side product arrives as ns2 partials
+        MMG_RSTAMP(b == 0 && t == 3, 250);
         if (!pf_wait(cZ, (uint32_t)(ns2 * (t + 1)), nullptr, tp.sync)) return;
+        MMG_RSTAMP(b == 0 && t == 3, 251);
         {
             float p4[4];
 #pragma unroll
@@ -1454,6 +1456,7 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
             }
         }
         __syncthreads();
+        MMG_RSTAMP(b == 0 && t == 3, 252);
         // ===== GRU state update
         if (tid < R) {
             const float rr = fsigmoid(s_gi[tid] + s_gh[tid]);
@@ -1575,6 +1578,7 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
                 else st_wt(&tp.g[row * R + n4], gv);
             }
         }
+        MMG_RSTAMP(b == 0 && t == 3, 253);
         if (MW) {
             __syncthreads();
             // ===== receiver message (model.py:454-475) -> the S1 roles
@@ -1598,7 +1602,9 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
                 if (lane == 0) { s_lpw[wave] = lpv; s_lpw[8 + wave] = nev; }
             }
         }
+        MMG_RSTAMP(b == 0 && t == 3, 254);
         pf_signal(cG);
+        MMG_RSTAMP(b == 0 && t == 3, 255);
         ++signalled;
         if (MW && binary && tid == 0) {                                    // (after the signal's barrier: off the sender roles' path)
             float a = 0.f, c = 0.f;
@@ -2063,6 +2069,50 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
 __host__ __device__ inline int bwd_pre_lds_floats(const Dims& d) {
     return MMG_TM * ld16(d.W) + MMG_TM * ld16(d.R) + tile_raw_floats_nn(d.R, MMG_BLOCK / 64) + 7 * 64 + 64 + ld16(d.R);
 }
+// weight fragment of an "NN" product with N <= 64 output columns, loaded ahead of its use: wave w owns k-part w (all four
+// n-tiles), lane (i, q) holds float4 Bm[16 kg + 4 q + c][4 i ..] for its <= MAXKG k-groups (tgemm_nn_body's layout)
+template <int MAXKG>
+struct NFrag { float4 b[MAXKG][4]; int kp, g0, n; };
+template <int MAXKG>
+__device__ __forceinline__ bool nfrag_fits(int N, int K, int nw) {
+    const int kgroups = (K + 15) >> 4, kparts = tile_kparts(1, nw);
+    return N <= 64 && kparts == nw && (kgroups + kparts - 1) / kparts <= MAXKG;
+}
+template <int MAXKG>
+__device__ __forceinline__ void nfrag_load(NFrag<MAXKG>& f, const float* __restrict__ Bm, int ldb, int N, int K, int wave, int nw) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int kgroups = (K + 15) >> 4, kparts = tile_kparts(1, nw), per = (kgroups + kparts - 1) / kparts;
+    f.kp = wave; f.g0 = wave * per; f.n = max(0, min(kgroups, f.g0 + per) - f.g0);
+#pragma unroll
+    for (int u = 0; u < MAXKG; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            f.b[u][c] = ldrow4c<true>(Bm + (size_t)min(min(f.g0 + u, kgroups - 1) * 16 + q * 4 + c, K - 1) * ldb, 4 * i, N);
+}
+template <int MAXKG>
+__device__ __forceinline__ void nfrag_mma(const NFrag<MAXKG>& f, const float* A, int lda, float* raw, int ldr) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const float* arow = A + i * lda + q * 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < MAXKG; ++u) {
+        if (u < f.n) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + (f.g0 + u) * 16);
+            acc[0] = mfma16(a.x, f.b[u][0].x, acc[0]); acc[1] = mfma16(a.x, f.b[u][0].y, acc[1]); acc[2] = mfma16(a.x, f.b[u][0].z, acc[2]); acc[3] = mfma16(a.x, f.b[u][0].w, acc[3]);
+            acc[0] = mfma16(a.y, f.b[u][1].x, acc[0]); acc[1] = mfma16(a.y, f.b[u][1].y, acc[1]); acc[2] = mfma16(a.y, f.b[u][1].z, acc[2]); acc[3] = mfma16(a.y, f.b[u][1].w, acc[3]);
+            acc[0] = mfma16(a.z, f.b[u][2].x, acc[0]); acc[1] = mfma16(a.z, f.b[u][2].y, acc[1]); acc[2] = mfma16(a.z, f.b[u][2].z, acc[2]); acc[3] = mfma16(a.z, f.b[u][2].w, acc[3]);
+            acc[0] = mfma16(a.w, f.b[u][3].x, acc[0]); acc[1] = mfma16(a.w, f.b[u][3].y, acc[1]); acc[2] = mfma16(a.w, f.b[u][3].z, acc[2]); acc[3] = mfma16(a.w, f.b[u][3].w, acc[3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float* dst = raw + ((f.kp * MMG_TM) + q * 4 + r) * ldr + 4 * i;
+        if (4 * i + 3 < ldr) *reinterpret_cast<float4*>(dst) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    }
+}
+
 __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre(Dims dm, Params P, Tape tp, int zero_dead) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = MMG_BLOCK, nw = NT / 64;
@@ -2076,61 +2126,85 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre(Dims dm, Params P, Tape t
     LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
     const int tid = threadIdx.x, wave = tid >> 6;
     const size_t rowb = (size_t)t * B;
-    for (int i = tid; i < MMG_TM * (ldW + ldR); i += NT) smem[i] = 0.f;
-    if (tid < MMG_TM) {
-        const int b = min(b0 + tid, B - 1);
-        misc[tid] = (tid < nb) ? (float)tp.tstar[b] : -1.f;
-        misc[16 + tid] = tp.logs[b];
+    // ---- every global load of the workgroup goes out NOW, in one round trip: statistics, row scalars, the message / g
+    // tiles of the step and (where they fit: N <= 64, <= 4 k-groups per wave) both weight fragments
+    const CoefRegs creg = coef_load(dm, tp.stats);
+    const int bm = min(b0 + min(tid, MMG_TM - 1), B - 1);
+    const float r_ts = (float)tp.tstar[bm], r_L = tp.logs[bm];
+    const float r_br = tp.br[rowb + bm], r_bs = tp.bs[rowb + bm];
+    const float r_s = dm.fixed ? 0.f : tp.s[rowb + bm], r_ps = dm.fixed ? 0.5f : tp.ps[rowb + bm];
+    constexpr int UW = 16, UR = 8;                                      // 16 * W <= UW * NT (W <= 256), 16 * R <= UR * NT (R <= 128)
+    F2 rw[UW]; float rg[UR];
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        const int idx = min(tid + u * NT, MMG_TM * W - 1), m = idx / W, j = idx - m * W;
+        const size_t o = (rowb + min(b0 + m, B - 1)) * W + j;
+        rw[u] = F2{tp.w[o], tp.pw[o]};
     }
-    for (int r = tid; r < ldR; r += NT) s_ws[r] = r < R ? P.p[R_S_W][r] : 0.f;
-    loss_coefficients(dm, tp.stats, lc, nullptr, nullptr);                  // (ends with a barrier)
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+        const int idx = min(tid + u * NT, MMG_TM * R - 1), m = idx / R, r = idx - m * R;
+        rg[u] = tp.g[(rowb + min(b0 + m, B - 1)) * R + r];
+    }
+    const bool fr1 = nfrag_fits<4>(R, W, nw), fr2 = nfrag_fits<2>(R, R, nw);
+    NFrag<4> fw; NFrag<2> fh;
+    fw.n = fh.n = 0;
+    if (fr1) nfrag_load<4>(fw, P.p[R_W_W], R, R, W, wave, nw);
+    if (fr2) nfrag_load<2>(fh, P.p[R_WH_W], R, R, R, wave, nw);
+    const float r_ws = P.p[R_S_W][min(tid, R - 1)];
+
+    for (int i = tid; i < MMG_TM * (ldW + ldR); i += NT) smem[i] = 0.f;
+    if (tid < MMG_TM) { misc[tid] = (tid < nb) ? r_ts : -1.f; misc[16 + tid] = r_L; }
+    for (int r = tid; r < ldR; r += NT) s_ws[r] = 0.f;
+    coef_compute(dm, creg, lc);                                             // (ends with a barrier)
+    if (tid < R) s_ws[tid] = r_ws;
     bool any = false;
     for (int m = 0; m < nb; ++m) any = any || ((float)t <= misc[m]);
     if (!any && !zero_dead) return;
     if (tid < MMG_TM) {
         const int m = tid;
         const bool live = (float)t <= misc[m];
-        const size_t ob = rowb + min(b0 + m, B - 1);
-        const float br = tp.br[ob], bs = tp.bs[ob];
-        const float sb = dm.fixed ? 0.f : tp.s[ob], ps = dm.fixed ? 0.5f : tp.ps[ob];
         float dls = 0.f, dbs = 0.f, dbr = 0.f;
         if (live) {
             const float Lr = misc[16 + m];
-            if (!dm.fixed) dls = bit_seed_fast(sb, ps, (Lr - br) * lc.cw[t], lc.ce[t]);
-            dbs = lc.cb[t] * (bs - Lr); dbr = lc.cb[t] * (br - Lr);              // MSE seeds, model.py:971-988
+            if (!dm.fixed) dls = bit_seed_fast(r_s, r_ps, (Lr - r_br) * lc.cw[t], lc.ce[t]);
+            dbs = lc.cb[t] * (r_bs - Lr); dbr = lc.cb[t] * (r_br - Lr);          // MSE seeds, model.py:971-988
         }
-        misc[32 + m] = br; misc[48 + m] = dls;
+        misc[32 + m] = r_br; misc[48 + m] = dls;
         if (m < nb && (live || zero_dead)) { tp.dls[rowb + b0 + m] = dls; tp.dbs[rowb + b0 + m] = dbs; tp.dbr[rowb + b0 + m] = dbr; }
     }
     __syncthreads();
     // seeds of the receiver-message stream (active while m_{t+1} == 1, i.e. t < t*)
-    batched_for<NT, 4>(MMG_TM * W, [&](int idx) {
-            const int m = idx / W, j = idx - m * W;
-            const size_t o = (rowb + min(b0 + m, B - 1)) * W + j;
-            return F2{tp.w[o], tp.pw[o]};
-        }, [&](int idx, F2 v) {
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < MMG_TM * W) {
             const int m = idx / W, j = idx - m * W;
             const bool act = (float)t < misc[m];
-            const float sv = act ? bit_seed_fast(v.x, v.y, (misc[16 + m] - misc[32 + m]) * lc.cw[T + t], lc.ce[T + t]) : 0.f;
+            const float sv = act ? bit_seed_fast(rw[u].x, rw[u].y, (misc[16 + m] - misc[32 + m]) * lc.cw[T + t], lc.ce[T + t]) : 0.f;
             s_dlw[m * ldW + j] = sv;
             if (m < nb && (zero_dead || (float)t <= misc[m])) tp.dlw[(rowb + b0 + m) * W + j] = sv;
-        });
+        }
+    }
     __syncthreads();
-    tgemm_nn_raw(s_dlw, ldW, P.p[R_W_W], R, R, W, raw, wave, nw);            // dg = dlw W_w
+    if (fr1) nfrag_mma<4>(fw, s_dlw, ldW, raw, ldR);                          // dg = dlw W_w
+    else tgemm_nn_raw(s_dlw, ldW, P.p[R_W_W], R, R, W, raw, wave, nw);
     __syncthreads();
     const int kp = tile_kparts((R + 63) >> 6, nw);
-    batched_for<NT, 4>(MMG_TM * R, [&](int idx) {
-            const int m = idx / R, r = idx - m * R;
-            return tp.g[(rowb + min(b0 + m, B - 1)) * R + r];
-        }, [&](int idx, float g) {
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < MMG_TM * R) {
             const int m = idx / R, r = idx - m * R;
             const bool act = (float)t < misc[m];
-            const float v = act ? raw_sum(raw, ldR, kp, m, r) * (1.f - g * g) : 0.f;
+            const float v = act ? raw_sum(raw, ldR, kp, m, r) * (1.f - rg[u] * rg[u]) : 0.f;
             s_dgp[m * ldR + r] = v;
             if (m < nb && (zero_dead || (float)t <= misc[m])) tp.dgpre[(rowb + b0 + m) * R + r] = v;
-        });
+        }
+    }
     __syncthreads();
-    tgemm_nn_raw(s_dgp, ldR, P.p[R_WH_W], R, R, R, raw, wave, nw);            // dgpre W_h
+    if (fr2) nfrag_mma<2>(fh, s_dgp, ldR, raw, ldR);                          // dgpre W_h
+    else tgemm_nn_raw(s_dgp, ldR, P.p[R_WH_W], R, R, R, raw, wave, nw);
     __syncthreads();
     for (int idx = tid; idx < MMG_TM * R; idx += NT) {
         const int m = idx / R, i = idx - m * R;

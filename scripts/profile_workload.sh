@@ -1,13 +1,13 @@
 #!/bin/bash
-# Full rocprofv3 evidence of one bench workload on the GPU box:  scripts/profile_workload.sh <c2|c3|c4|c5> <tag, e.g. r02>
+# Full rocprofv3 evidence of one bench workload on the GPU box:  scripts/profile_workload.sh <c2|c3|c4|c5> <tag, e.g. r02> [extra bench.py flags, e.g. "--scaling strong"]
 #   <tag>_<w>_kernel_stats.csv            --kernel-trace --stats summary
 #   <tag>_<w>_bench_under_rocprof.json    the JSON line of that run
 #   <tag>_<w>_pmc_hbm_traffic.json        FETCH_SIZE / WRITE_SIZE per dispatch (separate --pmc passes, --kernel-trace only)
 #   <tag>_<w>_pmc_sq.json                 SQ instruction / MFMA counters per dispatch
 # written under gpurun_out/; copy the ones to keep into profiles/.
-W=$1; TAG=$2; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+W=$1; TAG=$2; EXTRA=$3; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs"
+CMD="python $R/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs $EXTRA"
 rm -rf /tmp/ks /tmp/pf /tmp/pw /tmp/pc /tmp/pd
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- $CMD > $O/${TAG}_${W}_bench_under_rocprof.json 2> /tmp/ks.err
 find /tmp/ks -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_${W}_kernel_stats.csv \;

@@ -43,6 +43,13 @@ if dbg[200]:
         us(222, 210), us(222, 211), us(222, 205), us(211, 212), us(212, 213), us(213, 214), us(214, 215), us(222, 215)))
     print("R: wait-start %.2f -> wait done %.2f" % (us(222, 220), us(222, 221)))
 
+if dbg[250]:
+    us = lambda a, b: (dbg[b] - dbg[a]) * tick / 1e3
+    print("rs_role (sample 0, step 3), times relative to its signal of step 2: wait-start %.2f | wait done %.2f | gi gather %.2f | GRU .. g %.2f | message %.2f | signal %.2f (at %.2f)" % (
+        us(222, 250) if dbg[222] else float("nan"), us(250, 251), us(251, 252), us(252, 253), us(253, 254), us(254, 255), us(250, 255)))
+    print("  S1 (tile 0, role 0, step 3): wait-start %.2f -> wait done %.2f | load %.2f | [w gemm] %.2f | a gemm+epi %.2f | signal %.2f ; S2: wait done %.2f | a load %.2f | z gemm+epi %.2f | gi gemm+store %.2f | signal %.2f  (all vs rs_role wait-start)" % (
+        us(250, 200), us(250, 201), us(201, 202), us(202, 203), us(203, 204), us(204, 205), us(250, 211), us(211, 212), us(212, 213), us(213, 214), us(214, 215)))
+
 if dbg[224]:
     us = lambda a, b: (dbg[b] - dbg[a]) * tick / 1e3
     print("k_bwd_tile: init %.2f | dy+h* %.2f | dyT+A* %.2f | dA %.2f | dAy + W_hh cache %.2f | loop %.2f" % (
