@@ -437,6 +437,7 @@ __device__ __forceinline__ void build_row_map(const Dims& dm, const Tape& tp) {
         }
     }
     if (lane == 0) tp.rcount[0] = base;
+    for (int i = base + lane; i < T * B; i += 64) tp.rmap[i] = -1;       // (readers that index the list directly need no count)
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -2227,38 +2227,76 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape 
     float* raw = s_coef + 7 * 64 + 16;                     // [16][ld16(64 * bands)]
     LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int nrows = rmap ? rcount[0] : T * B;
+    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 240);
+    const int nrows = T * B;                               // (the live-row list ends with -1 entries: no dependent load of its length)
     const int r0 = blockIdx.x * MMG_TM;
     if (r0 >= nrows) return;
+    if (rmap && rmap[r0] < 0) return;
+    // ---- every global load of the workgroup in ONE round trip (after the row list): statistics, this band's weight
+    // fragment, the rows' message bits / probabilities, their scalars and their slice of the hidden tile
+    const int n0 = blockIdx.y * 64, Nb = min(64, H - n0);
+    const CoefRegs creg = coef_load(dm, tp.stats);
+    const bool fr = nfrag_fits<4>(Nb, W, nw);
+    NFrag<4> fb;
+    fb.n = 0;
+    if (fr) nfrag_load<4>(fb, P.p[S_BIN_W] + n0, H, Nb, W, wave, nw);
+    // tape row of tile row m (every thread derives the rows it touches itself: no LDS hop before the loads go out)
+    auto row_of = [&](int m) { return (r0 + m < nrows) ? (rmap ? rmap[r0 + m] : r0 + m) : -1; };
+    constexpr int UW = 16, UA = 4;                                      // 16 * W <= UW * NT (W <= 256), 16 * 64 = UA * NT
+    F2 rz[UW]; float ra[UA];
+    int rrow[UW];
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        const int idx = min(tid + u * NT, MMG_TM * W - 1), m = idx / W, j = idx - m * W;
+        rrow[u] = row_of(m);
+        const size_t o = (size_t)max(rrow[u], 0) * W + j;
+        rz[u] = F2{tp.z[o], tp.pz[o]};
+    }
+    float rlg[UW], rbs[UW]; int rts[UW];
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        const int row = max(rrow[u], 0), b = row % B;
+        rts[u] = rmap ? T : tp.tstar[b]; rlg[u] = tp.logs[b]; rbs[u] = tp.bs[row];      // (listed rows are live)
+    }
+    int arow[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int idx = min(tid + u * NT, MMG_TM * Nb - 1), m = idx / Nb, n = idx - m * Nb;
+        arow[u] = row_of(m);
+        ra[u] = tp.a[(size_t)max(arow[u], 0) * H + n0 + n];
+    }
+    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 241);
     for (int i = tid; i < MMG_TM * ldW; i += NT) s_dlz[i] = 0.f;
-    if (tid < MMG_TM) s_row[tid] = (r0 + tid < nrows) ? (rmap ? rmap[r0 + tid] : r0 + tid) : -1;
-    loss_coefficients(dm, tp.stats, lc, nullptr, nullptr);
-    batched_for<NT, 4>(MMG_TM * W, [&](int idx) {
-            const int m = idx / W, j = idx - m * W;
-            const size_t o = (size_t)max(s_row[m], 0) * W + j;
-            return F2{tp.z[o], tp.pz[o]};
-        }, [&](int idx, F2 v) {
-            const int m = idx / W, j = idx - m * W, row = s_row[m];
-            if (row < 0) return;
-            const int t = row / B, b = row - t * B;
+    coef_compute(dm, creg, lc);                                             // (ends with a barrier)
+    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 242);
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < MMG_TM * W && rrow[u] >= 0) {
+            const int m = idx / W, j = idx - m * W, row = rrow[u], t = row / B;
             float sv = 0.f;
-            if (t <= tp.tstar[b]) sv = bit_seed_fast(v.x, v.y, (tp.logs[b] - tp.bs[row]) * lc.cw[2 * T + t], lc.ce[2 * T + t]);
+            if (t <= rts[u]) sv = bit_seed_fast(rz[u].x, rz[u].y, (rlg[u] - rbs[u]) * lc.cw[2 * T + t], lc.ce[2 * T + t]);
             s_dlz[m * ldW + j] = sv;
             if (blockIdx.y == 0) tp.dlz[(size_t)row * W + j] = sv;
-        });
+        }
+    }
     __syncthreads();
-    // this workgroup's 64 columns of H; its four waves split K (one batch of weight rows in flight per wave)
-    const int n0 = blockIdx.y * 64, Nb = min(64, H - n0);
-    tgemm_nn_raw(s_dlz, ldW, P.p[S_BIN_W] + n0, H, Nb, W, raw, wave, nw);
+    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 243);
+    // this workgroup's 64 columns of H; its four waves split K
+    if (fr) nfrag_mma<4>(fb, s_dlz, ldW, raw, ld16(Nb));
+    else tgemm_nn_raw(s_dlz, ldW, P.p[S_BIN_W] + n0, H, Nb, W, raw, wave, nw);
     __syncthreads();
+    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 244);
     const int ldr = ld16(Nb), kp = tile_kparts((Nb + 63) >> 6, nw);
-    batched_for<NT, 8>(MMG_TM * Nb, [&](int idx) {
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < MMG_TM * Nb && arow[u] >= 0) {
             const int m = idx / Nb, n = idx - m * Nb;
-            return tp.a[(size_t)max(s_row[m], 0) * H + n0 + n];
-        }, [&](int idx, float a) {
-            const int m = idx / Nb, n = idx - m * Nb;
-            if (s_row[m] >= 0) tp.dpre[(size_t)s_row[m] * H + n0 + n] = raw_sum(raw, ldr, kp, m, n) * (1.f - a * a);
-        });
+            tp.dpre[(size_t)arow[u] * H + n0 + n] = raw_sum(raw, ldr, kp, m, n) * (1.f - ra[u] * ra[u]);
+        }
+    }
+    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 245);
 }
 
 }  // namespace mmg
