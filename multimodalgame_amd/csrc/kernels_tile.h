@@ -1319,6 +1319,157 @@ __device__ __forceinline__ void s2_role(const Dims& dm, const Params& P, const T
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused sender roles (ar.rsample == 3; message width 256, per-sample receiver roles that publish the message):
+//   sa_role j (H / 64 per tile): 64 units of the sender's hidden layer a_t AND its share of the message logits,
+//       zpart_j = a_t[:, slice j] W_b[:, slice j]^T   [16, W]   (K = 64: both matrices of the role live in registers)
+//   sb_role k (W / 16 per tile): adds the H / 64 partials for its 16 message bits, samples them, and forms its partial of the
+//       GRU input product z_slice W_ih[:, slice]^T (K = 16).
+// Against the s1 / s2 roles: no role reads the whole hidden tile (64 KB per role per step) and none runs a K = 1024 chain
+// of dependent MFMAs; the hand-off S1 -> S2 carries 16 x 16 x 16 floats per consumer instead of 16 x 1024.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void sa_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int j) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int nw = NT / 64;
+    const int wave = threadIdx.x >> 6;
+    const int B = dm.B, H = dm.H, W = dm.W, T = dm.T;
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0), n0 = j * 64;
+    const bool train = ar.train != 0;
+    const bool may_stop = !ar.run_all && !dm.fixed && train;
+    const int ldW = ld16(W), ldA = ld16(64);
+    float* s_w = smem; float* s_a = s_w + MMG_TM * ldW; float* raw = s_a + MMG_TM * ldA;      // raw: [16][ld16(W)] (>= [16][ld16(64)])
+    float* s_bc = raw + MMG_TM * ldW; float* s_hw0 = s_bc + 64; float* s_live = s_hw0 + 64;
+    {
+        const int tid = threadIdx.x;
+        for (int i = tid; i < MMG_TM * (ldW + ldA); i += NT) smem[i] = 0.f;
+        if (tid < 64) { s_bc[tid] = P.p[S_CODE_B][n0 + tid]; s_hw0[tid] = tp.hw0[n0 + tid]; }
+        if (tid < MMG_TM) s_live[tid] = tid < nb ? 1.f : 0.f;
+    }
+    float hxr[2];                                                       // h_x[b, n0 .. n0+63] of the tile: 1024 values on 512 threads
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int idx = threadIdx.x + u * NT, m = idx >> 6, n = idx & 63; hxr[u] = tp.hx[(size_t)min(b0 + m, B - 1) * H + n0 + n]; }
+    uint32_t* cG = pf_ctr(tp, 0, tile); uint32_t* cA = pf_ctr(tp, 1, tile); uint32_t* done = pf_ctr(tp, 3, tile);
+    WFrag<8> fc; WFrag<4> fz0, fz1;                                     // W_c rows n0 ..: 4 n-tiles x 2 k-parts of 8 k-groups; W_b^T slice: 16 n-tiles of 4 k-groups
+    wfrag_load<8>(fc, P.p[S_CODE_W] + (size_t)n0 * W, W, 64, W, wave, nw);
+    wfrag_load<4>(fz0, P.p[S_BIN_W] + n0, H, W, 64, wave, nw);
+    wfrag_load<4>(fz1, P.p[S_BIN_W] + n0, H, W, 64, wave + nw, nw);
+    float* zp = tp.zpart + ((size_t)tile * (H / 64) + j) * MMG_TM * W;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const size_t rowb = (size_t)t * B, rowp = (size_t)(t > 0 ? t - 1 : 0) * B;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (t >= 1) {
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 200);
+            if (!pf_wait(cG, (uint32_t)(nb * t), done, tp.sync)) return;
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201);
+            batched_for<NT, 8>(MMG_TM * W, [&](int idx) { const int m = idx / W, n = idx - m * W; return tp.w[(rowp + min(b0 + m, B - 1)) * W + n]; },
+                               [&](int idx, float v) { const int m = idx / W, n = idx - m * W; s_w[m * ldW + n] = v; });
+            if (tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
+            __syncthreads();
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 202);
+            wfrag_mma<8>(fc, s_w, ldW, raw, ldA);                       // this role's 64 units of the sender hidden state (model.py:195-216)
+            __syncthreads();
+        }
+        {
+            const int kp = tile_kparts(4, nw);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + u * NT, m = idx >> 6, n = idx & 63;
+                const float hw = (t == 0) ? s_hw0[n] : raw_sum(raw, ldA, kp, m, n) + s_bc[n];
+                const float av = ftanh(hxr[u] + hw);
+                s_a[m * ldA + n] = av;
+                if (m < nb && s_live[m] != 0.f) tp.a[(rowb + b0 + m) * H + n0 + n] = av;
+            }
+        }
+        __syncthreads();
+        MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 203);
+        wfrag_mma<4>(fz0, s_a, ldA, raw, ldW); wfrag_mma<4>(fz1, s_a, ldA, raw, ldW);      // partial message logits over this role's K slice
+        __syncthreads();
+        for (int idx = tid; idx < MMG_TM * W; idx += NT) {
+            const int m = idx / W, n = idx - m * W;
+            st_wt(zp + m * W + n, raw[m * ldW + n]);
+        }
+        MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 204);
+        pf_signal(cA);
+        MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 205);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int k) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int nw = NT / 64;
+    const int wave = threadIdx.x >> 6;
+    const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, T = dm.T;
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0), c0 = k * 16, ns1 = H / 64;
+    const bool binary = dm.use_binary != 0, train = ar.train != 0;
+    const bool may_stop = !ar.run_all && !dm.fixed && train;
+    const int ldZ = ld16(16), ld3R = ld16(3 * R);
+    float* s_zs = smem; float* raw = s_zs + MMG_TM * ldZ; float* s_live = raw + MMG_TM * ld3R;
+    {
+        const int tid = threadIdx.x;
+        for (int i = tid; i < MMG_TM * ldZ; i += NT) smem[i] = 0.f;
+        if (tid < MMG_TM) s_live[tid] = tid < nb ? 1.f : 0.f;
+    }
+    const uint32_t mb_counter = tp.counter[0];
+    uint32_t* cA = pf_ctr(tp, 1, tile); uint32_t* cZ = pf_ctr(tp, 2, tile); uint32_t* done = pf_ctr(tp, 3, tile);
+    WFrag<1> fi0, fi1;                                                   // W_ih[:, c0 .. c0+15]: 12 n-tiles, one k-group
+    wfrag_load<1>(fi0, P.p[R_WIH] + c0, W, 3 * R, 16, wave, nw);
+    wfrag_load<1>(fi1, P.p[R_WIH] + c0, W, 3 * R, 16, wave + nw, nw);
+    // thread (output o = tid / 2 = (sample m, bit c), half hf): adds the partials of roles hf, hf + 2, ...
+    const int o = threadIdx.x >> 1, hf = threadIdx.x & 1, om = o >> 4, oc = o & 15;
+    const float bbv = P.p[S_BIN_B][c0 + oc];
+    const float* zp = tp.zpart + (size_t)tile * ns1 * MMG_TM * W + (size_t)om * W + c0 + oc;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const size_t rowb = (size_t)t * B;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int bq = min(b0 + om, B - 1);
+        float uz = 0.f;                                                  // (drawn before the wait)
+        if (binary && train && hf == 0)
+            uz = ar.u_z ? ar.u_z[(rowb + bq) * W + c0 + oc] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + dm.boff + bq) * W + c0 + oc), mb_counter, 0u);
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 210);
+        if (!pf_wait(cA, (uint32_t)(ns1 * (t + 1)), done, tp.sync)) return;
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 211);
+        float p8[8], acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p8[u] = zp[(size_t)min(hf + 2 * u, ns1 - 1) * MMG_TM * W];
+        if (t >= 1 && tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (hf + 2 * u < ns1) ? p8[u] : 0.f;
+        acc = dpp_group_sum<2>(acc);
+        __syncthreads();                                                 // s_live
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 212);
+        if (hf == 0) {
+            const float lz = acc + bbv;
+            float zz = lz, pp = 0.f;
+            if (binary) {
+                pp = fsigmoid(lz);
+                zz = train ? ((uz < pp) ? 1.f : 0.f) : rintf(pp);                               // model.py:227 / 229
+            }
+            s_zs[om * ldZ + oc] = zz;
+            if (om < nb && s_live[om] != 0.f) {                                                 // (read back by the receiver roles: write-through)
+                st_wt(&tp.z[(rowb + b0 + om) * W + c0 + oc], zz);
+                if (binary) st_wt(&tp.pz[(rowb + b0 + om) * W + c0 + oc], pp);
+            }
+        }
+        __syncthreads();
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 213);
+        wfrag_mma<1>(fi0, s_zs, ldZ, raw, ld3R); wfrag_mma<1>(fi1, s_zs, ldZ, raw, ld3R);       // z_slice W_ih[:, slice]^T
+        __syncthreads();
+        for (int idx = tid; idx < MMG_TM * 3 * R; idx += NT) {
+            const int m = idx / (3 * R), n = idx - m * 3 * R;
+            if (m < nb) st_wt(&tp.gip[((size_t)k * B + b0 + m) * 3 * R + n], raw[m * ld3R + n]);
+        }
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 214);
+        pf_signal(cZ);
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 215);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // rs_role: the receiver of ONE sample as a role of k_conv_persist (agents with a large sender but the receiver shape of
 // BASELINE configs 1-4: R = 64, V = 100, D <= 32).  A 16-sample tile role walks through eight barrier-separated phases of
 // [16, K] x [K, N] products per step (~20 us); one workgroup per sample with every receiver weight in registers (the
@@ -1435,14 +1586,14 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
         if (!pf_wait(cZ, (uint32_t)(ns2 * (t + 1)), nullptr, tp.sync)) return;
         MMG_RSTAMP(b == 0 && t == 3, 251);
         {
-            float p4[4];
+            float p4[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p4[u] = tp.gip[((size_t)min(h3 + 2 * u, ns2 - 1) * B + b) * 3 * R + nr];
+            for (int u = 0; u < 8; ++u) p4[u] = tp.gip[((size_t)min(h3 + 2 * u, ns2 - 1) * B + b) * 3 * R + nr];
             float zz = 0.f, pp = 0.5f;
             if (binary && tid < W) { zz = tp.z[row * W + tid]; pp = tp.pz[row * W + tid]; }
             float gp = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) gp += (h3 + 2 * u < ns2) ? p4[u] : 0.f;
+            for (int u = 0; u < 8; ++u) gp += (h3 + 2 * u < ns2) ? p4[u] : 0.f;
             const float giv = bih + dpp_group_sum<2>(gp);
             if (gru_lane && h3 == 0) { s_gi[n3] = giv; s_gh[n3] = ghv; }
             if (binary && wave < 4) {                                      // log-likelihood / neg-entropy of the sender's bits, model.py:908-922
@@ -1650,8 +1801,14 @@ __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp,
     int blk = blockIdx.x;
     if (ar.rsample) {                                   // one receiver role per sample, then the sender roles of the tiles
         if (blk < dm.B) {
-            if (ar.rsample == 2) { if (dm.D == 30) rs_role<NT, 64, 100, 30, 256>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32, 256>(dm, P, tp, ar, blk); }
+            if (ar.rsample >= 2) { if (dm.D == 30) rs_role<NT, 64, 100, 30, 256>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32, 256>(dm, P, tp, ar, blk); }
             else { if (dm.D == 30) rs_role<NT, 64, 100, 30, 0>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32, 0>(dm, P, tp, ar, blk); }
+            return;
+        }
+        if (ar.rsample == 3) {                          // fused sender roles: ns2 sb roles, then ns1 sa roles per tile
+            const int r = blk - dm.B;
+            if (r < tiles * ar.ns2) sb_role<NT>(dm, P, tp, ar, r / ar.ns2, r % ar.ns2);
+            else { const int q = r - tiles * ar.ns2; sa_role<NT>(dm, P, tp, ar, q / ar.ns1, q % ar.ns1); }
             return;
         }
         blk += tiles - dm.B;                            // (the tile-role slots [0, tiles) stay empty)

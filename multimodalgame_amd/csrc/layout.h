@@ -93,6 +93,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(Apub, float, 0, 2, NTILE, 16 * R + 32, 1)  /* k_conv_split: A tile + row flags published by a tile's owner role       */ \
     X(cpart, float, 0, 3, NTILE * NHLP, 16, V + 2) /* k_conv_split: per helper: unnormalised mixture partial | slice max | slice sum */ \
     X(gip, float, 0, 3, NS2P, B, 3 * R)  /* per-sender-role partials of the GRU input product (k_conv_persist)           */ \
+    X(zpart, float, 0, 3, NZP, 16, W)    /* per-SA-role partial message logits of a tile (k_conv_persist, fused sender roles) */ \
     X(pflags, uint32_t, 2, 1, 4 * 64 * 64, 1, 1) /* k_conv_persist: per (kind, sample tile) counters, one per 256-byte block */ \
     X(alive, int32_t, 2, 1, T + 2, 1, 1) /* [t]: sample tiles with a live sample when step t starts (kernels_tile.h)  */ \
     X(hw0, float, 0, 1, H, 1, 1)         /* code_layer(sigmoid(code_bias)) :199-200*/ \
@@ -206,9 +207,9 @@ inline TapeLayout tape_layout(const mmg_config& c) {
     L.n = 0;
     const int64_t B = c.batch, D = c.n_classes, F = c.feat_dim, H = c.h_dim, W = c.w_dim, R = c.rec_hidden,
                   V = c.wv_dim, K = c.bas_hidden, T = c.max_exchange, T1 = T + 1,
-                  NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B), NS2P = (W + 31) / 32, NTILE = (B + 15) / 16, NHLP = split_helpers((int)B) > 0 ? split_helpers((int)B) : 1,
+                  NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B), NS2P = (W + 15) / 16, NTILE = (B + 15) / 16, NZP = ((B + 15) / 16) * ((H + 63) / 64), NHLP = split_helpers((int)B) > 0 ? split_helpers((int)B) : 1,
                   NWP = wgrad_nsplit((int)(T * B)) > 1 ? (int64_t)wgrad_nsplit((int)(T * B)) * (param_layout(c).total + 512 * 64) : 4;
-    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP;
+    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \

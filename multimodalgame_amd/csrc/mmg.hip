@@ -503,6 +503,10 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
         // receiver shape of the register-resident kernels: one receiver role per SAMPLE (rs_role) beside the tiles' sender roles
         ar.rsample = (d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && d.B + tiles * (ar.ns1 + ar.ns2) <= 240 && !getenv("MMG_NO_RSAMPLE")) ? 1 : 0;
         if (ar.rsample && d.W == 256 && !getenv("MMG_NO_RMSG")) ar.rsample = 2;      // ... which also form the receiver's message
+        if (ar.rsample == 2 && d.H % 64 == 0 && d.H / 64 <= 16 && d.B + tiles * (d.H / 64 + d.W / 16) <= 240 && !getenv("MMG_NO_FUSED_S")) {
+            ar.rsample = 3;                                 // fused sender roles (sa_role / sb_role)
+            ar.ns1 = d.H / 64; ar.ns2 = d.W / 16;
+        }
         if (ar.rsample) {
             hipLaunchKernelGGL(k_conv_persist<512>, dim3(d.B + tiles * (ar.ns1 + ar.ns2)), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
             return launch_check("k_conv_persist");
