@@ -26,6 +26,15 @@ namespace mmg {
 #define MMG_TM 16                                   // samples per tile = MFMA M
 // agent-scope (write-through) store: payload another workgroup of the same launch reads after a counter hand-off
 __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... 16 bytes at once (p 16-byte aligned): the agent-scope store of gfx942 / gfx950 is a global store with sc1 set
+__device__ __forceinline__ void st_wt4(float* p, float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+}
+// values of lanes l, l + 2, l + 4, l + 6 (the results of four neighbouring 2-lane groups) as one float4 in lane l
+__device__ __forceinline__ float4 gather4_even(float v) {
+    return make_float4(v, __shfl_down(v, 2), __shfl_down(v, 4), __shfl_down(v, 6));
+}
 __host__ __device__ inline int ld16(int n) { return ((n + 15) & ~15) + 4; }      // LDS row stride of a [16][n] activation tile
 
 // 4 consecutive floats of a weight row, BRANCH-FREE (a branch around a load makes hipcc wait vmcnt(0) at the join: one
@@ -1363,8 +1372,11 @@ __device__ __forceinline__ void sa_role(const Dims& dm, const Params& P, const T
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 200);
             if (!pf_wait(cG, (uint32_t)(nb * t), done, tp.sync)) return;
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201);
-            batched_for<NT, 8>(MMG_TM * W, [&](int idx) { const int m = idx / W, n = idx - m * W; return tp.w[(rowp + min(b0 + m, B - 1)) * W + n]; },
-                               [&](int idx, float v) { const int m = idx / W, n = idx - m * W; s_w[m * ldW + n] = v; });
+            {
+                const int W4 = W >> 2;
+                batched_for<NT, 2>(MMG_TM * W4, [&](int idx) { const int m = idx / W4, q = idx - m * W4; return reinterpret_cast<const float4*>(tp.w + (rowp + min(b0 + m, B - 1)) * W)[q]; },
+                                   [&](int idx, float4 v) { const int m = idx / W4, q = idx - m * W4; *reinterpret_cast<float4*>(s_w + m * ldW + 4 * q) = v; });
+            }
             if (tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
             __syncthreads();
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 202);
@@ -1386,9 +1398,9 @@ __device__ __forceinline__ void sa_role(const Dims& dm, const Params& P, const T
         MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 203);
         wfrag_mma<4>(fz0, s_a, ldA, raw, ldW); wfrag_mma<4>(fz1, s_a, ldA, raw, ldW);      // partial message logits over this role's K slice
         __syncthreads();
-        for (int idx = tid; idx < MMG_TM * W; idx += NT) {
-            const int m = idx / W, n = idx - m * W;
-            st_wt(zp + m * W + n, raw[m * ldW + n]);
+        for (int idx = tid; idx < MMG_TM * (W >> 2); idx += NT) {
+            const int m = idx / (W >> 2), n = (idx - m * (W >> 2)) * 4;
+            st_wt4(zp + m * W + n, *reinterpret_cast<const float4*>(raw + m * ldW + n));
         }
         MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 204);
         pf_signal(cA);
@@ -1442,6 +1454,7 @@ __device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const T
         acc = dpp_group_sum<2>(acc);
         __syncthreads();                                                 // s_live
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 212);
+        float zq = 0.f, pq = 0.f;
         if (hf == 0) {
             const float lz = acc + bbv;
             float zz = lz, pp = 0.f;
@@ -1450,18 +1463,22 @@ __device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const T
                 zz = train ? ((uz < pp) ? 1.f : 0.f) : rintf(pp);                               // model.py:227 / 229
             }
             s_zs[om * ldZ + oc] = zz;
-            if (om < nb && s_live[om] != 0.f) {                                                 // (read back by the receiver roles: write-through)
-                st_wt(&tp.z[(rowb + b0 + om) * W + c0 + oc], zz);
-                if (binary) st_wt(&tp.pz[(rowb + b0 + om) * W + c0 + oc], pp);
+            zq = zz; pq = pp;
+        }
+        {
+            const float4 z4 = gather4_even(zq), p4v = gather4_even(pq);                         // (read back by the receiver roles: write-through)
+            if ((tid & 7) == 0 && om < nb && s_live[om] != 0.f) {
+                st_wt4(&tp.z[(rowb + b0 + om) * W + c0 + oc], z4);
+                if (binary) st_wt4(&tp.pz[(rowb + b0 + om) * W + c0 + oc], p4v);
             }
         }
         __syncthreads();
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 213);
         wfrag_mma<1>(fi0, s_zs, ldZ, raw, ld3R); wfrag_mma<1>(fi1, s_zs, ldZ, raw, ld3R);       // z_slice W_ih[:, slice]^T
         __syncthreads();
-        for (int idx = tid; idx < MMG_TM * 3 * R; idx += NT) {
-            const int m = idx / (3 * R), n = idx - m * 3 * R;
-            if (m < nb) st_wt(&tp.gip[((size_t)k * B + b0 + m) * 3 * R + n], raw[m * ld3R + n]);
+        for (int idx = tid; idx < MMG_TM * (3 * R >> 2); idx += NT) {
+            const int m = idx / (3 * R >> 2), n = (idx - m * (3 * R >> 2)) * 4;
+            if (m < nb) st_wt4(&tp.gip[((size_t)k * B + b0 + m) * 3 * R + n], *reinterpret_cast<const float4*>(raw + m * ld3R + n));
         }
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 214);
         pf_signal(cZ);
@@ -1734,7 +1751,7 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
             __syncthreads();
             // ===== receiver message (model.py:454-475) -> the S1 roles
             const float acc = dpp_group_sum<2>(dot4<J3H>(ww, s_g + hw * 4, 8));
-            float lpv = 0.f, nev = 0.f;
+            float lpv = 0.f, nev = 0.f, wq = 0.f;
             if (hw == 0) {
                 const float lw = acc + bw;
                 float wv = lw, pp = 0.f;
@@ -1746,7 +1763,11 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
                     lpv = wv * l1 + (1.f - wv) * l0; nev = pp * l1 + (1.f - pp) * l0;
                 }
                 s_c[nw] = wv;
-                st_wt(&tp.w[row * W + nw], wv);
+                wq = wv;
+            }
+            {
+                const float4 w4 = gather4_even(wq);                         // four message bits per 16-byte write-through store
+                if ((tid & 7) == 0) st_wt4(&tp.w[row * W + nw], w4);
             }
             if (binary) {
                 lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
