@@ -1821,6 +1821,14 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles, int xcd_map) {
     int blk = blockIdx.x;
     if (ar.rsample) {                                   // one receiver role per sample, then the sender roles of the tiles
+        const int nrole = dm.B + tiles * (ar.ns1 + ar.ns2);
+        if (blk >= nrole) {
+            // trailing workgroups (dispatched after every role, onto CUs the roles leave idle): 16 x 16 tiles of
+            // basehx = h_x . baseline_sen.linear1.weight[:, :H]^T, which k_baselines4 needs next and nothing here produces
+            if (threadIdx.x >= MMG_BLOCK) return;        // gemm_nt_tile is a 4-wave routine
+            gemm_nt_tile(blk - nrole, tp.hx, dm.H, P.p[BS_L1_W], dm.H + dm.W, nullptr, tp.basehx, dm.K, dm.B, dm.K, dm.H);
+            return;
+        }
         if (blk < dm.B) {
             if (ar.rsample >= 2) { if (dm.D == 30) rs_role<NT, 64, 100, 30, 256>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32, 256>(dm, P, tp, ar, blk); }
             else { if (dm.D == 30) rs_role<NT, 64, 100, 30, 0>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32, 0>(dm, P, tp, ar, blk); }

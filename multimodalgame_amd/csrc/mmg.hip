@@ -45,6 +45,7 @@ struct mmg_handle {
     bool profiling;
     bool scores_in_parts;      // the last forward left baseline scores as partials (k_baselines2)
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
+    bool basehx_ready;         // this forward pass formed tape.basehx inside the conversation launch
     bool merge_roles;          // MMG_NO_MERGE=1 keeps k_stats / k_dC / basehx as separate launches / in-kernel work
     // sample-tile MFMA path (kernels_tile.h): every shape the register-resident kernels do not cover
     bool tile_ok;              // its LDS plan fits (MMG_NO_TILE=1: never use it)
@@ -508,7 +509,11 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
             ar.ns1 = d.H / 64; ar.ns2 = d.W / 16;
         }
         if (ar.rsample) {
-            hipLaunchKernelGGL(k_conv_persist<512>, dim3(d.B + tiles * (ar.ns1 + ar.ns2)), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
+            // basehx tiles for k_baselines4 ride along as trailing workgroups (training minibatches of <= 64 samples)
+            const bool want_base = ar.train && d.use_binary && !ar.run_all && d.B <= 64 && !(d.H & 3) && h->merge_roles;
+            const int bt = want_base ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
+            hipLaunchKernelGGL(k_conv_persist<512>, dim3(d.B + tiles * (ar.ns1 + ar.ns2) + bt), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
+            h->basehx_ready = want_base;
             return launch_check("k_conv_persist");
         }
         const int roles = 1 + ar.ns1 + ar.ns2;
@@ -553,6 +558,7 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     ar.x = d_x; ar.target = d_target; ar.desc = d_desc; ar.u_z = d_u_z; ar.u_s = d_u_s; ar.u_w = d_u_w; ar.seed = seed;
     ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
     bool base_ready = false;
+    h->basehx_ready = false;
     if (tile_path(h)) {
         if (launch_conv_tile(h, st, ar)) return -1;
     } else {
@@ -580,8 +586,9 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
             if (tile_path(h) && d.B <= 64 && !(d.H & 3)) {
                 // any message / state width: basehx as a GEMM launch, then one MFMA pass over the live rows (kernels_tile.h)
                 const int bt = ((d.B + 15) / 16) * ((d.K + 15) / 16);
-                hipLaunchKernelGGL(k_gemm_nt, dim3(bt), dim3(MMG_BLOCK), 0, st, (const float*)h->tp.hx, d.H, (const float*)h->P.p[BS_L1_W], d.H + d.W,
-                                   (const float*)nullptr, h->tp.basehx, d.K, d.B, d.K, d.H);
+                if (!h->basehx_ready)
+                    hipLaunchKernelGGL(k_gemm_nt, dim3(bt), dim3(MMG_BLOCK), 0, st, (const float*)h->tp.hx, d.H, (const float*)h->P.p[BS_L1_W], d.H + d.W,
+                                       (const float*)nullptr, h->tp.basehx, d.K, d.B, d.K, d.H);
                 hipLaunchKernelGGL(k_baselines4, dim3((d.T * d.B + 15) / 16, (d.K + 63) / 64, 2), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
             } else if (live_rows) {
                 hipLaunchKernelGGL(k_baselines3, dim3((d.T * d.B + 15) / 16, (d.K + 63) / 64, 2), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
