@@ -203,6 +203,7 @@ struct ConvArgs {
     float* sprod_state;        // receiver running stop product       [B]
     int sprod_first;
     int rsample;               // k_conv_persist: one receiver role per SAMPLE (register-resident weights) instead of one per tile
+    int b_begin, b_count;      // ... for the samples [b_begin, b_begin + b_count) (large batches run as consecutive launches)
     int persist, ns1, ns2;     // kernels_tile.h, k_conv_persist: sender roles per sample tile (0: not persistent)
     int nhelp, per;            // kernels_tile.h, k_conv_split: class helpers per sample tile, classes per slice
 };

@@ -1821,7 +1821,9 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles, int xcd_map) {
     int blk = blockIdx.x;
     if (ar.rsample) {                                   // one receiver role per sample, then the sender roles of the tiles
-        const int nrole = dm.B + tiles * (ar.ns1 + ar.ns2);
+        // this launch covers the samples [b_begin, b_begin + b_count) = the tiles ctile0 .. ctile0 + ctiles - 1
+        const int cb = ar.b_count, ctile0 = ar.b_begin / MMG_TM, ctiles = (cb + MMG_TM - 1) / MMG_TM;
+        const int nrole = cb + ctiles * (ar.ns1 + ar.ns2);
         if (blk >= nrole) {
             // trailing workgroups (dispatched after every role, onto CUs the roles leave idle): 16 x 16 tiles of
             // basehx = h_x . baseline_sen.linear1.weight[:, :H]^T, which k_baselines4 needs next and nothing here produces
@@ -1829,18 +1831,21 @@ __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp,
             gemm_nt_tile(blk - nrole, tp.hx, dm.H, P.p[BS_L1_W], dm.H + dm.W, nullptr, tp.basehx, dm.K, dm.B, dm.K, dm.H);
             return;
         }
-        if (blk < dm.B) {
-            if (ar.rsample >= 2) { if (dm.D == 30) rs_role<NT, 64, 100, 30, 256>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32, 256>(dm, P, tp, ar, blk); }
-            else { if (dm.D == 30) rs_role<NT, 64, 100, 30, 0>(dm, P, tp, ar, blk); else rs_role<NT, 64, 100, 32, 0>(dm, P, tp, ar, blk); }
+        if (blk < cb) {
+            const int b = ar.b_begin + blk;
+            if (ar.rsample >= 2) { if (dm.D == 30) rs_role<NT, 64, 100, 30, 256>(dm, P, tp, ar, b); else rs_role<NT, 64, 100, 32, 256>(dm, P, tp, ar, b); }
+            else { if (dm.D == 30) rs_role<NT, 64, 100, 30, 0>(dm, P, tp, ar, b); else rs_role<NT, 64, 100, 32, 0>(dm, P, tp, ar, b); }
             return;
         }
+        const int r = blk - cb;
         if (ar.rsample == 3) {                          // fused sender roles: ns2 sb roles, then ns1 sa roles per tile
-            const int r = blk - dm.B;
-            if (r < tiles * ar.ns2) sb_role<NT>(dm, P, tp, ar, r / ar.ns2, r % ar.ns2);
-            else { const int q = r - tiles * ar.ns2; sa_role<NT>(dm, P, tp, ar, q / ar.ns1, q % ar.ns1); }
-            return;
+            if (r < ctiles * ar.ns2) sb_role<NT>(dm, P, tp, ar, ctile0 + r / ar.ns2, r % ar.ns2);
+            else { const int q = r - ctiles * ar.ns2; sa_role<NT>(dm, P, tp, ar, ctile0 + q / ar.ns1, q % ar.ns1); }
+        } else {
+            if (r < ctiles * ar.ns2) s2_role<NT>(dm, P, tp, ar, ctile0 + r / ar.ns2, r % ar.ns2);
+            else { const int q = r - ctiles * ar.ns2; s1_role<NT>(dm, P, tp, ar, ctile0 + q / ar.ns1, q % ar.ns1); }
         }
-        blk += tiles - dm.B;                            // (the tile-role slots [0, tiles) stay empty)
+        return;
     }
     if (xcd_map) {
         // at most 8 tiles: workgroup i runs on XCD i % 8, so tile x takes the workgroups with i % 8 == x -- all roles of a

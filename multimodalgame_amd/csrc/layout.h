@@ -187,7 +187,12 @@ struct Tape {
 
 // row slices per output tile of k_wgrad's (step, sample)-row jobs: with thousands of rows the few dozen output tiles of the
 // small receiver matrices would otherwise be a handful of long-running workgroups
-__host__ __device__ inline int wgrad_nsplit(int TB) { int n = TB / 2048; return TB >= 4096 ? (n > 16 ? 16 : n) : 1; }
+__host__ __device__ inline int wgrad_nsplit(int TB, long long ptotal) {
+    int n = TB / 2048;
+    n = TB >= 4096 ? (n > 16 ? 16 : n) : 1;
+    const int cap = (int)(12000 / (ptotal / 512 + 64));          // (k_wgrad addresses at most 16384 workgroups: ~ptotal / 512 output tiles x slices)
+    return n > cap ? (cap < 1 ? 1 : cap) : n;
+}
 
 // class helpers per sample tile of the many-class forward (k_conv_split): every CU the sample tiles leave idle takes a
 // slice of the classes; 0: no split
@@ -208,7 +213,7 @@ inline TapeLayout tape_layout(const mmg_config& c) {
     const int64_t B = c.batch, D = c.n_classes, F = c.feat_dim, H = c.h_dim, W = c.w_dim, R = c.rec_hidden,
                   V = c.wv_dim, K = c.bas_hidden, T = c.max_exchange, T1 = T + 1,
                   NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B), NS2P = (W + 15) / 16, NTILE = (B + 15) / 16, NZP = ((B + 15) / 16) * ((H + 63) / 64), NHLP = split_helpers((int)B) > 0 ? split_helpers((int)B) : 1,
-                  NWP = wgrad_nsplit((int)(T * B)) > 1 ? (int64_t)wgrad_nsplit((int)(T * B)) * (param_layout(c).total + 512 * 64) : 4;
+                  NWP = wgrad_nsplit((int)(T * B), param_layout(c).total) > 1 ? (int64_t)wgrad_nsplit((int)(T * B), param_layout(c).total) * (param_layout(c).total + 512 * 64) : 4;
     (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};

@@ -136,7 +136,7 @@ static int build_jobs(mmg_handle* h) {
         g.A = A; g.Bm = Bm; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.rows = rows; g.N = N; g.K = Kk;
         g.bmod = bmod; g.bsrc = bsrc; g.tile_begin = tiles; g.tiles_k = (Kk + 31) / 32;     // 16 x 32 outputs per block
         g.vhid = nullptr; g.vw2 = nullptr; g.compact = (rows == TB) ? 1 : 0;
-        g.nsplit = (rows == TB) ? wgrad_nsplit(TB) : 1;
+        g.nsplit = (rows == TB) ? wgrad_nsplit(TB, h->pl.total) : 1;
         tiles += ((N + 15) / 16) * g.tiles_k * g.nsplit;
     };
     // dW = (dbeta * w2 * relu'(hid))^T . input  with the first factor formed on the fly
@@ -148,7 +148,7 @@ static int build_jobs(mmg_handle* h) {
     int cblocks = 0, nc = 0;
     // bias gradient = column sums of a (step, sample)-row tape.  With thousands of rows the 16-column blocks of a column job
     // are a handful of latency-bound workgroups: run it through the row-split GEMM pipeline instead, as delta^T . ones (K = 1)
-    const bool bias_as_gemm = wgrad_nsplit(TB) > 1;
+    const bool bias_as_gemm = wgrad_nsplit(TB, h->pl.total) > 1;
     auto col = [&](const float* src, int ld, int rows, int cols, float* dst, const float* scale) {
         ColJob& c = jt.c[nc++];
         c.src = src; c.dst = dst; c.scale = scale; c.ld = ld; c.rows = rows; c.cols = cols; c.blk_begin = cblocks;
@@ -336,8 +336,11 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         }
         // per-step sender products as ROLES of one persistent launch when all of them fit on the chip together
         h->persist_ns1 = d.H / 64; h->persist_ns2 = d.W / 32;
+        // (receiver shape of the register-resident kernels: per-sample receiver roles, and batches too large for one launch of
+        //  co-resident roles run as consecutive launches over sample ranges)
+        const bool rs_capable = d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && !getenv("MMG_NO_RSAMPLE");
         h->tile_persist = h->tile_ok && h->tile_ext && !(d.H % 64) && !(d.W % 32) && tiles <= 64 &&
-                          tiles * (1 + h->persist_ns1 + h->persist_ns2) <= 240 && MMG_TM * d.W <= 8 * 512 && !getenv("MMG_NO_PERSIST");
+                          (tiles * (1 + h->persist_ns1 + h->persist_ns2) <= 240 || rs_capable) && MMG_TM * d.W <= 8 * 512 && !getenv("MMG_NO_PERSIST");
         if (h->tile_persist) {
             const int a = tile_lds(d, 512 / 64, false).total * 4, b = srole_lds(d, 512 / 64).total * 4;
             h->persist_smem = a > b ? a : b;
@@ -502,20 +505,38 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
         ar.phases = 2; ar.t_begin = 0; ar.t_end = d.T; ar.persist = 1; ar.ns1 = h->persist_ns1; ar.ns2 = h->persist_ns2;
         // optional: one tile per XCD (32 CUs each hold the tile's roles)
         // receiver shape of the register-resident kernels: one receiver role per SAMPLE (rs_role) beside the tiles' sender roles
-        ar.rsample = (d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && d.B + tiles * (ar.ns1 + ar.ns2) <= 240 && !getenv("MMG_NO_RSAMPLE")) ? 1 : 0;
+        ar.rsample = (d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && !getenv("MMG_NO_RSAMPLE")) ? 1 : 0;
         if (ar.rsample && d.W == 256 && !getenv("MMG_NO_RMSG")) ar.rsample = 2;      // ... which also form the receiver's message
-        if (ar.rsample == 2 && d.H % 64 == 0 && d.H / 64 <= 16 && d.B + tiles * (d.H / 64 + d.W / 16) <= 240 && !getenv("MMG_NO_FUSED_S")) {
+        if (ar.rsample == 2 && d.H % 64 == 0 && d.H / 64 <= 16 && !getenv("MMG_NO_FUSED_S")) {
             ar.rsample = 3;                                 // fused sender roles (sa_role / sb_role)
             ar.ns1 = d.H / 64; ar.ns2 = d.W / 16;
         }
         if (ar.rsample) {
+            // all roles of a launch must be co-resident (<= 240 workgroups): as many whole tiles per launch as fit, the
+            // batch in consecutive launches (the conversations of different samples are independent)
+            const int per_tile = MMG_TM + ar.ns1 + ar.ns2;
+            int ct = 240 / per_tile;
+            if (ct < 1) ct = 1;
+            const int nchunk = (tiles + ct - 1) / ct;
+            ct = (tiles + nchunk - 1) / nchunk;
+            // (measured with config 4's agents: 256 samples in 4 launches 471 us against 858 us as per-step launches; 1024 samples
+            //  in 13 launches 1 723 against 1 544 -- beyond six launches the per-step GEMM launches over the whole batch win)
+            if (nchunk > 6) goto per_step;
             // basehx tiles for k_baselines4 ride along as trailing workgroups (training minibatches of <= 64 samples)
-            const bool want_base = ar.train && d.use_binary && !ar.run_all && d.B <= 64 && !(d.H & 3) && h->merge_roles;
+            const bool want_base = nchunk == 1 && ar.train && d.use_binary && !ar.run_all && d.B <= 64 && !(d.H & 3) && h->merge_roles;
             const int bt = want_base ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
-            hipLaunchKernelGGL(k_conv_persist<512>, dim3(d.B + tiles * (ar.ns1 + ar.ns2) + bt), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
+            for (int c = 0; c < nchunk; ++c) {
+                ar.b_begin = c * ct * MMG_TM;
+                ar.b_count = (d.B - ar.b_begin < ct * MMG_TM) ? d.B - ar.b_begin : ct * MMG_TM;
+                if (ar.b_count <= 0) break;
+                const int ctiles = (ar.b_count + MMG_TM - 1) / MMG_TM;
+                hipLaunchKernelGGL(k_conv_persist<512>, dim3(ar.b_count + ctiles * (ar.ns1 + ar.ns2) + bt), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
+            }
             h->basehx_ready = want_base;
             return launch_check("k_conv_persist");
         }
+        if (tiles * (1 + ar.ns1 + ar.ns2) > 240) goto per_step;            // (MMG_NO_RSAMPLE on a batch the tile roles do not fit)
+        {
         const int roles = 1 + ar.ns1 + ar.ns2;
         // (measured at config 4: 575 us per minibatch against 527 with plain role order -- the 25 roles of a tile then share
         //  ONE L2 for their weight and payload reads, and a load that follows a write-through store in the same L2 took 5-8 us
@@ -523,7 +544,10 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
         const int xcd_map = (tiles <= 8 && roles <= 30 && getenv("MMG_XCD_MAP")) ? 1 : 0;
         hipLaunchKernelGGL(k_conv_persist<512>, dim3(xcd_map ? 8 * roles : tiles * roles), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, xcd_map);
         return launch_check("k_conv_persist");
+        }
     }
+per_step:
+    ar.persist = 0; ar.rsample = 0;
     const int skip = (!ar.run_all && !d.fixed && ar.train) ? 1 : 0;
     for (int t = 0; t < d.T; ++t) {
         {
@@ -691,7 +715,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
 #endif
                            );
         if (launch_check("k_wgrad")) return -1;
-        if (wgrad_nsplit(d.T * d.B) > 1) {
+        if (wgrad_nsplit(d.T * d.B, h->pl.total) > 1) {
             hipLaunchKernelGGL(k_wreduce, dim3(h->jt.gemm_tiles), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt, (const float*)h->tp.wpart, h->tp.gnpart);
             if (launch_check("k_wreduce")) return -1;
         }

@@ -69,6 +69,12 @@ def test_config4_shape_vs_oracle(switch, monkeypatch):
     _compare_cached(_meta(C4, 30, 64, 2), skip=("y2.bias",), label="config4" + ("-" + switch if switch else ""), key="c4")
 
 
+def test_config4_shape_consecutive_role_launches():
+    """Config 4's agents at 88 samples: 6 tiles (the last one ragged) do not fit one launch of co-resident roles (240
+    workgroups), so the conversation runs as two launches over sample ranges (48 + 40 samples)."""
+    _compare(_meta(dict(C4, batch_size=88), 30, 88, 2), skip=("y2.bias",), label="config4-b88")
+
+
 @pytest.mark.parametrize("kernels", ["default", "tile"])
 def test_config5_flavour_vs_oracle(kernels, monkeypatch):
     """1000 classes, continuous messages, Fixed (configs[4]) at a batch the oracle can afford.  At this size the library
