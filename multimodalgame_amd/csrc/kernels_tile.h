@@ -119,6 +119,68 @@ __device__ __forceinline__ void tgemm_nt_raw(const float* A, int lda, const floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two small "NT" products of one phase (sender hidden + GRU hidden side; the two heads on h) in ONE memory round trip: run one
+// after the other, each pays its own weight-load latency (~3 us per product per step at 128 tiles).  Items of both jobs are
+// numbered together, a wave takes up to four of them and issues ALL their weight loads (<= 4 k-groups each) before the first
+// MFMA.  Same staging layout as tgemm_nt_body.  Needs <= 4 k-groups per item and <= 4 * nw items in total (nt_pair_fits).
+// ---------------------------------------------------------------------------------------------
+struct NtJob { const float* A; const float* Wm; float* raw; int lda, ldw, N, K; };
+__device__ __forceinline__ bool nt_pair_fits(const NtJob& a, const NtJob& b, int nw) {
+    const int ta = (a.N + 15) >> 4, tb = (b.N + 15) >> 4, ka = tile_kparts(ta, nw), kb = tile_kparts(tb, nw);
+    const int ga = (a.K + 15) >> 4, gb = (b.K + 15) >> 4;
+    return (ga + ka - 1) / ka <= 4 && (gb + kb - 1) / kb <= 4 && ta * ka + tb * kb <= 4 * nw;
+}
+__device__ __forceinline__ void tgemm_nt_pair(const NtJob& ja, const NtJob& jb, int wave, int nw) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int ta = (ja.N + 15) >> 4, ka = tile_kparts(ta, nw), na = ta * ka;
+    const int tb = (jb.N + 15) >> 4, kb = tile_kparts(tb, nw), nb_ = tb * kb;
+    float4 w[4][4];
+    int s_tn[4], s_kp[4], s_g0[4], s_n[4];
+    bool s_b[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        const int it = wave + sl * nw;
+        const bool isb = it >= na;
+        const int li = isb ? it - na : it;
+        const bool has = isb ? (li < nb_) : true;
+        const int kparts = isb ? kb : ka, N = isb ? jb.N : ja.N, K = isb ? jb.K : ja.K, ldw = isb ? jb.ldw : ja.ldw;
+        const float* Wm = isb ? jb.Wm : ja.Wm;
+        const int kgroups = (K + 15) >> 4, per = (kgroups + kparts - 1) / kparts;
+        const int lc = has ? li : 0;
+        const int tn = lc / kparts, kp = lc - tn * kparts, g0 = kp * per;
+        s_b[sl] = isb; s_tn[sl] = tn; s_kp[sl] = kp; s_g0[sl] = g0; s_n[sl] = has ? max(0, min(kgroups, g0 + per) - g0) : 0;
+        const float* wrow = Wm + (size_t)min(tn * 16 + i, N - 1) * ldw;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[sl][u] = ldrow4c<true>(wrow, min(g0 + u, kgroups - 1) * 16 + q * 4, K);
+    }
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        if (s_n[sl] == 0) continue;
+        const float* A = s_b[sl] ? jb.A : ja.A;
+        const int lda = s_b[sl] ? jb.lda : ja.lda, N = s_b[sl] ? jb.N : ja.N;
+        float* raw = s_b[sl] ? jb.raw : ja.raw;
+        const int ldr = ld16(N);
+        const float* arow = A + i * lda + q * 4 + s_g0[sl] * 16;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {
+            if (u < s_n[sl]) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + u * 16);
+                acc0 = mfma16(a.x, w[sl][u].x, acc0); acc0 = mfma16(a.y, w[sl][u].y, acc0);
+                acc0 = mfma16(a.z, w[sl][u].z, acc0); acc0 = mfma16(a.w, w[sl][u].w, acc0);
+            }
+            if (u + 1 < s_n[sl]) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + (u + 1) * 16);
+                acc1 = mfma16(a.x, w[sl][u + 1].x, acc1); acc1 = mfma16(a.y, w[sl][u + 1].y, acc1);
+                acc1 = mfma16(a.z, w[sl][u + 1].z, acc1); acc1 = mfma16(a.w, w[sl][u + 1].w, acc1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) raw[((s_kp[sl] * MMG_TM) + q * 4 + r) * ldr + s_tn[sl] * 16 + i] = acc0[r] + acc1[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Register-resident weight fragments for loops that multiply by the SAME matrix every step (the persistent roles): a wave's
 // work item (n-tile, k-part) of tgemm_nt is fixed, so its weight fragment -- one float4 per k-group -- is loaded once and
 // kept in MAXKG registers; the per-step product then has no global load at all.  Item numbering and staging layout are
@@ -614,7 +676,12 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
             case 7: if (!persist) add(s_g, L.ldR, P.p[R_W_W], R, W, R, raw0, 0); break;                  // receiver message logits, model.py:454 (persist: in the sender roles)
             default: break;
             }
-            for (int j = 0; j < nj; ++j) {
+            bool paired = false;
+            if (nj == 2 && !j0.nn && !j1.nn) {                           // two small NT products: one memory round trip for both
+                const NtJob pa = {j0.A, j0.Wm, j0.raw, j0.lda, j0.ldw, j0.N, j0.K}, pb = {j1.A, j1.Wm, j1.raw, j1.lda, j1.ldw, j1.N, j1.K};
+                if (nt_pair_fits(pa, pb, nw)) { tgemm_nt_pair(pa, pb, wave, nw); paired = true; }
+            }
+            for (int j = 0; j < (paired ? 0 : nj); ++j) {
                 const float* jA = j ? j1.A : j0.A; const float* jW = j ? j1.Wm : j0.Wm; float* jr = j ? j1.raw : j0.raw;
                 const int jlda = j ? j1.lda : j0.lda, jldw = j ? j1.ldw : j0.ldw, jN = j ? j1.N : j0.N, jK = j ? j1.K : j0.K;
                 if ((j ? j1.nn : j0.nn)) tgemm_nn_raw(jA, jlda, jW, jldw, jN, jK, jr, wave, nw);
@@ -662,6 +729,7 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
             __syncthreads();
             // ---------------- epilogue of the phase
             if (ph == 0) {
+                MMG_RSTAMP(tile_idx == 0 && t == 3, 170);
                 if (do_sen) {
                     const int kp = tile_kparts((H + 15) >> 4, nw);
                     const float* s_bc = smem + L.bc; const float* s_hw0 = smem + L.hw0;
@@ -676,6 +744,7 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                             if (misc[TL_LIVE + m] != 0.f) tp.a[(rowb + b0 + m) * H + n] = av;
                         }
                     }
+                    MMG_RSTAMP(tile_idx == 0 && t == 3, 171);
                     // (s_a shares its space with the class-logit tile: restore the zero padding of its K dimension)
                     for (int idx = tid; idx < MMG_TM * (L.ldH - H); idx += NT) s_a[(idx / (L.ldH - H)) * L.ldH + H + idx % (L.ldH - H)] = 0.f;
                     const float* s_sc = smem + L.sc;
@@ -687,12 +756,14 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                         tp.c[(rowb + b0 + m) * W + j] = (t == 0) ? s_sc[j] : cv;
                     }
                 }
+                MMG_RSTAMP(tile_idx == 0 && t == 3, 172);
                 const float* s_bhh = smem + L.bhh;
                 const int kp = tile_kparts((3 * R + 15) >> 4, nw);
                 for (int idx = tid; idx < MMG_TM * 3 * R; idx += NT) {
                     const int m = idx / (3 * R), n = idx - m * 3 * R;
                     s_gh[m * L.ld3R + n] = raw_sum(raw1, L.ld3R, kp, m, n) + s_bhh[n];
                 }
+                MMG_RSTAMP(tile_idx == 0 && t == 3, 173);
             } else if (ph == 1) {
                 if (do_sen) {                                            // sample the sender's message, model.py:218-236
                     const float* s_bb = smem + L.bb;

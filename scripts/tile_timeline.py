@@ -50,6 +50,11 @@ if dbg[250]:
     print("  S1 (tile 0, role 0, step 3): wait-start %.2f -> wait done %.2f | load %.2f | [w gemm] %.2f | a gemm+epi %.2f | signal %.2f ; S2: wait done %.2f | a load %.2f | z gemm+epi %.2f | gi gemm+store %.2f | signal %.2f  (all vs rs_role wait-start)" % (
         us(250, 200), us(250, 201), us(201, 202), us(202, 203), us(203, 204), us(204, 205), us(250, 211), us(211, 212), us(212, 213), us(213, 214), us(214, 215)))
 
+if dbg[170]:
+    us = lambda a, b: (dbg[b] - dbg[a]) * tick / 1e3
+    base = 8 + 16 * 3
+    print("ph0 of step 3 in detail: phase start -> epilogue start %.2f | a = tanh(..) + tape %.2f | pad + zr / c %.2f | gh %.2f" % (us(base, 170), us(170, 171), us(171, 172), us(172, 173)))
+
 if dbg[240]:
     us = lambda a, b: (dbg[b] - dbg[a]) * tick / 1e3
     print("k_send_bwd block (0,0): row list + all loads issued %.2f | statistics -> coefficients %.2f | seeds %.2f | product %.2f | epilogue %.2f" % (us(240, 241), us(241, 242), us(242, 243), us(243, 244), us(244, 245)))
