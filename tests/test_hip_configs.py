@@ -75,13 +75,16 @@ def test_config4_shape_consecutive_role_launches():
     _compare(_meta(dict(C4, batch_size=88), 30, 88, 2), skip=("y2.bias",), label="config4-b88")
 
 
-@pytest.mark.parametrize("kernels", ["default", "tile"])
+@pytest.mark.parametrize("kernels", ["default", "tile", "tile-nosplit"])
 def test_config5_flavour_vs_oracle(kernels, monkeypatch):
     """1000 classes, continuous messages, Fixed (configs[4]) at a batch the oracle can afford.  At this size the library
     picks the per-sample kernels; "tile" forces the sample-tile kernels with class helpers (k_conv_split) the full-size
-    configuration runs on."""
-    if kernels == "tile":
+    configuration runs on; "tile-nosplit" the many-class y head of one workgroup (4 samples x 4 classes register blocks),
+    the path of >= 1024 samples per GPU."""
+    if kernels.startswith("tile"):
         monkeypatch.setenv("MMG_TILE", "1")
+    if kernels == "tile-nosplit":                   # what 2 048 samples per GPU run: every tile takes all 1000 classes itself
+        monkeypatch.setenv("MMG_NO_SPLIT", "1")
     _compare(_meta(C5, 1000, 128, 2), skip=("y2.bias", ".bs", ".br"), label="config5-" + kernels)
 
 
