@@ -2375,13 +2375,13 @@ __device__ __forceinline__ void nfrag_mma(const NFrag<MAXKG>& f, const float* A,
     }
 }
 
-__global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre(Dims dm, Params P, Tape tp, int zero_dead) {
+__device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, const Tape& tp, const int zero_dead, const int blk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = MMG_BLOCK, nw = NT / 64;
     const int B = dm.B, W = dm.W, R = dm.R, T = dm.T;
     const int ldW = ld16(W), ldR = ld16(R);
     const int tiles = (B + MMG_TM - 1) / MMG_TM;
-    const int t = (int)blockIdx.x / tiles, b0 = ((int)blockIdx.x - t * tiles) * MMG_TM, nb = min(MMG_TM, B - b0);
+    const int t = blk / tiles, b0 = (blk - t * tiles) * MMG_TM, nb = min(MMG_TM, B - b0);
     float* s_dlw = smem; float* s_dgp = s_dlw + MMG_TM * ldW; float* raw = s_dgp + MMG_TM * ldR;
     float* s_coef = raw + tile_raw_floats_nn(R, nw); float* misc = s_coef + 7 * 64; float* s_ws = misc + 64;
     // misc: [0,16) t*   [16,32) reward L   [32,48) baseline_rec score of the row   [48,64) dls
@@ -2474,11 +2474,25 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre(Dims dm, Params P, Tape t
     }
 }
 
+__global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre(Dims dm, Params P, Tape tp, int zero_dead) {
+    bwd_pre_body(dm, P, tp, zero_dead, (int)blockIdx.x);
+}
+__device__ __forceinline__ void send_bwd_body(const Dims& dm, const Params& P, const Tape& tp, const int* __restrict__ rmap, const int bx, const int by);
+// k_bwd_pre and the sender's backward (k_send_bwd over all T * B rows, dead row blocks return) in ONE launch: neither depends
+// on the other, both are "statistics -> seeds -> one or two products" latency chains of ~20 us -- side by side instead of
+// one after the other.  Blocks [0, npre): bwd_pre_body; then nbands blocks per 16-row block: send_bwd_body.
+__global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre_send(Dims dm, Params P, Tape tp, int zero_dead, int npre, int nbands) {
+    const int blk = blockIdx.x;
+    if (blk < npre) { bwd_pre_body(dm, P, tp, zero_dead, blk); return; }
+    const int sb = blk - npre;
+    send_bwd_body(dm, P, tp, nullptr, sb / nbands, sb % nbands);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_send_bwd: sender backward over (step, sample) rows (binary mode): dlz = REINFORCE/entropy seed of the sender's bits,
 // dpre = (dlz W_b) (1 - a^2).  grid (ceil(rows/16), ceil(H/64)): a workgroup owns 16 rows and 64 columns of H; rows come from the live-row list (rmap) or are all T*B rows (dead rows zero-filled).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape tp, const int* __restrict__ rmap, const int* __restrict__ rcount) {
+__device__ __forceinline__ void send_bwd_body(const Dims& dm, const Params& P, const Tape& tp, const int* __restrict__ rmap, const int bx, const int by) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = MMG_BLOCK, nw = NT / 64;
     const int B = dm.B, H = dm.H, W = dm.W, T = dm.T;
@@ -2489,14 +2503,18 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape 
     float* raw = s_coef + 7 * 64 + 16;                     // [16][ld16(64 * bands)]
     LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
     const int tid = threadIdx.x, wave = tid >> 6;
-    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 240);
+    MMG_RSTAMP(bx == 0 && by == 0, 240);
     const int nrows = T * B;                               // (the live-row list ends with -1 entries: no dependent load of its length)
-    const int r0 = blockIdx.x * MMG_TM;
+    const int r0 = bx * MMG_TM;
     if (r0 >= nrows) return;
     if (rmap && rmap[r0] < 0) return;
+    if (!rmap) {                                           // all T * B rows: a block without a live row has nothing to do
+        const int row = min(r0 + (int)(threadIdx.x & 15), nrows - 1);
+        if (!__syncthreads_or((row / B) <= tp.tstar[row % B])) return;
+    }
     // ---- every global load of the workgroup in ONE round trip (after the row list): statistics, this band's weight
     // fragment, the rows' message bits / probabilities, their scalars and their slice of the hidden tile
-    const int n0 = blockIdx.y * 64, Nb = min(64, H - n0);
+    const int n0 = by * 64, Nb = min(64, H - n0);
     const CoefRegs creg = coef_load(dm, tp.stats);
     const bool fr = nfrag_fits<4>(Nb, W, nw);
     NFrag<4> fb;
@@ -2527,10 +2545,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape 
         arow[u] = row_of(m);
         ra[u] = tp.a[(size_t)max(arow[u], 0) * H + n0 + n];
     }
-    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 241);
+    MMG_RSTAMP(bx == 0 && by == 0, 241);
     for (int i = tid; i < MMG_TM * ldW; i += NT) s_dlz[i] = 0.f;
     coef_compute(dm, creg, lc);                                             // (ends with a barrier)
-    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 242);
+    MMG_RSTAMP(bx == 0 && by == 0, 242);
 #pragma unroll
     for (int u = 0; u < UW; ++u) {
         const int idx = tid + u * NT;
@@ -2539,16 +2557,16 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape 
             float sv = 0.f;
             if (t <= rts[u]) sv = bit_seed_fast(rz[u].x, rz[u].y, (rlg[u] - rbs[u]) * lc.cw[2 * T + t], lc.ce[2 * T + t]);
             s_dlz[m * ldW + j] = sv;
-            if (blockIdx.y == 0) tp.dlz[(size_t)row * W + j] = sv;
+            if (by == 0) tp.dlz[(size_t)row * W + j] = sv;
         }
     }
     __syncthreads();
-    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 243);
+    MMG_RSTAMP(bx == 0 && by == 0, 243);
     // this workgroup's 64 columns of H; its four waves split K
     if (fr) nfrag_mma<4>(fb, s_dlz, ldW, raw, ld16(Nb));
     else tgemm_nn_raw(s_dlz, ldW, P.p[S_BIN_W] + n0, H, Nb, W, raw, wave, nw);
     __syncthreads();
-    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 244);
+    MMG_RSTAMP(bx == 0 && by == 0, 244);
     const int ldr = ld16(Nb), kp = tile_kparts((Nb + 63) >> 6, nw);
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
@@ -2558,7 +2576,12 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape 
             tp.dpre[(size_t)arow[u] * H + n0 + n] = raw_sum(raw, ldr, kp, m, n) * (1.f - ra[u] * ra[u]);
         }
     }
-    MMG_RSTAMP(blockIdx.x == 0 && blockIdx.y == 0, 245);
+    MMG_RSTAMP(bx == 0 && by == 0, 245);
+}
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_send_bwd(Dims dm, Params P, Tape tp, const int* __restrict__ rmap, const int* __restrict__ rcount) {
+    (void)rcount;
+    send_bwd_body(dm, P, tp, rmap, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 }  // namespace mmg

@@ -359,6 +359,10 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
             e = hipFuncSetAttribute((const void*)k_bwd_pre, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_pre_lds_floats(d) * 4);
         if (h->tile_ok && e == hipSuccess && h->send_bwd_smem > 48 * 1024)
             e = hipFuncSetAttribute((const void*)k_send_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, h->send_bwd_smem);
+        if (h->tile_ok && e == hipSuccess) {
+            const int smem = bwd_pre_lds_floats(d) * 4 > h->send_bwd_smem ? bwd_pre_lds_floats(d) * 4 : h->send_bwd_smem;
+            if (smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_pre_send, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        }
         if (h->tile_ok && h->tile_smem > 48 * 1024) {
             e = hipFuncSetAttribute((const void*)k_conv_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
@@ -648,10 +652,17 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         row_map = d.T * d.B <= 2048;                     // k_wgrad keeps the live-row list in LDS (2048 entries)
         const int zero_dead = (!row_map && !d.fixed) ? 1 : 0;
         const int tiles = (d.B + MMG_TM - 1) / MMG_TM;
+        // the sender's backward rides in the same launch as k_bwd_pre (independent latency chains side by side) while the row
+        // blocks are few: it then walks all T * B rows instead of the live-row list (MMG_NO_MERGE=1: separate launches)
+        const bool merged_send = d.use_binary && h->merge_roles && d.T * d.B <= 2048;
         {
             Scope sc(h, st, "k_bwd_tile");
             // the dh-independent part of the receiver's BPTT (seeds, dgpre, dhin) for all (step, sample) rows, then the recurrence
-            if (d.use_binary)
+            if (d.use_binary && merged_send) {
+                const int nbands = (d.H + 63) / 64, nrb = (d.T * d.B + MMG_TM - 1) / MMG_TM;
+                const int smem = bwd_pre_lds_floats(d) * 4 > h->send_bwd_smem ? bwd_pre_lds_floats(d) * 4 : h->send_bwd_smem;
+                hipLaunchKernelGGL(k_bwd_pre_send, dim3(d.T * tiles + nrb * nbands), dim3(MMG_BLOCK), smem, st, h->dm, h->P, h->tp, zero_dead, d.T * tiles, nbands);
+            } else if (d.use_binary)
                 hipLaunchKernelGGL(k_bwd_pre, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
             if (d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && !getenv("MMG_NO_RSAMPLE")) {
                 // receiver shape of the register-resident kernels: one workgroup per sample (+ one for the live-row list)
@@ -665,8 +676,9 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         }
         if (d.use_binary) {
             Scope sc(h, st, "k_send_bwd");
-            hipLaunchKernelGGL(k_send_bwd, dim3((d.T * d.B + MMG_TM - 1) / MMG_TM, (d.H + 63) / 64), dim3(MMG_BLOCK), h->send_bwd_smem, st,
-                               h->dm, h->P, h->tp, (const int*)(row_map ? h->tp.rmap : nullptr), (const int*)(row_map ? h->tp.rcount : nullptr));
+            if (!merged_send)
+                hipLaunchKernelGGL(k_send_bwd, dim3((d.T * d.B + MMG_TM - 1) / MMG_TM, (d.H + 63) / 64), dim3(MMG_BLOCK), h->send_bwd_smem, st,
+                                   h->dm, h->P, h->tp, (const int*)(row_map ? h->tp.rmap : nullptr), (const int*)(row_map ? h->tp.rcount : nullptr));
             const int nblk = (d.B * (d.H / 4) + MMG_BLOCK - 1) / MMG_BLOCK;
             hipLaunchKernelGGL(k_dhx, dim3(nblk + (d.H / 4 + 63) / 64), dim3(MMG_BLOCK), 0, st, h->dm, h->tp, nblk);
             if (launch_check("k_send_bwd")) return -1;
