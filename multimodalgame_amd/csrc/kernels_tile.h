@@ -2591,11 +2591,11 @@ namespace mmg {
 // over all live (step, sample) rows).  One float4 per thread, all of the sample's steps in flight.
 // Trailing blocks: u0[h] = sum_b dpre[t = 0, b, h] -- code_bias only sees step 0, where the code input sigmoid(code_bias) is
 // the same for every sample, so its gradient is dsig * W_c^T u0: a row-weighted column sum over code_layer.weight (k_wgrad).
-__global__ __launch_bounds__(MMG_BLOCK) void k_dhx(Dims dm, Tape tp, int nblk_dhx) {
+__device__ __forceinline__ void dhx_body(const Dims& dm, const Tape& tp, const int nblk_dhx, const int blk) {
     const int H4 = dm.H >> 2;
-    if ((int)blockIdx.x >= nblk_dhx) {
+    if (blk >= nblk_dhx) {
         __shared__ float4 s_p[4][64];
-        const int h4 = ((int)blockIdx.x - nblk_dhx) * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+        const int h4 = (blk - nblk_dhx) * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
         const int hc = min(h4, H4 - 1);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int b0 = part; b0 < dm.B; b0 += 4 * 16) {
@@ -2613,7 +2613,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_dhx(Dims dm, Tape tp, int nblk_dh
         }
         return;
     }
-    const int idx = blockIdx.x * MMG_BLOCK + threadIdx.x;
+    const int idx = blk * MMG_BLOCK + threadIdx.x;
     if (idx >= dm.B * H4) return;
     const int b = idx / H4, h4 = idx - b * H4;
     const int ts = dm.use_binary ? tp.tstar[b] : -1;
@@ -2627,6 +2627,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_dhx(Dims dm, Tape tp, int nblk_dh
     }
     reinterpret_cast<float4*>(tp.dhx + (size_t)b * dm.H)[h4] = acc;
 }
+__global__ __launch_bounds__(MMG_BLOCK) void k_dhx(Dims dm, Tape tp, int nblk_dhx) { dhx_body(dm, tp, nblk_dhx, (int)blockIdx.x); }
 }  // namespace mmg
 
 namespace mmg {
@@ -2695,7 +2696,8 @@ namespace mmg {
 // of B / 16.  Same tape contract as k_bwd_tile (zero_dead / live rows; block 0 builds the live-row list).
 // ---------------------------------------------------------------------------------------------
 template <int R, int V, int D>
-__global__ __launch_bounds__(256, 1) void k_bwd_sample(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int zero_dead, int make_map) {
+__global__ __launch_bounds__(256, 1) void k_bwd_sample(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int zero_dead, int make_map,
+                                                       int nblk_dhx) {
     constexpr int NT = 256, K4 = NT / R, TMAX = 16;
     static_assert(R == 64 && D <= 32 && K4 == 4, "receiver shape of the register-resident kernels");
     __shared__ __attribute__((aligned(16))) float s_dh[R], s_dgh[3 * R], s_dy[32], s_A[R], s_dA[R], s_dAy[R];
@@ -2703,7 +2705,11 @@ __global__ __launch_bounds__(256, 1) void k_bwd_sample(Dims dm, Params P, Tape t
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int B = dm.B, T = dm.T, Dr = dm.D;
     const bool binary = dm.use_binary != 0;
-    if (b >= B) {                                                            // extra workgroup: live (step, sample) rows for k_wgrad / k_send_bwd
+    if (b > B) {                                                             // trailing workgroups: dhx = sum_t dpre, u0 (k_dhx) -- dpre is complete
+        dhx_body(dm, tp, nblk_dhx, b - B - 1);                               // (the sender's backward ran in the launch before this one)
+        return;
+    }
+    if (b == B) {                                                            // extra workgroup: live (step, sample) rows for k_wgrad / k_send_bwd
         if (make_map && tid < 64) build_row_map(dm, tp);
         return;
     }

@@ -655,6 +655,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         // the sender's backward rides in the same launch as k_bwd_pre (independent latency chains side by side) while the row
         // blocks are few: it then walks all T * B rows instead of the live-row list (MMG_NO_MERGE=1: separate launches)
         const bool merged_send = d.use_binary && h->merge_roles && d.T * d.B <= 2048;
+        bool dhx_done = false;
         {
             Scope sc(h, st, "k_bwd_tile");
             // the dh-independent part of the receiver's BPTT (seeds, dgpre, dhin) for all (step, sample) rows, then the recurrence
@@ -666,8 +667,11 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
                 hipLaunchKernelGGL(k_bwd_pre, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
             if (d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && !getenv("MMG_NO_RSAMPLE")) {
                 // receiver shape of the register-resident kernels: one workgroup per sample (+ one for the live-row list)
-                if (d.D == 30) hipLaunchKernelGGL((k_bwd_sample<64, 100, 30>), dim3(d.B + 1), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
-                else hipLaunchKernelGGL((k_bwd_sample<64, 100, 32>), dim3(d.B + 1), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+                // (+ k_dhx's blocks when the sender's backward already ran: its dpre is complete)
+                const int nblk = (d.B * (d.H / 4) + MMG_BLOCK - 1) / MMG_BLOCK, ndhx = merged_send ? nblk + (d.H / 4 + 63) / 64 : 0;
+                dhx_done = merged_send;
+                if (d.D == 30) hipLaunchKernelGGL((k_bwd_sample<64, 100, 30>), dim3(d.B + 1 + ndhx), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0, nblk);
+                else hipLaunchKernelGGL((k_bwd_sample<64, 100, 32>), dim3(d.B + 1 + ndhx), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0, nblk);
             } else if (d.R <= 64)
                 hipLaunchKernelGGL((k_bwd_tile<512, 2>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             else
@@ -680,7 +684,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
                 hipLaunchKernelGGL(k_send_bwd, dim3((d.T * d.B + MMG_TM - 1) / MMG_TM, (d.H + 63) / 64), dim3(MMG_BLOCK), h->send_bwd_smem, st,
                                    h->dm, h->P, h->tp, (const int*)(row_map ? h->tp.rmap : nullptr), (const int*)(row_map ? h->tp.rcount : nullptr));
             const int nblk = (d.B * (d.H / 4) + MMG_BLOCK - 1) / MMG_BLOCK;
-            hipLaunchKernelGGL(k_dhx, dim3(nblk + (d.H / 4 + 63) / 64), dim3(MMG_BLOCK), 0, st, h->dm, h->tp, nblk);
+            if (!dhx_done) hipLaunchKernelGGL(k_dhx, dim3(nblk + (d.H / 4 + 63) / 64), dim3(MMG_BLOCK), 0, st, h->dm, h->tp, nblk);
             if (launch_check("k_send_bwd")) return -1;
         }
     } else {
