@@ -2198,9 +2198,11 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
                         for (int u = 0; u < 32; u += 4) {
 #pragma unroll
                             for (int m = 0; m < MMG_TM; ++m) {
-                                const float* dp = s_dy + m * L.ldD + d0 + u;      // d0 is a multiple of 4 only if d_lo is: scalar reads otherwise
-                                const float y0 = (d0 + u < d_hi) ? dp[0] : 0.f, y1 = (d0 + u + 1 < d_hi) ? dp[1] : 0.f;
-                                const float y2 = (d0 + u + 2 < d_hi) ? dp[2] : 0.f, y3 = (d0 + u + 3 < d_hi) ? dp[3] : 0.f;
+                                // (d_lo and the 32-class chunks are multiples of 4, rows of s_dy are 16-byte aligned and padded past D:
+                                //  one 16-byte LDS read per four classes -- with scalar reads this loop is bound by LDS instructions)
+                                const float4 dq = *reinterpret_cast<const float4*>(s_dy + m * L.ldD + d0 + u);
+                                const float y0 = (d0 + u < d_hi) ? dq.x : 0.f, y1 = (d0 + u + 1 < d_hi) ? dq.y : 0.f;
+                                const float y2 = (d0 + u + 2 < d_hi) ? dq.z : 0.f, y3 = (d0 + u + 3 < d_hi) ? dq.w : 0.f;
                                 acc[m] = fmaf(__builtin_amdgcn_fmed3f(fmaf(cv[u], BIG, av[m]), 0.f, 1.f), y0, acc[m]);
                                 acc[m] = fmaf(__builtin_amdgcn_fmed3f(fmaf(cv[u + 1], BIG, av[m]), 0.f, 1.f), y1, acc[m]);
                                 acc[m] = fmaf(__builtin_amdgcn_fmed3f(fmaf(cv[u + 2], BIG, av[m]), 0.f, 1.f), y2, acc[m]);
