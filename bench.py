@@ -11,8 +11,10 @@ every exchange step of the sharded game advances N such batches, so value = N * 
 (the whole-job aggregate; identical to the 1-GPU definition at N = 1).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  N > 1: launched by torch.distributed.run, one rank per GPU; the global minibatch is 64*N
-  (weak scaling), sharded along the batch axis (multimodalgame_amd/dist.py).
+  N > 1: one rank per GPU; the global minibatch is 64*N (weak scaling), sharded along the batch axis
+  (multimodalgame_amd/dist.py).  Either the caller launches the ranks (torch.distributed.run sets WORLD_SIZE / RANK /
+  LOCAL_RANK) or -- plain `python bench.py --gpus N` -- this script re-executes itself under
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (launch_ranks()).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -104,7 +106,32 @@ def algorithmic_work(kernel, d, B, t_steps):
     return "hbm", 0
 
 
-MIN_TIMED_SECONDS = 0.25       # the timed region is repeated until it lasts at least this long
+MIN_TIMED_SECONDS = float(os.environ.get("MMG_BENCH_MIN_SECONDS", "2.0"))   # the timed region is repeated until it lasts at least this long
+
+
+def traffic_lookup(workload, kernel, strong, profiles_dir=None):
+    """HBM traffic (bytes per dispatch, FETCH_SIZE + WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes) of `kernel`
+    from the newest committed PMC summary of THIS workload: profiles/rNN_config<N>_pmc_hbm_traffic.json for the per-GPU
+    batch, profiles/rNN_strong_config<N>_pmc_hbm_traffic.json for --scaling strong (the whole global batch on one GPU).
+    Counters need their own rocprofv3 passes and cannot be collected inside the bench run.  Returns (bytes | None, source)."""
+    import glob
+    import re
+    pdir = profiles_dir or os.path.join(REPO, "profiles")
+    num = {"c2": "2", "c3": "3", "c4": "4", "c5": "5"}[workload]
+    pat = re.compile(r"^r(\d+)_%sconfig%s_pmc_hbm_traffic\.json$" % ("strong_" if strong else "", num))
+    files = sorted((int(pat.match(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(pdir, "r*_pmc_hbm_traffic.json"))
+                   if pat.match(os.path.basename(f)))
+    alias = {"k_conversation": ("k_conversation_fast2", "k_conversation_mc", "k_conversation"), "k_bwd_conv": ("k_bwd_conv_fast", "k_bwd_conv"),
+             "k_baselines": ("k_baselines3", "k_baselines4", "k_baselines2", "k_baselines")}
+    for _, f in reversed(files):
+        try:
+            pmc = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        for key in alias.get(kernel, (kernel,)):
+            if key in pmc and pmc[key].get("traffic_bytes_corrected") is not None:
+                return pmc[key]["traffic_bytes_corrected"], "%s (per dispatch of %s, committed file; not measured in this run)" % (os.path.relpath(f, REPO), key)
+    return None, None
 
 
 def build_batches(CFG, Bg, B, rank, n, dev):
@@ -162,21 +189,27 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
     sync()
     totals_before = eng.tape["totals"].cpu().numpy().copy()   # device-side running sums (semantic exchange steps, ..., sample-steps)
     # EXACTLY `steps` minibatches per pass; passes are repeated (all inside one timed region, same count on every rank)
-    # until the region lasts MIN_TIMED_SECONDS: a 20-step run of a 75 us minibatch is 1.5 ms, too short for any sampler
-    passes, done, elapsed = 1, 0, 0.0
+    # until the region lasts MIN_TIMED_SECONDS (2 s): a 20-step run of a 75 us minibatch is 1.5 ms, too short for any sampler
+    # pass 1 is measured (one sync), then as many further passes as the window needs are enqueued back to back and
+    # synchronised ONCE: a sync per 20-step pass would leave the GPU idle while the host refills the launch queue
+    done, elapsed = 0, 0.0
     t0 = time.perf_counter()
-    while True:
-        for i in range(steps):
-            one(warmup + done + i)
-        done += steps
+    for i in range(steps):
+        one(warmup + i)
+    done += steps
+    sync()
+    elapsed = time.perf_counter() - t0
+    more = torch.tensor([max(0.0, (MIN_TIMED_SECONDS - elapsed) / max(elapsed, 1e-6))], device=dev)
+    if world > 1:
+        dist.all_reduce(more, op=dist.ReduceOp.MAX)
+    n_more = min(int(np.ceil(more.item())), 1 << 20)
+    if n_more > 0:
+        for _ in range(n_more):
+            for i in range(steps):
+                one(warmup + done + i)
+            done += steps
         sync()
         elapsed = time.perf_counter() - t0
-        more = torch.tensor([1.0 if elapsed < MIN_TIMED_SECONDS else 0.0], device=dev)
-        if world > 1:
-            dist.all_reduce(more, op=dist.ReduceOp.MAX)
-        if more.item() == 0.0 or passes >= 4096:
-            break
-        passes += 1
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -185,8 +218,13 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
     ex_steps = float(totals_after[0] - totals_before[0])
     sample_steps = float(totals_after[3] - totals_before[3])        # sum_t n_active,t over the GLOBAL minibatches
     eng.check_sync()                                                # no in-launch dependency wait may have timed out
+    collective = "none (single rank)"
+    if world > 1:
+        collective = ("direct RCCL communicator on the engine's stream (multimodalgame_amd/rccl.py), world %d" % dp.comm.world
+                      if dp.comm is not None else "torch.distributed.all_reduce, backend %s" % dist.get_backend())
     res = dict(workload=workload, label=label, B=B, Bg=Bg, elapsed=elapsed, minibatches=done, ex_steps=ex_steps,
-               sample_steps=sample_steps, cfg=CFG, roofline=None)
+               sample_steps=sample_steps, cfg=CFG, roofline=None, collective=collective,
+               dist_world=(dist.get_world_size() if world > 1 else 1))
     if not want_roofline:
         return res
     # per-kernel durations of the same workload, HIP events on the launch stream (rank 0); per-step launches of one kernel
@@ -217,20 +255,7 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
             achieved, peak, unit = amount / secs / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
         # HBM traffic of that kernel from the committed PMC summary of THIS workload (counters need their own rocprofv3
         # passes and cannot be collected inside this run): per-dispatch FETCH_SIZE / WRITE_SIZE
-        traffic, traffic_source = None, None
-        try:
-            import glob
-            files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_config%s_pmc_hbm_traffic.json" % {"c2": "2", "c3": "3", "c4": "4", "c5": "5"}[workload])))
-            if files:
-                pmc = json.load(open(files[-1]))["kernels"]
-                key = {"c2:k_conversation": "k_conversation_fast2", "c3:k_conversation": "k_conversation_fast2",
-                       "c2:k_bwd_conv": "k_bwd_conv_fast", "c3:k_bwd_conv": "k_bwd_conv_fast",
-                       "c2:k_baselines": "k_baselines3"}.get("%s:%s" % (workload, dom), dom)
-                if key in pmc:
-                    traffic = pmc[key]["traffic_bytes_corrected"]
-                    traffic_source = "%s (per dispatch, committed file; not measured in this run)" % os.path.relpath(files[-1], REPO)
-        except Exception:
-            traffic = None
+        traffic, traffic_source = traffic_lookup(workload, dom, strong)
         per_kernel = {}
         for k, ms in avg.items():
             bk, amt = algorithmic_work(k, CFG, B, tstar)
@@ -287,6 +312,28 @@ def cpu_baseline(seconds_budget=24.0):
                     ", ".join("%d thr: %.1f" % (k, v["steps_per_s"]) for k, v in sorted(out.items())), ncpu))
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node (one per GPU, RCCL) under
+    torch.distributed.run and return its exit code.  MMG_BENCH_BACKEND=gloo lets N ranks share the visible GPUs (smoke
+    test of this path on a 1-GPU box); with the default nccl (= RCCL) backend every rank needs its own GPU."""
+    import socket
+    import subprocess
+    backend = os.environ.get("MMG_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and have < n:
+        sys.stderr.write("bench.py: --gpus %d needs %d GPUs on this node, %d visible (one rank per GPU over RCCL; "
+                         "MMG_BENCH_BACKEND=gloo shares GPUs between ranks for a smoke test)\n" % (n, n, have))
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MMG_BENCH_LAUNCHED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,9 +350,15 @@ def main():
     args = ap.parse_args()
     if args.scaling == "strong" and args.workload not in STRONG_GLOBAL_BATCH:
         ap.error("--scaling strong needs --workload c3 or c5 (the configs BASELINE.json defines with a global batch)")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # the ranks print the JSON line (rank 0)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; reporting n_gpus=%d\n" % (args.gpus, world, world))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -326,6 +379,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * per_mb, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": r["label"], "global_batch": r["Bg"], "per_gpu_batch": r["B"], "parallelism": "dp%d" % world,
+                       "rccl_world": r["dist_world"], "collective": r["collective"],
                        "exchange_steps_per_minibatch": r["ex_steps"] / r["minibatches"], "sampling": "in-kernel Philox4x32-10",
                        "timed_minibatches": r["minibatches"], "timed_seconds": r["elapsed"],
                        "minibatches_per_s": (1.0 if strong else world) * r["minibatches"] / r["elapsed"],
@@ -338,10 +392,12 @@ def main():
         if world == 1 and args.workload == "c2" and not args.no_other_configs:
             # the other BASELINE.json configs on this GPU (short runs; parity-test cases, not the metric)
             other = {}
-            for w in ("c3", "c4", "c5"):
-                o = run_workload(w, 30, 5, args.seed, 0, 1, local_rank)
+            # c3s / c5s: the whole global batch (512 / 2048 samples) on this one GPU = the N = 1 point of --scaling strong;
+            # (its ms_per_minibatch) / (the per-GPU shard's) is the ceiling of the strong-scaling speed-up at 8 GPUs
+            for w in ("c3", "c4", "c5", "c3s", "c5s"):
+                o = run_workload(w[:2], 30, 5, args.seed, 0, 1, local_rank, strong=w.endswith("s"))
                 rf = o["roofline"] or {}
-                other[w] = dict(workload=o["label"], batch=o["B"], ms_per_minibatch=1e3 * o["elapsed"] / o["minibatches"],
+                other[w] = dict(workload=o["label"] + (" -- all %d samples on one GPU (--scaling strong, N=1)" % o["Bg"] if w.endswith("s") else ""), batch=o["B"], ms_per_minibatch=1e3 * o["elapsed"] / o["minibatches"],
                                 exchange_steps_per_s=o["ex_steps"] / o["elapsed"],
                                 roofline={k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_us", "traffic", "traffic_source")},
                                 kernels_us=rf.get("kernels_us"))

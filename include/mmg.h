@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define MMG_VERSION 1
+#define MMG_VERSION 2
+#define MMG_GRAD_TAIL 4       /* floats behind the gradients in d_grads, owned by the library (see mmg_grad_floats) */
 
 enum { MMG_OPT_RMSPROP = 0, MMG_OPT_ADAM = 1, MMG_OPT_SGD = 2 };          /* model.py:1725 */
 enum { MMG_AGENT_RECEIVER = 0, MMG_AGENT_SENDER = 1, MMG_AGENT_BASELINE_REC = 2, MMG_AGENT_BASELINE_SEN = 3 };
@@ -92,11 +93,17 @@ int     mmg_version(void);
 
 /* Layout queries (host only, no GPU needed). */
 int64_t mmg_param_count(const mmg_config* cfg);                                   /* floats incl. padding */
+/* Floats the caller allocates for d_grads: mmg_param_count() + MMG_GRAD_TAIL.  The tail quad is written by mmg_backward:
+ * [0] = 1.0 if an in-launch dependency wait of this minibatch timed out on this rank (stale gradients), else 0.0.  A
+ * data-parallel caller all-reduces (sum) ALL mmg_grad_floats() floats, so the flag reaches every rank with the gradients
+ * and mmg_clip_step skips the update on all ranks alike (the reference has no counterpart: model.py:1307-1330 is
+ * single-process). */
+int64_t mmg_grad_floats(const mmg_config* cfg);
 int     mmg_param_table(const mmg_config* cfg, mmg_param_entry* out, int max_entries);   /* returns count */
 int64_t mmg_workspace_bytes(const mmg_config* cfg);
 int     mmg_tape_table(const mmg_config* cfg, mmg_tape_entry* out, int max_entries);     /* returns count */
 
-/* d_params / d_grads: flat fp32 buffers of mmg_param_count() floats.  d_opt_state: 2x that
+/* d_params: flat fp32 buffer of mmg_param_count() floats; d_grads: mmg_grad_floats() floats.  d_opt_state: 2x mmg_param_count()
  * (RMSprop square_avg | unused; Adam exp_avg | exp_avg_sq; SGD unused), zero-initialised by the
  * caller.  d_workspace: mmg_workspace_bytes() bytes, 256-byte aligned. */
 mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int64_t workspace_bytes,
@@ -131,7 +138,8 @@ int mmg_loss_stats(mmg_handle* h, void* stream);
 int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, void* stream);
 
 /* Per-agent clip_grad_norm(max_norm=1) + optimizer update on the flat buffers.  In continuous mode
- * (use_binary==0) only the receiver is updated (model.py:1313). */
+ * (use_binary==0) only the receiver is updated (model.py:1313).  Skips the update (and makes every later training call
+ * fail) when the dependency-error flag of this rank or -- through the tail quad of d_grads -- of any rank is set. */
 int mmg_clip_step(mmg_handle* h, void* stream);
 
 /* forward(train, run_all_steps = 0) + stats + backward + clip_step for a single-GPU minibatch, as six

@@ -36,7 +36,7 @@ class MmgError(RuntimeError):
 _lib = None
 
 # every symbol include/mmg.h declares (tests check that the library exports all of them)
-SYMBOLS = ["mmg_last_error", "mmg_version", "mmg_param_count", "mmg_param_table", "mmg_workspace_bytes",
+SYMBOLS = ["mmg_last_error", "mmg_version", "mmg_param_count", "mmg_grad_floats", "mmg_param_table", "mmg_workspace_bytes",
            "mmg_tape_table", "mmg_create", "mmg_destroy", "mmg_exchange_forward", "mmg_loss_stats",
            "mmg_backward", "mmg_clip_step", "mmg_train_step", "mmg_sender_forward", "mmg_receiver_forward",
            "mmg_baseline_forward", "mmg_set_profiling", "mmg_get_kernel_times"]
@@ -56,6 +56,7 @@ def load():
     lib.mmg_last_error.restype = C.c_char_p
     lib.mmg_version.restype = i32
     lib.mmg_param_count.restype = i64; lib.mmg_param_count.argtypes = [cfgp]
+    lib.mmg_grad_floats.restype = i64; lib.mmg_grad_floats.argtypes = [cfgp]
     lib.mmg_param_table.restype = i32; lib.mmg_param_table.argtypes = [cfgp, C.POINTER(ParamEntry), i32]
     lib.mmg_workspace_bytes.restype = i64; lib.mmg_workspace_bytes.argtypes = [cfgp]
     lib.mmg_tape_table.restype = i32; lib.mmg_tape_table.argtypes = [cfgp, C.POINTER(TapeEntry), i32]

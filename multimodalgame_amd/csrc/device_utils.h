@@ -11,6 +11,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MMG_EPS 1e-8f          // the reference's log(p + 1e-8)   model.py:908
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// max(a, b) of the class-logit inner loops as ONE v_med3_f32 (median of a, b, +inf): IEEE fmaxf canonicalises both
+// operands when they come straight from memory (three v_max per relu); building the whole library with -fno-honor-nans
+// would remove that too, but would also let the compiler assume "no NaN" in the loss / clip / optimizer kernels.
+__device__ __forceinline__ float fmax_nn(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 
 // ---- DPP cross-lane adds: a VALU operand modifier, no LDS round trip (ds_bpermute costs ~60+ cycles
 // on a dependent chain).  quad_perm swaps inside quads, row_half_mirror / row_mirror fold 8 / 16 lanes.
@@ -303,6 +307,7 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint
 //   sync[128k] = arrivals of dependency k, sync[128k+64] = consumers that have passed it (the last one re-arms both).
 // ---------------------------------------------------------------------------------------------
 #define MMG_SYNC_ERR 511
+#define MMG_SYNC_ERR_REMOTE 1001u   // k_opt: another rank of the data-parallel job reported a timed-out dependency
 // every counter in its own 256-byte block (pollers of one dependency do not queue behind the increments of another)
 #define MMG_SYNC_ARR(dep) (128 * (dep))
 #define MMG_SYNC_PASS(dep) (128 * (dep) + 64)

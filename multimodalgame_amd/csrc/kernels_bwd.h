@@ -536,7 +536,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                                                      const float* __restrict__ desc, float* __restrict__ part,
                                                      Dims dm, const double* __restrict__ stats, float* __restrict__ losses,
                                                      double* __restrict__ totals, const int* __restrict__ rmap,
-                                                     const int* __restrict__ rcount, float* __restrict__ wpart
+                                                     const int* __restrict__ rcount, float* __restrict__ wpart,
+                                                     const uint32_t* __restrict__ sync, float* __restrict__ grad_tail
 #ifdef MMG_TIMING
                                                      , long long* __restrict__ dbg2
 #endif
@@ -581,6 +582,11 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         __shared__ float s_lc[7 * 64];
         LossCoef lc; lc.cw = s_lc; lc.ce = s_lc + 3 * dm.T; lc.cb = s_lc + 6 * dm.T;
         loss_coefficients(dm, stats, lc, losses, totals);
+        // the quad behind the gradients (include/mmg.h: mmg_grad_floats): [0] = 1.0 when a dependency wait of this minibatch
+        // timed out on THIS rank.  The data-parallel all-reduce sums it with the gradients, so every rank's k_opt sees that
+        // some rank's contribution is built from stale data and all of them skip the update together.
+        if (threadIdx.x == 0)
+            grad_tail[0] = (__hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.f : 0.f;
         return;
     }
     if ((int)blockIdx.x < jt->gemm_tiles) {
@@ -904,15 +910,17 @@ struct OptArgs {
 __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ jt, OptArgs oa, float* __restrict__ params,
                                                    const float* __restrict__ grads, float* __restrict__ state,
                                                    const float* __restrict__ part, const uint32_t* __restrict__ counter,
-                                                   const uint32_t* __restrict__ sync, uint32_t* __restrict__ err_host) {
-    // the dependency-error word goes to a pinned HOST word (device-mapped) with a posted store: the host reads it before the
-    // next minibatch without any stream operation or synchronisation
-    if (err_host && blockIdx.x == 0 && threadIdx.x == 0)
-        *err_host = __hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // An in-launch dependency wait of this minibatch timed out (device_utils.h: role_wait sets sync[MMG_SYNC_ERR]): the
-    // gradients may be built from stale data -- leave parameters and optimizer state untouched.  The word is sticky;
-    // mmg_train_step reports it on the next call.
-    if (__hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+                                                   const uint32_t* __restrict__ sync, uint32_t* __restrict__ err_host,
+                                                   const float* __restrict__ grad_tail) {
+    // An in-launch dependency wait of this minibatch timed out (device_utils.h: role_wait sets sync[MMG_SYNC_ERR]) -- on this
+    // rank, or (grad_tail: the flag quad that travelled through the gradient all-reduce) on ANY rank of a data-parallel job:
+    // the gradients may be built from stale data -- leave parameters and optimizer state untouched, on every rank alike.
+    uint32_t err = __hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (err == 0u && grad_tail && grad_tail[0] != 0.f) err = MMG_SYNC_ERR_REMOTE;
+    // the word goes to a pinned HOST word (device-mapped) with a posted store: the host reads it before the next minibatch
+    // without any stream operation or synchronisation; it is sticky, every later training call fails (mmg.hip: sticky_error)
+    if (err_host && blockIdx.x == 0 && threadIdx.x == 0 && (err != 0u || *err_host == 0u)) *err_host = err;
+    if (err != 0u) return;
     // oa.from_wgrad: the squared-norm partials are the ones k_wgrad left per block (single GPU);
     // otherwise the MMG_GN_BLOCKS partials of k_gradnorm over the all-reduced gradient (data parallel).
     __shared__ float s_coef[4];

@@ -693,10 +693,10 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
         // ===== (6) class logits
         {
             const float4 a4 = *reinterpret_cast<const float4*>(s_A + kpy * 4);
-            float acc = w2[0] * fmaxf(a4.x + cd[0], 0.f);
-            acc = fmaf(w2[1], fmaxf(a4.y + cd[1], 0.f), acc);
-            acc = fmaf(w2[2], fmaxf(a4.z + cd[2], 0.f), acc);
-            acc = fmaf(w2[3], fmaxf(a4.w + cd[3], 0.f), acc);
+            float acc = w2[0] * fmax_nn(a4.x + cd[0], 0.f);
+            acc = fmaf(w2[1], fmax_nn(a4.y + cd[1], 0.f), acc);
+            acc = fmaf(w2[2], fmax_nn(a4.z + cd[2], 0.f), acc);
+            acc = fmaf(w2[3], fmax_nn(a4.w + cd[3], 0.f), acc);
             acc = dpp_group_sum<LY>(acc);
             if (kpy == 0) {
                 const float yv = (dy < Dr) ? acc + b2 : -3.0e38f;

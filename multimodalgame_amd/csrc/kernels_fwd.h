@@ -404,8 +404,8 @@ __global__ __launch_bounds__(NT) void k_conversation(Dims dm, Params P, Tape tp,
                         const float4 wv = reinterpret_cast<const float4*>(w2)[k];
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            acc[u] = fmaf(wv.x, fmaxf(av.x + cv[u].x, 0.f), acc[u]); acc[u] = fmaf(wv.y, fmaxf(av.y + cv[u].y, 0.f), acc[u]);
-                            acc[u] = fmaf(wv.z, fmaxf(av.z + cv[u].z, 0.f), acc[u]); acc[u] = fmaf(wv.w, fmaxf(av.w + cv[u].w, 0.f), acc[u]);
+                            acc[u] = fmaf(wv.x, fmax_nn(av.x + cv[u].x, 0.f), acc[u]); acc[u] = fmaf(wv.y, fmax_nn(av.y + cv[u].y, 0.f), acc[u]);
+                            acc[u] = fmaf(wv.z, fmax_nn(av.z + cv[u].z, 0.f), acc[u]); acc[u] = fmaf(wv.w, fmax_nn(av.w + cv[u].w, 0.f), acc[u]);
                         }
                     }
                 } else {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(NT) void k_conversation(Dims dm, Params P, Tape tp,
 #pragma unroll
                         for (int u = 0; u < U; ++u) cv[u] = crow[u][k];
 #pragma unroll
-                        for (int u = 0; u < U; ++u) acc[u] = fmaf(w2[k], fmaxf(s.A[k] + cv[u], 0.f), acc[u]);
+                        for (int u = 0; u < U; ++u) acc[u] = fmaf(w2[k], fmax_nn(s.A[k] + cv[u], 0.f), acc[u]);
                     }
                 }
 #pragma unroll

@@ -339,8 +339,8 @@ __device__ __forceinline__ void class_logits(const Dims& dm, const Tape& tp, con
                     if (r < R) {                                                            // (w2 is zero beyond R)
                         const float4 av = *reinterpret_cast<const float4*>(arow + r);
                         const float4 wq = *reinterpret_cast<const float4*>(s_w2 + r);
-                        a0 = fmaf(wq.x, fmaxf(av.x + cq[u].x, 0.f), a0); a1 = fmaf(wq.y, fmaxf(av.y + cq[u].y, 0.f), a1);
-                        a0 = fmaf(wq.z, fmaxf(av.z + cq[u].z, 0.f), a0); a1 = fmaf(wq.w, fmaxf(av.w + cq[u].w, 0.f), a1);
+                        a0 = fmaf(wq.x, fmax_nn(av.x + cq[u].x, 0.f), a0); a1 = fmaf(wq.y, fmax_nn(av.y + cq[u].y, 0.f), a1);
+                        a0 = fmaf(wq.z, fmax_nn(av.z + cq[u].z, 0.f), a0); a1 = fmaf(wq.w, fmax_nn(av.w + cq[u].w, 0.f), a1);
                     }
                 }
             }
@@ -376,14 +376,14 @@ __device__ __forceinline__ void class_logits(const Dims& dm, const Tape& tp, con
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const float4 av = *reinterpret_cast<const float4*>(s_A + (4 * mg + a) * ldR + r0);
-                acc[a][0] = fmaf(wq.x, fmaxf(av.x, cv[0].x), acc[a][0]); acc[a][1] = fmaf(wq.x, fmaxf(av.x, cv[0].y), acc[a][1]);
-                acc[a][2] = fmaf(wq.x, fmaxf(av.x, cv[0].z), acc[a][2]); acc[a][3] = fmaf(wq.x, fmaxf(av.x, cv[0].w), acc[a][3]);
-                acc[a][0] = fmaf(wq.y, fmaxf(av.y, cv[1].x), acc[a][0]); acc[a][1] = fmaf(wq.y, fmaxf(av.y, cv[1].y), acc[a][1]);
-                acc[a][2] = fmaf(wq.y, fmaxf(av.y, cv[1].z), acc[a][2]); acc[a][3] = fmaf(wq.y, fmaxf(av.y, cv[1].w), acc[a][3]);
-                acc[a][0] = fmaf(wq.z, fmaxf(av.z, cv[2].x), acc[a][0]); acc[a][1] = fmaf(wq.z, fmaxf(av.z, cv[2].y), acc[a][1]);
-                acc[a][2] = fmaf(wq.z, fmaxf(av.z, cv[2].z), acc[a][2]); acc[a][3] = fmaf(wq.z, fmaxf(av.z, cv[2].w), acc[a][3]);
-                acc[a][0] = fmaf(wq.w, fmaxf(av.w, cv[3].x), acc[a][0]); acc[a][1] = fmaf(wq.w, fmaxf(av.w, cv[3].y), acc[a][1]);
-                acc[a][2] = fmaf(wq.w, fmaxf(av.w, cv[3].z), acc[a][2]); acc[a][3] = fmaf(wq.w, fmaxf(av.w, cv[3].w), acc[a][3]);
+                acc[a][0] = fmaf(wq.x, fmax_nn(av.x, cv[0].x), acc[a][0]); acc[a][1] = fmaf(wq.x, fmax_nn(av.x, cv[0].y), acc[a][1]);
+                acc[a][2] = fmaf(wq.x, fmax_nn(av.x, cv[0].z), acc[a][2]); acc[a][3] = fmaf(wq.x, fmax_nn(av.x, cv[0].w), acc[a][3]);
+                acc[a][0] = fmaf(wq.y, fmax_nn(av.y, cv[1].x), acc[a][0]); acc[a][1] = fmaf(wq.y, fmax_nn(av.y, cv[1].y), acc[a][1]);
+                acc[a][2] = fmaf(wq.y, fmax_nn(av.y, cv[1].z), acc[a][2]); acc[a][3] = fmaf(wq.y, fmax_nn(av.y, cv[1].w), acc[a][3]);
+                acc[a][0] = fmaf(wq.z, fmax_nn(av.z, cv[2].x), acc[a][0]); acc[a][1] = fmaf(wq.z, fmax_nn(av.z, cv[2].y), acc[a][1]);
+                acc[a][2] = fmaf(wq.z, fmax_nn(av.z, cv[2].z), acc[a][2]); acc[a][3] = fmaf(wq.z, fmax_nn(av.z, cv[2].w), acc[a][3]);
+                acc[a][0] = fmaf(wq.w, fmax_nn(av.w, cv[3].x), acc[a][0]); acc[a][1] = fmaf(wq.w, fmax_nn(av.w, cv[3].y), acc[a][1]);
+                acc[a][2] = fmaf(wq.w, fmax_nn(av.w, cv[3].z), acc[a][2]); acc[a][3] = fmaf(wq.w, fmax_nn(av.w, cv[3].w), acc[a][3]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) cv[u] = cn[u];
@@ -871,8 +871,8 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                                 if (r < R) {                                                // (w2 is zero beyond R: clamped class values are harmless)
                                     const float4 av = *reinterpret_cast<const float4*>(arow + r);
                                     const float4 wq = *reinterpret_cast<const float4*>(s_w2 + r);
-                                    a0 = fmaf(wq.x, fmaxf(av.x + cq[u].x, 0.f), a0); a1 = fmaf(wq.y, fmaxf(av.y + cq[u].y, 0.f), a1);
-                                    a0 = fmaf(wq.z, fmaxf(av.z + cq[u].z, 0.f), a0); a1 = fmaf(wq.w, fmaxf(av.w + cq[u].w, 0.f), a1);
+                                    a0 = fmaf(wq.x, fmax_nn(av.x + cq[u].x, 0.f), a0); a1 = fmaf(wq.y, fmax_nn(av.y + cq[u].y, 0.f), a1);
+                                    a0 = fmaf(wq.z, fmax_nn(av.z + cq[u].z, 0.f), a0); a1 = fmaf(wq.w, fmax_nn(av.w + cq[u].w, 0.f), a1);
                                 }
                             }
                         }
@@ -1742,10 +1742,10 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
         // ===== class logits
         {
             const float4 a4 = *reinterpret_cast<const float4*>(s_A + kpy * 4);
-            float acc = w2[0] * fmaxf(a4.x + cd[0], 0.f);
-            acc = fmaf(w2[1], fmaxf(a4.y + cd[1], 0.f), acc);
-            acc = fmaf(w2[2], fmaxf(a4.z + cd[2], 0.f), acc);
-            acc = fmaf(w2[3], fmaxf(a4.w + cd[3], 0.f), acc);
+            float acc = w2[0] * fmax_nn(a4.x + cd[0], 0.f);
+            acc = fmaf(w2[1], fmax_nn(a4.y + cd[1], 0.f), acc);
+            acc = fmaf(w2[2], fmax_nn(a4.z + cd[2], 0.f), acc);
+            acc = fmaf(w2[3], fmax_nn(a4.w + cd[3], 0.f), acc);
             acc = dpp_group_sum<LY>(acc);
             if (kpy == 0) {
                 const float yv = (dy < Dr) ? acc + b2 : -3.0e38f;

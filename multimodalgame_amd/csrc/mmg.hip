@@ -61,7 +61,34 @@ struct mmg_handle {
     size_t timers_used;
     uint32_t* h_err;           // pinned host copy of sync[MMG_SYNC_ERR], written by k_opt of every step (posted store to mapped host memory)
     uint32_t* d_err;           // its device-side address
+    // debugging switches of the launch paths (environment, read ONCE at mmg_create -- never on the per-minibatch path)
+    bool sw_rsample, sw_rmsg, sw_fused_s, sw_xcd_map, rs_capable;
+    // workgroups of 512 threads that are guaranteed to be resident together on this device (occupancy query at mmg_create,
+    // minus a margin): the role launches (k_conv_persist / k_conv_split / k_conversation_mc) spin on each other, so a launch
+    // may never hold more roles than this
+    int resident_budget, split_budget, n_cu;
+    mmg_handle() : params(nullptr), grads(nullptr), opt_state(nullptr), ws(nullptr), d_jt(nullptr), h_err(nullptr), d_err(nullptr) {}
+    ~mmg_handle() {
+        for (auto& t : timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
+        if (h_err) hipHostFree(h_err);
+    }
 };
+
+// dependency-error word posted by an EARLIER minibatch's k_opt (pinned, device-mapped host word; read without any
+// synchronisation): a timed-out role wait never trains on silently -- k_opt skipped that update, and every later call of the
+// training entry points (fused or phased / data-parallel) fails
+static int sticky_error(const mmg_handle* h) {
+    if (h->h_err && *(volatile uint32_t*)h->h_err != 0u)
+    {
+        const uint32_t code = *(volatile uint32_t*)h->h_err;
+        if (code == 1001u)
+            return fail("another rank of the data-parallel job reported a timed-out in-launch dependency in an earlier minibatch; "
+                        "every rank skipped that optimizer update");
+        return fail("in-launch dependency %u timed out on the device in an earlier minibatch (workgroup roles out of order, or fewer "
+                    "compute units available than the launch needs?); its optimizer update was skipped", code - 1u);
+    }
+    return 0;
+}
 
 extern "C" const char* mmg_last_error(void) { return g_err; }
 extern "C" int mmg_version(void) { return MMG_VERSION; }
@@ -97,6 +124,11 @@ extern "C" int mmg_param_table(const mmg_config* cfg, mmg_param_entry* out, int 
         }
     }
     return P_COUNT;
+}
+
+extern "C" int64_t mmg_grad_floats(const mmg_config* cfg) {
+    if (validate(cfg)) return -1;
+    return param_layout(*cfg).total + MMG_GRAD_TAIL;
 }
 
 extern "C" int64_t mmg_workspace_bytes(const mmg_config* cfg) {
@@ -289,6 +321,24 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         if (hipHostGetDevicePointer((void**)&h->d_err, h->h_err, 0) != hipSuccess) h->d_err = nullptr;
     } else h->h_err = nullptr;
     h->use_fast = !getenv("MMG_NO_FAST"); h->merge_roles = !getenv("MMG_NO_MERGE");
+    h->sw_rsample = !getenv("MMG_NO_RSAMPLE"); h->sw_rmsg = !getenv("MMG_NO_RMSG"); h->sw_fused_s = !getenv("MMG_NO_FUSED_S");
+    h->sw_xcd_map = getenv("MMG_XCD_MAP") != nullptr;
+    int n_cu = 0;
+    {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) { fail("cannot query the device (multiProcessorCount)"); delete h; return nullptr; }
+    }
+    // co-resident workgroups a role launch may hold: occupancy of the kernel at its LDS size x compute units, minus a margin
+    // of 1/16 of the chip (256 CUs -> 240, the value the role launches were tuned with).  A partitioned device (CPX), a
+    // smaller SKU or a masked process simply gets a smaller budget and, where the roles do not fit, the per-step / generic launches.
+    auto budget_of = [&](const void* fn, int threads, int smem) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, (size_t)smem) != hipSuccess || nb < 1) return 0;
+        const int total = nb * n_cu;
+        return total - (total + 15) / 16;
+    };
+    h->resident_budget = 0; h->split_budget = 0; h->n_cu = n_cu;
     // few samples and large sender matrices or class tables: 512-thread variant of the generic conversation kernel
     h->conv_threads = (h->dm.B <= 256 && ((int64_t)h->dm.H * h->dm.W >= 65536 || (int64_t)h->dm.D * (h->dm.R + h->dm.V) >= 65536)) ? 512 : 256;
     h->conv_smem = conv_smem_floats(h->dm, h->conv_threads) * 4;
@@ -333,19 +383,31 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
             h->split_smem = a > b ? a : b;
             if (h->split_smem > 160 * 1024) h->tile_split = false;
             else if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_split<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->split_smem);
+            if (h->tile_split && e == hipSuccess) {
+                h->split_budget = budget_of((const void*)k_conv_split<512>, 512, h->split_smem);
+                if (tiles * (1 + h->split_nh) > h->split_budget) h->tile_split = false;     // not all co-resident here: k_conv_tile instead
+            }
         }
         // per-step sender products as ROLES of one persistent launch when all of them fit on the chip together
         h->persist_ns1 = d.H / 64; h->persist_ns2 = d.W / 32;
         // (receiver shape of the register-resident kernels: per-sample receiver roles, and batches too large for one launch of
         //  co-resident roles run as consecutive launches over sample ranges)
-        const bool rs_capable = d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && !getenv("MMG_NO_RSAMPLE");
+        const bool rs_capable = d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && h->sw_rsample;
         h->tile_persist = h->tile_ok && h->tile_ext && !(d.H % 64) && !(d.W % 32) && tiles <= 64 &&
-                          (tiles * (1 + h->persist_ns1 + h->persist_ns2) <= 240 || rs_capable) && MMG_TM * d.W <= 8 * 512 && !getenv("MMG_NO_PERSIST");
+                          MMG_TM * d.W <= 8 * 512 && !getenv("MMG_NO_PERSIST");
+        h->rs_capable = rs_capable;
         if (h->tile_persist) {
             const int a = tile_lds(d, 512 / 64, false).total * 4, b = srole_lds(d, 512 / 64).total * 4;
             h->persist_smem = a > b ? a : b;
             if (h->persist_smem > 160 * 1024) h->tile_persist = false;
             else if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_persist<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->persist_smem);
+            if (h->tile_persist && e == hipSuccess) {
+                h->resident_budget = budget_of((const void*)k_conv_persist<512>, 512, h->persist_smem);
+                // tile roles: every tile's roles in one launch; per-sample receiver roles: at least ONE whole tile per launch
+                const bool fits = rs_capable ? (MMG_TM + d.H / 64 + d.W / 16 <= h->resident_budget || MMG_TM + h->persist_ns1 + h->persist_ns2 <= h->resident_budget)
+                                             : tiles * (1 + h->persist_ns1 + h->persist_ns2) <= h->resident_budget;
+                if (!fits) h->tile_persist = false;                                       // per-step launches instead (no co-residency needed)
+            }
         }
         h->tile_bwd_smem = bwd_tile_lds(d, 512 / 64).total * 4;
         h->send_bwd_smem = (MMG_TM * ld16(d.W) + 7 * 64 + 16 + tile_raw_floats_nn(64, MMG_BLOCK / 64)) * 4;
@@ -376,7 +438,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     if (e == hipSuccess && h->bwd_smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->bwd_smem);
     if (e == hipSuccess && h->bwd_smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->bwd_smem);
     if (e == hipSuccess) e = hipMemset(d_workspace, 0, h->tl.total);
-    if (e == hipSuccess) e = hipMemset(d_grads, 0, sizeof(float) * h->pl.total);
+    if (e == hipSuccess) e = hipMemset(d_grads, 0, sizeof(float) * (h->pl.total + MMG_GRAD_TAIL));
     if (e != hipSuccess) { fail("device init failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
     if (build_jobs(h)) { delete h; return nullptr; }
     {
@@ -389,12 +451,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     return h;
 }
 
-extern "C" void mmg_destroy(mmg_handle* h) {
-    if (!h) return;
-    for (auto& t : h->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
-    if (h->h_err) hipHostFree(h->h_err);
-    delete h;
-}
+extern "C" void mmg_destroy(mmg_handle* h) { delete h; }      // (~mmg_handle releases the events and the pinned error word)
 
 // ---------------------------------------------------------------------------------------------
 // launch helper with optional HIP-event timing on the launch stream
@@ -505,27 +562,28 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
         return launch_check("k_conv_tile");
     }
     if (h->tile_persist) {
-        Scope sc(h, st, "k_conv_persist");
         ar.phases = 2; ar.t_begin = 0; ar.t_end = d.T; ar.persist = 1; ar.ns1 = h->persist_ns1; ar.ns2 = h->persist_ns2;
-        // optional: one tile per XCD (32 CUs each hold the tile's roles)
         // receiver shape of the register-resident kernels: one receiver role per SAMPLE (rs_role) beside the tiles' sender roles
-        ar.rsample = (d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && !getenv("MMG_NO_RSAMPLE")) ? 1 : 0;
-        if (ar.rsample && d.W == 256 && !getenv("MMG_NO_RMSG")) ar.rsample = 2;      // ... which also form the receiver's message
-        if (ar.rsample == 2 && d.H % 64 == 0 && d.H / 64 <= 16 && !getenv("MMG_NO_FUSED_S")) {
+        ar.rsample = (h->rs_capable) ? 1 : 0;
+        if (ar.rsample && d.W == 256 && h->sw_rmsg) ar.rsample = 2;      // ... which also form the receiver's message
+        if (ar.rsample == 2 && d.H % 64 == 0 && d.H / 64 <= 16 && h->sw_fused_s) {
             ar.rsample = 3;                                 // fused sender roles (sa_role / sb_role)
             ar.ns1 = d.H / 64; ar.ns2 = d.W / 16;
         }
-        if (ar.rsample) {
-            // all roles of a launch must be co-resident (<= 240 workgroups): as many whole tiles per launch as fit, the
-            // batch in consecutive launches (the conversations of different samples are independent)
-            const int per_tile = MMG_TM + ar.ns1 + ar.ns2;
-            int ct = 240 / per_tile;
-            if (ct < 1) ct = 1;
-            const int nchunk = (tiles + ct - 1) / ct;
-            ct = (tiles + nchunk - 1) / nchunk;
-            // (measured with config 4's agents: 256 samples in 4 launches 471 us against 858 us as per-step launches; 1024 samples
-            //  in 13 launches 1 723 against 1 544 -- beyond six launches the per-step GEMM launches over the whole batch win)
-            if (nchunk > 6) goto per_step;
+        // all roles of a launch must be co-resident (resident_budget workgroups, occupancy query at mmg_create): as many whole
+        // tiles per launch as fit, the batch in consecutive launches (the conversations of different samples are independent).
+        // The path is chosen BEFORE the timing scope opens (a fall-back to the per-step launches leaves no empty timer).
+        const int per_tile = MMG_TM + ar.ns1 + ar.ns2;
+        int ct = h->resident_budget / per_tile;
+        if (ct < 1) ct = 1;
+        const int nchunk = (tiles + ct - 1) / ct;
+        ct = (tiles + nchunk - 1) / nchunk;
+        // (measured with config 4's agents: 256 samples in 4 launches 471 us against 858 us as per-step launches; 1024 samples
+        //  in 13 launches 1 723 against 1 544 -- beyond six launches the per-step GEMM launches over the whole batch win)
+        const bool sample_roles = ar.rsample && nchunk <= 6 && per_tile <= h->resident_budget;
+        const bool tile_roles = !ar.rsample && tiles * (1 + ar.ns1 + ar.ns2) <= h->resident_budget;
+        if (sample_roles) {
+            Scope sc(h, st, "k_conv_persist");
             // basehx tiles for k_baselines4 ride along as trailing workgroups (training minibatches of <= 64 samples)
             const bool want_base = nchunk == 1 && ar.train && d.use_binary && !ar.run_all && d.B <= 64 && !(d.H & 3) && h->merge_roles;
             const int bt = want_base ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
@@ -539,18 +597,18 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
             h->basehx_ready = want_base;
             return launch_check("k_conv_persist");
         }
-        if (tiles * (1 + ar.ns1 + ar.ns2) > 240) goto per_step;            // (MMG_NO_RSAMPLE on a batch the tile roles do not fit)
-        {
-        const int roles = 1 + ar.ns1 + ar.ns2;
-        // (measured at config 4: 575 us per minibatch against 527 with plain role order -- the 25 roles of a tile then share
-        //  ONE L2 for their weight and payload reads, and a load that follows a write-through store in the same L2 took 5-8 us
-        //  instead of 2.3; off unless MMG_XCD_MAP=1)
-        const int xcd_map = (tiles <= 8 && roles <= 30 && getenv("MMG_XCD_MAP")) ? 1 : 0;
-        hipLaunchKernelGGL(k_conv_persist<512>, dim3(xcd_map ? 8 * roles : tiles * roles), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, xcd_map);
-        return launch_check("k_conv_persist");
+        if (tile_roles) {
+            Scope sc(h, st, "k_conv_persist");
+            const int roles = 1 + ar.ns1 + ar.ns2;
+            // (measured at config 4: 575 us per minibatch against 527 with plain role order -- the 25 roles of a tile then share
+            //  ONE L2 for their weight and payload reads, and a load that follows a write-through store in the same L2 took 5-8 us
+            //  instead of 2.3; off unless MMG_XCD_MAP=1)
+            const int xcd_map = (tiles <= 8 && roles <= 30 && h->sw_xcd_map) ? 1 : 0;
+            hipLaunchKernelGGL(k_conv_persist<512>, dim3(xcd_map ? 8 * roles : tiles * roles), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, xcd_map);
+            return launch_check("k_conv_persist");
         }
     }
-per_step:
+    // per-step launches: no co-residency needed (any device, any batch)
     ar.persist = 0; ar.rsample = 0;
     const int skip = (!ar.run_all && !d.fixed && ar.train) ? 1 : 0;
     for (int t = 0; t < d.T; ++t) {
@@ -577,6 +635,7 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
                                     int train, int run_all_steps, void* stream) {
     if (!h) return fail("NULL handle");
     if (!d_x || !d_desc) return fail("x / desc must not be NULL");
+    if (train && sticky_error(h)) return -1;
     hipStream_t st = (hipStream_t)stream;
     const Dims& d = h->dm;
     if (launch_prep(h, st, d_desc, d_x)) return -1;
@@ -665,7 +724,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
                 hipLaunchKernelGGL(k_bwd_pre_send, dim3(d.T * tiles + nrb * nbands), dim3(MMG_BLOCK), smem, st, h->dm, h->P, h->tp, zero_dead, d.T * tiles, nbands);
             } else if (d.use_binary)
                 hipLaunchKernelGGL(k_bwd_pre, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
-            if (d.R == 64 && d.V == 100 && d.D <= 32 && d.T <= 16 && !getenv("MMG_NO_RSAMPLE")) {
+            if (h->rs_capable) {
                 // receiver shape of the register-resident kernels: one workgroup per sample (+ one for the live-row list)
                 // (+ k_dhx's blocks when the sender's backward already ran: its dpre is complete)
                 const int nblk = (d.B * (d.H / 4) + MMG_BLOCK - 1) / MMG_BLOCK, ndhx = merged_send ? nblk + (d.H / 4 + 63) / 64 : 0;
@@ -725,7 +784,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         hipLaunchKernelGGL(k_wgrad, dim3(h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
                            (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
                            h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
-                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart
+                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total
 #ifdef MMG_TIMING
                            , h->tp.dbg2
 #endif
@@ -742,6 +801,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
 extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, void* stream) {
     if (!h) return fail("NULL handle");
     if (!d_x || !d_target || !d_desc) return fail("x / target / desc must not be NULL");
+    if (sticky_error(h)) return -1;
     return backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, false);
 }
 
@@ -765,7 +825,8 @@ static int clip_step_impl(mmg_handle* h, hipStream_t st, bool from_wgrad) {
     {
         Scope sc(h, st, "k_opt");
         hipLaunchKernelGGL(k_opt, dim3(blocks), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt, oa, h->params,
-                           (const float*)h->grads, h->opt_state, (const float*)part, (const uint32_t*)h->tp.counter, (const uint32_t*)h->tp.sync, h->d_err);
+                           (const float*)h->grads, h->opt_state, (const float*)part, (const uint32_t*)h->tp.counter, (const uint32_t*)h->tp.sync, h->d_err,
+                           (const float*)(from_wgrad ? nullptr : h->grads + h->pl.total));
         if (launch_check("k_opt")) return -1;
     }
     return 0;
@@ -773,6 +834,7 @@ static int clip_step_impl(mmg_handle* h, hipStream_t st, bool from_wgrad) {
 
 extern "C" int mmg_clip_step(mmg_handle* h, void* stream) {
     if (!h) return fail("NULL handle");
+    if (sticky_error(h)) return -1;
     return clip_step_impl(h, (hipStream_t)stream, false);
 }
 
@@ -781,12 +843,7 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
     if (!h) return fail("NULL handle");
     if (h->cfg.global_batch != h->cfg.batch) return fail("mmg_train_step is single-GPU; with several ranks all-reduce between the phases");
     if (!d_target) return fail("target must not be NULL");
-    // state of the dependency-error word as of an EARLIER step (k_opt posts it to a pinned, device-mapped host word;
-    // read here without any synchronisation): a timed-out role_wait never trains on silently -- k_opt already
-    // skipped that update, and every later call fails
-    if (h->h_err && *(volatile uint32_t*)h->h_err != 0u)
-        return fail("in-launch dependency %u timed out on the device in an earlier minibatch (workgroup roles out of order?); "
-                    "its optimizer update was skipped", *(volatile uint32_t*)h->h_err - 1u);
+    if (sticky_error(h)) return -1;
     if (mmg_exchange_forward(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, 0, stream)) return -1;
     const bool merged = merge_stats(h);
     if (!merged && mmg_loss_stats(h, stream)) return -1;

@@ -30,7 +30,8 @@ class Engine(object):
                 self.flat_params, self.flat_grads, self.opt_state = share.flat_params, share.flat_grads, share.opt_state
             else:
                 self.flat_params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
-                self.flat_grads = torch.zeros_like(self.flat_params)
+                # gradients + the library's tail quad (dependency-error flag; all-reduced WITH the gradients in DP)
+                self.flat_grads = torch.zeros(int(self.lib.mmg_grad_floats(C.byref(self.cfg))), dtype=torch.float32, device=self.device)
                 self.opt_state = torch.zeros(2 * self.n_params, dtype=torch.float32, device=self.device)
             ws_bytes = int(self.lib.mmg_workspace_bytes(C.byref(self.cfg)))
             self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)

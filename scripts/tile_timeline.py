@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from multimodalgame_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmmg_timing.so")
+from multimodalgame_amd import build as _build
+_lib.LIB_PATH = _build.build_timing_library()      # -DMMG_TIMING build, compiled on demand (never shipped with the tree)
 from multimodalgame_amd.engine import Engine
 from multimodalgame_amd.agents import init_state_dicts
 import bench

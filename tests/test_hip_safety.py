@@ -29,3 +29,53 @@ def test_dependency_timeout_skips_update_and_raises():
         eng.train_step(xd, td, dd, seed=3)
     with pytest.raises(_lib.MmgError):
         eng.check_sync()
+
+
+def _dp_engine(meta):
+    """An engine configured as one rank of a 2-rank job (global_batch = 2 x batch): the phased entry points only."""
+    eng = common.make_engine(meta, global_batch=2 * int(meta["batch"]))
+    x, target, desc, _ = common.case_inputs(meta, 0)
+    return eng, [torch.from_numpy(a).to(eng.device) for a in (x, target, desc)]
+
+
+def _phased_step(eng, xd, td, dd):
+    eng.forward(xd, td, dd, seed=3, train=True, run_all=False)
+    eng.loss_stats()
+    eng.backward(xd, td, dd)
+    eng.clip_step()
+
+
+def test_phased_path_skips_update_and_every_entry_point_raises():
+    """The data-parallel path (forward / loss_stats / backward / clip_step called separately) sees the same sticky error."""
+    z, meta = common.load_golden("g2_adaptive_c1")
+    eng, (xd, td, dd) = _dp_engine(meta)
+    _phased_step(eng, xd, td, dd)
+    torch.cuda.synchronize()
+    assert float(eng.flat_grads[-4]) == 0.0                  # healthy step: the flag quad behind the gradients is clear
+    before = eng.flat_params.clone()
+    eng.tape["sync"][511] = 2
+    _phased_step(eng, xd, td, dd)                            # mmg_backward raises the flag, k_opt leaves everything untouched
+    torch.cuda.synchronize()
+    assert float(eng.flat_grads[-4]) == 1.0
+    torch.testing.assert_close(eng.flat_params, before, rtol=0, atol=0)
+    for call in (lambda: eng.forward(xd, td, dd, seed=3, train=True), lambda: eng.backward(xd, td, dd), eng.clip_step):
+        with pytest.raises(_lib.MmgError, match="timed out"):
+            call()
+
+
+def test_remote_rank_error_reaches_this_rank_through_the_gradient_all_reduce():
+    """Another rank's flag arrives summed into the tail quad of the gradient buffer: this rank skips the update too."""
+    z, meta = common.load_golden("g2_adaptive_c1")
+    eng, (xd, td, dd) = _dp_engine(meta)
+    _phased_step(eng, xd, td, dd)
+    torch.cuda.synchronize()
+    before = eng.flat_params.clone()
+    eng.forward(xd, td, dd, seed=3, train=True, run_all=False)
+    eng.loss_stats()
+    eng.backward(xd, td, dd)
+    eng.flat_grads[-4] += 1.0                                # what the all-reduce (sum) would add from the failing rank
+    eng.clip_step()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(eng.flat_params, before, rtol=0, atol=0)
+    with pytest.raises(_lib.MmgError, match="another rank"):
+        eng.forward(xd, td, dd, seed=3, train=True)
