@@ -66,9 +66,11 @@ def algorithmic_work(kernel, d, B, t_steps):
     p_sender = H * W + W * H + 2 * H + 2 * W
     p_recv = 3 * R * (W + R) + 6 * R + R * R + R + R * V + W * R + W + R * R + 2 * R + 2 + D * R + D * V
     mac_recv = 3 * R * W + 3 * R * R + 2 * R * R + R + D * V + R * V + W * R      # products of one receiver step of one sample
-    if kernel == "k_conversation":
+    if kernel in ("k_conversation", "k_conversation_mc"):
         tape = rows * 4 * (H + 4 * W + 5 * R + R + D + V + 12)          # floats written per (step, sample)
         return "hbm", 4 * (p_sender + p_recv) + tape + 4 * B * H
+    if kernel == "k_bwd_mc":                  # continuous many-class backward: softmax in, dy out, class tables once, GRU tape in, gate gradients out
+        return "hbm", 4 * (2 * B * D + 3 * D * R + rows * 11 * R + 3 * R * R)
     if kernel == "k_bwd_conv":
         tape = rows * 4 * (2 * H + 6 * W + 13 * R + 2 * K + D + V + 16)  # read fwd tape + write delta tape
         return "hbm", 4 * (p_sender + p_recv) + tape

@@ -123,6 +123,8 @@ void    mmg_destroy(mmg_handle* h);
  *   out of every loss, so training results are identical); per-(step, sample) arrays -- messages,
  *   baseline scores and hiddens, gradient tapes -- are then defined on the LIVE rows only
  *   (t <= the sample's own last step); the others keep whatever an earlier call left there.
+ *   ==2: as 0, and in Fixed mode the class logits "y" are kept for the output step (T-1) only -- the losses read nothing
+ *   else of them (model.py:885-904, 1264-1275); this is what mmg_train_step runs.
  * Results land in the workspace arrays listed by mmg_tape_table(). */
 int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
                          const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed,

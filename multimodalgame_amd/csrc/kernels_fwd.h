@@ -73,6 +73,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         const bool first = (int)blockIdx.x == dm.D;
         if (first && tid < dm.T + 2) tp.alive[tid] = (tid == 0) ? 1 : 0;     // per-step live-tile counts (kernels_tile.h)
         if (first) for (int i = tid; i < 4 * 64; i += blockDim.x) tp.pflags[(size_t)i * 64] = 0u;   // role counters of k_conv_persist
+        if (first && mc_shape(dm.H, dm.W, dm.R, dm.V, dm.D, dm.T))                                    // ... and of k_conversation_mc
+            for (int i = tid; i < 2 * ((dm.B + 15) / 16); i += blockDim.x) tp.mcflags[(size_t)i * 64] = 0u;
         if (first && tid == 0) {
             tp.counter[0] += 1u;                    // minibatch counter: the Philox stream of this conversation
             if (tp.counter[2] > tp.counter[1]) tp.counter[1] = tp.counter[2];   // optimizer step bumped by k_opt

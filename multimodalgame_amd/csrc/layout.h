@@ -95,6 +95,12 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(gip, float, 0, 3, NS2P, B, 3 * R)  /* per-sender-role partials of the GRU input product (k_conv_persist)           */ \
     X(zpart, float, 0, 3, NZP, 16, W)    /* per-SA-role partial message logits of a tile (k_conv_persist, fused sender roles) */ \
     X(pflags, uint32_t, 2, 1, 4 * 64 * 64, 1, 1) /* k_conv_persist: per (kind, sample tile) counters, one per 256-byte block */ \
+    X(mcA, float, 0, 3, NMC, 16, R + 4)  /* k_conversation_mc: A rows (+ take flag) published by the 16 members of a tile       */ \
+    X(mcpart, float, 0, 3, NMC * 16, 16, 104) /* k_conversation_mc: per (tile, class slice): [16 samples][V mixture terms | m | s | pad] */ \
+    X(mcflags, uint32_t, 2, 1, 2 * NMC * 64, 1, 1) /* k_conversation_mc: per (kind, tile) hand-off counters, one per 256-byte block (zeroed by k_prep) */ \
+    X(mcdA, float, 0, 3, NMCB, B, R)     /* k_bwd_mc1: per class block: partial dA of every sample                        */ \
+    X(mcdys, float, 0, 2, NMCB, B, 1)    /* k_bwd_mc1: per class block: partial sum_d dy                                  */ \
+    X(mcdC, float, 0, 3, NMCB, 2 * D, R) /* k_bwd_mc1: per sample group: partial dC | Py2                                 */ \
     X(alive, int32_t, 2, 1, T + 2, 1, 1) /* [t]: sample tiles with a live sample when step t starts (kernels_tile.h)  */ \
     X(hw0, float, 0, 1, H, 1, 1)         /* code_layer(sigmoid(code_bias)) :199-200*/ \
     X(dsig, float, 0, 1, W, 1, 1)        /* sigmoid'(code_bias)                    */ \
@@ -199,6 +205,10 @@ __host__ __device__ inline int wgrad_nsplit(int TB, long long ptotal) {
 __host__ __device__ inline int split_helpers(int B) { const int tiles = (B + 15) / 16; int nh = 224 / tiles - 1; return nh > 15 ? 15 : (nh < 0 ? 0 : nh); }   // (all roles must be co-resident: margin below the 256 CUs)
 
 // sample slices of the class-side reduction (k_dC_tile): enough workgroups for the chip when there are few class blocks
+// many-class register-resident conversation (kernels_mc.h): the small-agent shape with more classes than the 32 a sample's
+// own workgroup holds, up to 16 slices x 64 classes
+__host__ __device__ inline bool mc_shape(int H, int W, int R, int V, int D, int T) { return H == 256 && W == 32 && R == 64 && V == 100 && D > 32 && D <= 1024 && T <= 16; }
+
 __host__ __device__ inline int dc_slices(int B) { return B >= 1024 ? 4 : 1; }
 
 struct TapeLayout {
@@ -213,8 +223,10 @@ inline TapeLayout tape_layout(const mmg_config& c) {
     const int64_t B = c.batch, D = c.n_classes, F = c.feat_dim, H = c.h_dim, W = c.w_dim, R = c.rec_hidden,
                   V = c.wv_dim, K = c.bas_hidden, T = c.max_exchange, T1 = T + 1,
                   NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B), NS2P = (W + 15) / 16, NTILE = (B + 15) / 16, NZP = ((B + 15) / 16) * ((H + 63) / 64), NHLP = split_helpers((int)B) > 0 ? split_helpers((int)B) : 1,
+                  NMC = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) ? (B + 15) / 16 : 1,
+                  NMCB = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) && !c.use_binary ? 16 : 0,
                   NWP = wgrad_nsplit((int)(T * B), param_layout(c).total) > 1 ? (int64_t)wgrad_nsplit((int)(T * B), param_layout(c).total) * (param_layout(c).total + 512 * 64) : 4;
-    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP;
+    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \

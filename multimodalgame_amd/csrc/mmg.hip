@@ -16,6 +16,7 @@
 #include "kernels_bwd.h"
 #include "kernels_fast.h"
 #include "kernels_tile.h"
+#include "kernels_mc.h"
 
 using namespace mmg;
 
@@ -63,6 +64,9 @@ struct mmg_handle {
     uint32_t* d_err;           // its device-side address
     // debugging switches of the launch paths (environment, read ONCE at mmg_create -- never on the per-minibatch path)
     bool sw_rsample, sw_rmsg, sw_fused_s, sw_xcd_map, rs_capable;
+    bool mc_ok;                // many-class register-resident conversation (kernels_mc.h); MMG_NO_MC=1: off
+    bool mc_always, mc_bwd_ok;
+    int mc_per, mc_xcd;        // classes per member of a tile; MMG_MC_XCD=1: a tile's 16 workgroups on one XCD
     // workgroups of 512 threads that are guaranteed to be resident together on this device (occupancy query at mmg_create,
     // minus a margin): the role launches (k_conv_persist / k_conv_split / k_conversation_mc) spin on each other, so a launch
     // may never hold more roles than this
@@ -152,6 +156,7 @@ extern "C" int mmg_tape_table(const mmg_config* cfg, mmg_tape_entry* out, int ma
 // ---------------------------------------------------------------------------------------------
 static bool fast_shape(const mmg_handle* h);
 static bool tile_path(const mmg_handle* h);
+static bool mc_path(const mmg_handle* h);
 
 static int build_jobs(mmg_handle* h) {
     JobTable& jt = h->jt;
@@ -323,6 +328,11 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->use_fast = !getenv("MMG_NO_FAST"); h->merge_roles = !getenv("MMG_NO_MERGE");
     h->sw_rsample = !getenv("MMG_NO_RSAMPLE"); h->sw_rmsg = !getenv("MMG_NO_RMSG"); h->sw_fused_s = !getenv("MMG_NO_FUSED_S");
     h->sw_xcd_map = getenv("MMG_XCD_MAP") != nullptr;
+    h->mc_ok = h->use_fast && mc_shape(h->dm.H, h->dm.W, h->dm.R, h->dm.V, h->dm.D, h->dm.T) && !getenv("MMG_NO_MC");
+    h->mc_per = (((h->dm.D + 15) / 16) + 3) & ~3;
+    h->mc_xcd = getenv("MMG_MC_XCD") ? 1 : 0;
+    h->mc_always = getenv("MMG_MC_ALWAYS") != nullptr;
+    h->mc_bwd_ok = !getenv("MMG_NO_MC_BWD");
     int n_cu = 0;
     {
         int dev = 0; hipDeviceProp_t prop;
@@ -539,7 +549,10 @@ static bool fast_shape(const mmg_handle* h) {
 }
 // every other shape: sample tiles on the matrix cores (kernels_tile.h); the per-sample generic kernels remain for
 // dimensions whose tile does not fit the LDS and for the agent-level entry points
-static bool tile_path(const mmg_handle* h) { return h->tile_ok && !fast_shape(h); }
+// the small agents with many classes (32 < D <= 1024): register-resident conversation with class slices (kernels_mc.h) up to
+// 1024 samples per GPU (beyond that the sample tiles fill the chip; MMG_MC_ALWAYS=1 / MMG_TILE=1 force either)
+static bool mc_path(const mmg_handle* h) { return h->mc_ok && !(h->tile_ok && h->tile_force) && (h->dm.B < 1024 || h->mc_always || !h->tile_ok); }
+static bool tile_path(const mmg_handle* h) { return h->tile_ok && !fast_shape(h) && !mc_path(h); }
 
 static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
     const Dims& d = h->dm;
@@ -643,11 +656,21 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     ConvArgs ar;
     memset(&ar, 0, sizeof(ar));
     ar.x = d_x; ar.target = d_target; ar.desc = d_desc; ar.u_z = d_u_z; ar.u_s = d_u_s; ar.u_w = d_u_w; ar.seed = seed;
+    // run_all_steps == 2: training-minimal (as 0; the class logits y[t] of the steps before the output step are not kept)
+    const int y_last_only = (run_all_steps == 2 && d.fixed) ? 1 : 0;
+    if (run_all_steps == 2) run_all_steps = 0;
     ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
     bool base_ready = false;
     h->basehx_ready = false;
     if (tile_path(h)) {
         if (launch_conv_tile(h, st, ar)) return -1;
+    } else if (mc_path(h)) {
+        Scope sc(h, st, "k_conversation_mc");
+        const int ntile = (d.B + 15) / 16;
+        ar.per = h->mc_per;
+        const int grid = h->mc_xcd ? ((ntile + 7) / 8) * 128 : ntile * 16;
+        hipLaunchKernelGGL((k_conversation_mc<256, 32, 64, 100, 64>), dim3(grid), dim3(512), 0, st, h->dm, h->P, h->tp, ar, ntile, h->mc_xcd, y_last_only);
+        if (launch_check("k_conversation_mc")) return -1;
     } else {
         Scope sc(h, st, "k_conversation");
         const bool fast = fast_shape(h);
@@ -700,7 +723,10 @@ extern "C" int mmg_loss_stats(mmg_handle* h, void* stream) {
 }
 
 // single-GPU minibatch: the statistics run as extra roles of the backward launch (no all-reduce in between)
+// continuous many-class path: the two-launch backward of kernels_mc.h (MMG_NO_MC_BWD=1: generic per-sample kernels)
+static bool mc_bwd(const mmg_handle* h) { return mc_path(h) && !h->dm.use_binary && h->mc_bwd_ok; }
 static bool merge_stats(const mmg_handle* h) {
+    if (mc_bwd(h)) return h->merge_roles;            // (sum of rewards / hits only: one extra workgroup of k_bwd_mc2)
     return fast_shape(h) && h->dm.use_binary && h->scores_in_parts && h->merge_roles;
 }
 
@@ -746,6 +772,15 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             if (!dhx_done) hipLaunchKernelGGL(k_dhx, dim3(nblk + (d.H / 4 + 63) / 64), dim3(MMG_BLOCK), 0, st, h->dm, h->tp, nblk);
             if (launch_check("k_send_bwd")) return -1;
         }
+    } else if (mc_bwd(h)) {
+        Scope sc(h, st, "k_bwd_mc");
+        const int ntile = (d.B + 15) / 16;
+        int ngroup = (ntile + 1) / 2;
+        ngroup = ngroup < 1 ? 1 : (ngroup > 16 ? 16 : ngroup);
+        hipLaunchKernelGGL((k_bwd_mc1<64, 64>), dim3(16 * ngroup), dim3(512), 0, st, h->dm, h->P, h->tp, d_target, h->mc_per, ntile, ngroup);
+        const int nred = (2 * d.D * d.R / 4 + MMG_BLOCK - 1) / MMG_BLOCK;
+        hipLaunchKernelGGL((k_bwd_mc2<64, 100>), dim3(d.B + nred + (with_stats ? 1 : 0)), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, ngroup, nred, with_stats ? 1 : 0);
+        if (launch_check("k_bwd_mc")) return -1;
     } else {
         Scope sc(h, st, "k_bwd_conv");
         const bool fast = fast_shape(h);
@@ -774,7 +809,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         hipLaunchKernelGGL(k_dC_tile, dim3((d.D + CPB - 1) / CPB, nsb), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, nsb, 0);
         if (nsb > 1) hipLaunchKernelGGL(k_dC_tile, dim3((d.D + CPB - 1) / CPB, 1), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, nsb, 1);
         if (launch_check("k_dC_tile")) return -1;
-    } else if (!(fast_shape(h) && h->merge_roles)) {
+    } else if (!(fast_shape(h) && h->merge_roles) && !mc_bwd(h)) {
         Scope sc(h, st, "k_dC");
         hipLaunchKernelGGL(k_dC, dim3(d.D), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp);
         if (launch_check("k_dC")) return -1;
@@ -844,7 +879,7 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
     if (h->cfg.global_batch != h->cfg.batch) return fail("mmg_train_step is single-GPU; with several ranks all-reduce between the phases");
     if (!d_target) return fail("target must not be NULL");
     if (sticky_error(h)) return -1;
-    if (mmg_exchange_forward(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, 0, stream)) return -1;
+    if (mmg_exchange_forward(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, 2, stream)) return -1;
     const bool merged = merge_stats(h);
     if (!merged && mmg_loss_stats(h, stream)) return -1;
     if (backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, merged)) return -1;

@@ -202,3 +202,33 @@ def test_register_resident_path_class_counts(n_classes):
     names = [n for n, _ in eng.kernel_times()]
     eng.set_profiling(False)
     assert "k_conversation" in names and "k_conv_tile" not in names and "k_bwd_tile" not in names, names
+
+
+@pytest.mark.parametrize("n_classes,batch", [(200, 40), (33, 16), (1000, 24)])
+def test_many_class_binary_adaptive_vs_oracle(n_classes, batch):
+    """Binary messages, Adaptive, more classes than the register-resident kernels hold (D > 32): the conversation runs on
+    k_conversation_mc (a workgroup per sample that also owns a class slice of its 16-sample tile; ragged last tile, class
+    slices that end before / after D), every per-step array of exchange() against the oracle in run-all mode, then the
+    fused training step (no early exit on this path) on what training sees."""
+    meta = _meta(dict(C1, batch_size=batch), n_classes, batch, 2)
+    got, eng = common.hip_train_case(None, meta)
+    want = common.oracle_train_case(None, meta)
+    problems = common.compare_packed(got, want, atol=1e-4, rtol=1e-3, skip=("y2.bias",), shift_invariant=True, label="mcD%d" % n_classes)
+    hard = [p for p in problems if not common.is_grad_key(p.split(" ")[0])]
+    assert not hard, "\n".join(hard[:20])
+    assert len(problems) <= 6, "\n".join(problems[:20])
+    got_f, eng = common.hip_train_case(None, meta, fused=True)
+    keep = ("losses", "n_steps", "hits", "logs", "outp", "dist", ".g.", ".p.", "gradnorm")
+    pick = lambda d: {k: v for k, v in d.items() if any(t in k for t in keep)}
+    problems = common.compare_packed(pick(got_f), pick(want), atol=1e-4, rtol=1e-3, skip=("y2.bias",), shift_invariant=True, label="mcD%d-fused" % n_classes)
+    hard = [p for p in problems if not common.is_grad_key(p.split(" ")[0])]
+    assert not hard, "\n".join(hard[:20])
+    assert len(problems) <= 6, "\n".join(problems[:20])
+    x, target, desc, _ = common.case_inputs(meta, 0)
+    dev = eng.device
+    eng.set_profiling(True)
+    eng.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(target).to(dev), torch.from_numpy(desc).to(dev), seed=1)
+    torch.cuda.synchronize()
+    names = [n for n, _ in eng.kernel_times()]
+    eng.set_profiling(False)
+    assert "k_conversation_mc" in names, names
