@@ -319,6 +319,7 @@ __device__ __forceinline__ void batched_for(int total, Ld ld, Use use) {
 template <int NT>
 __device__ __forceinline__ void class_logits(const Dims& dm, const Tape& tp, const float* s_A, int ldR, const float* s_w2, float* s_y, int ldY,
                                              int d_lo, int Dl, size_t rowb, int b0, const float* live, const float* take, int tid, float b2v) {
+    // (live: rows whose logits go to tape.y -- the caller passes the take flags here when only the output step's are kept)
     const int D = dm.D, R = dm.R;
     if (Dl * MMG_TM <= 4 * NT) {
         // a narrow slice (class helpers of a 16-tile batch hold ~70 classes): the 4 x 4 blocks would occupy a fraction of the
@@ -878,7 +879,7 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                         }
                         const float yv = (a0 + a1) + b2;
                         s_y[m * L.ldD + d] = yv;
-                        if (misc[TL_LIVE + m] != 0.f) tp.y[(rowb + b0 + m) * D + d] = yv;
+                        if (misc[(ar.y_last_only ? TL_TAKE : TL_LIVE) + m] != 0.f) tp.y[(rowb + b0 + m) * D + d] = yv;
                     }
                 } else {
                     if (SPLIT) {
@@ -889,7 +890,7 @@ __device__ __forceinline__ void conv_tile_body(const Dims& dm, const Params& P, 
                         pf_signal(pf_ctr(tp, 0, tile_idx));
                         ++published;
                     }
-                    class_logits<NT>(dm, tp, s_A, L.ldR, s_w2, s_y, L.ldD, 0, Dl, rowb, b0, misc + TL_LIVE, misc + TL_TAKE, tid, b2);
+                    class_logits<NT>(dm, tp, s_A, L.ldR, s_w2, s_y, L.ldD, 0, Dl, rowb, b0, misc + (ar.y_last_only ? TL_TAKE : TL_LIVE), misc + TL_TAKE, tid, b2);
                 }
                 if (!bigD) for (int idx = tid; idx < MMG_TM * (L.ldD - D); idx += NT) s_y[(idx / (L.ldD - D)) * L.ldD + D + idx % (L.ldD - D)] = 0.f;   // K padding of the mixture product
                 __syncthreads();
@@ -1122,7 +1123,7 @@ __device__ __forceinline__ void class_helper_role(const Dims& dm, const Params& 
                            [&](int idx, float v) { if (idx < MMG_TM * R) s_A[(idx / R) * ldR + idx % R] = v; else flags[idx - MMG_TM * R] = v; });
         __syncthreads();
         if (Dl > 0) {
-            class_logits<NT>(dm, tp, s_A, ldR, s_w2, s_y, ldY, d_lo, Dl, rowb, b0, flags, flags + 16, tid, b2h);
+            class_logits<NT>(dm, tp, s_A, ldR, s_w2, s_y, ldY, d_lo, Dl, rowb, b0, ar.y_last_only ? flags + 16 : flags, flags + 16, tid, b2h);
             __syncthreads();
             class_softmax_num<NT>(s_y, ldY, Dl, flags + 32, wave, lane);
             __syncthreads();

@@ -200,6 +200,15 @@ __host__ __device__ inline int wgrad_nsplit(int TB, long long ptotal) {
     return n > cap ? (cap < 1 ? 1 : cap) : n;
 }
 
+// ... per job: with more than 2048 (step, sample) rows a job with few output tiles (the receiver's small matrices: a dozen
+// tiles that would each walk all the rows, 0.7 us per 64) is split further, down to ~5 chunks of 64 rows per workgroup
+__host__ __device__ inline int wgrad_job_nsplit(int TB, long long ptotal, int job_tiles) {
+    int n = wgrad_nsplit(TB, ptotal);
+    if (TB > 2048 && job_tiles <= 64) { int m = TB / 320; m = m > 16 ? 16 : m; if (m > n) n = m; }
+    return n;
+}
+__host__ __device__ inline bool wgrad_any_split(int TB, long long ptotal) { return TB > 2048 || wgrad_nsplit(TB, ptotal) > 1; }
+
 // class helpers per sample tile of the many-class forward (k_conv_split): every CU the sample tiles leave idle takes a
 // slice of the classes; 0: no split
 __host__ __device__ inline int split_helpers(int B) { const int tiles = (B + 15) / 16; int nh = 224 / tiles - 1; return nh > 15 ? 15 : (nh < 0 ? 0 : nh); }   // (all roles must be co-resident: margin below the 256 CUs)
@@ -225,7 +234,7 @@ inline TapeLayout tape_layout(const mmg_config& c) {
                   NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B), NS2P = (W + 15) / 16, NTILE = (B + 15) / 16, NZP = ((B + 15) / 16) * ((H + 63) / 64), NHLP = split_helpers((int)B) > 0 ? split_helpers((int)B) : 1,
                   NMC = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) ? (B + 15) / 16 : 1,
                   NMCB = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) && !c.use_binary ? 16 : 0,
-                  NWP = wgrad_nsplit((int)(T * B), param_layout(c).total) > 1 ? (int64_t)wgrad_nsplit((int)(T * B), param_layout(c).total) * (param_layout(c).total + 512 * 64) : 4;
+                  NWP = wgrad_any_split((int)(T * B), param_layout(c).total) ? (int64_t)16 * (param_layout(c).total + 512 * 64) : 4;   /* (every job splits <= 16 ways) */
     (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};

@@ -66,6 +66,8 @@ struct mmg_handle {
     bool sw_rsample, sw_rmsg, sw_fused_s, sw_xcd_map, rs_capable;
     bool mc_ok;                // many-class register-resident conversation (kernels_mc.h); MMG_NO_MC=1: off
     bool mc_always, mc_bwd_ok;
+    bool any_split;            // some k_wgrad job splits its rows over workgroups (k_wreduce adds the partial tiles)
+    bool wgrad_small_split;    // jobs with few output tiles split their (step, sample) rows further (layout.h: wgrad_job_nsplit)
     int mc_per, mc_xcd;        // classes per member of a tile; MMG_MC_XCD=1: a tile's 16 workgroups on one XCD
     // workgroups of 512 threads that are guaranteed to be resident together on this device (occupancy query at mmg_create,
     // minus a margin): the role launches (k_conv_persist / k_conv_split / k_conversation_mc) spin on each other, so a launch
@@ -173,7 +175,8 @@ static int build_jobs(mmg_handle* h) {
         g.A = A; g.Bm = Bm; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.rows = rows; g.N = N; g.K = Kk;
         g.bmod = bmod; g.bsrc = bsrc; g.tile_begin = tiles; g.tiles_k = (Kk + 31) / 32;     // 16 x 32 outputs per block
         g.vhid = nullptr; g.vw2 = nullptr; g.compact = (rows == TB) ? 1 : 0;
-        g.nsplit = (rows == TB) ? wgrad_nsplit(TB, h->pl.total) : 1;
+        g.nsplit = (rows != TB) ? 1 : h->wgrad_small_split ? wgrad_job_nsplit(TB, h->pl.total, ((N + 15) / 16) * ((Kk + 31) / 32))
+                                                           : wgrad_nsplit(TB, h->pl.total);
         tiles += ((N + 15) / 16) * g.tiles_k * g.nsplit;
     };
     // dW = (dbeta * w2 * relu'(hid))^T . input  with the first factor formed on the fly
@@ -185,7 +188,7 @@ static int build_jobs(mmg_handle* h) {
     int cblocks = 0, nc = 0;
     // bias gradient = column sums of a (step, sample)-row tape.  With thousands of rows the 16-column blocks of a column job
     // are a handful of latency-bound workgroups: run it through the row-split GEMM pipeline instead, as delta^T . ones (K = 1)
-    const bool bias_as_gemm = wgrad_nsplit(TB, h->pl.total) > 1;
+    const bool bias_as_gemm = wgrad_nsplit(TB, h->pl.total) > 1 || (h->wgrad_small_split && TB > 2048);
     auto col = [&](const float* src, int ld, int rows, int cols, float* dst, const float* scale) {
         ColJob& c = jt.c[nc++];
         c.src = src; c.dst = dst; c.scale = scale; c.ld = ld; c.rows = rows; c.cols = cols; c.blk_begin = cblocks;
@@ -255,12 +258,15 @@ static int build_jobs(mmg_handle* h) {
         col(tp.dbs, 1, TB, 1, G.p[BS_L2_B], nullptr);
     }
     if (ng > MMG_MAX_GEMM || nc > MMG_MAX_COL) return fail("job table overflow");
+    h->any_split = false;
+    for (int g = 0; g < ng; ++g) h->any_split = h->any_split || jt.g[g].nsplit > 1;
     jt.n_gemm = ng; jt.n_col = nc; jt.gemm_tiles = tiles; jt.gemm_blocks = tiles; jt.col_blocks = cblocks;
     jt.n_wblocks = tiles + cblocks;
     for (int k = 0; k < 64; ++k) {
         jt.g_begin[k] = k < ng ? jt.g[k].tile_begin : 0x7fffffff;
         jt.c_begin[k] = k < nc ? jt.c[k].blk_begin : 0x7fffffff;
     }
+    if (jt.n_wblocks > MMG_MAX_WBLOCKS && h->wgrad_small_split) { h->wgrad_small_split = false; return build_jobs(h); }   // (k_wgrad addresses 16384 workgroups)
     if (jt.n_wblocks > MMG_MAX_WBLOCKS) return fail("too many weight-gradient tiles (%d)", jt.n_wblocks);
     {
         auto agent_of = [&](const float* dst) {
@@ -330,9 +336,10 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->sw_xcd_map = getenv("MMG_XCD_MAP") != nullptr;
     h->mc_ok = h->use_fast && mc_shape(h->dm.H, h->dm.W, h->dm.R, h->dm.V, h->dm.D, h->dm.T) && !getenv("MMG_NO_MC");
     h->mc_per = (((h->dm.D + 15) / 16) + 3) & ~3;
-    h->mc_xcd = getenv("MMG_MC_XCD") ? 1 : 0;
+    h->mc_xcd = (getenv("MMG_MC_XCD") && atoi(getenv("MMG_MC_XCD")) == 0) ? 0 : 1;     // (measured at config 5, 256 samples: 192 us per minibatch against 201)
     h->mc_always = getenv("MMG_MC_ALWAYS") != nullptr;
     h->mc_bwd_ok = !getenv("MMG_NO_MC_BWD");
+    h->wgrad_small_split = !getenv("MMG_NO_SMALL_SPLIT");
     int n_cu = 0;
     {
         int dev = 0; hipDeviceProp_t prop;
@@ -450,7 +457,18 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     if (e == hipSuccess) e = hipMemset(d_workspace, 0, h->tl.total);
     if (e == hipSuccess) e = hipMemset(d_grads, 0, sizeof(float) * (h->pl.total + MMG_GRAD_TAIL));
     if (e != hipSuccess) { fail("device init failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
-    if (build_jobs(h)) { delete h; return nullptr; }
+    // jobs with few output tiles split their rows further only when the whole table leaves the chip idle otherwise (continuous
+    // mode: the receiver's dozen small matrices; measured at config 5, 256 samples: k_wgrad 32 -> 22 us.  With a full table --
+    // config 3 at 512 samples, 1 660 tiles -- the extra tiles made it slower: 104 -> 205 us)
+    {
+        const bool want = h->wgrad_small_split;
+        h->wgrad_small_split = false;
+        if (build_jobs(h)) { delete h; return nullptr; }
+        if (want && h->jt.gemm_tiles <= 256 && h->dm.T * h->dm.B > 2048) {
+            h->wgrad_small_split = true;
+            if (build_jobs(h)) { delete h; return nullptr; }
+        }
+    }
     {
         std::vector<float> one(256, 1.0f);
         e = hipMemcpy(h->tp.ones, one.data(), sizeof(float) * one.size(), hipMemcpyHostToDevice);
@@ -659,6 +677,7 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     // run_all_steps == 2: training-minimal (as 0; the class logits y[t] of the steps before the output step are not kept)
     const int y_last_only = (run_all_steps == 2 && d.fixed) ? 1 : 0;
     if (run_all_steps == 2) run_all_steps = 0;
+    ar.y_last_only = y_last_only;
     ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
     bool base_ready = false;
     h->basehx_ready = false;
@@ -825,7 +844,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
 #endif
                            );
         if (launch_check("k_wgrad")) return -1;
-        if (wgrad_nsplit(d.T * d.B, h->pl.total) > 1) {
+        if (h->any_split) {
             hipLaunchKernelGGL(k_wreduce, dim3(h->jt.gemm_tiles), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt, (const float*)h->tp.wpart, h->tp.gnpart);
             if (launch_check("k_wreduce")) return -1;
         }
