@@ -314,6 +314,45 @@ def cpu_baseline(seconds_budget=24.0):
                     ", ".join("%d thr: %.1f" % (k, v["steps_per_s"]) for k, v in sorted(out.items())), ncpu))
 
 
+def run_cli(seconds=2.0, epochs=None):
+    """The SHIPPED training loop -- `python -m multimodalgame_amd.model`, i.e. model.run(): flag parsing, description
+    pipeline, device-resident HDF5 epoch loop (misc.load_hdf5), Game.train_step per minibatch, a log line every 50 steps --
+    on synthetic HDF5 / CSV / GloVe files of configs[1]'s shape (3000 train samples, 30 classes).  Returns
+    exchange-steps/s of the epoch loop as model.run() itself measures it (device-synchronised, dev evaluation and
+    checkpointing pushed beyond the run: the metric excludes them)."""
+    import shutil
+    import tempfile
+    from multimodalgame_amd import flags as _flags, model as _model, misc as _misc
+    tmp = tempfile.mkdtemp(prefix="mmg_cli_")
+    try:
+        paths = _misc.write_synthetic_dataset(os.path.join(tmp, "data"), n_classes=30, per_class=100, feat_dim=512, wv_dim=100)
+        per_epoch = 3000 // 64
+        if epochs is None:
+            epochs = max(2, int(seconds / (per_epoch * 80e-6)))
+        stats = {}
+        argv = ["model.py", "-experiment_name", "bench_cli", "-log_path", os.path.join(tmp, "logs"), "-model_type", "Adaptive",
+                "-batch_size", "64", "-max_exchange", "10", "-rec_w_dim", "32", "-sender_out_dim", "32", "-img_h_dim", "256",
+                "-rec_hidden", "64", "-learning_rate", "1e-4", "-entropy_rec", "0.01", "-entropy_sen", "0.01", "-entropy_s", "0.08",
+                "-use_binary", "-max_epoch", str(epochs), "-log_dev", str(10 ** 9), "-save_after", str(10 ** 9), "-exchange_samples", "0",
+                "-top_k_train", "6"] + [a for k, v in paths.items() for a in ("-" + k, v)]
+        _flags.define_flags()
+        _flags.FLAGS.Reset()
+        _flags.FLAGS(argv)
+        _flags.default_flags(argv)
+        import contextlib
+        with open(os.devnull, "w") as devnull, contextlib.redirect_stderr(devnull):      # (FileLogger echoes every line to stderr)
+            _model.run(stats=stats)
+        _flags.FLAGS.Reset()
+        return dict(cli_steps_per_s=stats["exchange_steps"] / stats["train_seconds"],
+                    cli_ms_per_minibatch=1e3 * stats["train_seconds"] / stats["minibatches"],
+                    cli_minibatches=stats["minibatches"], cli_seconds=stats["train_seconds"],
+                    cli_exchange_steps_per_minibatch=stats["exchange_steps"] / stats["minibatches"],
+                    cli_what="model.run() of `python -m multimodalgame_amd.model -model_type Adaptive -batch_size 64 -max_exchange 10 ...` on "
+                             "synthetic HDF5 (3000 samples, %d epochs), log line every 50 steps, dev evaluation / checkpoints excluded" % epochs)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node (one per GPU, RCCL) under
     torch.distributed.run and return its exit code.  MMG_BENCH_BACKEND=gloo lets N ranks share the visible GPUs (smoke
@@ -344,6 +383,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short c3 / c4 / c5 runs of the default invocation")
+    ap.add_argument("--cli", action="store_true", help="only time the shipped training loop (model.run() on synthetic HDF5) and print its numbers")
+    ap.add_argument("--no-cli", action="store_true", help="skip the model.run() measurement of the default invocation (config.cli_steps_per_s)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 = BASELINE.json's metric config (default); c3/c4/c5 = the other listed configs, for reference")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -354,6 +395,9 @@ def main():
         ap.error("--scaling strong needs --workload c3 or c5 (the configs BASELINE.json defines with a global batch)")
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.cli:
+        print(json.dumps(run_cli()))
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # the ranks print the JSON line (rank 0)
     rank = int(os.environ.get("RANK", "0"))
@@ -404,6 +448,10 @@ def main():
                                 roofline={k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_us", "traffic", "traffic_source")},
                                 kernels_us=rf.get("kernels_us"))
             line["other_configs"] = other
+        if world == 1 and args.workload == "c2" and not args.no_cli and not strong:
+            # what `python -m multimodalgame_amd.model` sustains end to end (same GPU, right after the HBM-resident measurement)
+            line["config"].update(run_cli())
+            line["config"]["cli_over_resident"] = line["config"]["cli_steps_per_s"] / value
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

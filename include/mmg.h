@@ -169,6 +169,11 @@ int mmg_receiver_forward(mmg_handle* h, const float* d_z, const float* d_desc, f
 int mmg_baseline_forward(mmg_handle* h, int which, const float* d_x, const float* d_binary,
                          const float* d_inp, int rows, float* d_score, void* stream);
 
+/* Host-only helper of the epoch loop (no GPU work): shuffles perm[0..n) in place exactly as CPython's
+ * `random.shuffle` would from the Mersenne-Twister state (624 words + position, `random.getstate()[1]`) -- the batch order of
+ * misc.py:270-271 (`random.seed(11 + epoch); random.shuffle(order)`) without the per-sample interpreter loop. */
+int mmg_host_shuffle(const uint32_t* mt_state, int pos, int64_t n, int64_t* perm);
+
 /* Test/bench hooks: per-kernel timing of the most recent mmg_train_step measured with HIP events on
  * the launch stream (enable before the step; read after a stream sync). */
 int mmg_set_profiling(mmg_handle* h, int enabled);

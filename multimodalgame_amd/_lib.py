@@ -39,7 +39,7 @@ _lib = None
 SYMBOLS = ["mmg_last_error", "mmg_version", "mmg_param_count", "mmg_grad_floats", "mmg_param_table", "mmg_workspace_bytes",
            "mmg_tape_table", "mmg_create", "mmg_destroy", "mmg_exchange_forward", "mmg_loss_stats",
            "mmg_backward", "mmg_clip_step", "mmg_train_step", "mmg_sender_forward", "mmg_receiver_forward",
-           "mmg_baseline_forward", "mmg_set_profiling", "mmg_get_kernel_times"]
+           "mmg_baseline_forward", "mmg_set_profiling", "mmg_get_kernel_times", "mmg_host_shuffle"]
 
 
 def load():
@@ -73,6 +73,7 @@ def load():
     lib.mmg_receiver_forward.restype = i32
     lib.mmg_receiver_forward.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, fp, fp, u64, fp, fp, fp, fp, fp, fp, vp]
     lib.mmg_baseline_forward.restype = i32; lib.mmg_baseline_forward.argtypes = [vp, i32, fp, fp, fp, i32, fp, vp]
+    lib.mmg_host_shuffle.restype = i32; lib.mmg_host_shuffle.argtypes = [vp, i32, i64, vp]
     lib.mmg_set_profiling.restype = i32; lib.mmg_set_profiling.argtypes = [vp, i32]
     lib.mmg_get_kernel_times.restype = i32
     lib.mmg_get_kernel_times.argtypes = [vp, C.c_char_p, i32, C.POINTER(C.c_float), i32]

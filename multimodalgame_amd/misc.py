@@ -184,31 +184,136 @@ def _dataset(hdf5_file, feats):
     return _DATASET_CACHE[key]
 
 
-def load_hdf5(hdf5_file, batch_size, random_seed, shuffle, truncate_final_batch=False, map_labels=int,
-              feats=("avgpool_512",), device=None):
-    """Generator of batch dicts with the reference's order semantics: random.seed(11 + epoch) shuffle of
-    range(N), consecutive slices of the shuffled order, indices SORTED inside a batch, last partial batch
-    dropped unless truncate_final_batch.  Only the requested feature datasets are read (the reference
-    reads layer4_2 / avgpool_512 / fc for every batch even when unused)."""
-    data = _dataset(hdf5_file, feats)
-    dataset_size = data["Target"].shape[0]
-    order = list(range(dataset_size))
+def _squeeze_feat(arr):
+    """(N, 1, F) -> (N, F): the singleton axes of the stored features are dropped, the sample axis never is."""
+    return arr.reshape(arr.shape[0], *[s for s in arr.shape[1:] if s != 1]) if arr.ndim > 2 else arr
+
+
+_FAST_SHUFFLE = None          # None: not probed yet; True / False: libmmg's mmg_host_shuffle reproduces random.shuffle here
+
+
+def _shuffled_order(n):
+    """range(n) shuffled by Python's global generator AS random.shuffle WOULD (the state is read, the permutation is formed by
+    libmmg's host helper, ~100x faster than the interpreter loop); falls back to random.shuffle itself if the library is
+    missing or its result ever differed from the interpreter's on this Python build (probed once)."""
+    global _FAST_SHUFFLE
+    import ctypes as C
+
+    def fast(m):
+        from . import _lib
+        st = random.getstate()[1]
+        words = np.array(st[:-1], dtype=np.uint32)
+        perm = np.arange(m, dtype=np.int64)
+        _lib.check(_lib.load().mmg_host_shuffle(words.ctypes.data_as(C.c_void_p), int(st[-1]), m, perm.ctypes.data_as(C.c_void_p)))
+        return perm
+    if _FAST_SHUFFLE is None:
+        try:
+            saved = random.getstate()
+            ok = True
+            for seed, m in ((11, 1), (12, 2), (13, 1000), (14, 4099)):
+                random.seed(seed)
+                got = fast(m)
+                want = list(range(m))
+                random.shuffle(want)
+                ok = ok and got.tolist() == want
+            random.setstate(saved)
+            _FAST_SHUFFLE = ok
+        except Exception:                               # noqa: BLE001  (no library in this process: the interpreter's own loop)
+            _FAST_SHUFFLE = False
+    if _FAST_SHUFFLE:
+        return fast(n)
+    order = list(range(n))
+    random.shuffle(order)
+    return np.fromiter(order, dtype=np.int64, count=n)
+
+
+def _epoch_order(dataset_size, batch_size, random_seed, shuffle, truncate_final_batch):
+    """Per-batch index arrays in the reference's order (misc.py:262-282): random.seed(11 + epoch) shuffle of range(N)
+    (Python's generator: the permutation is the contract), consecutive slices, indices SORTED inside a batch, last partial
+    batch dropped unless truncate_final_batch.  The slicing / sorting is one numpy call over the whole epoch."""
     if shuffle:
         random.seed(11 + random_seed)
-        random.shuffle(order)
-    num_batches = dataset_size // batch_size
-    if truncate_final_batch and dataset_size - num_batches * batch_size > 0:
-        num_batches += 1
-    for i in range(num_batches):
-        idx = sorted(order[i * batch_size:(i + 1) * batch_size])
-        batch = {"target": torch.tensor([map_labels(int(t)) for t in data["Target"][idx]], dtype=torch.int64),
-                 "example_ids": data["Location"][idx]}
+        arr = _shuffled_order(dataset_size)
+    else:
+        arr = np.arange(dataset_size, dtype=np.int64)
+    n_full = dataset_size // batch_size
+    full = np.sort(arr[:n_full * batch_size].reshape(n_full, batch_size), axis=1)
+    batches = list(full)
+    if truncate_final_batch and dataset_size - n_full * batch_size > 0:
+        batches.append(np.sort(arr[n_full * batch_size:]))
+    return batches
+
+
+_RESIDENT_CACHE = {}
+
+
+class _ResidentDataset(object):
+    """One HDF5 file preloaded to `device`: the requested feature arrays as [N, F] float32 tensors and the
+    class indices (map_labels applied ONCE per distinct raw label, not per sample per batch) as an int64 tensor."""
+
+    def __init__(self, data, feats, device):
+        self.device = device
+        self.n = int(data["Target"].shape[0])
+        self.location = data["Location"]
+        self.raw_target = np.asarray(data["Target"]).astype(np.int64)
+        self.feats = {name: torch.from_numpy(np.ascontiguousarray(_squeeze_feat(np.asarray(data[name], dtype=np.float32)))).to(device)
+                      for name in feats}
+        self._mapped = []                           # [(map_labels, device tensor)]: one entry per label map seen
+
+    def targets(self, map_labels):
+        for fn, t in self._mapped:
+            if fn is map_labels:
+                return t
+        uniq = np.unique(self.raw_target)
+        table = {int(u): map_labels(int(u)) for u in uniq}
+        mapped = np.array([table[int(v)] for v in self.raw_target], dtype=np.int64)
+        t = torch.from_numpy(mapped).to(self.device)
+        self._mapped.append((map_labels, t))
+        return t
+
+
+def _resident(hdf5_file, feats, device):
+    key = (os.path.abspath(os.path.expanduser(hdf5_file)), tuple(feats), str(device))
+    if key not in _RESIDENT_CACHE:
+        _RESIDENT_CACHE[key] = _ResidentDataset(_dataset(hdf5_file, feats), feats, device)
+    return _RESIDENT_CACHE[key]
+
+
+def load_hdf5(hdf5_file, batch_size, random_seed, shuffle, truncate_final_batch=False, map_labels=int,
+              feats=("avgpool_512",), device=None, with_ids=True):
+    """Generator of batch dicts with the reference's order semantics (misc.py:257-302): random.seed(11 + epoch) shuffle of
+    range(N), consecutive slices of the shuffled order, indices SORTED inside a batch, last partial batch
+    dropped unless truncate_final_batch.  Only the requested feature datasets are read (the reference
+    reads layer4_2 / avgpool_512 / fc for every batch even when unused).
+
+    device given: the epoch loop is DEVICE-RESIDENT.  The file is preloaded to the device once (features + mapped targets), the
+    epoch's permutation is built on the host once, and ONE gather per epoch lays the samples out in batch order; a batch is
+    then two tensor views -- no per-batch numpy indexing, no per-sample Python, no host-to-device copy.
+    with_ids=False skips the per-batch `example_ids` string array (the training loop never reads it)."""
+    data = _dataset(hdf5_file, feats)
+    batches = _epoch_order(int(data["Target"].shape[0]), batch_size, random_seed, shuffle, truncate_final_batch)
+    if device is not None:
+        res = _resident(hdf5_file, feats, torch.device(device))
+        flat = torch.from_numpy(np.concatenate(batches) if batches else np.zeros(0, np.int64)).to(res.device)
+        target_ep = res.targets(map_labels).index_select(0, flat)
+        feats_ep = {name: res.feats[name].index_select(0, flat) for name in feats}
+        lo = 0
+        for idx in batches:
+            hi = lo + len(idx)
+            batch = {"target": target_ep[lo:hi]}
+            if with_ids:
+                batch["example_ids"] = res.location[idx]
+            for name in feats:
+                batch[name] = feats_ep[name][lo:hi]
+            lo = hi
+            yield batch
+        return
+    for idx in batches:
+        batch = {"target": torch.tensor([map_labels(int(t)) for t in data["Target"][idx]], dtype=torch.int64)}
+        if with_ids:
+            batch["example_ids"] = data["Location"][idx]
         for name in feats:
-            arr = torch.from_numpy(data[name][idx]).float()
-            arr = arr.reshape(arr.shape[0], *[s for s in arr.shape[1:] if s != 1]) if arr.dim() > 2 else arr
-            batch[name] = arr
-        if device is not None:
-            batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            batch[name] = torch.from_numpy(_squeeze_feat(np.asarray(data[name][idx]))).float()
         yield batch
 
 

@@ -68,7 +68,9 @@ def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels
     return correct / total, extra
 
 
-def run():
+def run(stats=None):
+    """stats: optional dict; the training loop leaves there what bench.py --cli reports: wall seconds of the epoch loop
+    (device-synchronised at both ends, eval_dev time excluded), minibatches and exchange steps (device-side count)."""
     _flags.check_supported(FLAGS)                     # unsupported reference switches fail before anything is written
     os.makedirs(FLAGS.log_path, exist_ok=True)
     flogger = FileLogger(FLAGS.log_file)
@@ -138,21 +140,40 @@ def run():
         flogger.Log("Wrote " + FLAGS.binary_output)
         return
 
-    hits_ring = torch.zeros(max(FLAGS.log_interval, 1), device=device)
-    steps_run = 0                                    # minibatches of THIS process (a resumed run starts with an empty ring)
+    # Training accuracy of a log line = top-k hits of the last min(log_interval, minibatches of this process) minibatches
+    # (model.py:1333-1348).  The hits accumulate on the device (tape "totals"); a log line reads the running sum and
+    # subtracts what the previous log line read -- nothing is copied or enqueued per minibatch.
+    steps_run, steps_at_log, hits_at_log = 0, 0, 0.0
+    totals0 = None
+    eval_seconds = 0.0
+    import time as _time
+
+    def finish():
+        if stats is not None and totals0 is not None:
+            torch.cuda.synchronize(device)
+            tot = game._train_engine.tape["totals"].cpu().tolist()
+            stats.update(train_seconds=_time.perf_counter() - t_loop - eval_seconds, minibatches=steps_run,
+                         exchange_steps=tot[0] - totals0[0], sample_steps=tot[3] - totals0[3])
+    torch.cuda.synchronize(device)
+    t_loop = _time.perf_counter()
     while epoch < FLAGS.max_epoch:
         flogger.Log("Starting epoch: {}".format(epoch))
         if FLAGS.images != "mammal":
             raise NotImplementedError                                      # model.py:1211 (cifar branch is broken upstream)
         for i_batch, batch in enumerate(load_hdf5(FLAGS.train_file, FLAGS.batch_size, epoch, FLAGS.shuffle_train,
-                                                  map_labels=map_labels_train, feats=(FLAGS.img_feat,), device=device)):
+                                                  map_labels=map_labels_train, feats=(FLAGS.img_feat,), device=device,
+                                                  with_ids=False)):
+            if totals0 is None:                      # (the first minibatch creates the engine)
+                totals0 = game.engine_for(batch["target"].size(0), desc_train.size(0)).tape["totals"].cpu().tolist()
+                hits_at_log = totals0[1]
             eng = game.train_step(batch[FLAGS.img_feat], batch["target"], desc_train)     # model.py:1240-1339
-            hits_ring[steps_run % hits_ring.numel()] = eng.tape["losses"][7]
             steps_run += 1
             if step % FLAGS.log_interval == 0:                             # model.py:1342-1377
                 L = eng.losses()
-                n_seen = min(steps_run, hits_ring.numel())               # only the slots filled since this process started
-                avg_batch_acc = float(hits_ring[:n_seen].sum()) / float(FLAGS.batch_size) / n_seen
+                hits_now = float(eng.tape["totals"][1])
+                n_seen = steps_run - steps_at_log                       # = min(minibatches of this process, log_interval)
+                avg_batch_acc = (hits_now - hits_at_log) / float(FLAGS.batch_size) / n_seen
+                steps_at_log, hits_at_log = steps_run, hits_now
                 pre = "Epoch: {} Step: {} Batch: {} ".format(epoch, step, i_batch)
                 flogger.Log(pre + "Training Accuracy: {}".format(avg_batch_acc))
                 flogger.Log(pre + "Loss Sender: {}".format(L["loss_binary_sen"]))
@@ -166,7 +187,11 @@ def run():
                 if FLAGS.exchange_samples > 0:                             # model.py:1411-1461 (train sample dump)
                     flogger.Log(_sample_dump(eng, "Train:"))
             if step % FLAGS.log_dev == 0:                                  # model.py:1545-1576
+                torch.cuda.synchronize(device)
+                t_ev = _time.perf_counter()
                 dev_acc, extra = do_eval()
+                torch.cuda.synchronize(device)
+                eval_seconds += _time.perf_counter() - t_ev
                 pre = "Epoch: {} Step: {} Batch: {} ".format(epoch, step, i_batch)
                 flogger.Log(pre + "Development Accuracy: {}".format(dev_acc))
                 flogger.Log(pre + "Conversation Length (avg/std): {}/{}".format(
@@ -181,9 +206,11 @@ def run():
                 torch_save(FLAGS.checkpoint, dict(step=step, best_dev_acc=best_dev_acc, mmg_minibatch_counter=game.counters()[0]), models_dict, optimizers_dict)
             step += 1
             if FLAGS.max_steps and step >= FLAGS.max_steps:
+                finish()
                 flogger.Log("Finished training.")
                 return
         epoch += 1
+    finish()
     flogger.Log("Finished training.")
 
 

@@ -7,6 +7,7 @@
 # written under gpurun_out/; copy the ones to keep into profiles/.
 W=$1; TAG=$2; EXTRA=$3; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export MMG_BENCH_MIN_SECONDS=${MMG_BENCH_MIN_SECONDS:-0.3}     # (short timed window: the traces stay small; the un-profiled bench uses 2 s)
 CMD="python $R/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs $EXTRA"
 rm -rf /tmp/ks /tmp/pf /tmp/pw /tmp/pc /tmp/pd
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- $CMD > $O/${TAG}_${W}_bench_under_rocprof.json 2> /tmp/ks.err

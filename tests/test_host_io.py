@@ -42,6 +42,29 @@ def test_load_hdf5_order_semantics(tmp_path):
     assert list(misc.load_hdf5(paths["dev_file"], 4, 0, False, truncate_final_batch=True))[-1]["target"].shape[0] == 1
 
 
+def test_load_hdf5_device_resident_equals_host_path(tmp_path):
+    """device=...: the file is preloaded once, one gather per epoch lays the samples out in batch order, a batch is two
+    views -- same batches, same order, same mapped targets as the per-batch host path (misc.py:257-302 semantics)."""
+    paths = misc.write_synthetic_dataset(str(tmp_path), n_classes=5, per_class=9, feat_dim=6, wv_dim=5)
+    label_map = {c: (c * 3) % 5 for c in range(5)}
+    calls = []
+    fn = lambda v: calls.append(v) or label_map.get(v)
+    for epoch, shuffle, trunc in ((0, True, False), (3, True, False), (1, False, True)):
+        host = list(misc.load_hdf5(paths["train_file"], 8, epoch, shuffle, truncate_final_batch=trunc, map_labels=label_map.get))
+        calls.clear()
+        dev = list(misc.load_hdf5(paths["train_file"], 8, epoch, shuffle, truncate_final_batch=trunc, map_labels=fn, device="cpu"))
+        assert len(host) == len(dev) == (45 // 8 + (1 if trunc else 0))
+        assert len(calls) <= 5                                               # map_labels runs per distinct label, once per file
+        for a, b in zip(host, dev):
+            assert torch.equal(a["target"], b["target"]) and b["target"].dtype == torch.int64
+            assert torch.equal(a["avgpool_512"], b["avgpool_512"]) and b["avgpool_512"].dim() == 2
+            np.testing.assert_array_equal(a["example_ids"], b["example_ids"])
+    # views of ONE per-epoch gather: consecutive batches share storage; with_ids=False drops the string array
+    dev = list(misc.load_hdf5(paths["train_file"], 8, 0, True, map_labels=fn, device="cpu", with_ids=False))
+    assert "example_ids" not in dev[0]
+    assert dev[1]["avgpool_512"].data_ptr() == dev[0]["avgpool_512"].data_ptr() + 8 * 6 * 4
+
+
 def test_description_pipeline(tmp_path):
     csv = tmp_path / "d.csv"
     csv.write_text("7,agama,small terrestrial lizard of warm regions, of the Old World\n3,drake,adult male of a wild duck\n")
