@@ -95,9 +95,6 @@ def word_tokenize(text):
     return out
 
 
-_PUNCT = frozenset(string.punctuation)
-
-
 def clean_desc(desc):
     """Distinct lower-cased tokens of a description, first-occurrence order, without stop words and punctuation marks
     (the reference's filter chain, misc.py:220-226; it de-duplicates through set(), i.e. in hash order)."""
@@ -106,7 +103,9 @@ def clean_desc(desc):
         if tok in seen:
             continue
         seen.add(tok)
-        if tok not in STOPWORDS and tok not in _PUNCT:
+        # `w not in string.punctuation` is a SUBSTRING test on the string (misc.py:224): it also drops multi-character
+        # tokens such as "()" , "<=" or "./" that a tokenizer like nltk's can emit
+        if tok not in STOPWORDS and tok not in string.punctuation:
             kept.append(tok)
     return kept
 
@@ -135,7 +134,7 @@ def embed(word_dict, emb):
     with open(emb, "r") as f:
         for line in f:
             head, _, tail = line.rstrip("\n").partition(" ")
-            if head in word_dict and head not in rows:
+            if head in word_dict:                      # a word listed twice: the LAST row wins, as in the reference's loop (misc.py:312-318)
                 rows[head] = torch.from_numpy(np.array(tail.split(), dtype=np.float32))
     for word, entry in word_dict.items():
         entry["emb"] = rows.get(word)
@@ -353,6 +352,9 @@ def build_mask(region_str, size):
     positions; -corrupt_region, misc.py:388-402)."""
     mask = torch.zeros(size, 1)
     for piece in region_str.split(","):
-        lo, _, hi = piece.partition(":")
-        mask[int(lo):(int(hi) if hi else int(lo) + 1)] = 1
+        lo, sep, hi = piece.partition(":")
+        if sep:
+            mask[int(lo):int(hi)] = 1
+        else:
+            mask[int(lo)] = 1                          # a single position, negative ones included (misc.py:398-400)
     return mask

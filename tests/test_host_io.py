@@ -90,6 +90,18 @@ def test_file_logger_format(tmp_path, capsys):
 def test_build_mask():
     m = misc.build_mask("0:3,5", 8)
     assert m.view(-1).tolist() == [1, 1, 1, 0, 0, 1, 0, 0]
+    assert misc.build_mask("-1", 4).view(-1).tolist() == [0, 0, 0, 1]        # a single negative position (misc.py:398-400)
+
+
+def test_clean_desc_and_embed_follow_the_reference_filters(tmp_path, monkeypatch):
+    # the punctuation filter is a substring test on string.punctuation (misc.py:224): multi-character marks go too
+    monkeypatch.setattr(misc, "word_tokenize", lambda text: text.split())
+    assert misc.clean_desc("small () lizard <= of ./ warm :; regions ,-") == ["small", "lizard", "warm", "regions"]
+    monkeypatch.undo()
+    glove = tmp_path / "g.txt"
+    glove.write_text("duck 1 1\nlizard 0 1\nduck 2 3\n")                    # a repeated word: the last row wins (misc.py:312-318)
+    wd = misc.embed({"duck": {"id": 1}, "newt": {"id": 2}}, str(glove))
+    assert wd["duck"]["emb"].tolist() == [2.0, 3.0] and wd["newt"]["emb"] is None
 
 
 def test_hdf5_compound_roundtrip(tmp_path):
