@@ -32,11 +32,6 @@ namespace mmg {
 
 __device__ __forceinline__ uint32_t* mc_ctr(const Tape& tp, int kind, int tile, int ntile) { return tp.mcflags + ((size_t)kind * ntile + tile) * 64; }
 
-// 8 bytes with an agent-scope (sc1) load: coherent across the XCDs' L2s without an acquire fence (buffer_inv)
-__device__ __forceinline__ float2 ld_cc2(const float* p) {
-    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__builtin_bit_cast(float, (unsigned)u), __builtin_bit_cast(float, (unsigned)(u >> 32)));
-}
 // consumer side of a hand-off: lane 0 polls, everybody leaves through a barrier.  The payload is then read with ld_cc2.
 __device__ __forceinline__ void mc_wait(uint32_t* ctr, uint32_t target, uint32_t* sync_err) {
     if (threadIdx.x == 0) {

@@ -31,6 +31,14 @@ __device__ __forceinline__ void st_wt4(float* p, float4 v) {
     const f32x4 x = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
 }
+// agent-scope (sc1) loads of such a payload: coherent across the XCDs' L2s by themselves, so the consumer needs NO acquire fence
+// (an agent-scope acquire is a buffer_inv of the whole L2: everything the role reads afterwards comes from memory again)
+__device__ __forceinline__ float ld_cc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float2 ld_cc2(const float* p) {
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__builtin_bit_cast(float, (unsigned)u), __builtin_bit_cast(float, (unsigned)(u >> 32)));
+}
+__device__ __forceinline__ float4 ld_cc4(const float* p) { const float2 a = ld_cc2(p), b = ld_cc2(p + 2); return make_float4(a.x, a.y, b.x, b.y); }
 // values of lanes l, l + 2, l + 4, l + 6 (the results of four neighbouring 2-lane groups) as one float4 in lane l
 __device__ __forceinline__ float4 gather4_even(float v) {
     return make_float4(v, __shfl_down(v, 2), __shfl_down(v, 4), __shfl_down(v, 6));
@@ -521,7 +529,9 @@ __device__ __forceinline__ void pf_signal(uint32_t* ctr) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// consumer: returns false when the tile's conversation ended instead (done counter set); bounded spin -> error word
+// consumer: returns false when the tile's conversation ended instead (done counter set); bounded spin -> error word.
+// ACQ = false: the caller reads the payload with ld_cc* (agent-scope loads) and needs no acquire fence.
+template <bool ACQ = true>
 __device__ __forceinline__ bool pf_wait(uint32_t* ctr, uint32_t target, uint32_t* done, uint32_t* sync_err) {
     __shared__ int s_ok;
     if (threadIdx.x == 0) {
@@ -537,7 +547,7 @@ __device__ __forceinline__ bool pf_wait(uint32_t* ctr, uint32_t target, uint32_t
         s_ok = ok;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const bool r = s_ok != 0;
     __syncthreads();                                    // (s_ok may be rewritten by the next wait)
     return r;
@@ -1442,14 +1452,14 @@ __device__ __forceinline__ void sa_role(const Dims& dm, const Params& P, const T
         asm volatile("" : "+v"(tid));
         if (t >= 1) {
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 200);
-            if (!pf_wait(cG, (uint32_t)(nb * t), done, tp.sync)) return;
+            if (!pf_wait<false>(cG, (uint32_t)(nb * t), done, tp.sync)) return;
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201);
             {
                 const int W4 = W >> 2;
-                batched_for<NT, 2>(MMG_TM * W4, [&](int idx) { const int m = idx / W4, q = idx - m * W4; return reinterpret_cast<const float4*>(tp.w + (rowp + min(b0 + m, B - 1)) * W)[q]; },
+                batched_for<NT, 2>(MMG_TM * W4, [&](int idx) { const int m = idx / W4, q = idx - m * W4; return ld_cc4(tp.w + (rowp + min(b0 + m, B - 1)) * W + 4 * q); },
                                    [&](int idx, float4 v) { const int m = idx / W4, q = idx - m * W4; *reinterpret_cast<float4*>(s_w + m * ldW + 4 * q) = v; });
             }
-            if (tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
+            if (tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || ld_cc(&tp.mstate[min(b0 + tid, B - 1)]) != 0.f)) ? 1.f : 0.f;
             __syncthreads();
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 202);
             wfrag_mma<8>(fc, s_w, ldW, raw, ldA);                       // this role's 64 units of the sender hidden state (model.py:195-216)
@@ -1515,12 +1525,12 @@ __device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const T
         if (binary && train && hf == 0)
             uz = ar.u_z ? ar.u_z[(rowb + bq) * W + c0 + oc] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + dm.boff + bq) * W + c0 + oc), mb_counter, 0u);
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 210);
-        if (!pf_wait(cA, (uint32_t)(ns1 * (t + 1)), done, tp.sync)) return;
+        if (!pf_wait<false>(cA, (uint32_t)(ns1 * (t + 1)), done, tp.sync)) return;
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 211);
         float p8[8], acc = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) p8[u] = zp[(size_t)min(hf + 2 * u, ns1 - 1) * MMG_TM * W];
-        if (t >= 1 && tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || tp.mstate[min(b0 + tid, B - 1)] != 0.f)) ? 1.f : 0.f;
+        for (int u = 0; u < 8; ++u) p8[u] = ld_cc(zp + (size_t)min(hf + 2 * u, ns1 - 1) * MMG_TM * W);
+        if (t >= 1 && tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || ld_cc(&tp.mstate[min(b0 + tid, B - 1)]) != 0.f)) ? 1.f : 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += (hf + 2 * u < ns1) ? p8[u] : 0.f;
         acc = dpp_group_sum<2>(acc);
@@ -1672,14 +1682,14 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
         }
         // ===== the sender roles' message of this step: its GRU input-side product arrives as ns2 partials
         MMG_RSTAMP(b == 0 && t == 3, 250);
-        if (!pf_wait(cZ, (uint32_t)(ns2 * (t + 1)), nullptr, tp.sync)) return;
+        if (!pf_wait<false>(cZ, (uint32_t)(ns2 * (t + 1)), nullptr, tp.sync)) return;
         MMG_RSTAMP(b == 0 && t == 3, 251);
         {
             float p4[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p4[u] = tp.gip[((size_t)min(h3 + 2 * u, ns2 - 1) * B + b) * 3 * R + nr];
+            for (int u = 0; u < 8; ++u) p4[u] = ld_cc(&tp.gip[((size_t)min(h3 + 2 * u, ns2 - 1) * B + b) * 3 * R + nr]);
             float zz = 0.f, pp = 0.5f;
-            if (binary && tid < W) { zz = tp.z[row * W + tid]; pp = tp.pz[row * W + tid]; }
+            if (binary && tid < W) { zz = ld_cc(&tp.z[row * W + tid]); pp = ld_cc(&tp.pz[row * W + tid]); }
             float gp = 0.f;
 #pragma unroll
             for (int u = 0; u < 8; ++u) gp += (h3 + 2 * u < ns2) ? p4[u] : 0.f;
@@ -1889,10 +1899,13 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
     }
 }
 
-template <int NT>
+// SAMPLE_ROLES: the launch of per-sample receiver roles (ar.rsample != 0) and the variant with one 16-sample receiver role per
+// tile are two kernels -- the tile role needs every one of its 256 registers (and spills a few), the per-sample roles do not,
+// and a workgroup should not carry the code of roles its launch never runs (62 k lines of ISA for the union)
+template <int NT, bool SAMPLE_ROLES>
 __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles, int xcd_map) {
     int blk = blockIdx.x;
-    if (ar.rsample) {                                   // one receiver role per sample, then the sender roles of the tiles
+    if (SAMPLE_ROLES) {                                 // one receiver role per sample, then the sender roles of the tiles
         // this launch covers the samples [b_begin, b_begin + b_count) = the tiles ctile0 .. ctile0 + ctiles - 1
         const int cb = ar.b_count, ctile0 = ar.b_begin / MMG_TM, ctiles = (cb + MMG_TM - 1) / MMG_TM;
         const int nrole = cb + ctiles * (ar.ns1 + ar.ns2);
@@ -1935,6 +1948,25 @@ __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp,
     const int q = r - tiles * ar.ns2;
     s1_role<NT>(dm, P, tp, ar, q / ar.ns1, q % ar.ns1);
 }
+
+#ifdef MMG_ROLE_DIAG
+// diagnosis only (scripts/isa_stats.py -D MMG_ROLE_DIAG --kernel k_diag): every role of k_conv_persist as a kernel of its own,
+// so that register counts / spills can be attributed to a role
+template <int NT> __global__ __launch_bounds__(NT) void k_diag_sa(Dims dm, Params P, Tape tp, ConvArgs ar) { sa_role<NT>(dm, P, tp, ar, blockIdx.x, 0); }
+template <int NT> __global__ __launch_bounds__(NT) void k_diag_sb(Dims dm, Params P, Tape tp, ConvArgs ar) { sb_role<NT>(dm, P, tp, ar, blockIdx.x, 0); }
+template <int NT> __global__ __launch_bounds__(NT) void k_diag_s1(Dims dm, Params P, Tape tp, ConvArgs ar) { s1_role<NT>(dm, P, tp, ar, blockIdx.x, 0); }
+template <int NT> __global__ __launch_bounds__(NT) void k_diag_s2(Dims dm, Params P, Tape tp, ConvArgs ar) { s2_role<NT>(dm, P, tp, ar, blockIdx.x, 0); }
+template <int NT> __global__ __launch_bounds__(NT) void k_diag_rs256(Dims dm, Params P, Tape tp, ConvArgs ar) { rs_role<NT, 64, 100, 30, 256>(dm, P, tp, ar, blockIdx.x); }
+template <int NT> __global__ __launch_bounds__(NT) void k_diag_rs0(Dims dm, Params P, Tape tp, ConvArgs ar) { rs_role<NT, 64, 100, 30, 0>(dm, P, tp, ar, blockIdx.x); }
+template <int NT> __global__ __launch_bounds__(NT) void k_diag_body(Dims dm, Params P, Tape tp, ConvArgs ar) { conv_tile_body<NT, true>(dm, P, tp, ar, blockIdx.x); }
+template __global__ void k_diag_sa<512>(Dims, Params, Tape, ConvArgs);
+template __global__ void k_diag_sb<512>(Dims, Params, Tape, ConvArgs);
+template __global__ void k_diag_s1<512>(Dims, Params, Tape, ConvArgs);
+template __global__ void k_diag_s2<512>(Dims, Params, Tape, ConvArgs);
+template __global__ void k_diag_rs256<512>(Dims, Params, Tape, ConvArgs);
+template __global__ void k_diag_rs0<512>(Dims, Params, Tape, ConvArgs);
+template __global__ void k_diag_body<512>(Dims, Params, Tape, ConvArgs);
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Per-step sender launches (large sender MLP, few samples: BASELINE config 4).  One workgroup per 16x16 output tile,

@@ -417,9 +417,11 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
             const int a = tile_lds(d, 512 / 64, false).total * 4, b = srole_lds(d, 512 / 64).total * 4;
             h->persist_smem = a > b ? a : b;
             if (h->persist_smem > 160 * 1024) h->tile_persist = false;
-            else if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_persist<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->persist_smem);
+            else if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_persist<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->persist_smem);
+            if (h->tile_persist && e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_persist<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->persist_smem);
             if (h->tile_persist && e == hipSuccess) {
-                h->resident_budget = budget_of((const void*)k_conv_persist<512>, 512, h->persist_smem);
+                h->resident_budget = rs_capable ? budget_of((const void*)k_conv_persist<512, true>, 512, h->persist_smem)
+                                               : budget_of((const void*)k_conv_persist<512, false>, 512, h->persist_smem);
                 // tile roles: every tile's roles in one launch; per-sample receiver roles: at least ONE whole tile per launch
                 const bool fits = rs_capable ? (MMG_TM + d.H / 64 + d.W / 16 <= h->resident_budget || MMG_TM + h->persist_ns1 + h->persist_ns2 <= h->resident_budget)
                                              : tiles * (1 + h->persist_ns1 + h->persist_ns2) <= h->resident_budget;
@@ -623,7 +625,7 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
                 ar.b_count = (d.B - ar.b_begin < ct * MMG_TM) ? d.B - ar.b_begin : ct * MMG_TM;
                 if (ar.b_count <= 0) break;
                 const int ctiles = (ar.b_count + MMG_TM - 1) / MMG_TM;
-                hipLaunchKernelGGL(k_conv_persist<512>, dim3(ar.b_count + ctiles * (ar.ns1 + ar.ns2) + bt), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
+                hipLaunchKernelGGL((k_conv_persist<512, true>), dim3(ar.b_count + ctiles * (ar.ns1 + ar.ns2) + bt), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
             }
             h->basehx_ready = want_base;
             return launch_check("k_conv_persist");
@@ -635,7 +637,7 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
             //  ONE L2 for their weight and payload reads, and a load that follows a write-through store in the same L2 took 5-8 us
             //  instead of 2.3; off unless MMG_XCD_MAP=1)
             const int xcd_map = (tiles <= 8 && roles <= 30 && h->sw_xcd_map) ? 1 : 0;
-            hipLaunchKernelGGL(k_conv_persist<512>, dim3(xcd_map ? 8 * roles : tiles * roles), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, xcd_map);
+            hipLaunchKernelGGL((k_conv_persist<512, false>), dim3(xcd_map ? 8 * roles : tiles * roles), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, xcd_map);
             return launch_check("k_conv_persist");
         }
     }
