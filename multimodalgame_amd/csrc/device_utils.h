@@ -330,7 +330,9 @@ __device__ __forceinline__ void role_signal_wt(uint32_t* sync, int dep) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + MMG_SYNC_ARR(dep), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int SLEEP = 1>
+// ACQ = false: the caller reads what the producers wrote with agent-scope loads (__hip_atomic_load, relaxed) -- coherent by
+// themselves -- and skips the acquire fence (a buffer_inv of the L2: measured at config 4, 40 us per conversation of 7 steps).
+template <int SLEEP = 1, bool ACQ = true>
 __device__ __forceinline__ void role_wait(uint32_t* sync, int dep, uint32_t producers, uint32_t consumers) {
     if (threadIdx.x == 0) {
         int spins = 0;
@@ -345,7 +347,7 @@ __device__ __forceinline__ void role_wait(uint32_t* sync, int dep, uint32_t prod
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale cache lines before reading what the producers wrote
+    if (ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale cache lines before reading what the producers wrote
 }
 
 // one 16x16x4 fp32 MFMA step:  D += A(16x4) * B(4x16);  lane l holds A[l&15][l>>4], B[l>>4][l&15],

@@ -191,19 +191,23 @@ __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* 
 // coef_load() (call first) fetches this thread's share, coef_compute() turns it into cw / ce / cb in LDS.
 struct CoefRegs { double s5[5]; double nsum; };
 
+// CC: the statistics were written by other workgroups of THIS launch (write-through stores): agent-scope loads, so that the
+// caller's role_wait needs no acquire fence (= no L2 invalidate on the recurrence's critical path)
+template <bool CC = false>
 __device__ __forceinline__ CoefRegs coef_load(const Dims& dm, const double* __restrict__ st) {
     // thread i < 4T handles (k = i / T, t = i % T); k == 3 are the baseline coefficients (sender-stream counts)
+    auto ld = [](const double* p) { return CC ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
     CoefRegs c;
     const int T = dm.T;
     const int i = min((int)threadIdx.x, 4 * T - 1);
     const int k = i / T, t = i - k * T;
     const int ks = (k < 3) ? k : 2;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) c.s5[j] = st[stat_stream(T, ks, t, j)];
+    for (int j = 0; j < 5; ++j) c.s5[j] = ld(&st[stat_stream(T, ks, t, j)]);
     double nsum = 0;
 #pragma unroll
     for (int tt = 0; tt < 16; ++tt) {
-        const double v = st[stat_stream(T, ks, min(tt, T - 1), 0)];
+        const double v = ld(&st[stat_stream(T, ks, min(tt, T - 1), 0)]);
         nsum += (tt < T) ? v : 0.0;
     }
     c.nsum = nsum;
@@ -444,7 +448,10 @@ __device__ __forceinline__ void build_row_map(const Dims& dm, const Tape& tp) {
 // k_dC: grid = D.  dC[d,r] = sum_b dy[b,d] * w_y2[r] * 1[A*[b,r] + Cd[d,r] > 0]   (-> y1.weight[:,R:], y1.bias)
 //                  Py2[d,r] = sum_b dy[b,d] * relu(A*[b,r] + Cd[d,r])              (-> y2.weight)
 // ---------------------------------------------------------------------------------------------
+// CC: dy / A* were written by other workgroups of this launch (write-through stores): read them with agent-scope loads
+template <bool CC = false>
 __device__ __forceinline__ void dC_class(const Dims& dm, const Params& P, const Tape& tp, int d, float* s_c, float* s_p) {
+    auto ld = [](const float* p) { return CC ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
     const int tid = threadIdx.x, R = dm.R, B = dm.B, D = dm.D;
     const int cols = R < 64 ? R : 64;                 // up to 64 columns per pass, >= 4 sample groups
     const int groups = MMG_BLOCK / cols;
@@ -461,8 +468,8 @@ __device__ __forceinline__ void dC_class(const Dims& dm, const Params& P, const 
                 for (int u = 0; u < 16; ++u) {
                     const int bb = b + u * groups;
                     const bool ok = bb < B;
-                    yv[u] = ok ? tp.dy[(size_t)bb * D + d] : 0.f;
-                    pv[u] = ok ? tp.Astar[(size_t)bb * R + r] + cv : 0.f;
+                    yv[u] = ok ? ld(&tp.dy[(size_t)bb * D + d]) : 0.f;
+                    pv[u] = ok ? ld(&tp.Astar[(size_t)bb * R + r]) + cv : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 16; u += 2) {

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     if (MERGE_DC && (int)blockIdx.x >= n_stats + dm.B) {
         float* s_c = t_a; float* s_p = t_a + 256;
         if ((int)blockIdx.x == n_stats + dm.B && threadIdx.x < 64) build_row_map(dm, tp);   // while waiting: rows k_wgrad will reduce over
-        role_wait<8>(tp.sync, 1, (uint32_t)dm.B, (uint32_t)dm.D);
-        dC_class(dm, P, tp, (int)blockIdx.x - n_stats - dm.B, s_c, s_p);
+        role_wait<8, false>(tp.sync, 1, (uint32_t)dm.B, (uint32_t)dm.D);
+        dC_class<true>(dm, P, tp, (int)blockIdx.x - n_stats - dm.B, s_c, s_p);
         return;
     }
     const int b = blockIdx.x - n_stats, tid = threadIdx.x, lane = tid & 63;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     // ---- prologue: issue EVERY independent global load before the first dependent use (one memory round trip for the
     // weight fragments, overlapping the tstar -> tape-preload chain), then stage the tape into LDS.
     CoefRegs creg;
-    if (!MERGED) creg = coef_load(dm, tp.stats);        // statistics first: they gate the first arithmetic of the kernel
+    if (!MERGED) creg = coef_load<false>(dm, tp.stats);        // statistics first: they gate the first arithmetic of the kernel
     const int tstar = tp.tstar[b];
     const int tgt = (int)target[b];
     const float L = tp.logs[b];
@@ -314,9 +314,10 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     }
     MMG_BSTAMP(11);
     if (MERGED) {                                       // the statistics roles of this launch publish stats, bs, br
-        role_wait(tp.sync, 0, (uint32_t)n_stats, (uint32_t)B);
-        creg = coef_load(dm, tp.stats);
-        rbs_ = tp.bs[so]; rbr_ = tp.br[so];
+        role_wait<1, false>(tp.sync, 0, (uint32_t)n_stats, (uint32_t)B);
+        creg = coef_load<true>(dm, tp.stats);
+        rbs_ = __hip_atomic_load(&tp.bs[so], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rbr_ = __hip_atomic_load(&tp.br[so], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         coef_compute(dm, creg, lc);
     }
     MMG_BSTAMP(2);
