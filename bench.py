@@ -40,6 +40,7 @@ WORKLOADS = {
                    "RMSprop; one bench step = one training minibatch"),
     "c3": (dict(C2, fixed_exchange=True), 64, "configs[2]: Fixed-exchange 30-class, global batch 512 = 64 per GPU on 8 GPUs, max_exchange 10"),
     "c4": (dict(C2, w_dim=256, h_dim=1024), 64, "configs[3]: Adaptive 30-class, batch 64, rec_w_dim 256 / img_h_dim 1024 (sample-tile MFMA kernels, co-resident receiver / sender roles in one launch)"),
+    "c4r256": (dict(C2, w_dim=256, h_dim=1024, rec_hidden=256), 64, "configs[3] with rec_hidden 256 (SURVEY.md 8d C4: 'use 64 and additionally report R = 256')"),
     "c5": (dict(C2, use_binary=False, fixed_exchange=True, n_classes=1000), 256,
            "configs[4]: 1000 classes, continuous messages, global batch 2048 = 256 per GPU on 8 GPUs (256 samples per GPU: one workgroup per sample; the sample-tile MFMA kernels take over from 1024 samples per GPU, --scaling strong at N=1)"),
 }
@@ -119,7 +120,7 @@ def traffic_lookup(workload, kernel, strong, profiles_dir=None):
     import glob
     import re
     pdir = profiles_dir or os.path.join(REPO, "profiles")
-    num = {"c2": "2", "c3": "3", "c4": "4", "c5": "5"}[workload]
+    num = {"c2": "2", "c3": "3", "c4": "4", "c5": "5"}.get(workload, workload)
     pat = re.compile(r"^r(\d+)_%sconfig%s_pmc_hbm_traffic\.json$" % ("strong_" if strong else "", num))
     files = sorted((int(pat.match(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(pdir, "r*_pmc_hbm_traffic.json"))
                    if pat.match(os.path.basename(f)))

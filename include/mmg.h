@@ -123,8 +123,10 @@ void    mmg_destroy(mmg_handle* h);
  *   out of every loss, so training results are identical); per-(step, sample) arrays -- messages,
  *   baseline scores and hiddens, gradient tapes -- are then defined on the LIVE rows only
  *   (t <= the sample's own last step); the others keep whatever an earlier call left there.
- *   ==2: as 0, and in Fixed mode the class logits "y" are kept for the output step (T-1) only -- the losses read nothing
- *   else of them (model.py:885-904, 1264-1275); this is what mmg_train_step runs.
+ *   ==2: as 0, and only what the training step itself reads is guaranteed to be stored: in Fixed mode the class logits "y"
+ *   are kept for the output step (T-1) only -- the losses read nothing else of them (model.py:885-904, 1264-1275) -- and in
+ *   continuous mode (only the receiver is trained, model.py:1313) the sender-side and message arrays (a, c, zr, dbar, g, w)
+ *   may be left unwritten.  This is what mmg_train_step runs.
  * Results land in the workspace arrays listed by mmg_tape_table(). */
 int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
                          const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed,

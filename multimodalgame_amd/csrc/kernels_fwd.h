@@ -209,6 +209,7 @@ struct ConvArgs {
     int persist, ns1, ns2;     // kernels_tile.h, k_conv_persist: sender roles per sample tile (0: not persistent)
     int nhelp, per;            // kernels_tile.h, k_conv_split: class helpers per sample tile, classes per slice
     int y_last_only;           // Fixed-mode training step (mmg_train_step): tape.y keeps the output step's logits only
+    int lean;                  // training-minimal call in continuous mode: tape arrays the receiver-only backward never reads are not stored
 };
 
 struct ConvSmem {

@@ -90,6 +90,10 @@ __global__ __launch_bounds__(512, 2) void k_conversation_mc(Dims dm, Params P, T
     const int B = dm.B, T = dm.T, D = dm.D;
     const int b_raw = tile * TM + member;
     const bool have = b_raw < B;                        // a real sample (otherwise: class-slice owner only)
+    // ar.lean (fused training step, continuous messages): only the receiver is trained and through the NLL alone, so the
+    // backward pass reads z, h, the GRU gates and the output step -- the sender's hidden layer, the code inputs, dbar, g and
+    // the receiver's message are not stored (1.9 KB of 3.4 KB per sample-step)
+    const bool have_full = have && !ar.lean;
     const int b = have ? b_raw : B - 1;
     const bool binary = dm.use_binary != 0, train = ar.train != 0;
     const bool inject = ar.u_s != nullptr;
@@ -222,8 +226,8 @@ __global__ __launch_bounds__(512, 2) void k_conversation_mc(Dims dm, Params P, T
             float hw = hw0;
             if (t > 0) hw = bc + dpp_group_sum<2>(dot4<J1>(wc, s_c + h1 * 4, 8));
             const float av = ftanh(hx + hw);
-            if (h1 == 0) { s_a[n1] = av; if (have) tp.a[row * H + n1] = av; }
-            if (tid < W && have) {
+            if (h1 == 0) { s_a[n1] = av; if (have_full) tp.a[row * H + n1] = av; }
+            if (tid < W && have_full) {
                 const float cv = s_c[tid];
                 tp.zr[row * W + tid] = cv;
                 tp.c[row * W + tid] = (t == 0) ? sig_cb : cv;
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_mc(Dims dm, Params P, T
                 acc = fmaf(s_in[k * MMG_MC_LDP + v], sc, acc);
             }
             const float dv = acc * __builtin_amdgcn_rcpf(S);
-            if (tid < V) { s_dbar[tid] = dv; if (have) tp.dbar[row * V + tid] = dv; }
+            if (tid < V) { s_dbar[tid] = dv; if (have_full) tp.dbar[row * V + tid] = dv; }
         }
         __syncthreads();
         // ===== (8) h_w = tanh(w_h h + b_h + w_d dbar)
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_mc(Dims dm, Params P, T
             if (kp4 == 0) {
                 const float gv = ftanh(gpre_h + acc);
                 s_g[n4] = gv;
-                if (have) tp.g[row * R + n4] = gv;
+                if (have_full) tp.g[row * R + n4] = gv;
             }
         }
         __syncthreads();
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_mc(Dims dm, Params P, T
                     if (have) tp.pw[row * W + nb] = pp;
                 }
                 s_c[nb] = wv; s_lpw[nb] = pp;
-                if (have) tp.w[row * W + nb] = wv;
+                if (have_full) tp.w[row * W + nb] = wv;
             }
         }
         __syncthreads();

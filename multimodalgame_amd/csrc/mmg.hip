@@ -678,8 +678,9 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     ar.x = d_x; ar.target = d_target; ar.desc = d_desc; ar.u_z = d_u_z; ar.u_s = d_u_s; ar.u_w = d_u_w; ar.seed = seed;
     // run_all_steps == 2: training-minimal (as 0; the class logits y[t] of the steps before the output step are not kept)
     const int y_last_only = (run_all_steps == 2 && d.fixed) ? 1 : 0;
+    const int lean = (run_all_steps == 2 && !d.use_binary) ? 1 : 0;
     if (run_all_steps == 2) run_all_steps = 0;
-    ar.y_last_only = y_last_only;
+    ar.y_last_only = y_last_only; ar.lean = lean;
     ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
     bool base_ready = false;
     h->basehx_ready = false;

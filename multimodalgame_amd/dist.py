@@ -40,7 +40,7 @@ class DataParallel(object):
 
     def train_step(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0):
         e = self.engine
-        e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=False)
+        e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=False, minimal=True)
         e.loss_stats()
         if self.world > 1:
             self._all_reduce(e.stats)

@@ -97,12 +97,14 @@ class Engine(object):
         return {a: {k: v.detach().cpu().clone() for k, v in d.items()} for a, d in self.params.items()}
 
     # ------------------------------------------------------------------ phases
-    def forward(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0, train=True, run_all=False):
+    def forward(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0, train=True, run_all=False, minimal=False):
+        """run_all: every sample runs all T steps (what exchange() returns).  minimal (training only): store just what the
+        backward pass reads (include/mmg.h: run_all_steps == 2) -- what the fused mmg_train_step does."""
         f32 = torch.float32
         _lib.check(self.lib.mmg_exchange_forward(
             self.handle, self._ptr(x, f32), self._ptr(target, torch.int64), self._ptr(desc, f32),
             self._ptr(u_z, f32), self._ptr(u_s, f32), self._ptr(u_w, f32), C.c_uint64(seed),
-            int(bool(train)), int(bool(run_all)), self._stream()))
+            int(bool(train)), 1 if run_all else (2 if minimal and train else 0), self._stream()))
 
     def loss_stats(self):
         _lib.check(self.lib.mmg_loss_stats(self.handle, self._stream()))

@@ -70,7 +70,7 @@ class ShardEngine(object):
         self.flat_grads = torch.zeros(sum(dict(models[a].named_parameters())[k].numel() for a, k in self.order))
         self.optimizers = cpu_ref.build_optimizers(models, flags)
 
-    def forward(self, x, target, desc, u_z, u_s, u_w, seed=0, train=True, run_all=False):
+    def forward(self, x, target, desc, u_z, u_s, u_w, seed=0, train=True, run_all=False, minimal=False):
         fl, m = self.fl, self.models
         tape = cpu_ref.UniformTape(u_z, u_s, u_w)
         for a in ("sender", "receiver"):

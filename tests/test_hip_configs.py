@@ -59,6 +59,12 @@ def test_config4_shape_vs_oracle(switch, monkeypatch):
     _compare_cached(_meta(C4, 30, 64, 2), skip=("y2.bias",), label="config4" + ("-" + switch if switch else ""), key="c4")
 
 
+def test_config4_with_rec_hidden_256_vs_oracle():
+    """'rec_w_dim 256 / img_h_dim 1024 ... use R = 64 and additionally report R = 256'.  R = 256 is beyond the
+    sample-tile kernels (R <= 128): the generic per-sample kernels run it; same gate against the oracle."""
+    _compare(_meta(dict(C4, rec_hidden=256, batch_size=16), 30, 16, 2), skip=("y2.bias",), label="config4-R256")
+
+
 def test_config4_shape_consecutive_role_launches():
     """Config 4's agents at 88 samples: 6 tiles (the last one ragged) do not fit one launch of co-resident roles (240
     workgroups), so the conversation runs as two launches over sample ranges (48 + 40 samples)."""
