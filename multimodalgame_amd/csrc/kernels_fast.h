@@ -464,8 +464,6 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     __shared__ __attribute__((aligned(16))) float s_c[W];
     __shared__ __attribute__((aligned(16))) float s_z[W];
     __shared__ __attribute__((aligned(16))) float s_h[R];
-    __shared__ __attribute__((aligned(16))) float s_gi[3 * R];
-    __shared__ __attribute__((aligned(16))) float s_gh[3 * R];
     __shared__ __attribute__((aligned(16))) float s_A[R];
     __shared__ __attribute__((aligned(16))) float s_y[32];
     __shared__ __attribute__((aligned(16))) float s_yout[32];
@@ -525,14 +523,15 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     }
     const float bb = P.p[S_BIN_B][nb];
     const float bw = P.p[R_W_B][nb];
-    // (3) GRU: row n3 = tid/2 (< 3R), half h3
-    const int n3 = tid >> 1, h3 = tid & 1;
-    const bool gru_lane = n3 < 3 * R;
+    // (3) GRU: unit j3 = tid / 8 owns eight lanes: slot q3 = 2 * gate + half (gates r, u, n; slots 6, 7 idle), so that the three
+    // gate pre-activations of a unit meet inside one DPP row and the state update needs no LDS round trip
+    static_assert(NT == 8 * R, "eight lanes per GRU unit");
+    const int j3 = tid >> 3, q3 = tid & 7, h3 = q3 & 1;
     constexpr int J3I = W / 8, J3H = R / 8;
     float wih[4 * J3I], whh[4 * J3H];
     float bih = 0.f, bhh = 0.f;
     {
-        const int nr = gru_lane ? n3 : 0;
+        const int nr = min(q3 >> 1, 2) * R + j3;
 #pragma unroll
         for (int j = 0; j < J3I; ++j) {
             const float4 v = *reinterpret_cast<const float4*>(P.p[R_WIH] + (size_t)nr * W + (h3 + 2 * j) * 4);
@@ -635,12 +634,36 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             }
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 1);                       // B2
-        // ===== (3) GRU gate pre-activations
+        // ===== (3 + 4) GRU gate pre-activations and state update in ONE phase: the r / u sums travel to the unit's n lane by DPP
+        // row shifts (slots 0, 2 -> slot 4), which then forms the new state
         {
             const float giv = bih + dpp_group_sum<2>(dot4<J3I>(wih, s_z + h3 * 4, 8));
-            if (gru_lane && h3 == 0) { s_gi[n3] = giv; s_gh[n3] = ghv; }
+            const float xs = giv + ghv;
+            const float xr = dpp_f<0x114>(xs);                             // row_shr:4  (slot 4 <- slot 0)
+            const float xu = dpp_f<0x112>(xs);                             // row_shr:2  (slot 4 <- slot 2)
+            if (q3 == 4) {
+                const float rr = fsigmoid(xr);
+                const float uu = fsigmoid(xu);
+                const float ghn = ghv;
+                const float nn = ftanh(giv + rr * ghn);
+                const float hv = nn + uu * (s_h[j3] - nn);
+                float* gr = tp.gru + row * 4 * R;
+                gr[j3] = rr; gr[R + j3] = uu; gr[2 * R + j3] = nn; gr[3 * R + j3] = ghn;
+                tp.h[((size_t)(t + 1) * B + b) * R + j3] = hv;
+                s_h[j3] = hv;
+            }
         }
-        if (binary && wave == 6) {                                         // waves 6, 7 hold no GRU rows: sender log-lik terms
+        MMG_STAMP(8 + 10 * t + 2);
+        __syncthreads(); MMG_STAMP(8 + 10 * t + 3);                       // B4
+        // ===== (5) heads on h
+        float gpre_h;
+        {
+            const float accA = dpp_group_sum<L4>(dot4<J4>(wy1, s_h + kp4 * 4, 4 * L4));
+            const float accH = dpp_group_sum<L4>(dot4<J4>(wh, s_h + kp4 * 4, 4 * L4));
+            if (kp4 == 0) s_A[n4] = accA;
+            gpre_h = accH + bh;
+        }
+        if (binary && wave == 6) {                                         // sender log-lik terms (z, p of phase 2), off the recurrence's path
             float lpv = 0.f, nev = 0.f;
             if (lane < W) {
                 const float p = s_lp[lane], zz = s_z[lane];
@@ -650,28 +673,6 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             }
             lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
             if (lane == 0) { tp.lp_z[row] = lpv; tp.ne_z[row] = nev; }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 2);                       // B3
-        // ===== (4) GRU state update
-        if (tid < R) {
-            const float rr = fsigmoid(s_gi[tid] + s_gh[tid]);
-            const float uu = fsigmoid(s_gi[R + tid] + s_gh[R + tid]);
-            const float ghn = s_gh[2 * R + tid];
-            const float nn = ftanh(s_gi[2 * R + tid] + rr * ghn);
-            const float hv = nn + uu * (s_h[tid] - nn);
-            float* gr = tp.gru + row * 4 * R;
-            gr[tid] = rr; gr[R + tid] = uu; gr[2 * R + tid] = nn; gr[3 * R + tid] = ghn;
-            tp.h[((size_t)(t + 1) * B + b) * R + tid] = hv;
-            s_h[tid] = hv;
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 3);                       // B4
-        // ===== (5) heads on h
-        float gpre_h;
-        {
-            const float accA = dpp_group_sum<L4>(dot4<J4>(wy1, s_h + kp4 * 4, 4 * L4));
-            const float accH = dpp_group_sum<L4>(dot4<J4>(wh, s_h + kp4 * 4, 4 * L4));
-            if (kp4 == 0) s_A[n4] = accA;
-            gpre_h = accH + bh;
         }
         if (wave == 7) {                                                   // stop head on an otherwise lightly loaded wave
             const float sv = dpp_wave_sum(ws * s_h[lane]);
