@@ -67,10 +67,15 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
                 const int ts = tp.tstar[b];
                 const float L = tp.logs[b];
                 const bool sen_side = (kind == 2) || (kind == 4);
+                // the array is chosen FIRST (wave-uniform pointer selects), then ONE load each: a ternary over loads is a chain
+                // of branches, and every join drains vmcnt -- three or four dependent memory round trips instead of one
+                const float* lp_ptr = (kind == 0) ? tp.lp_s : (kind == 1) ? tp.lp_w : tp.lp_z;
+                const float* ne_ptr = (kind == 0) ? tp.ne_s : (kind == 1) ? tp.ne_w : tp.ne_z;
+                const float lp_raw = lp_ptr[row], ne_raw = ne_ptr[row];
                 const float beta_all = from_parts ? combine_score(sen_side ? tp.bs_part : tp.br_part, row, npb, sen_side ? b2s : b2r)
-                                                  : (sen_side ? tp.bs[row] : tp.br[row]);
-                const float lp_all = (kind == 0) ? tp.lp_s[row] : (kind == 1) ? tp.lp_w[row] : (kind == 2) ? tp.lp_z[row] : 0.f;
-                const float ne_all = (kind == 0) ? tp.ne_s[row] : (kind == 1) ? tp.ne_w[row] : (kind == 2) ? tp.ne_z[row] : 0.f;
+                                                  : (sen_side ? tp.bs : tp.br)[row];
+                const float lp_all = (kind < 3) ? lp_raw : 0.f;
+                const float ne_all = (kind < 3) ? ne_raw : 0.f;
                 const bool act = (kind == 1) ? (t < ts) : (t <= ts);
                 if (from_parts && kind >= 3 && t <= ts) {
                     put_f(kind == 3 ? &tp.br[row] : &tp.bs[row], beta_all);

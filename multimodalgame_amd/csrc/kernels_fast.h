@@ -470,7 +470,11 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     __shared__ __attribute__((aligned(16))) float s_dbar[V];
     __shared__ __attribute__((aligned(16))) float s_g[R];
     __shared__ float s_pi[8][32];
-    __shared__ float s_lp[W], s_lpw[W];
+    // bits and probabilities of every step: their log-likelihood / neg-entropy sums (model.py:908-922) are formed for ALL steps in
+    // one pass after the conversation -- inside the step loop they were 0.2 us per step on one straggling wave
+    constexpr int TMAXL = 16;
+    static_assert(W == 32 && TMAXL * W == 512, "one (step, bit) per thread in the log-likelihood pass");
+    __shared__ float s_pzT[TMAXL * W], s_zT[TMAXL * W], s_pwT[TMAXL * W], s_wT[TMAXL * W], s_psT[TMAXL], s_sbT[TMAXL];
     __shared__ float s_misc[8];
     constexpr int TMAX = 16;
     __shared__ float s_uz[TMAX * W], s_uw[TMAX * W], s_us[TMAX];
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     if (tid == 0) { s_misc[0] = 1.f; s_misc[1] = -1.f; s_misc[2] = 1.f; tp.mask[b] = 1; }
     __syncthreads();
 
-    float stop_p = 0.5f, stop_bit = 0.f;
+    int t_done = T, w_done = T;                         // steps executed / steps whose receiver message was formed
     MMG_STAMP(2);
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)t * B + b;
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
                     zz = train ? ((s_uz[t * W + nb] < pp) ? 1.f : 0.f) : rintf(pp);
                     tp.pz[row * W + nb] = pp;
                 }
-                s_z[nb] = zz; s_lp[nb] = pp;
+                s_z[nb] = zz; s_zT[t * W + nb] = zz; s_pzT[t * W + nb] = pp;
                 tp.z[row * W + nb] = zz;
             }
         }
@@ -663,17 +667,6 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             if (kp4 == 0) s_A[n4] = accA;
             gpre_h = accH + bh;
         }
-        if (binary && wave == 6) {                                         // sender log-lik terms (z, p of phase 2), off the recurrence's path
-            float lpv = 0.f, nev = 0.f;
-            if (lane < W) {
-                const float p = s_lp[lane], zz = s_z[lane];
-                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                lpv = zz * l1 + (1.f - zz) * l0;
-                nev = p * l1 + (1.f - p) * l0;
-            }
-            lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
-            if (lane == 0) { tp.lp_z[row] = lpv; tp.ne_z[row] = nev; }
-        }
         if (wave == 7) {                                                   // stop head on an otherwise lightly loaded wave
             const float sv = dpp_wave_sum(ws * s_h[lane]);
             if (lane == 0) {
@@ -688,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
                 }
                 s_misc[3] = sbit;                                          // (the barrier is waiting for this wave)
                 tp.s[row] = sbit; tp.ps[row] = p;
-                stop_p = p; stop_bit = sbit;                               // log terms: after B9, off the critical path
+                s_psT[t] = p; s_sbT[t] = sbit;                             // (log terms: after the conversation)
             }
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 4);                       // B5
@@ -717,14 +710,7 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
             if (take_out) s_misc[1] = (float)t;
             s_misc[0] = m_next;
         }
-        if (!ar.run_all && !dm.fixed && train && m_next == 0.f) {
-            if (wave == 7 && lane == 0) {
-                const float l1 = flog(stop_p + MMG_EPS), l0 = flog(1.f - stop_p + MMG_EPS);
-                tp.lp_s[row] = stop_bit * l1 + (1.f - stop_bit) * l0;
-                tp.ne_s[row] = stop_p * l1 + (1.f - stop_p) * l0;
-            }
-            ++t; __syncthreads(); break;
-        }
+        if (!ar.run_all && !dm.fixed && train && m_next == 0.f) { t_done = t + 1; w_done = t; __syncthreads(); break; }
         // ===== (7) softmax (per wave, lanes < 32) -> wave-private LDS -> description mixture (2 lanes per column)
         {
             const float yv = (lane < 32) ? s_y[lane] : -3.0e38f;
@@ -782,30 +768,40 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
                     wv = train ? ((s_uw[t * W + nb] < pp) ? 1.f : 0.f) : rintf(pp);
                     tp.pw[row * W + nb] = pp;
                 }
-                s_c[nb] = wv; s_lpw[nb] = pp;
+                s_c[nb] = wv; s_wT[t * W + nb] = wv; s_pwT[t * W + nb] = pp;
                 tp.w[row * W + nb] = wv;
             }
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 8);                       // B9
-        if (wave == 7 && lane == 0) {
-            const float l1 = flog(stop_p + MMG_EPS), l0 = flog(1.f - stop_p + MMG_EPS);
-            tp.lp_s[row] = stop_bit * l1 + (1.f - stop_bit) * l0;
-            tp.ne_s[row] = stop_p * l1 + (1.f - stop_p) * l0;
-        }
-        if (binary && wave == 7) {                                         // overlaps with phase (1) of the next step
-            float lpv = 0.f, nev = 0.f;
-            if (lane < W) {
-                const float p = s_lpw[lane], wv = s_c[lane];
-                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                lpv = wv * l1 + (1.f - wv) * l0;
-                nev = p * l1 + (1.f - p) * l0;
-            }
-            lpv = dpp_wave_sum(lpv); nev = dpp_wave_sum(nev);
-            if (lane == 0) { tp.lp_w[row] = lpv; tp.ne_w[row] = nev; }
-        }
     }
     __syncthreads();
     MMG_STAMP(3);
+    // ------------------------------------------------------------ log-likelihood / neg-entropy sums of all steps (model.py:908-922)
+    {
+        const int tt = tid >> 5, j = tid & 31;                              // one (step, bit) per thread
+        if (binary) {
+            float lz = 0.f, nz = 0.f, lw = 0.f, nw = 0.f;
+            if (tt < t_done) {
+                const float p = s_pzT[tid], q = s_zT[tid];
+                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                lz = q * l1 + (1.f - q) * l0; nz = p * l1 + (1.f - p) * l0;
+            }
+            if (tt < w_done) {
+                const float p = s_pwT[tid], q = s_wT[tid];
+                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                lw = q * l1 + (1.f - q) * l0; nw = p * l1 + (1.f - p) * l0;
+            }
+            lz = group_sum(lz, 32); nz = group_sum(nz, 32); lw = group_sum(lw, 32); nw = group_sum(nw, 32);
+            if (j == 0 && tt < t_done) { tp.lp_z[(size_t)tt * B + b] = lz; tp.ne_z[(size_t)tt * B + b] = nz; }
+            if (j == 0 && tt < w_done) { tp.lp_w[(size_t)tt * B + b] = lw; tp.ne_w[(size_t)tt * B + b] = nw; }
+        }
+        if (tid < t_done) {
+            const float p = s_psT[tid], sb = s_sbT[tid];
+            const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+            tp.lp_s[(size_t)tid * B + b] = sb * l1 + (1.f - sb) * l0;
+            tp.ne_s[(size_t)tid * B + b] = p * l1 + (1.f - p) * l0;
+        }
+    }
     // ------------------------------------------------------------ output selection / reward / top-k
     const int tstar = dm.fixed ? (T - 1) : (int)s_misc[1];
     if (tid < 64) {
