@@ -65,7 +65,7 @@ struct mmg_handle {
     // debugging switches of the launch paths (environment, read ONCE at mmg_create -- never on the per-minibatch path)
     bool sw_rsample, sw_rmsg, sw_fused_s, sw_xcd_map, rs_capable;
     bool mc_ok;                // many-class register-resident conversation (kernels_mc.h); MMG_NO_MC=1: off
-    bool mc_always, mc_bwd_ok;
+    bool mc_never_big, mc_bwd_ok;
     bool any_split;            // some k_wgrad job splits its rows over workgroups (k_wreduce adds the partial tiles)
     bool wgrad_small_split;    // jobs with few output tiles split their (step, sample) rows further (layout.h: wgrad_job_nsplit)
     int mc_per, mc_xcd;        // classes per member of a tile; MMG_MC_XCD=1: a tile's 16 workgroups on one XCD
@@ -337,7 +337,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->mc_ok = h->use_fast && mc_shape(h->dm.H, h->dm.W, h->dm.R, h->dm.V, h->dm.D, h->dm.T) && !getenv("MMG_NO_MC");
     h->mc_per = (((h->dm.D + 15) / 16) + 3) & ~3;
     h->mc_xcd = (getenv("MMG_MC_XCD") && atoi(getenv("MMG_MC_XCD")) == 0) ? 0 : 1;     // (measured at config 5, 256 samples: 192 us per minibatch against 201)
-    h->mc_always = getenv("MMG_MC_ALWAYS") != nullptr;
+    h->mc_never_big = getenv("MMG_MC_SMALL_ONLY") != nullptr;
     h->mc_bwd_ok = !getenv("MMG_NO_MC_BWD");
     h->wgrad_small_split = !getenv("MMG_NO_SMALL_SPLIT");
     int n_cu = 0;
@@ -569,9 +569,10 @@ static bool fast_shape(const mmg_handle* h) {
 }
 // every other shape: sample tiles on the matrix cores (kernels_tile.h); the per-sample generic kernels remain for
 // dimensions whose tile does not fit the LDS and for the agent-level entry points
-// the small agents with many classes (32 < D <= 1024): register-resident conversation with class slices (kernels_mc.h) up to
-// 1024 samples per GPU (beyond that the sample tiles fill the chip; MMG_MC_ALWAYS=1 / MMG_TILE=1 force either)
-static bool mc_path(const mmg_handle* h) { return h->mc_ok && !(h->tile_ok && h->tile_force) && (h->dm.B < 1024 || h->mc_always || !h->tile_ok); }
+// the small agents with many classes (32 < D <= 1024): register-resident conversation with class slices (kernels_mc.h) at every
+// batch size (measured at D = 1000, 2 048 samples: 1 064 us per minibatch against 1 113 on the sample tiles; MMG_MC_SMALL_ONLY=1
+// keeps the tiles from 1 024 samples, MMG_TILE=1 forces them)
+static bool mc_path(const mmg_handle* h) { return h->mc_ok && !(h->tile_ok && h->tile_force) && (!h->mc_never_big || h->dm.B < 1024 || !h->tile_ok); }
 static bool tile_path(const mmg_handle* h) { return h->tile_ok && !fast_shape(h) && !mc_path(h); }
 
 static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
