@@ -332,7 +332,17 @@ __device__ __forceinline__ void role_signal_wt(uint32_t* sync, int dep) {
 }
 // ACQ = false: the caller reads what the producers wrote with agent-scope loads (__hip_atomic_load, relaxed) -- coherent by
 // themselves -- and skips the acquire fence (a buffer_inv of the L2: measured at config 4, 40 us per conversation of 7 steps).
-template <int SLEEP = 1, bool ACQ = true>
+// The consumers count themselves; the last one re-arms both counters for the next launch.  This is a RETURNING atomic (a memory
+// round trip, ~1 us): role_wait<.., REARM = false> leaves it to the caller, who runs role_rearm (one thread) where nothing waits
+// for it -- at the end of the role.
+__device__ __forceinline__ void role_rearm(uint32_t* sync, int dep, uint32_t consumers) {
+    const uint32_t passed = __hip_atomic_fetch_add(sync + MMG_SYNC_PASS(dep), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (passed + 1 == consumers) {                      // everyone has seen the final count
+        __hip_atomic_store(sync + MMG_SYNC_ARR(dep), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + MMG_SYNC_PASS(dep), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int SLEEP = 1, bool ACQ = true, bool REARM = true>
 __device__ __forceinline__ void role_wait(uint32_t* sync, int dep, uint32_t producers, uint32_t consumers) {
     if (threadIdx.x == 0) {
         int spins = 0;
@@ -340,11 +350,7 @@ __device__ __forceinline__ void role_wait(uint32_t* sync, int dep, uint32_t prod
             __builtin_amdgcn_s_sleep(SLEEP);
             if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(sync + MMG_SYNC_ERR, (uint32_t)(dep + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
-        const uint32_t passed = __hip_atomic_fetch_add(sync + MMG_SYNC_PASS(dep), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (passed + 1 == consumers) {                  // everyone has seen the final count: re-arm for the next launch
-            __hip_atomic_store(sync + MMG_SYNC_ARR(dep), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sync + MMG_SYNC_PASS(dep), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (REARM) role_rearm(sync, dep, consumers);
     }
     __syncthreads();
     if (ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale cache lines before reading what the producers wrote

@@ -94,8 +94,17 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     static_assert(2 * TMAX * W == TMAX * R, "a pair of message arrays holds one [16][R] tile");
     __shared__ float t_gru[TMAX * 4 * R], t_h[(TMAX + 1) * R], t_a[TMAX * H];
     if (MERGED && (int)blockIdx.x < n_stats) {          // four pairs per workgroup (one per wave): few releasing workgroups
+#ifdef MMG_TIMING
+        if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[128 + 48] = (long long)wall_clock64();
+#endif
         stats_pairs<true>(dm, P, tp, 1, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
+#ifdef MMG_TIMING
+        if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[128 + 49] = (long long)wall_clock64();
+#endif
         role_signal_wt(tp.sync, 0);
+#ifdef MMG_TIMING
+        if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[128 + 50] = (long long)wall_clock64();
+#endif
         return;
     }
     if (MERGE_DC && (int)blockIdx.x >= n_stats + dm.B) {
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     }
     MMG_BSTAMP(11);
     if (MERGED) {                                       // the statistics roles of this launch publish stats, bs, br
-        role_wait<1, false>(tp.sync, 0, (uint32_t)n_stats, (uint32_t)B);
+        role_wait<1, false, false>(tp.sync, 0, (uint32_t)n_stats, (uint32_t)B);     // (re-armed at the end of the role)
         creg = coef_load<true>(dm, tp.stats);
         rbs_ = __hip_atomic_load(&tp.bs[so], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         rbr_ = __hip_atomic_load(&tp.br[so], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -429,6 +438,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         __syncthreads();
     }
     MMG_BSTAMP(4);
+    if (MERGED && tid == 0) role_rearm(tp.sync, 0, (uint32_t)B);
     // (code_bias: k_wgrad's special column job forms dsig * W_c^T (sum_b dpre_0) once, instead of W_c^T dpre_0 per sample here)
 }
 
