@@ -124,3 +124,21 @@ def test_hdf5_compound_roundtrip(tmp_path):
         np.testing.assert_array_equal(c2[k], comm[k])
     for k in preds_t.names:
         np.testing.assert_array_equal(p2[k], preds[k])
+
+
+def test_host_shuffle_reproduces_random_shuffle():
+    """libmmg's mmg_host_shuffle continues the interpreter's Mersenne-Twister state exactly as random.shuffle would
+    (misc.py:270-271 order contract), for sizes around the rejection-sampling bit-length boundaries too."""
+    import ctypes as C
+    from multimodalgame_amd import _lib
+    lib = _lib.load()
+    for seed, n in ((11, 1), (12, 2), (11 + 7, 3000), (99, 4096), (5, 4097), (123, 65537)):
+        random.seed(seed)
+        st = random.getstate()[1]
+        words = np.array(st[:-1], dtype=np.uint32)
+        perm = np.arange(n, dtype=np.int64)
+        assert lib.mmg_host_shuffle(words.ctypes.data_as(C.c_void_p), int(st[-1]), n, perm.ctypes.data_as(C.c_void_p)) == 0
+        want = list(range(n))
+        random.shuffle(want)
+        assert perm.tolist() == want
+    assert misc._shuffled_order(10) is not None and misc._FAST_SHUFFLE is True
