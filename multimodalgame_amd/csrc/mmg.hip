@@ -569,10 +569,11 @@ static bool fast_shape(const mmg_handle* h) {
 }
 // every other shape: sample tiles on the matrix cores (kernels_tile.h); the per-sample generic kernels remain for
 // dimensions whose tile does not fit the LDS and for the agent-level entry points
-// the small agents with many classes (32 < D <= 1024): register-resident conversation with class slices (kernels_mc.h) at every
-// batch size (measured at D = 1000, 2 048 samples: 1 064 us per minibatch against 1 113 on the sample tiles; MMG_MC_SMALL_ONLY=1
-// keeps the tiles from 1 024 samples, MMG_TILE=1 forces them)
-static bool mc_path(const mmg_handle* h) { return h->mc_ok && !(h->tile_ok && h->tile_force) && (!h->mc_never_big || h->dm.B < 1024 || !h->tile_ok); }
+// the small agents with many classes (32 < D <= 1024): register-resident conversation with class slices (kernels_mc.h) up to 2 048
+// samples per GPU (measured at D = 1000: 2 048 samples 1 064 us per minibatch against 1 113 on the sample tiles, 4 096 samples
+// 2 090 against 1 242 -- from 256 tiles on, the tiles fill the chip and a workgroup per sample is 16 waves of it;
+// MMG_MC_SMALL_ONLY=1 keeps the tiles from 1 024 samples, MMG_TILE=1 forces them)
+static bool mc_path(const mmg_handle* h) { return h->mc_ok && !(h->tile_ok && h->tile_force) && (h->dm.B <= (h->mc_never_big ? 1023 : 2048) || !h->tile_ok); }
 static bool tile_path(const mmg_handle* h) { return h->tile_ok && !fast_shape(h) && !mc_path(h); }
 
 static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
