@@ -57,10 +57,21 @@ def synthetic_dataset(n_samples, n_classes, feat_dim, wv_dim, seed=1234):
     return feats, target, desc
 
 
-def algorithmic_work(kernel, d, B, t_steps):
+def conversation_flops(d, B, t_steps):
+    """SURVEY.md 8(d) "minimal" forward flops of the conversation launch: per (step, sample) row the sender MLP, the GRU cell,
+    A = W_y1h h, the y head over D classes (3 flops per (class, r): add, relu, fma), softmax . desc, the query head and the
+    stop bit; per minibatch nothing (h_x / Cd belong to k_prep; the baselines are their own launch and do not run in
+    continuous mode).  C1-C3 shard: 2 * 64 * 137 k = 17.5 MFLOP per exchange step; C5's 256-sample shard: 134 MFLOP."""
+    H, W, R, V, D = (d[k] for k in ("h_dim", "w_dim", "rec_hidden", "wv_dim", "n_classes"))
+    per_row = 2 * W * H + 2 * H * W + 6 * R * (W + R) + 2 * R * R + 3 * D * R + 2 * D * V + 2 * V * R + 2 * R * R + 2 * R * W + 2 * R
+    return B * t_steps * per_row
+
+
+def algorithmic_work(kernel, d, B, t_steps, lean=False):
     """Algorithmic (minimal) work of ALL launches of `kernel` in one minibatch: (bound, amount) with amount in bytes for
     HBM-bound kernels and flops for MFMA-bound ones.  B samples, t_steps = exchange steps a sample takes on average
-    (B * t_steps live (step, sample) rows).  Formulas: DESIGN.md §3."""
+    (B * t_steps live (step, sample) rows).  Formulas: DESIGN.md §3.
+    lean: the fused continuous-mode step (include/mmg.h: run_all_steps == 2) stores only what its backward reads."""
     F, H, W, R, V, K, D, T = (d[k] for k in ("feat_dim", "h_dim", "w_dim", "rec_hidden", "wv_dim", "bas_hidden",
                                              "n_classes", "max_exchange"))
     rows = B * t_steps
@@ -68,7 +79,13 @@ def algorithmic_work(kernel, d, B, t_steps):
     p_recv = 3 * R * (W + R) + 6 * R + R * R + R + R * V + W * R + W + R * R + 2 * R + 2 + D * R + D * V
     mac_recv = 3 * R * W + 3 * R * R + 2 * R * R + R + D * V + R * V + W * R      # products of one receiver step of one sample
     if kernel in ("k_conversation", "k_conversation_mc"):
-        tape = rows * 4 * (H + 4 * W + 5 * R + R + D + V + 12)          # floats written per (step, sample)
+        if lean and not d["use_binary"]:
+            # lean tape: per (step, sample) the message z [W], the GRU state h [R] and gates [4R], stop bit / prob / mask /
+            # bookkeeping (~8 floats); per sample the output step's logits, outp, dist and softmax [4D]; no a / c / zr / dbar /
+            # g / w and no per-step y
+            tape = rows * 4 * (W + 5 * R + 8) + B * 4 * 4 * D
+        else:
+            tape = rows * 4 * (H + 4 * W + 5 * R + R + D + V + 12)      # floats written per (step, sample)
         return "hbm", 4 * (p_sender + p_recv) + tape + 4 * B * H
     if kernel == "k_bwd_mc":                  # continuous many-class backward: softmax in, dy out, class tables once, GRU tape in, gate gradients out
         return "hbm", 4 * (2 * B * D + 3 * D * R + rows * 11 * R + 3 * R * R)
@@ -202,6 +219,11 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
     done += steps
     sync()
     elapsed = time.perf_counter() - t0
+    # the first pass on its own: `steps` minibatches from the SAME start (warmup minibatches after the seed-0 initialisation) in
+    # every round -- ms per minibatch and conversation length here are comparable across rounds, whatever the 2 s window
+    # trains the agents into afterwards (one 32-byte copy; the stream is idle after the sync above)
+    first_elapsed = elapsed
+    first_steps = float(eng.tape["totals"][0].item()) - float(totals_before[0])
     more = torch.tensor([max(0.0, (MIN_TIMED_SECONDS - elapsed) / max(elapsed, 1e-6))], device=dev)
     if world > 1:
         dist.all_reduce(more, op=dist.ReduceOp.MAX)
@@ -227,6 +249,7 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
                       if dp.comm is not None else "torch.distributed.all_reduce, backend %s" % dist.get_backend())
     res = dict(workload=workload, label=label, B=B, Bg=Bg, elapsed=elapsed, minibatches=done, ex_steps=ex_steps,
                sample_steps=sample_steps, cfg=CFG, roofline=None, collective=collective,
+               first_pass_ms_per_minibatch=1e3 * first_elapsed / steps, first_pass_steps_per_minibatch=first_steps / steps,
                dist_world=(dist.get_world_size() if world > 1 else 1))
     if not want_roofline:
         return res
@@ -250,7 +273,8 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
         avg = {k: float(np.mean(v)) for k, v in kern_ms.items()}
         dom = max(avg, key=avg.get)
         tstar = eng.tape["tstar"].float().mean().item() + 1.0      # live steps per sample (B * tstar live rows)
-        bound, amount = algorithmic_work(dom, CFG, B, tstar)
+        lean = not CFG["use_binary"]                                # (mmg_train_step and the phased DP step both run the lean tape)
+        bound, amount = algorithmic_work(dom, CFG, B, tstar, lean=lean)
         secs = avg[dom] * 1e-3
         if bound == "hbm":
             achieved, peak, unit = amount / secs / 1e9, HBM_PEAK_GBS, "GB/s"
@@ -261,23 +285,50 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
         traffic, traffic_source = traffic_lookup(workload, dom, strong)
         per_kernel = {}
         for k, ms in avg.items():
-            bk, amt = algorithmic_work(k, CFG, B, tstar)
+            bk, amt = algorithmic_work(k, CFG, B, tstar, lean=lean)
             if amt:
                 a_k = amt / (ms * 1e-3) / (1e9 if bk == "hbm" else 1e12)
                 per_kernel[k] = dict(bound=bk, achieved=round(a_k, 3), unit="GB/s" if bk == "hbm" else "TFLOP/s",
                                      frac=round(a_k / (HBM_PEAK_GBS if bk == "hbm" else MFMA_F32_PEAK_TFLOPS), 5))
         res["roofline"] = dict(bound=bound, kernel=dom, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
                                traffic=traffic, traffic_source=traffic_source, launch_us=avg[dom] * 1e3,
+                               algorithmic_amount=amount,
                                note="launch_us / kernels_us: HIP-event time of ALL launches of the kernel in one minibatch",
                                kernels_us={k: round(v * 1e3, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
                                per_kernel=per_kernel)
+        # the conversation launch against the OTHER roof as well: SURVEY.md 8(d)'s minimal forward flops of the shard over the
+        # fp32 matrix peak (most of them -- the 3 B D R relu-dot of the y head -- are VALU work by nature)
+        conv = next((k for k in avg if k.startswith(("k_conversation", "k_conv_"))), None)
+        if conv is not None:
+            fl = conversation_flops(CFG, B, tstar)
+            res["roofline"]["conversation_flop"] = dict(kernel=conv, flops=fl, tflops=fl / (avg[conv] * 1e-3) / 1e12,
+                                                        flop_frac=fl / (avg[conv] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                                        peak="fp32 MFMA %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS)
     del eng
     return res
 
 
+def same_initial_weights(models):
+    """Loads into the oracle's modules the very weights run_workload() starts the GPU from (agents.init_state_dicts, seed 0,
+    drawn in the flat buffer's tensor order), so that both legs train the same agents from the same point."""
+    from multimodalgame_amd import _lib
+    from multimodalgame_amd.agents import init_state_dicts
+
+    class _Shapes(object):
+        pass
+    st = _Shapes()
+    st.params = {a: {} for a in _lib.AGENTS}
+    for e in _lib.param_table(_lib.make_config(batch=PER_GPU_BATCH, **C2)):
+        st.params[e["agent"]][e["name"]] = torch.zeros((e["rows"], e["cols"]) if e["cols"] else (e["rows"],))
+    sd = init_state_dicts(st, seed=0)
+    for a, m in models.items():
+        m.load_state_dict(sd[a])
+
+
 def cpu_baseline(seconds_budget=24.0):
     """The CPU oracle (literal restatement of the reference, oracle/cpu_ref.py) timed on this host: same config, same
-    synthetic data, RMSprop, data loading excluded.  Thread counts {1, 4, 8, 16, all} are tried and the best is reported."""
+    synthetic data, same initial weights, RMSprop, data loading excluded.  Thread counts {1, 4, 8, 16, all} are tried and
+    the best is reported."""
     from oracle import cpu_ref
     fl = cpu_ref.Flags(use_binary=True, fixed_exchange=False, max_exchange=10, batch_size=64, learning_rate=1e-4,
                        entropy_s=0.08, entropy_sen=0.01, entropy_rec=0.01, img_feat_dim=512, img_h_dim=256,
@@ -294,6 +345,7 @@ def cpu_baseline(seconds_budget=24.0):
         torch.manual_seed(0)
         np.random.seed(0)
         models = cpu_ref.build_agents(fl)
+        same_initial_weights(models)
         opts = cpu_ref.build_optimizers(models, fl)
         steps, n_mb, t_used = 0, 0, 0.0
         for i in range(3 + 400):
@@ -306,12 +358,14 @@ def cpu_baseline(seconds_budget=24.0):
                 steps += res["n_steps"]; n_mb += 1; t_used += dt
                 if t_used > seconds_budget / len(counts):
                     break
-        out[threads] = dict(steps_per_s=steps / t_used, minibatches=n_mb, seconds=t_used, threads=threads)
+        out[threads] = dict(steps_per_s=steps / t_used, minibatches=n_mb, seconds=t_used, threads=threads, steps_per_mb=steps / max(n_mb, 1))
     torch.set_num_threads(all_threads)
     best = max(out.values(), key=lambda v: v["steps_per_s"])
     return dict(value=best["steps_per_s"], unit="exchange-steps/s", cores=best["threads"], kind="port",
-                sample="%d minibatches of config 1 (B=64) in %.1f s on %d thread(s); sweep %s exchange-steps/s; host has %d logical CPUs" % (
-                    best["minibatches"], best["seconds"], best["threads"],
+                exchange_steps_per_minibatch=best["steps_per_mb"], ms_per_minibatch=1e3 * best["seconds"] / best["minibatches"],
+                sample="%d minibatches of config 1 (B=64) from the GPU leg's initial weights, %.2f exchange steps each, in %.1f s on %d thread(s); "
+                       "sweep %s exchange-steps/s; host has %d logical CPUs" % (
+                    best["minibatches"], best["steps_per_mb"], best["seconds"], best["threads"],
                     ", ".join("%d thr: %.1f" % (k, v["steps_per_s"]) for k, v in sorted(out.items())), ncpu))
 
 
@@ -428,6 +482,9 @@ def main():
             "config": {"workload": r["label"], "global_batch": r["Bg"], "per_gpu_batch": r["B"], "parallelism": "dp%d" % world,
                        "rccl_world": r["dist_world"], "collective": r["collective"],
                        "exchange_steps_per_minibatch": r["ex_steps"] / r["minibatches"], "sampling": "in-kernel Philox4x32-10",
+                       # the first --steps minibatches after the warmup, from the seed-0 initialisation: comparable across rounds
+                       "first_pass_ms_per_minibatch": r["first_pass_ms_per_minibatch"],
+                       "first_pass_exchange_steps_per_minibatch": r["first_pass_steps_per_minibatch"],
                        "timed_minibatches": r["minibatches"], "timed_seconds": r["elapsed"],
                        "minibatches_per_s": (1.0 if strong else world) * r["minibatches"] / r["elapsed"],
                        "sample_steps_per_s": r["sample_steps"] / r["elapsed"],       # sum_t n_active,t per second, whole job
@@ -446,7 +503,8 @@ def main():
                 rf = o["roofline"] or {}
                 other[w] = dict(workload=o["label"] + (" -- all %d samples on one GPU (--scaling strong, N=1)" % o["Bg"] if w.endswith("s") else ""), batch=o["B"], ms_per_minibatch=1e3 * o["elapsed"] / o["minibatches"],
                                 exchange_steps_per_s=o["ex_steps"] / o["elapsed"],
-                                roofline={k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_us", "traffic", "traffic_source")},
+                                first_pass_ms_per_minibatch=o["first_pass_ms_per_minibatch"],
+                                roofline={k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_us", "algorithmic_amount", "traffic", "traffic_source", "conversation_flop")},
                                 kernels_us=rf.get("kernels_us"))
             line["other_configs"] = other
         if world == 1 and args.workload == "c2" and not args.no_cli and not strong:

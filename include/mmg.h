@@ -97,7 +97,9 @@ int64_t mmg_param_count(const mmg_config* cfg);                                 
  * [0] = 1.0 if an in-launch dependency wait of this minibatch timed out on this rank (stale gradients), else 0.0.  A
  * data-parallel caller all-reduces (sum) ALL mmg_grad_floats() floats, so the flag reaches every rank with the gradients
  * and mmg_clip_step skips the update on all ranks alike (the reference has no counterpart: model.py:1307-1330 is
- * single-process). */
+ * single-process); [1], [2] = this rank's sum of rewards (log-likelihood of the target, model.py:1274) and top-k hit count,
+ * from which mmg_clip_step rewrites the logged NLL / hits of the GLOBAL minibatch in continuous mode (use_binary == 0), where
+ * the shards couple through nothing else and no statistics all-reduce is needed; [3] = 0. */
 int64_t mmg_grad_floats(const mmg_config* cfg);
 int     mmg_param_table(const mmg_config* cfg, mmg_param_entry* out, int max_entries);   /* returns count */
 int64_t mmg_workspace_bytes(const mmg_config* cfg);
@@ -134,7 +136,10 @@ int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_targe
 
 /* Per-rank partial sums of every batch statistic the losses need (counts, sums and squared sums
  * of reward-minus-baseline per stream and step, ...) into the f64 tape array "stats".  With more
- * than one rank the caller all-reduces (sum) that array between this call and mmg_backward. */
+ * than one rank the caller all-reduces (sum) that array between this call and mmg_backward
+ * (model.py:912-915, 947-961: the REINFORCE weights are normalised by statistics of the WHOLE minibatch).
+ * Continuous mode (use_binary == 0; model.py:1297-1305: loss = NLL mean) has no such coupling: the call and the
+ * all-reduce may be skipped, mmg_backward forms the two logged sums itself (see mmg_grad_floats). */
 int mmg_loss_stats(mmg_handle* h, void* stream);
 
 /* Gradient of the four losses (model.py:1296-1305) w.r.t. all parameters into d_grads (the whole
@@ -146,8 +151,11 @@ int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const
  * fail) when the dependency-error flag of this rank or -- through the tail quad of d_grads -- of any rank is set. */
 int mmg_clip_step(mmg_handle* h, void* stream);
 
-/* forward(train, run_all_steps = 0) + stats + backward + clip_step for a single-GPU minibatch, as six
- * kernel launches; nothing returns to the host.  Equivalent to the four calls above in sequence. */
+/* forward(train, run_all_steps = 2) + stats + backward + clip_step for a single-GPU minibatch; nothing returns to the
+ * host.  Equivalent to the four calls above in sequence.  Launches per minibatch depend on the shape: 6 for the agents of
+ * BASELINE configs 1-3 (k_prep, k_conversation_fast2, k_baselines3, k_bwd_conv_fast, k_wgrad, k_opt), 7 for config 5's
+ * shard (k_prep, k_conversation_mc, k_bwd_mc1, k_bwd_mc2, k_wgrad, k_wreduce, k_opt), 10-11 for config 4 (k_prep,
+ * k_conv_persist, [k_gemm_nt], k_baselines4, k_stats, k_bwd_pre_send, k_bwd_sample, k_dC_tile, k_wgrad, k_opt). */
 int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
                    const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed, void* stream);
 

@@ -597,8 +597,15 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         // the quad behind the gradients (include/mmg.h: mmg_grad_floats): [0] = 1.0 when a dependency wait of this minibatch
         // timed out on THIS rank.  The data-parallel all-reduce sums it with the gradients, so every rank's k_opt sees that
         // some rank's contribution is built from stale data and all of them skip the update together.
-        if (threadIdx.x == 0)
+        // [1], [2]: this rank's sum of rewards and top-k hits.  Continuous messages couple the shards through nothing else
+        // (loss = NLL mean over the GLOBAL batch, model.py:1297-1305): the data-parallel step then needs no statistics
+        // all-reduce -- the two sums travel with the gradients and k_gradnorm rewrites the logged NLL / hit count from them.
+        if (threadIdx.x == 0) {
             grad_tail[0] = (__hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.f : 0.f;
+            grad_tail[1] = (float)stats[stat_glob(dm.T, 0)];
+            grad_tail[2] = (float)stats[stat_glob(dm.T, 1)];
+            grad_tail[3] = 0.f;
+        }
         return;
     }
     if ((int)blockIdx.x < jt->gemm_tiles) {
@@ -895,8 +902,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wreduce(const JobTable* __restric
 // ---------------------------------------------------------------------------------------------
 // Per-agent gradient norm (clip_grad_norm, model.py:1310) and the optimizer update.
 // ---------------------------------------------------------------------------------------------
+// fix_bg > 0 (continuous messages, data parallel): the tail quad behind the all-reduced gradients holds the GLOBAL sum of
+// rewards and hit count (k_wgrad's spare block wrote this rank's share): the logged NLL / hits / running hit total, which
+// that block derived from the local sums, are rewritten here.
 __global__ __launch_bounds__(MMG_BLOCK) void k_gradnorm(const JobTable* __restrict__ jt, const float* __restrict__ grads,
-                                                        float* __restrict__ part, uint32_t* __restrict__ counter) {
+                                                        float* __restrict__ part, uint32_t* __restrict__ counter,
+                                                        const float* __restrict__ grad_tail, float* __restrict__ losses,
+                                                        double* __restrict__ totals, int fix_bg) {
     __shared__ float s_red[8];
     const int blk = blockIdx.x;
     const int64_t b0 = jt->np.begin[blk], b1 = jt->np.end[blk];      // multiples of 4 floats
@@ -909,6 +921,12 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_gradnorm(const JobTable* __restri
     if (threadIdx.x == 0) {
         part[blk] = acc;
         if (blk == 0) counter[1] += 1u;                               // optimizer step count (Adam bias correction)
+        if (blk == 0 && fix_bg > 0) {
+            const float hits = grad_tail[2];
+            totals[1] += (double)hits - (double)losses[7];
+            losses[0] = -grad_tail[1] / (float)fix_bg;                // NLL of the global minibatch (model.py:1271)
+            losses[7] = hits;
+        }
     }
 }
 

@@ -861,7 +861,15 @@ extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_ta
     if (!h) return fail("NULL handle");
     if (!d_x || !d_target || !d_desc) return fail("x / target / desc must not be NULL");
     if (sticky_error(h)) return -1;
-    return backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, false);
+    // continuous messages: the statistics are this rank's sum of rewards and hit count only, nothing a gradient depends on
+    // (model.py:1297-1305) -- the call forms them itself (as a workgroup of the backward launch where the path has one, else as
+    // k_stats) and no mmg_loss_stats / statistics all-reduce is needed; they reach the other ranks in the gradient tail
+    bool own_stats = false;
+    if (!h->dm.use_binary) {
+        own_stats = mc_bwd(h) && h->merge_roles;
+        if (!own_stats && mmg_loss_stats(h, stream)) return -1;
+    }
+    return backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, own_stats);
 }
 
 static int clip_step_impl(mmg_handle* h, hipStream_t st, bool from_wgrad) {
@@ -871,7 +879,8 @@ static int clip_step_impl(mmg_handle* h, hipStream_t st, bool from_wgrad) {
     if (!from_wgrad) {
         Scope sc(h, st, "k_gradnorm");
         hipLaunchKernelGGL(k_gradnorm, dim3(MMG_GN_BLOCKS), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt,
-                           (const float*)h->grads, part, h->tp.counter);
+                           (const float*)h->grads, part, h->tp.counter, (const float*)(h->grads + h->pl.total), h->tp.losses,
+                           h->tp.totals, h->dm.use_binary ? 0 : h->dm.Bg);
         if (launch_check("k_gradnorm")) return -1;
     }
     OptArgs oa;

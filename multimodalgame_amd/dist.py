@@ -4,7 +4,9 @@ parameters / optimizer state replicated.
 Two collectives per optimizer step (RCCL over xGMI through torch.distributed backend "nccl"):
   1. a ~1.4 KB float64 all-reduce of the batch statistics the REINFORCE losses couple the shards
      through (per stream and step: n_t, sum w, sum w^2, ... -- SURVEY.md §8e option A), so every
-     rank scales its gradient seeds with the statistics of the WHOLE minibatch;
+     rank scales its gradient seeds with the statistics of the WHOLE minibatch.  Continuous messages (-nouse_binary) have
+     no such coupling (loss = NLL mean over the global batch, model.py:1297-1305): this collective and the
+     statistics launch are skipped, the two logged sums (rewards, hits) ride in the tail quad of the gradient buffer;
   2. one all-reduce of the flat gradient buffer of all four agents.
 Gradient clipping uses the norm of the reduced gradient, so all ranks take the identical update
 (model.py:1310 semantics on the global batch)."""
@@ -16,7 +18,7 @@ import torch.distributed as dist
 
 class DataParallel(object):
     """`engine` needs: forward(...), loss_stats(), backward(...), clip_step(), .stats (1-D f64 tensor),
-    .flat_grads (1-D f32 tensor).  multimodalgame_amd.engine.Engine satisfies this on a GPU."""
+    .flat_grads (1-D f32 tensor), .use_binary.  multimodalgame_amd.engine.Engine satisfies this on a GPU."""
 
     def __init__(self, engine, group=None, direct=None):
         """direct: enqueue the collectives on the engine's stream through multimodalgame_amd.rccl (default: when the
@@ -41,9 +43,10 @@ class DataParallel(object):
     def train_step(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0):
         e = self.engine
         e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=False, minimal=True)
-        e.loss_stats()
-        if self.world > 1:
-            self._all_reduce(e.stats)
+        if e.use_binary:
+            e.loss_stats()
+            if self.world > 1:
+                self._all_reduce(e.stats)
         e.backward(x, target, desc)
         if self.world > 1:
             self._all_reduce(e.flat_grads)

@@ -20,6 +20,7 @@ class Engine(object):
         self.device = torch.device(device)
         self.cfg = _lib.make_config(**cfg_kwargs)
         self.cfg_kwargs = dict(cfg_kwargs)
+        self.use_binary = bool(self.cfg.use_binary)
         n = self.lib.mmg_param_count(C.byref(self.cfg))
         if n < 0:
             raise _lib.MmgError(self.lib.mmg_last_error().decode())

@@ -69,6 +69,7 @@ class ShardEngine(object):
                       for k, _ in models[a].named_parameters()]
         self.flat_grads = torch.zeros(sum(dict(models[a].named_parameters())[k].numel() for a, k in self.order))
         self.optimizers = cpu_ref.build_optimizers(models, flags)
+        self.use_binary = bool(flags.use_binary)
 
     def forward(self, x, target, desc, u_z, u_s, u_w, seed=0, train=True, run_all=False, minimal=False):
         fl, m = self.fl, self.models
@@ -140,7 +141,8 @@ class ShardEngine(object):
         loss_sen = torch.zeros(())
         loss_br = torch.zeros(())
         loss_bs = torch.zeros(())
-        for t, d in enumerate(self._streams()):
+        # continuous messages: loss_rec = NLL, the other three agents are not trained (model.py:1297-1305, 1313)
+        for t, d in enumerate(self._streams() if fl.use_binary else ()):
             for k, key in enumerate(("s", "rec", "sen")):
                 if key == "s" and fl.fixed_exchange:
                     continue
@@ -179,7 +181,8 @@ class ShardEngine(object):
             p = dict(self.models[a].named_parameters())[k]
             p.grad = self.flat_grads[off:off + p.numel()].view_as(p).clone()
             off += p.numel()
-        for agent, opt in (("receiver", "optimizer_rec"), ("sender", "optimizer_sen"),
-                           ("baseline_rec", "optimizer_bas_rec"), ("baseline_sen", "optimizer_bas_sen")):
+        for agent, opt in ((("receiver", "optimizer_rec"), ("sender", "optimizer_sen"),
+                            ("baseline_rec", "optimizer_bas_rec"), ("baseline_sen", "optimizer_bas_sen"))
+                           if self.fl.use_binary else (("receiver", "optimizer_rec"),)):
             nn.utils.clip_grad_norm_(self.models[agent].parameters(), max_norm=1.)
             self.optimizers[opt].step()

@@ -68,34 +68,46 @@ def case_inputs(meta, i, name=None):
 RELU_EPS = 2e-5     # |pre-activation| below which two correct fp32 implementations may put a ReLU unit on different sides
 
 
-def _relu_flips(res, y1_out, bas_out, n_classes):
+def _relu_flips(res, y1_out, bas_out, n_classes, binary=True):
     """Near-threshold ReLU units of one oracle minibatch, from the outputs its own y1 / baseline linear1 layers produced
     (forward hooks): the units whose mask may differ in another correct fp32 implementation.
       "y":        {r}  columns of the y head with |W_y1 [h_t* || desc_d] + b|[b, d, r] < RELU_EPS at the sample's OUTPUT step
-      "bas_rec" / "bas_sen": {k}  hidden units of a baseline with |pre| < RELU_EPS on a live (step, sample) row."""
+      "bas_rec" / "bas_sen": {k}  hidden units of a baseline with |pre| < RELU_EPS on a live (step, sample) row
+      "pos":      the same units with their position and the side the ORACLE put them on:
+                  ("y", t*, b, d, r, pre > 0) / ("bas_rec" | "bas_sen", t, b, k, pre > 0)."""
     masks = np.stack([m.detach().numpy().reshape(-1) for m in res["s_masks"]])      # [n + 1, B]; the last one is forced to 0
     n, B = res["n_steps"], masks.shape[1]
     stopped = masks[1:n + 1] == 0
     tstar = np.where(stopped.any(0), stopped.argmax(0), n - 1)
-    flips = {"y": set(), "bas_rec": set(), "bas_sen": set(), "where": []}
+    flips = {"y": set(), "bas_rec": set(), "bas_sen": set(), "where": [], "pos": []}
     for b in range(B):
-        pre = y1_out[int(tstar[b])].view(B, n_classes, -1)[b].abs()                 # [D, R] at the output step (build_inp rows b * D + d)
+        raw = y1_out[int(tstar[b])].view(B, n_classes, -1)[b]                       # [D, R] at the output step (build_inp rows b * D + d)
+        pre = raw.abs()
         d_idx, r_idx = torch.nonzero(pre < RELU_EPS, as_tuple=True)
         for d, r in zip(d_idx.tolist(), r_idx.tolist()):
             flips["y"].add(r); flips["where"].append("y1 unit r=%d at sample %d class %d: |pre| = %.2e" % (r, b, d, float(pre[d, r])))
-    for which in ("bas_rec", "bas_sen"):
+            flips["pos"].append(("y", int(tstar[b]), b, d, r, bool(raw[d, r] > 0)))
+    for which in (("bas_rec", "bas_sen") if binary else ()):
         for t, out in enumerate(bas_out[which][:n]):
             live = torch.from_numpy(np.asarray(t <= tstar))
             small = (out.abs() < RELU_EPS) & live.view(-1, 1)
             for b, k in torch.nonzero(small).tolist():
                 flips[which].add(k); flips["where"].append("%s hidden unit k=%d at step %d sample %d: |pre| = %.2e" % (which, k, t, b, float(out[b, k].abs())))
+                flips["pos"].append((which, t, b, k, bool(out[b, k] > 0)))
     return flips
 
 
-def oracle_train_case(name, meta, flips=None):
+_FORCE_TINY = 1e-30       # a forced unit's pre-activation: +tiny (mask on, value ~0) / -tiny (mask off)
+
+
+def oracle_train_case(name, meta, flips=None, force=None):
     """Re-run a golden train case with the CPU oracle; returns the packed dict.
-    flips: a list that receives, per minibatch, the near-threshold ReLU units (_relu_flips) -- the only gradient entries a
-    test may excuse (unexcused_gradient_problems)."""
+    flips: a list that receives, per minibatch, the near-threshold ReLU units (_relu_flips) and the case they belong to.
+    force: per minibatch, a set of positions ("y", t, b, d, r, side) / ("bas_*", t, b, k, side) whose ReLU mask is forced to
+    `side` (forced_masks: the side ANOTHER fp32 implementation put a near-threshold unit on).  The unit's pre-activation is
+    replaced by +-1e-30 with the gradient path kept, so the forward pass moves by at most RELU_EPS * |w2| per unit and the
+    backward pass sees the other implementation's mask -- the re-run must then agree within the normal tolerance
+    (assert_parity), nothing is excused blanket-wise."""
     fl = flags_from_meta(meta)
     torch.manual_seed(0)
     tape = cpu_ref.UniformTape()
@@ -105,22 +117,68 @@ def oracle_train_case(name, meta, flips=None):
     out = {}
     y1_out, bas_out = [], {"bas_rec": [], "bas_sen": []}
     hooks = []
-    if flips is not None:
-        hooks.append(models["receiver"].y1.register_forward_hook(lambda m, i, o: y1_out.append(o.detach().clone())))
-        hooks.append(models["baseline_rec"].linear1.register_forward_hook(lambda m, i, o: bas_out["bas_rec"].append(o.detach().clone())))
-        hooks.append(models["baseline_sen"].linear1.register_forward_hook(lambda m, i, o: bas_out["bas_sen"].append(o.detach().clone())))
+    state = {"mb": 0}
+    D = meta["n_classes"]
+
+    def hook(kind, store):
+        def fn(mod, inp, o):
+            t = len(store)
+            todo = [p for p in (force[state["mb"]] if force else ()) if p[0] == kind and p[1] == t]
+            if todo:
+                delta = torch.zeros_like(o)
+                for p in todo:
+                    row, col = (p[2] * D + p[3], p[4]) if kind == "y" else (p[2], p[3])
+                    delta[row, col] = (_FORCE_TINY if p[-1] else -_FORCE_TINY) - float(o[row, col].detach())
+                o = o + delta                                   # gradient path kept (d/d pre = 1 where the mask is on)
+            store.append(o.detach().clone())
+            return o
+        return fn
+    if flips is not None or force:
+        hooks.append(models["receiver"].y1.register_forward_hook(hook("y", y1_out)))
+        hooks.append(models["baseline_rec"].linear1.register_forward_hook(hook("bas_rec", bas_out["bas_rec"])))
+        hooks.append(models["baseline_sen"].linear1.register_forward_hook(hook("bas_sen", bas_out["bas_sen"])))
     for i in range(meta["n_minibatches"]):
         x, target, desc, (u_z, u_s, u_w) = case_inputs(meta, i, name)
         tape.u = {"z": u_z, "s": u_s, "w": u_w}
         tape.t = {"z": 0, "s": 0, "w": 0}
+        state["mb"] = i
         del y1_out[:], bas_out["bas_rec"][:], bas_out["bas_sen"][:]
         res = cpu_ref.train_minibatch(models, optimizers, torch.from_numpy(x), torch.from_numpy(target),
                                       torch.from_numpy(desc), fl)
         if flips is not None:
-            flips.append(_relu_flips(res, y1_out, bas_out, meta["n_classes"]))
+            f = _relu_flips(res, y1_out, bas_out, meta["n_classes"], binary=bool(fl.use_binary))
+            f["case"] = (name, meta)
+            flips.append(f)
         out.update(cpu_ref.pack_train(res, models, prefix="mb%d." % i))
     for h in hooks:
         h.remove()
+    return out
+
+
+def forced_masks(flips, capture, already=None):
+    """Per minibatch: the near-threshold units of the oracle run (flips[i]["pos"]) that the OTHER implementation put on the other
+    side.  capture[i] = that implementation's own pre-activations for minibatch i: {"Astar": [B, R], "Cd": [D, R]} (the y head's
+    pre-activation at the output step is Astar[b, r] + Cd[d, r]) and {"hid_r", "hid_s": [T, B, K]} (post-ReLU
+    hidden units of the baselines).  already: positions forced in an earlier pass (kept, with the side they were given)."""
+    out = []
+    for i, f in enumerate(flips):
+        cap = capture[i]
+        forced = {p[:-1]: p[-1] for p in (already[i] if already else ())}
+        for p in f["pos"]:
+            if p[:-1] in forced:
+                continue
+            if p[0] == "y":
+                _, t, b, d, r, side = p
+                if "y_pre" in cap:                               # explicit per-(b, d, r) values (tests of the gate itself)
+                    other = bool(cap["y_pre"][(b, d, r)] > 0)
+                else:
+                    other = bool(float(cap["Astar"][b, r]) + float(cap["Cd"][d, r]) > 0)
+            else:
+                which, t, b, k, side = p
+                other = bool(float(cap["hid_r" if which == "bas_rec" else "hid_s"][t, b, k]) > 0)
+            if other != side:
+                forced[p[:-1]] = other
+        out.append({k + (v,) for k, v in forced.items()})
     return out
 
 
@@ -165,71 +223,18 @@ def separate_draws(name, meta, margin=1e-4):
     return adjusted
 
 
-_DOWNSTREAM_OF_Y_HEAD = ("rnn.weight_ih", "rnn.weight_hh", "rnn.bias_ih", "rnn.bias_hh")      # through dh at the output step
-
-
-def unexcused_gradient_problems(details, flips, shapes):
-    """The gradient / parameter / gradient-norm mismatches of `details` (compare_packed(..., details=[...])) that NO
-    near-threshold ReLU unit of the oracle run explains.  d relu/dx is discontinuous: a unit with |pre| < RELU_EPS may land on
-    the other side in a correct fp32 implementation with another summation order, and then the entries it FEEDS differ:
-      y head unit r (output step)  -> receiver y1.weight row r, y1.bias[r], y2.weight[0, r]; through dA -> dh: every rnn.* entry
-      baseline hidden unit k       -> that baseline's linear1.weight row k, linear1.bias[k], linear2.weight[0, k]
-    A flip in minibatch j also moves that agent's parameters, hence ALL of the agent's later gradients (minibatches > j).
-    Everything else -- the sender, the receiver's message / stop heads, forward quantities -- is never excused.
-    shapes: {agent: {tensor: shape}}.  Returns the list of unexcused problem strings (empty = all explained)."""
-    bad = []
-    for key, idx, msg in details:
-        parts = key.split(".")
-        mb = int(parts[0][2:])
-        if parts[1] == "gradnorm":
-            agent, tensor, kind = parts[2], None, "norm"
-        else:
-            agent, tensor, kind = parts[2], ".".join(parts[3:-1]), parts[-1]
-        fam = {"receiver": "y", "baseline_rec": "bas_rec", "baseline_sen": "bas_sen"}.get(agent)
-        if fam is None:
-            bad.append(msg + "  [sender entries depend on no ReLU unit]"); continue
-        if any(flips[j][fam] for j in range(mb)):       # an earlier flip moved this agent's parameters
-            continue
-        units = flips[mb][fam]
-        if not units:
-            bad.append(msg + "  [no near-threshold ReLU unit feeds %s in minibatch %d]" % (agent, mb)); continue
-        if tensor is None or kind in ("norm", "sum"):   # a scalar over the whole tensor / agent
-            if agent == "receiver" and tensor is not None and not (tensor in _DOWNSTREAM_OF_Y_HEAD or tensor.startswith(("y1.", "y2."))):
-                bad.append(msg + "  [%s is not downstream of the y head]" % tensor)
-            continue
-        shape = shapes[agent][tensor]
-        numel = int(np.prod(shape))
-        stride = max(1, numel // 512)                   # cpu_ref.pack_train: strided sample
-        flat = np.asarray(idx) * stride
-        if agent == "receiver":
-            if tensor in _DOWNSTREAM_OF_Y_HEAD:
-                continue
-            if tensor == "y1.weight": rows = flat // shape[1]
-            elif tensor in ("y1.bias",): rows = flat
-            elif tensor == "y2.weight": rows = flat % shape[1]
-            else:
-                bad.append(msg + "  [%s is not downstream of the y head]" % tensor); continue
-        else:
-            if tensor == "linear1.weight": rows = flat // shape[1]
-            elif tensor == "linear1.bias": rows = flat
-            elif tensor == "linear2.weight": rows = flat % shape[1]
-            else:
-                bad.append(msg + "  [%s does not depend on a hidden unit's mask]" % tensor); continue
-        stray = sorted(set(int(r) for r in rows) - units)
-        if stray:
-            bad.append(msg + "  [rows %s of %s.%s differ but the near-threshold units are %s]" % (stray[:8], agent, tensor, sorted(units)[:8]))
-    return bad
-
-
 SHIFT_INVARIANT = ("y", "outp")
 
 # north_star: "logits/loss within 1e-4 of the reference CPU path".  Forward quantities -- logits, log-probabilities,
-# probabilities, rewards, baseline scores and the six loss scalars -- are compared with an ABSOLUTE tolerance of 1e-4 and no
-# relative slack up to magnitude 1; beyond that the bound scales with the magnitude (1e-4 * |v|): the REINFORCE losses of
-# config 4 are sums of 256-bit log-likelihoods of magnitude ~10^2, where one fp32 ulp is already 8e-6 and the CPU
-# reference's own summation order moves the value by several 1e-4 (test_oracle_golden pins oracle vs reference at 2e-6
-# only on O(1) cases).  Gradients / updated parameters / gradient norms (sums over up to 10^4 products) keep atol + rtol.
+# probabilities, rewards, baseline scores and the six loss scalars -- are compared with an ABSOLUTE tolerance of 1e-4, whatever
+# their magnitude.  The only exception is an explicit allow-list (RELATIVE_ALLOW): the REINFORCE losses of config 4 are means
+# of 256-bit log-likelihood sums times a reward weight, |loss| ~ 600, where ONE fp32 ulp is 6.1e-5 -- two correct fp32
+# summation orders differ by several ulp there (the oracle itself moves by 4e-4 between hosts), so those entries get
+# max(1e-4, 16 ulp) = max(1e-4, 1.9e-6 |want|).  Gradients / updated parameters / gradient norms (sums over up to 10^4
+# products) keep atol + rtol.
 FORWARD_ATOL = 1e-4
+RELATIVE_ALLOW = (("config4", ".losses"),)          # (case-label prefix, key suffix)
+RELATIVE_ULPS = 16 * 2.0 ** -23
 GRAD_KEYS = (".g.", ".p.", "gradnorm")
 
 # max abs error per (case label, quantity) seen by compare_packed in this process; tests/conftest.py writes it to
@@ -241,13 +246,17 @@ def is_grad_key(k):
     return any(t in k for t in GRAD_KEYS)
 
 
-GATE = {}           # per (case label, quantity): which forward gate applied -- "abs 1e-4" or "rel 1e-4 |want| (max |want| = ...)"
+GATE = {}           # per (case label, quantity): which forward gate applied -- "abs 1e-4" or "rel 16 ulp (max |want| = ...)"
+
+
+def relative_allowed(label, key):
+    return label is not None and any(label.startswith(a) and key.endswith(b) for a, b in RELATIVE_ALLOW)
 
 
 def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None, shift_invariant=False, label=None, details=None):
     """Compare two packed dicts.  Bit/mask/count entries must match exactly; forward float entries within
-    min(atol, 1e-4) * max(1, |want|) (absolute 1e-4 on O(1) values, see FORWARD_ATOL); gradient / parameter entries within
-    atol + rtol*|want|.
+    min(atol, 1e-4) ABSOLUTE (FORWARD_ATOL; max(1e-4, 16 ulp of |want|) only for the (label, key) pairs of RELATIVE_ALLOW);
+    gradient / parameter entries within atol + rtol*|want|.
 
     shift_invariant: compare the class logits (``y``, ``outp``) after removing each row's mean.
     dL/d(y2.bias) is identically zero (softmax is shift invariant), so what reaches the optimizer
@@ -283,15 +292,16 @@ def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None, s
             err = np.abs(a.astype(np.float64) - b.astype(np.float64))
             if is_grad_key(k):
                 tol = atol + rtol * np.abs(b.astype(np.float64))
+            elif relative_allowed(label, k):
+                tol = np.maximum(min(atol, FORWARD_ATOL), RELATIVE_ULPS * np.abs(b.astype(np.float64)))
             else:
-                tol = min(atol, FORWARD_ATOL) * np.maximum(1.0, np.abs(b.astype(np.float64)))
+                tol = np.full(b.shape, min(atol, FORWARD_ATOL), dtype=np.float64)
             if a.size:
                 if label is not None:
                     key = "%s:%s" % (label, k)
                     MAXERR[key] = max(MAXERR.get(key, 0.0), float(err.max()))
                     if not is_grad_key(k):
-                        big = float(np.abs(b).max())
-                        GATE[key] = "abs 1e-4" if big <= 1.0 else "rel 1e-4 * |want| (max |want| = %.3g)" % big
+                        GATE[key] = ("rel 16 ulp (max |want| = %.3g)" % float(np.abs(b).max())) if relative_allowed(label, k) else "abs 1e-4"
                 if not np.all(err <= tol):
                     msg = "%s max err %.3e (tol %.1e)" % (k, float(err.max()), float(tol.flat[err.argmax()]))
                     problems.append(msg)
@@ -304,19 +314,53 @@ def param_shapes(eng):
     return {a: {k: tuple(v.shape) for k, v in d.items()} for a, d in eng.params.items()}
 
 
-def assert_parity(got, want, flips, eng, label, skip=(), atol=1e-4, rtol=1e-3):
+def assert_parity(got, want, flips, eng, label, skip=(), atol=1e-4, rtol=1e-3, max_passes=4):
     """THE parity gate of the GPU tests.  Forward quantities (logits, probabilities, rewards, baseline scores, the six losses):
-    |got - want| <= 1e-4 where |want| <= 1 and <= 1e-4 |want| beyond (GATE records which applied); bits / masks / counts exact.
-    Gradients, updated parameters, gradient norms: atol + rtol |want| -- and an entry beyond that passes ONLY if a ReLU unit
-    with |pre-activation| < RELU_EPS in the oracle's run feeds it (unexcused_gradient_problems); anything else fails."""
+    |got - want| <= 1e-4 absolute (RELATIVE_ALLOW lists the only exceptions; GATE records which applied); bits / masks /
+    counts exact.  Gradients, updated parameters, gradient norms: atol + rtol |want|.
+
+    d relu/dx is discontinuous: a y-head or baseline hidden unit whose pre-activation is within RELU_EPS of zero may land on
+    the other side in a correct fp32 implementation with another summation order, and then the gradients it feeds differ by
+    O(dy * w2).  Such a mismatch is NOT excused: the oracle is re-run with exactly those units -- near-threshold in the
+    oracle's own run AND on the other side on the GPU (eng.relu_capture: the GPU's own pre-activations, forced_masks) --
+    forced to the GPU's side, and the re-run must agree with the GPU on EVERY compared entry within the normal tolerances
+    (a forced unit moves the forward pass by < RELU_EPS * |w2|).  New near-threshold units of the re-run (its later
+    minibatches start from slightly different parameters) are forced the same way, at most `max_passes` times.  A mismatch
+    with no such unit, or one that survives the re-run, fails."""
     details = []
     problems = compare_packed(got, want, atol=atol, rtol=rtol, skip=skip, shift_invariant=True, label=label, details=details)
-    hard = [p for p in problems if not is_grad_key(p.split(" ")[0])]
+    # a forward mismatch fails at once -- unless an EARLIER minibatch has a gradient mismatch (its update then moved the
+    # parameters this minibatch starts from): those are left to the forced re-run, which must clear them too
+    mb_of = lambda p: int(p.split(".")[0][2:]) if p.startswith("mb") and p.split(".")[0][2:].isdigit() else -1
+    grad_mbs = [mb_of(p) for p in problems if is_grad_key(p.split(" ")[0])]
+    first_grad = min(grad_mbs) if grad_mbs else 1 << 30
+    hard = [p for p in problems if not is_grad_key(p.split(" ")[0]) and mb_of(p) <= first_grad]
     assert not hard, "forward mismatch:\n" + "\n".join(hard[:20])
-    bad = unexcused_gradient_problems([d for d in details if is_grad_key(d[0])], flips, param_shapes(eng))
+    if not problems:
+        return problems
+    capture = getattr(eng, "relu_capture", None)
     where = [w for f in flips for w in f["where"]][:12]
-    assert not bad, "gradient entries no near-threshold ReLU unit explains:\n" + "\n".join(bad[:20]) + "\nnear-threshold units: " + "; ".join(where)
-    return problems
+    assert capture is not None and flips and "case" in flips[0], \
+        "gradient mismatch and no mask capture to re-run the oracle with:\n" + "\n".join(problems[:20])
+    name, meta = flips[0]["case"]
+    force, cur_flips, left = None, flips, problems
+    for _ in range(max_passes):
+        new_force = forced_masks(cur_flips, capture, already=force)
+        if force is not None and all(a == b for a, b in zip(new_force, force)):
+            break                                         # nothing new to force: the mismatch is real
+        if force is None and not any(new_force):
+            break                                         # no near-threshold unit sits on the other side on the GPU
+        force = new_force
+        cur_flips = []
+        want2 = oracle_train_case(name, meta, flips=cur_flips, force=force)
+        want2 = {k: want2[k] for k in (want.keys() if hasattr(want, "keys") else want.files) if k in want2}
+        left = compare_packed(got, want2, atol=atol, rtol=rtol, skip=skip, shift_invariant=True,
+                              label=(label + "/forced") if label else None)
+        if not left:
+            return problems
+    n_forced = sum(len(f) for f in force) if force else 0
+    assert False, ("gradient entries that differ from the oracle, also with the oracle's %d near-threshold ReLU units forced "
+                   "to the GPU's side:\n" % n_forced) + "\n".join(left[:20]) + "\nnear-threshold units: " + "; ".join(where)
 
 
 def relu_margin(eng):
@@ -397,6 +441,7 @@ def hip_train_case(name, meta, early_exit=False, fused=False):
     dev = eng.device
     out = {}
     agents = ("receiver", "sender", "baseline_rec", "baseline_sen") if fl.use_binary else ("receiver",)
+    eng.relu_capture = []
     for i in range(meta["n_minibatches"]):
         x, target, desc, (u_z, u_s, u_w) = case_inputs(meta, i, name)
         xd, td, dd = torch.from_numpy(x).to(dev), torch.from_numpy(target).to(dev), torch.from_numpy(desc).to(dev)
@@ -408,6 +453,10 @@ def hip_train_case(name, meta, early_exit=False, fused=False):
             eng.loss_stats()
             eng.backward(xd, td, dd)
         res = engine_result(eng, fl)
+        # the GPU's own ReLU pre-activations of this minibatch (assert_parity / forced_masks): y head at the output step =
+        # Astar + Cd, baselines = their stored hidden units
+        eng.relu_capture.append({k: eng.tape[k].detach().cpu().clone() for k in
+                                 (("Astar", "Cd", "hid_r", "hid_s") if fl.use_binary else ("Astar", "Cd"))})
         grads, norms = {}, {}
         for a in agents:
             grads[a] = {k: v.detach().cpu().clone() for k, v in eng.grads[a].items()}

@@ -37,11 +37,12 @@ def pytest_sessionfinish(session, exitstatus):
     with open(os.path.join(out, "parity_maxerr.json"), "w") as f:
         rel = {k: v for k, v in common.GATE.items() if v.startswith("rel")}
         json.dump({"note": "max |HIP - reference| per (case:quantity) over this pytest session.  Gate of the forward quantities "
-                           "(tests/common.py: compare_packed / assert_parity): |got - want| <= 1e-4 where |want| <= 1, and "
-                           "<= 1e-4 * |want| where |want| > 1 (summed log-likelihood losses of config 4 reach |want| ~ 100: "
-                           "one fp32 ulp there is 8e-6).  'relative_gate' lists every quantity the relative branch applied to; "
-                           "gradients / parameters: atol 1e-4 + rtol 1e-3 |want|, an entry beyond that must be fed by a ReLU unit "
-                           "with |pre-activation| < 2e-5 in the oracle's run (unexcused_gradient_problems)",
+                           "(tests/common.py: compare_packed / assert_parity): |got - want| <= 1e-4 ABSOLUTE for every quantity except the "
+                           "(label prefix, key suffix) pairs of common.RELATIVE_ALLOW = %r, which get max(1e-4, 16 fp32 ulp of |want|) "
+                           "(summed 256-bit log-likelihood losses of config 4: |want| ~ 600, one ulp = 6.1e-5).  'relative_gate' lists "
+                           "every quantity that branch applied to; gradients / parameters: atol 1e-4 + rtol 1e-3 |want| -- a mismatch "
+                           "is never excused: the oracle is re-run with its near-threshold ReLU units (|pre| < 2e-5) forced to the "
+                           "side the GPU put them on and must then agree on every entry ('<label>/forced' entries)" % (common.RELATIVE_ALLOW,),
                    "worst_forward": worst_fwd, "worst_forward_absolute_gate": max([v for k, v in common.MAXERR.items() if not common.is_grad_key(k) and k not in rel] or [0.0]),
                    "relative_gate": dict(sorted(rel.items())),
                    "entries": dict(sorted(common.MAXERR.items()))}, f, indent=1)

@@ -22,6 +22,9 @@ CASES = {
     "fixed": dict(use_binary=True, fixed_exchange=True, max_exchange=4, batch_size=12, entropy_rec=0.02,
                   learning_rate=1e-3, top_k_train=2,
                   img_feat_dim=16, img_h_dim=8, rec_w_dim=6, sender_out_dim=6, rec_hidden=5, wv_dim=7, baseline_hid_dim=9),
+    # -nouse_binary: loss = NLL mean over the global batch -- DataParallel skips the statistics launch and its all-reduce
+    "continuous": dict(use_binary=False, fixed_exchange=True, max_exchange=4, batch_size=12, learning_rate=1e-3, top_k_train=2,
+                       img_feat_dim=16, img_h_dim=8, rec_w_dim=6, sender_out_dim=6, rec_hidden=5, wv_dim=7, baseline_hid_dim=9),
 }
 N_CLASSES, N_MB = 4, 2
 

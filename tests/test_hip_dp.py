@@ -17,15 +17,29 @@ pytestmark = pytest.mark.gpu
 NAME = "g2_adaptive_c1"
 
 
+def _case(case):
+    """(name, meta): a golden case, or "c5": BASELINE configs[4]'s agents (D = 1000, continuous, Fixed) at 64 samples -- the
+    many-class path (k_conversation_mc / k_bwd_mc1/2), whose data-parallel step has no statistics collective."""
+    if case == "c5":
+        from oracle import cpu_ref
+        fl = cpu_ref.Flags(use_binary=False, fixed_exchange=True, max_exchange=10, batch_size=64, learning_rate=1e-4,
+                           img_feat_dim=512, img_h_dim=256, rec_w_dim=32, sender_out_dim=32, rec_hidden=64, wv_dim=100,
+                           baseline_hid_dim=500, top_k_train=6)
+        meta = dict(fl.__dict__)
+        meta.update(n_classes=1000, batch=64, n_minibatches=2, seed_weights=5, seed_data=6, seed_uniforms=7)
+        return None, meta
+    return case, common.load_golden(case)[1]
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
 
 
-def _run(eng, dp, meta, lo, n, philox):
+def _run(eng, dp, meta, lo, n, philox, name=NAME):
     dev = eng.device
     for i in range(meta["n_minibatches"]):
-        x, target, desc, (u_z, u_s, u_w) = common.case_inputs(meta, i, NAME)
+        x, target, desc, (u_z, u_s, u_w) = common.case_inputs(meta, i, name)
         xd, td, dd = [torch.from_numpy(a).to(dev) for a in (x[lo:lo + n], target[lo:lo + n], desc)]
         if philox:
             u = (None, None, None)
@@ -38,30 +52,34 @@ def _run(eng, dp, meta, lo, n, philox):
     torch.cuda.synchronize()
     out = {"%s.%s" % (a, k): v.cpu().numpy() for a, d in eng.params.items() for k, v in d.items()}
     out["losses"] = eng.tape["losses"].cpu().numpy()
+    out["totals"] = eng.tape["totals"].cpu().numpy()
     return out
 
 
-def _worker(rank, world, port, philox, out_dir):
+def _worker(rank, world, port, philox, out_dir, case=NAME):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from multimodalgame_amd.dist import DataParallel, shard_range
-    z, meta = common.load_golden(NAME)
+    name, meta = _case(case)
     lo, n = shard_range(meta["batch"], rank, world)
     eng = common.make_engine(meta, batch=n, global_batch=meta["batch"], batch_offset=lo)
-    out = _run(eng, DataParallel(eng), meta, lo, n, philox)
+    out = _run(eng, DataParallel(eng), meta, lo, n, philox, name)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("philox", [False, True])
-def test_two_ranks_on_one_gpu_equal_single_process(philox, tmp_path):
+@pytest.mark.parametrize("case,philox", [(NAME, False), (NAME, True), ("g3_continuous", False), ("c5", True)])
+def test_two_ranks_on_one_gpu_equal_single_process(case, philox, tmp_path):
+    """Binary / Adaptive: statistics all-reduce + gradient all-reduce.  Continuous cases ("g3_continuous": register-resident
+    kernels, k_stats launched by mmg_backward itself; "c5": many-class path, statistics workgroup inside k_bwd_mc2): ONE
+    collective -- the logged NLL and hit count of the global minibatch come out of the gradient buffer's tail quad."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), philox, str(tmp_path)), nprocs=world, join=True)
-    z, meta = common.load_golden(NAME)
+    mp.spawn(_worker, args=(world, _free_port(), philox, str(tmp_path), case), nprocs=world, join=True)
+    name, meta = _case(case)
     eng = common.make_engine(meta)
-    want = _run(eng, None, meta, 0, meta["batch"], philox)
+    want = _run(eng, None, meta, 0, meta["batch"], philox, name)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k, v in want.items():
         np.testing.assert_array_equal(r0[k], r1[k], err_msg="ranks diverged: " + k)

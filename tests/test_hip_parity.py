@@ -25,29 +25,25 @@ def _key(problem):
 
 @pytest.mark.parametrize("name", common.TRAIN_CASES)
 def test_train_case_vs_golden_and_oracle(name):
-    """Forward quantities, sampled bits, losses: must match the golden vectors (the reference's own
-    run) AND the CPU oracle run on this host.  Gradients / updated parameters: every entry must match
-    the golden vectors OR this host's oracle.  Reason: d relu/dx is discontinuous -- when a hidden unit
-    of the TARGET class row has |pre-activation| ~ 1e-6 its mask flips with the fp32 summation order
-    (observed: the oracle itself differs by 6.9e-3 in y1.bias.grad between a Xeon and an EPYC host
-    on g3_continuous mb1, one unit, dy = -1/B), so two correct implementations can legitimately
-    disagree there; an entry that matches neither pin is a real error."""
+    """Forward quantities, sampled bits, losses: must match the golden vectors (the reference's own run) AND the CPU oracle run
+    on this host, 1e-4 absolute.  Gradients / updated parameters: must match this host's oracle -- where a ReLU unit sits
+    within RELU_EPS of its threshold and the GPU put it on the other side, the oracle is re-run with that unit forced to the
+    GPU's side and must then agree everywhere (common.assert_parity; nothing is excused).  Against the golden vectors (made on
+    another host, whose oracle run may have put such a unit on either side: observed 6.9e-3 in y1.bias.grad between a Xeon
+    and an EPYC host on g3_continuous mb1, one unit, dy = -1/B) a gradient entry may differ only where this host's oracle
+    differs from the golden vectors too, or where the forced re-run was needed."""
     z, meta = common.load_golden(name)
     got, eng = common.hip_train_case(name, meta)
-    flips, dg, do = [], [], []
+    flips = []
     want = common.oracle_train_case(name, meta, flips=flips)
-    pg = common.compare_packed(got, z, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta), shift_invariant=True, label=name + "/golden", details=dg)
-    po = common.compare_packed(got, want, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta), shift_invariant=True, label=name + "/oracle", details=do)
-    is_grad = common.is_grad_key
-    hard = [p for p in pg + po if not is_grad(_key(p))]
-    both = sorted(set(map(_key, pg)) & set(map(_key, po)))
-    assert not hard, "forward mismatch (atol 1e-4, rtol 0):\n" + "\n".join(hard[:25])
-    assert not both, "gradient entries matching neither golden nor oracle:\n" + "\n".join(
-        [p for p in pg + po if _key(p) in both][:25])
-    # entries that match only ONE of the two pins: each must be fed by a ReLU unit whose pre-activation is on the threshold in
-    # this host's oracle run (|pre| < RELU_EPS) -- located per entry, not counted (common.unexcused_gradient_problems)
-    bad = common.unexcused_gradient_problems([d for d in dg + do if is_grad(d[0])], flips, common.param_shapes(eng))
-    assert not bad, "gradient mismatch no near-threshold ReLU unit explains:\n" + "\n".join(bad[:10])
+    first = common.assert_parity(got, want, flips, eng, name + "/oracle", skip=_skip_keys(meta), atol=ATOL, rtol=RTOL)
+    pg = common.compare_packed(got, z, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta), shift_invariant=True, label=name + "/golden")
+    hard = [p for p in pg if not common.is_grad_key(_key(p))]
+    assert not hard, "forward mismatch vs golden (atol 1e-4, rtol 0):\n" + "\n".join(hard[:25])
+    og = common.compare_packed(want, z, atol=ATOL, rtol=RTOL, skip=_skip_keys(meta), shift_invariant=True)
+    explained = set(map(_key, og)) | set(map(_key, first))
+    stray = [p for p in pg if _key(p) not in explained]
+    assert not stray, "gradient entries that match this host's oracle but not the golden vectors, although the oracle does:\n" + "\n".join(stray[:25])
 
 
 @pytest.mark.parametrize("name", ["g2_adaptive_c1", "g5_one_active", "g3_tiny_adam"])
