@@ -450,6 +450,14 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
         }
     }
+    if (h->mc_ok) {
+        // k_conversation_mc's 16 workgroups per tile spin on each other: with the per-XCD mapping a tile's members are 16 of 128
+        // consecutive ids, so in-order dispatch needs 128 of them resident (16 with consecutive ids); below that the tile /
+        // generic kernels run instead -- never a timed-out wait on a partitioned or masked device
+        const int mc_budget = budget_of((const void*)(k_conversation_mc<256, 32, 64, 100, 64>), 512, 0);
+        if (mc_budget < 128) h->mc_xcd = 0;
+        if (mc_budget < 16) h->mc_ok = false;
+    }
     if (h->conv_smem > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
@@ -692,7 +700,7 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
         Scope sc(h, st, "k_conversation_mc");
         const int ntile = (d.B + 15) / 16;
         ar.per = h->mc_per;
-        const int grid = h->mc_xcd ? ((ntile + 7) / 8) * 128 : ntile * 16;
+        const int grid = h->mc_xcd ? ((ntile + 7) / 8) * 128 : ntile * 16;     // (mc_xcd assumes the 8 XCDs of an unpartitioned MI355X; mmg_create clears it otherwise)
         hipLaunchKernelGGL((k_conversation_mc<256, 32, 64, 100, 64>), dim3(grid), dim3(512), 0, st, h->dm, h->P, h->tp, ar, ntile, h->mc_xcd, y_last_only);
         if (launch_check("k_conversation_mc")) return -1;
     } else {

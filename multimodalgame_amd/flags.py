@@ -176,6 +176,11 @@ def define_flags():
     DEFINE_integer("max_steps", 0, "stop training after this many optimizer steps (0 = run max_epoch epochs)")
     DEFINE_string("synthetic_data", None, "write synthetic train/dev HDF5 + descriptions + GloVe files into this "
                                           "directory (if missing) and train on them")
+    # data-parallel epoch loop: one process per GPU (python -m torch.distributed.run ... -m multimodalgame_amd.model ...);
+    # every minibatch of -batch_size samples is sharded over the ranks (multimodalgame_amd/dist.py)
+    DEFINE_integer("world_size", 0, "number of data-parallel ranks (0: WORLD_SIZE from the launcher's environment, else 1)")
+    DEFINE_integer("rank", -1, "this process's rank (-1: RANK from the launcher's environment, else 0)")
+    DEFINE_string("dist_backend", "nccl", "torch.distributed backend of the data-parallel job (\"nccl\" is RCCL on ROCm)")
 
 
 # presets, model.py:1605-1636

@@ -90,6 +90,7 @@ class Game(object):
             "Both sender and receiver should communicate with same dim vectors for now."     # model.py:1756
         self.seed = seed
         self._call = 0
+        self.rank, self.world, self.group, self._dp = 0, 1, None, {}
         self.engines = {}
         self.engine = None            # the first engine owns the flat buffers
         self.optimizers = None
@@ -108,6 +109,12 @@ class Game(object):
 
     def next_seed(self):
         return self.seed
+
+    def set_parallel(self, rank, world, group=None):
+        """Data-parallel training (dist.DataParallel): train_step() then takes THIS rank's rows of the global minibatch --
+        [rank * B / world, (rank + 1) * B / world) of the reference's batch (misc.py:257-302 order) -- and every rank ends
+        each step with the parameters of the single-process step on the whole batch."""
+        self.rank, self.world, self.group = int(rank), int(world), group
 
     def _adopt(self, eng):
         """Move the modules' parameters into the engine's flat buffer (values preserved)."""
@@ -131,6 +138,10 @@ class Game(object):
                 self._adopt(eng)
             self.engines[key] = eng
         return self.engines[key]
+
+    def train_engine_for(self, local_batch, n_classes=None):
+        """The engine train_step() uses for `local_batch` samples on this rank (the whole batch on one GPU)."""
+        return self.engine_for(local_batch, n_classes, global_batch=local_batch * self.world, batch_offset=self.rank * local_batch)
 
     # ------------------------------------------------------------------ model.py:725-876
     def exchange(self, exchange_args):
@@ -178,9 +189,14 @@ class Game(object):
     # ------------------------------------------------------------------ model.py:1240-1339
     def train_step(self, data, target, desc, uniforms=None):
         """exchange + masks + losses + four backward/clip/optimizer blocks, fused on the device.
-        Nothing is copied to the host; read ``losses()`` when a log line needs them."""
+        Nothing is copied to the host; read ``losses()`` when a log line needs them.
+        The step keeps only what training reads (include/mmg.h: run_all_steps == 2): per-(step, sample) tape arrays are valid on
+        the LIVE rows (t <= tstar[b]) only, in Fixed mode tape["y"] holds the output step only, and in continuous mode
+        (-nouse_binary) the arrays a / c / zr / dbar / g / w are NOT written -- code that wants them after a training step
+        calls exchange() (run-all) instead.  model.run's sample dump reads live rows of binary runs only
+        (flags.default_flags sets -exchange_samples 0 without -use_binary, model.py:1758-1759)."""
         B = data.size(0)
-        eng = self.engine_for(B, desc.size(0))
+        eng = self.train_engine_for(B, desc.size(0))
         u = uniforms or (None, None, None)
         # the Philox minibatch counter and the optimizer step (Adam bias correction) live in each engine's workspace: hand
         # them over when the batch size / class count -- hence the engine -- changes between steps
@@ -188,7 +204,14 @@ class Game(object):
         if last is not None and last is not eng:
             eng.tape["counter"].copy_(last.tape["counter"])
         self._train_engine = eng
-        eng.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed)
+        if self.world > 1:
+            dp = self._dp.get(id(eng))
+            if dp is None:
+                from .dist import DataParallel
+                dp = self._dp[id(eng)] = DataParallel(eng, group=self.group)
+            dp.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed)
+        else:
+            eng.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed)
         return eng
 
     def counters(self):

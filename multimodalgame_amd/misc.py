@@ -171,9 +171,18 @@ def cbow(descr, word_dict):
 _DATASET_CACHE = {}
 
 
+def _file_key(hdf5_file):
+    """Path + size + mtime: a file rewritten at the same path is a different dataset."""
+    path = os.path.abspath(os.path.expanduser(hdf5_file))
+    st = os.stat(path)
+    return (path, st.st_size, st.st_mtime_ns)
+
+
 def _dataset(hdf5_file, feats):
-    key = (os.path.abspath(os.path.expanduser(hdf5_file)), tuple(feats))
+    key = (_file_key(hdf5_file), tuple(feats))
     if key not in _DATASET_CACHE:
+        for old in [k for k in _DATASET_CACHE if k[0][0] == key[0][0] and k[1] == key[1]]:
+            del _DATASET_CACHE[old]                      # the previous contents of this path
         with hdf5io.File(hdf5_file, "r") as f:
             d = {"Target": f.read("Target")}
             d["Location"] = f.read("Location") if "Location" in f else np.array([b""] * len(d["Target"]))
@@ -206,8 +215,8 @@ def _shuffled_order(n):
         _lib.check(_lib.load().mmg_host_shuffle(words.ctypes.data_as(C.c_void_p), int(st[-1]), m, perm.ctypes.data_as(C.c_void_p)))
         return perm
     if _FAST_SHUFFLE is None:
+        saved = random.getstate()
         try:
-            saved = random.getstate()
             ok = True
             for seed, m in ((11, 1), (12, 2), (13, 1000), (14, 4099)):
                 random.seed(seed)
@@ -215,10 +224,13 @@ def _shuffled_order(n):
                 want = list(range(m))
                 random.shuffle(want)
                 ok = ok and got.tolist() == want
-            random.setstate(saved)
             _FAST_SHUFFLE = ok
         except Exception:                               # noqa: BLE001  (no library in this process: the interpreter's own loop)
             _FAST_SHUFFLE = False
+        finally:
+            random.setstate(saved)                      # the probe never leaves the caller's generator reseeded
+    # (the fast path reads the generator's state without advancing it; the epoch loop re-seeds before every shuffle --
+    #  random.seed(11 + epoch), misc.py:270 -- so nothing downstream depends on the state a shuffle leaves behind)
     if _FAST_SHUFFLE:
         return fast(n)
     order = list(range(n))
@@ -272,14 +284,31 @@ class _ResidentDataset(object):
 
 
 def _resident(hdf5_file, feats, device):
-    key = (os.path.abspath(os.path.expanduser(hdf5_file)), tuple(feats), str(device))
+    key = (_file_key(hdf5_file), tuple(feats), str(device))
     if key not in _RESIDENT_CACHE:
+        for old in [k for k in _RESIDENT_CACHE if k[0][0] == key[0][0] and k[1:] == key[1:]]:
+            del _RESIDENT_CACHE[old]                     # the previous contents of this path
         _RESIDENT_CACHE[key] = _ResidentDataset(_dataset(hdf5_file, feats), feats, device)
     return _RESIDENT_CACHE[key]
 
 
+RESIDENT_FRACTION = 0.5       # of the device's free memory: resident copy + the epoch's gathered copy must fit below it
+
+
+def _fits_on_device(data, feats, device):
+    """The device-resident epoch holds every requested feature array twice (the preloaded file and the epoch's batch-ordered
+    gather).  A dataset beyond RESIDENT_FRACTION of the free device memory streams from the host instead, batch by batch, as
+    the reference does (misc.py:284-302)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return True
+    need = 2 * sum(int(np.prod(data[name].shape)) * 4 for name in feats)
+    free, _ = torch.cuda.mem_get_info(device)
+    return need <= RESIDENT_FRACTION * free
+
+
 def load_hdf5(hdf5_file, batch_size, random_seed, shuffle, truncate_final_batch=False, map_labels=int,
-              feats=("avgpool_512",), device=None, with_ids=True):
+              feats=("avgpool_512",), device=None, with_ids=True, shard=None):
     """Generator of batch dicts with the reference's order semantics (misc.py:257-302): random.seed(11 + epoch) shuffle of
     range(N), consecutive slices of the shuffled order, indices SORTED inside a batch, last partial batch
     dropped unless truncate_final_batch.  Only the requested feature datasets are read (the reference
@@ -288,9 +317,26 @@ def load_hdf5(hdf5_file, batch_size, random_seed, shuffle, truncate_final_batch=
     device given: the epoch loop is DEVICE-RESIDENT.  The file is preloaded to the device once (features + mapped targets), the
     epoch's permutation is built on the host once, and ONE gather per epoch lays the samples out in batch order; a batch is
     then two tensor views -- no per-batch numpy indexing, no per-sample Python, no host-to-device copy.
-    with_ids=False skips the per-batch `example_ids` string array (the training loop never reads it)."""
+    with_ids=False skips the per-batch `example_ids` string array (the training loop never reads it).
+    shard=(rank, world): data-parallel epoch loop -- the GLOBAL batch order above is formed on every rank and this rank keeps
+    rows [rank * B / world, (rank + 1) * B / world) of every (sorted) batch (dist.shard_range), so the union over the ranks is
+    exactly the single-process batch."""
     data = _dataset(hdf5_file, feats)
     batches = _epoch_order(int(data["Target"].shape[0]), batch_size, random_seed, shuffle, truncate_final_batch)
+    if shard is not None and shard[1] > 1:
+        from .dist import shard_range
+        assert not truncate_final_batch, "a ragged final batch cannot be sharded evenly (training drops it, misc.py:279)"
+        lo, per = shard_range(batch_size, shard[0], shard[1])
+        batches = [idx[lo:lo + per] for idx in batches]
+    if device is not None and not _fits_on_device(data, feats, device):
+        for idx in batches:                              # streaming fallback: host batches, one copy per batch
+            batch = {"target": torch.tensor([map_labels(int(t)) for t in data["Target"][idx]], dtype=torch.int64).to(device)}
+            if with_ids:
+                batch["example_ids"] = data["Location"][idx]
+            for name in feats:
+                batch[name] = torch.from_numpy(_squeeze_feat(np.asarray(data[name][idx]))).float().to(device)
+            yield batch
+        return
     if device is not None:
         res = _resident(hdf5_file, feats, torch.device(device))
         flat = torch.from_numpy(np.concatenate(batches) if batches else np.zeros(0, np.int64)).to(res.device)

@@ -68,20 +68,77 @@ def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels
     return correct / total, extra
 
 
-def run(stats=None):
-    """stats: optional dict; the training loop leaves there what bench.py --cli reports: wall seconds of the epoch loop
-    (device-synchronised at both ends, eval_dev time excluded), minibatches and exchange steps (device-side count)."""
-    _flags.check_supported(FLAGS)                     # unsupported reference switches fail before anything is written
-    os.makedirs(FLAGS.log_path, exist_ok=True)
-    flogger = FileLogger(FLAGS.log_file)
-    VisdomLogger(env=FLAGS.env, experiment_name=FLAGS.experiment_name, enabled=FLAGS.visdom)
-    flogger.Log("Flag Values:\n" + json.dumps(FLAGS.FlagValuesDict(), indent=4, sort_keys=True))
-    if not os.path.exists(FLAGS.json_file):
-        with open(FLAGS.json_file, "w") as f:
-            f.write(json.dumps(FLAGS.FlagValuesDict(), indent=4, sort_keys=True))
+def _device(local_rank):
     if not torch.cuda.is_available():
         raise RuntimeError("multimodalgame_amd runs on MI355X only: no GPU visible and there is no CPU fallback")
-    device = torch.device("cuda", 0)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    return dev
+
+
+def _sync(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def parallel_env():
+    """(rank, world, local_rank) of the data-parallel job: -rank / -world_size, else what torch.distributed.run exports."""
+    world = FLAGS.world_size if FLAGS.world_size > 0 else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = FLAGS.rank if FLAGS.rank >= 0 else int(os.environ.get("RANK", "0"))
+    if not 0 <= rank < world:
+        raise ValueError("rank %d outside world_size %d" % (rank, world))
+    return rank, world, int(os.environ.get("LOCAL_RANK", str(rank)))
+
+
+class _Silent(object):
+    """Ranks > 0 of a data-parallel job: rank 0 alone writes the log, the flag dump, the confusion matrix and checkpoints."""
+
+    def Log(self, message, level=1):
+        pass
+
+
+def run(stats=None):
+    """The reference's run() (model.py:1001-1592) on the MI355X path.  One process per GPU: started under
+    `python -m torch.distributed.run --nproc-per-node N -m multimodalgame_amd.model ...` the OUTER EPOCH LOOP is data
+    parallel -- every rank forms the reference's global batch order (misc.py:257-302), keeps its B/N rows of every minibatch
+    (load_hdf5(shard=...)), and Game.train_step runs dist.DataParallel.train_step (statistics all-reduce + ONE gradient
+    all-reduce over RCCL, clip on the reduced gradient: the update of model.py:1307-1330 on the whole minibatch, identical on
+    all ranks).  Rank 0 logs, evaluates (eval_dev) and checkpoints; losses / training accuracy in its log lines are those of
+    the GLOBAL minibatch (they derive from the all-reduced statistics).
+
+    stats: optional dict; the training loop leaves there what bench.py --cli reports: wall seconds of the epoch loop
+    (device-synchronised at both ends, eval_dev time excluded), minibatches and exchange steps (device-side count)."""
+    _flags.check_supported(FLAGS)                     # unsupported reference switches fail before anything is written
+    rank, world, local_rank = parallel_env()
+    if world > 1 and FLAGS.batch_size % world:
+        raise ValueError("-batch_size %d does not divide over %d ranks" % (FLAGS.batch_size, world))
+    os.makedirs(FLAGS.log_path, exist_ok=True)
+    flogger = FileLogger(FLAGS.log_file) if rank == 0 else _Silent()
+    VisdomLogger(env=FLAGS.env, experiment_name=FLAGS.experiment_name, enabled=FLAGS.visdom and rank == 0)
+    flogger.Log("Flag Values:\n" + json.dumps(FLAGS.FlagValuesDict(), indent=4, sort_keys=True))
+    if rank == 0 and not os.path.exists(FLAGS.json_file):
+        with open(FLAGS.json_file, "w") as f:
+            f.write(json.dumps(FLAGS.FlagValuesDict(), indent=4, sort_keys=True))
+    device = _device(local_rank)
+    own_group = False
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group(FLAGS.dist_backend, rank=rank, world_size=world)
+            own_group = True
+        flogger.Log("Data parallel: {} ranks, {} samples of every {}-sample minibatch per rank, backend {}".format(
+            world, FLAGS.batch_size // world, FLAGS.batch_size, dist.get_backend()))
+    try:
+        _run(stats, flogger, device, rank, world)
+    finally:
+        if own_group:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def _run(stats, flogger, device, rank, world):
     torch.manual_seed(FLAGS.seed)
 
     sender = Sender(feature_type=FLAGS.img_feat, feat_dim=FLAGS.img_feat_dim, h_dim=FLAGS.img_h_dim,
@@ -103,7 +160,11 @@ def run(stats=None):
     desc_train, desc_dev = desc_train.to(device), desc_dev.to(device)
 
     game = Game(sender, receiver, baseline_sen, baseline_rec, device=device, seed=FLAGS.seed)
-    game.engine_for(FLAGS.batch_size, desc_train.size(0))                # parameters move into the flat GPU buffer
+    game.set_parallel(rank, world)
+    game.train_engine_for(FLAGS.batch_size // world, desc_train.size(0))  # parameters move into the flat GPU buffer
+    if world > 1:                                                        # every rank starts from rank 0's weights
+        import torch.distributed as dist
+        dist.broadcast(game.engine.flat_params, src=0)
     models_dict, optimizers_dict = game.models_dict(), game.optimizers_dict()
 
     epoch, step, best_dev_acc = 0, 0, 0
@@ -115,10 +176,12 @@ def run(stats=None):
         if "mmg_minibatch_counter" in data:              # resume the sampling stream where the checkpoint left it
             game.set_counters(data["mmg_minibatch_counter"], game.counters()[1])
 
-    def do_eval():
+    def do_eval():                                                        # (rank 0 only in a data-parallel job)
         return eval_dev(FLAGS.dev_file, FLAGS.batch_size_dev, epoch, FLAGS.shuffle_dev, FLAGS.top_k_dev, game, desc_dev,
                         map_labels_dev, FLAGS.conf_mat, device)
 
+    if (FLAGS.eval_only or FLAGS.binary_only) and rank != 0:
+        return                                                             # single-process modes: rank 0 does them
     if FLAGS.eval_only:                                                    # model.py:1166-1180
         if not os.path.exists(FLAGS.checkpoint):
             raise Exception("Must provide valid checkpoint.")
@@ -150,11 +213,11 @@ def run(stats=None):
 
     def finish():
         if stats is not None and totals0 is not None:
-            torch.cuda.synchronize(device)
+            _sync(device)
             tot = game._train_engine.tape["totals"].cpu().tolist()
             stats.update(train_seconds=_time.perf_counter() - t_loop - eval_seconds, minibatches=steps_run,
                          exchange_steps=tot[0] - totals0[0], sample_steps=tot[3] - totals0[3])
-    torch.cuda.synchronize(device)
+    _sync(device)
     t_loop = _time.perf_counter()
     while epoch < FLAGS.max_epoch:
         flogger.Log("Starting epoch: {}".format(epoch))
@@ -162,13 +225,13 @@ def run(stats=None):
             raise NotImplementedError                                      # model.py:1211 (cifar branch is broken upstream)
         for i_batch, batch in enumerate(load_hdf5(FLAGS.train_file, FLAGS.batch_size, epoch, FLAGS.shuffle_train,
                                                   map_labels=map_labels_train, feats=(FLAGS.img_feat,), device=device,
-                                                  with_ids=False)):
+                                                  with_ids=False, shard=(rank, world))):
             if totals0 is None:                      # (the first minibatch creates the engine)
-                totals0 = game.engine_for(batch["target"].size(0), desc_train.size(0)).tape["totals"].cpu().tolist()
+                totals0 = game.train_engine_for(batch["target"].size(0), desc_train.size(0)).tape["totals"].cpu().tolist()
                 hits_at_log = totals0[1]
             eng = game.train_step(batch[FLAGS.img_feat], batch["target"], desc_train)     # model.py:1240-1339
             steps_run += 1
-            if step % FLAGS.log_interval == 0:                             # model.py:1342-1377
+            if step % FLAGS.log_interval == 0 and rank == 0:               # model.py:1342-1377 (global-minibatch figures)
                 L = eng.losses()
                 hits_now = float(eng.tape["totals"][1])
                 n_seen = steps_run - steps_at_log                       # = min(minibatches of this process, log_interval)
@@ -186,11 +249,11 @@ def run(stats=None):
                     flogger.Log(pre + "Loss Baseline (R): {}".format(L["loss_bas_rec"]))
                 if FLAGS.exchange_samples > 0:                             # model.py:1411-1461 (train sample dump)
                     flogger.Log(_sample_dump(eng, "Train:"))
-            if step % FLAGS.log_dev == 0:                                  # model.py:1545-1576
-                torch.cuda.synchronize(device)
+            if step % FLAGS.log_dev == 0 and rank == 0:                    # model.py:1545-1576
+                _sync(device)
                 t_ev = _time.perf_counter()
                 dev_acc, extra = do_eval()
-                torch.cuda.synchronize(device)
+                _sync(device)
                 eval_seconds += _time.perf_counter() - t_ev
                 pre = "Epoch: {} Step: {} Batch: {} ".format(epoch, step, i_batch)
                 flogger.Log(pre + "Development Accuracy: {}".format(dev_acc))
@@ -201,7 +264,7 @@ def run(stats=None):
                     best_dev_acc = dev_acc
                     flogger.Log("Checkpointing with best Development Accuracy: {}".format(best_dev_acc))
                     torch_save(FLAGS.checkpoint + "_best", dict(step=step, best_dev_acc=best_dev_acc, mmg_minibatch_counter=game.counters()[0]), models_dict, optimizers_dict)
-            if step >= FLAGS.save_after and step % FLAGS.save_interval == 0:   # model.py:1579-1584
+            if step >= FLAGS.save_after and step % FLAGS.save_interval == 0 and rank == 0:   # model.py:1579-1584
                 flogger.Log("Checkpointing.")
                 torch_save(FLAGS.checkpoint, dict(step=step, best_dev_acc=best_dev_acc, mmg_minibatch_counter=game.counters()[0]), models_dict, optimizers_dict)
             step += 1

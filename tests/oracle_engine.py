@@ -1,0 +1,163 @@
+"""TEST INFRASTRUCTURE: an oracle-backed stand-in for multimodalgame_amd.engine.Engine, so that the HOST side of the product --
+Game, dist.DataParallel and the (data-parallel) epoch loop of model.run() -- can run on the CPU, with gloo, in the
+`-m "not gpu"` suite.  The product never imports this file: a test swaps it in explicitly (monkeypatching game.Engine and
+model._device); without that, Engine / model.run() raise on a machine without a GPU.
+
+It offers what those callers touch of the real engine: the flat parameter / gradient / optimizer-state buffers with the
+{agent: {state_dict key: view}} tables, the tape entries the host reads (totals, counter, losses and, after an eval-mode
+forward, the per-step arrays exchange() slices), forward / loss_stats / backward / clip_step / train_step, .stats, .use_binary.
+The math is oracle/dp_ref.ShardEngine (the literal oracle + autograd on the surrogate loss built from the GLOBAL statistics)."""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref, dp_ref
+from multimodalgame_amd import _lib
+
+
+class _Cfg(object):
+    pass
+
+
+class OracleEngine(dp_ref.ShardEngine):
+    instances = []
+
+    def __init__(self, device="cpu", share=None, batch=None, n_classes=None, global_batch=None, batch_offset=0, **cfg):
+        fl = cpu_ref.Flags(use_binary=cfg["use_binary"], fixed_exchange=cfg["fixed_exchange"], max_exchange=cfg["max_exchange"],
+                           batch_size=global_batch or batch, learning_rate=cfg["learning_rate"], entropy_s=cfg["entropy_s"],
+                           entropy_sen=cfg["entropy_sen"], entropy_rec=cfg["entropy_rec"], img_feat_dim=cfg["feat_dim"],
+                           img_h_dim=cfg["h_dim"], rec_w_dim=cfg["w_dim"], sender_out_dim=cfg["w_dim"], rec_hidden=cfg["rec_hidden"],
+                           wv_dim=cfg["wv_dim"], baseline_hid_dim=cfg["bas_hidden"], top_k_train=cfg["top_k"],
+                           optim_type=cfg["optim_type"], first_rec=cfg["first_rec"], s_prob_prod=cfg["s_prob_prod"])
+        self.device = torch.device("cpu")
+        self.cfg = _Cfg()
+        self.cfg.batch, self.cfg.use_binary, self.cfg.n_classes = batch, int(bool(cfg["use_binary"])), n_classes
+        self.B, self.boff, self.top_k = batch, batch_offset, cfg["top_k"]
+        # the flat buffer's layout is the library's (host-only layout query; no GPU involved)
+        table = _lib.param_table(_lib.make_config(batch=batch, n_classes=n_classes, **cfg))
+        self.n_params = int(_lib.load().mmg_param_count(C.byref(_lib.make_config(batch=batch, n_classes=n_classes, **cfg))))
+        if share is not None:
+            models = share.models
+            self.flat_params, self.opt_state = share.flat_params, share.opt_state
+        else:
+            torch.manual_seed(0)
+            models = cpu_ref.build_agents(fl, rng=cpu_ref.UniformTape())
+            self.flat_params = torch.zeros(self.n_params)
+            self.opt_state = torch.zeros(2 * self.n_params)
+        dp_ref.ShardEngine.__init__(self, fl, models, global_batch or batch)
+        if share is not None:
+            self.optimizers = share.optimizers
+        self._n_grad = self.flat_grads.numel()
+        self.flat_grads = torch.zeros(self._n_grad + 4)            # + the library's tail quad (include/mmg.h: mmg_grad_floats)
+        self.params = {a: {} for a in _lib.AGENTS}
+        for e in table:
+            numel = e["rows"] * max(e["cols"], 1)
+            view = self.flat_params[e["offset"]:e["offset"] + numel].view((e["rows"], e["cols"]) if e["cols"] else (e["rows"],))
+            self.params[e["agent"]][e["name"]] = view
+            if share is None:
+                p = dict(models[e["agent"]].named_parameters())[e["name"]]
+                view.copy_(p.data)
+                p.data = view                       # the oracle's modules train the flat buffer in place
+        T = self.T
+        self.tape = {"totals": torch.zeros(4, dtype=torch.float64), "counter": torch.zeros(4, dtype=torch.int64),
+                     "losses": torch.zeros(8), "tstar": torch.zeros(batch, dtype=torch.int32)}
+        OracleEngine.instances.append(self)
+
+    # ------------------------------------------------------------------ sampling: invariant to the sharding
+    def _uniforms(self, seed):
+        """Counter-based stand-in for the in-kernel Philox streams: keyed by (seed, minibatch counter), drawn for the GLOBAL
+        minibatch, this rank's columns cut out -- so any sharding consumes the same numbers per global sample."""
+        fl = self.fl
+        rs = np.random.RandomState((int(seed) * 1000003 + int(self.tape["counter"][0])) % (2 ** 31))
+        lo, hi = self.boff, self.boff + self.B
+        u_z = rs.rand(self.T, self.Bg, fl.rec_w_dim)[:, lo:hi]
+        u_s = rs.rand(self.T, self.Bg, 1)[:, lo:hi]
+        u_w = rs.rand(self.T, self.Bg, fl.rec_w_dim)[:, lo:hi]
+        return u_z, u_s, u_w
+
+    def forward(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0, train=True, run_all=False, minimal=False):
+        if not train:
+            return self._eval_forward(x, target, desc)
+        if u_z is None:
+            u_z, u_s, u_w = self._uniforms(seed)
+        dp_ref.ShardEngine.forward(self, x, target, desc, u_z, u_s, u_w)
+        self.tape["tstar"] = self.saved["tstar"].to(torch.int32)
+
+    def _eval_forward(self, x, target, desc):
+        fl, m = self.fl, self.models
+        with torch.no_grad():
+            s, sen_w, rec_w, y, _, _ = cpu_ref.exchange(m["sender"], m["receiver"], None, None,
+                                                        dict(data=x, target=target, desc=desc, train=False, break_early=False), fl)
+        B, T = x.size(0), self.T
+        st = lambda lst: torch.stack([t.detach().float().view(B, -1) for t in lst])
+        self.tape.update(mask=torch.stack([mm.view(B, 1) for mm in s[0]]).to(torch.uint8), s=st(s[1]), ps=st(s[2]),
+                         z=st(sen_w[0]), pz=st(sen_w[1]) if fl.use_binary else None, w=st(rec_w[0]),
+                         pw=st(rec_w[1]) if fl.use_binary else None, y=st(y),
+                         hx=torch.zeros(B, fl.img_h_dim), h=torch.zeros(T + 1, B, fl.rec_hidden), g=torch.zeros(T, B, fl.rec_hidden))
+        # (exchange() re-forces the last mask itself; the engine's tape keeps the running minimum: undo cpu_ref's fill_(0))
+        self.tape["mask"][-1] = torch.min(self.tape["mask"][-2], self.tape["s"][-1].to(torch.uint8))
+
+    def loss_stats(self):
+        if self.fl.use_binary:
+            dp_ref.ShardEngine.loss_stats(self)
+        else:
+            self.stats.zero_()
+            self.stats[dp_ref.stat_glob(self.T, 0)] = self.saved["logs"].double().sum()
+        sv = self.saved
+        top = sv["dist"].detach().numpy().argsort()[:, -self.top_k:]
+        self.stats[dp_ref.stat_glob(self.T, 1)] = float((top == sv["target"].view(-1, 1).numpy()).sum())
+
+    def backward(self, x, target, desc):
+        if not self.fl.use_binary:                  # (the real mmg_backward forms the two sums itself in continuous mode)
+            self.loss_stats()
+        full, self.flat_grads = self.flat_grads, self.flat_grads[:self._n_grad]      # (a view: the copy lands in `full`)
+        dp_ref.ShardEngine.backward(self, x, target, desc)
+        self.flat_grads = full
+        self._bookkeeping()
+        # the library's tail quad behind the gradients: [1] sum of rewards, [2] hits of THIS rank (include/mmg.h)
+        self.flat_grads[self._n_grad:] = torch.tensor([0.0, float(self.stats[dp_ref.stat_glob(self.T, 0)]),
+                                                      float(self.stats[dp_ref.stat_glob(self.T, 1)]), 0.0])
+
+    def _bookkeeping(self):
+        """tape["losses"] from the (global) statistics -- kernels_bwd.h: loss_coefficients."""
+        T, fl, st = self.T, self.fl, self.stats
+        cw, ce, cb = dp_ref.coefficients(st, T, fl)
+        L = [0.0] * 5
+        for k in range(3):
+            for t in range(T):
+                L[k] += -cw[k, t] * float(st[dp_ref.stat_stream(T, k, t, 3)]) + ce[k, t] * float(st[dp_ref.stat_stream(T, k, t, 4)])
+        for t in range(T):
+            L[3] += 0.5 * cb[t] * float(st[dp_ref.stat_bas(T, 0, t)])
+            L[4] += 0.5 * cb[t] * float(st[dp_ref.stat_bas(T, 1, t)])
+        n_steps = sum(1 for t in range(T) if float(st[dp_ref.stat_stream(T, 2, t, 0)]) > 0) if fl.use_binary else T
+        self.tape["losses"] = torch.tensor([-float(st[dp_ref.stat_glob(T, 0)]) / self.Bg] + L + [float(n_steps), float(st[dp_ref.stat_glob(T, 1)])])
+
+    def clip_step(self):
+        tail = self.flat_grads[self._n_grad:]
+        grads = self.flat_grads[:self._n_grad]
+        if not self.fl.use_binary:                  # k_gradnorm's rewrite from the all-reduced tail
+            self.tape["losses"][0] = -float(tail[1]) / self.Bg
+            self.tape["losses"][7] = float(tail[2])
+        keep, self.flat_grads = self.flat_grads, grads
+        dp_ref.ShardEngine.clip_step(self)
+        self.flat_grads = keep
+        tot, L = self.tape["totals"], self.tape["losses"]
+        live = sum(float(self.stats[dp_ref.stat_stream(self.T, 2, t, 0)]) for t in range(self.T)) if self.fl.use_binary else self.T * self.Bg
+        tot += torch.tensor([float(L[6]), float(L[7]), 1.0, live], dtype=torch.float64)
+        self.tape["counter"][0] += 1
+        self.tape["counter"][1:3] += 1
+
+    def train_step(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0):
+        self.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True)
+        self.loss_stats()
+        self.backward(x, target, desc)
+        self.clip_step()
+
+    def losses(self):
+        keys = ("nll_loss", "loss_binary_s", "loss_binary_rec", "loss_binary_sen", "loss_bas_rec", "loss_bas_sen", "n_steps", "hits")
+        return dict(zip(keys, self.tape["losses"].tolist()))
+
+    def check_sync(self):
+        pass

@@ -115,3 +115,47 @@ def test_optimizer_state_roundtrip_with_torch_optim(kind):
     opt2.load_state_dict(sd)
     for i in range(len(names)):
         torch.testing.assert_close(opt2.state_dict()["state"][i][key], opt.state_dict()["state"][i][key])
+
+
+def _dp_worker(rank, world, port, argv):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    from multimodalgame_amd import model, flags
+    flags.define_flags(); flags.FLAGS.Reset()
+    model.main(argv)
+
+
+@pytest.mark.parametrize("mode", ["adaptive", "continuous"])
+def test_data_parallel_model_run(mode, tmp_path):
+    """the OUTER EPOCH LOOP sharded over the ranks.  Two gloo ranks of `python -m multimodalgame_amd.model`
+    share this box's GPU (LOCAL_RANK % device_count), each trains on its 32 rows of every 64-sample minibatch of the
+    reference's batch order; rank 0 alone logs / evaluates / checkpoints.  The checkpoint after 12 optimizer steps must hold
+    the parameters of the one-process run (in-kernel Philox sampling is keyed by the global sample index), and the log lines
+    the losses / training accuracy of the global minibatch.  (The CPU twin of this test, with an oracle-backed engine, is
+    tests/test_dp_epoch_loop.py.)"""
+    import socket
+    import torch.multiprocessing as mp
+    from multimodalgame_amd import model, flags
+    tmp = str(tmp_path)
+    extra = ["-max_steps", "12", "-save_after", "0", "-save_interval", "1", "-exchange_samples", "0"]
+    if mode == "continuous":
+        extra += ["-nouse_binary", "-model_type", "Fixed", "-max_exchange", "4"]
+    flags.define_flags(); flags.FLAGS.Reset()
+    model.main(_argv(tmp, "one", extra))
+    flags.FLAGS.Reset()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_worker, args=(2, port, _argv(tmp, "dp", extra + ["-dist_backend", "gloo"])), nprocs=2, join=True)
+    one = torch.load(os.path.join(tmp, "logs", "one.pt"), weights_only=False)
+    dp = torch.load(os.path.join(tmp, "logs", "dp.pt"), weights_only=False)
+    assert one["data"]["step"] == dp["data"]["step"] == 11
+    for agent, sd in one["models"].items():
+        for k, v in sd.items():
+            if agent == "receiver" and k == "y2.bias":
+                continue                                  # exact gradient 0: see tests/common.py
+            torch.testing.assert_close(dp["models"][agent][k], v, rtol=2e-4, atol=2e-6, msg="%s.%s" % (agent, k))
+    grab = lambda name: [ln.split("] ", 1)[1] for ln in open(os.path.join(tmp, "logs", name + ".log"))
+                         if "Training Accuracy" in ln or "Loss Receiver (Y)" in ln]
+    a, b = grab("dp"), grab("one")
+    assert len(a) == len(b) >= 4 and "Data parallel: 2 ranks, 32 samples of every 64-sample minibatch per rank" in open(os.path.join(tmp, "logs", "dp.log")).read()
+    for la, lb in zip(a, b):
+        assert la.rsplit(": ", 1)[0] == lb.rsplit(": ", 1)[0]
+        assert abs(float(la.rsplit(": ", 1)[1]) - float(lb.rsplit(": ", 1)[1])) < 1e-4, (la, lb)
