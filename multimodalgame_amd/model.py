@@ -58,9 +58,10 @@ def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels
                 prev = msg
             acc.append(h / float(len(feats)))
     true_labels, pred_labels = np.concatenate(true_labels), np.concatenate(pred_labels)
-    n_cls = int(max(true_labels.max(), pred_labels.max())) + 1
-    conf = np.zeros((n_cls, n_cls), np.int64)
-    np.add.at(conf, (true_labels, pred_labels), 1)                      # sklearn.confusion_matrix (model.py:709)
+    # sklearn.metrics.confusion_matrix (model.py:709): rows / columns = the SORTED CLASSES THAT OCCUR in truth or prediction
+    labels = np.unique(np.concatenate([true_labels, pred_labels]))
+    conf = np.zeros((labels.size, labels.size), np.int64)
+    np.add.at(conf, (np.searchsorted(labels, true_labels), np.searchsorted(labels, pred_labels)), 1)
     np.savetxt(conf_mat_path, conf, delimiter=",", fmt="%d")
     cl = np.array(conversation_lengths)
     extra = dict(conversation_lengths_mean=cl.mean(), conversation_lengths_std=cl.std(),

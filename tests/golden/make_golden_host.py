@@ -11,6 +11,11 @@
                           recorder: the `Communication` / `Predictions` records incl. the Rank formula (:98) and the
                           Index convention (sender 2i, receiver 2i + 1).
 
+  g8_eval_dev.npz         model.eval_dev (model.py:580-722) itself, on two deterministic dev batches (the second one SHORT: the
+                          nominal-batch denominator of :667), load_hdf5 replaced by a generator of the seeded batches:
+                          accuracy, conversation-length mean / std, both mean Hamming distances and the confusion matrix
+                          (sklearn.metrics.confusion_matrix: labels = the sorted classes that OCCUR in truth or prediction).
+
 Run in the build container only (needs /root/reference); only numbers are written.
 usage: python tests/golden/make_golden_host.py [--ref /root/reference] [--out tests/golden]
 """
@@ -144,6 +149,41 @@ def case_g7(ref, FLAGS, ref_dir):
     return out
 
 
+def case_g8(ref, FLAGS, tmp_dir):
+    fl = MG.make_flags(use_binary=True, fixed_exchange=False, max_exchange=5, batch_size=8, top_k_train=2, top_k_dev=2, **MG.TINY)
+    MG.set_flags(FLAGS, fl)
+    FLAGS.conf_mat = os.path.join(tmp_dir, "g8.conf_mat.txt")
+    FLAGS.attn_extra_context, FLAGS.bit_flip, FLAGS.corrupt_region = False, False, None
+    torch.manual_seed(0)
+    models = MG.build_ref_models(ref, FLAGS)
+    seeds = dict(weights=79, data=62)
+    cpu_ref.load_filled(models, seed=seeds["weights"])
+    with torch.no_grad():
+        models["receiver"].s.bias.fill_(0.9)                           # conversations of mixed lengths (round(prod p_s))
+    n_classes, batch, sizes = 7, 8, (8, 5)                             # nominal dev batch 8, the final one holds 5 samples
+    x0, t0, desc = cpu_ref.synthetic_batch(sizes[0], n_classes, fl.img_feat_dim, fl.wv_dim, seed=seeds["data"])
+    x1, t1, _ = cpu_ref.synthetic_batch(sizes[1], n_classes, fl.img_feat_dim, fl.wv_dim, seed=seeds["data"] + 1)
+    t0, t1 = np.minimum(t0, 5), np.minimum(t1, 5)                      # class 6 never occurs as a target: confusion-matrix labels
+
+    def fake_load_hdf5(dev_file, batch_size, epoch, shuffle, truncate_final_batch=False, map_labels=int):
+        assert truncate_final_batch and batch_size == batch
+        for x, t in ((x0, t0), (x1, t1)):
+            yield {"target": torch.from_numpy(t), "avgpool_512": torch.from_numpy(x)}
+    ref.load_hdf5 = fake_load_hdf5
+    for m in models.values():
+        m.eval()
+    acc, extra = ref.eval_dev("dev", batch, 0, False, False, fl.top_k_dev, models["sender"], models["receiver"],
+                              {"desc": torch.from_numpy(desc)}, int, "unused")
+    conf = np.loadtxt(FLAGS.conf_mat, delimiter=",", dtype=np.int64, ndmin=2)
+    out = dict(seed_weights=seeds["weights"], seed_data=seeds["data"], n_classes=n_classes, batch=batch, sizes=np.array(sizes),
+               target0=t0, target1=t1, accuracy=float(acc), conversation_lengths_mean=float(extra["conversation_lengths_mean"]),
+               conversation_lengths_std=float(extra["conversation_lengths_std"]),
+               hamming_sen_mean=float(extra["hamming_sen_mean"]), hamming_rec_mean=float(extra["hamming_rec_mean"]),
+               conf_mat=conf, s_bias=0.9)
+    out["meta"] = MG.flags_to_meta(fl, n_classes, batch, dict(weights=79, data=62, uniforms=0), 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -152,7 +192,10 @@ def main():
     ref, FLAGS = MG.load_reference(a.ref)
     np.savez_compressed(os.path.join(a.out, "g6_desc_pipeline.npz"), **case_g6(a.ref))
     np.savez_compressed(os.path.join(a.out, "g7_binary_vectors.npz"), **case_g7(ref, FLAGS, a.ref))
-    print("wrote g6_desc_pipeline.npz, g7_binary_vectors.npz")
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez_compressed(os.path.join(a.out, "g8_eval_dev.npz"), **case_g8(ref, FLAGS, tmp))
+    print("wrote g6_desc_pipeline.npz, g7_binary_vectors.npz, g8_eval_dev.npz")
 
 
 if __name__ == "__main__":

@@ -105,3 +105,68 @@ def test_binary_vectors_match_reference(tmp_path):
     np.testing.assert_allclose(preds["StopProb"], z["pred_stop_prob"], atol=1e-5)
     np.testing.assert_array_equal(preds["StopVec"], z["pred_stop_vec"])
     np.testing.assert_array_equal(preds["StopMask"], z["pred_stop_mask"])
+
+
+def _eval_dev_vs_reference(tmp_path, monkeypatch, dev):
+    """model.eval_dev against the reference's own eval_dev (model.py:580-722) on the same weights and the same two dev batches
+    (the second one short): accuracy with the NOMINAL batch size in the denominator (:667), conversation-length mean / std,
+    mean Hamming distances of both agents' messages, and the confusion matrix as sklearn lays it out (only classes that occur)."""
+    from multimodalgame_amd import flags as _flags, model
+    from multimodalgame_amd.agents import Baseline, Receiver, Sender
+    from multimodalgame_amd.game import Game
+    from oracle import cpu_ref
+    z, meta = common.load_golden("g8_eval_dev")
+    fl = common.flags_from_meta(meta)
+    _flags.define_flags(); _flags.FLAGS.Reset()
+    argv = ["model.py", "-model_type", "Adaptive", "-max_exchange", str(fl.max_exchange), "-rec_w_dim", str(fl.rec_w_dim),
+            "-sender_out_dim", str(fl.sender_out_dim), "-img_h_dim", str(fl.img_h_dim), "-rec_hidden", str(fl.rec_hidden),
+            "-wv_dim", str(fl.wv_dim), "-baseline_hid_dim", str(fl.baseline_hid_dim), "-use_binary", "-top_k_dev", "2",
+            "-log_path", str(tmp_path)]
+    _flags.FLAGS(argv)
+    _flags.default_flags(argv)
+    F = _flags.FLAGS
+    F.img_feat_dim = fl.img_feat_dim
+    sender = Sender("avgpool_512", fl.img_feat_dim, fl.img_h_dim, fl.rec_w_dim, fl.sender_out_dim, True, False, 0, False, 0)
+    receiver = Receiver(fl.sender_out_dim, fl.wv_dim, fl.rec_hidden, 1, fl.rec_w_dim, 1, True)
+    game = Game(sender, receiver, Baseline(fl.baseline_hid_dim, fl.img_h_dim, fl.rec_w_dim, 0),
+                Baseline(fl.baseline_hid_dim, 0, fl.rec_w_dim, fl.rec_hidden), device=dev)
+    B, D = int(z["batch"]), int(z["n_classes"])
+    eng = game.engine_for(B, D)
+    shapes = {a: {k: tuple(v.shape) for k, v in d.items()} for a, d in eng.params.items()}
+    for a, d in cpu_ref.fill_state_dicts(shapes, seed=int(z["seed_weights"])).items():
+        for k, v in d.items():
+            eng.params[a][k].copy_(torch.as_tensor(v, dtype=torch.float32).view_as(eng.params[a][k]))
+    eng.params["receiver"]["s.bias"].fill_(float(z["s_bias"]))
+    sizes = [int(v) for v in z["sizes"]]
+    x0, _, desc = cpu_ref.synthetic_batch(sizes[0], D, fl.img_feat_dim, fl.wv_dim, seed=int(z["seed_data"]))
+    x1, _, _ = cpu_ref.synthetic_batch(sizes[1], D, fl.img_feat_dim, fl.wv_dim, seed=int(z["seed_data"]) + 1)
+    dev = torch.device(dev)
+
+    def fake_load_hdf5(dev_file, batch_size, epoch, shuffle, truncate_final_batch=False, map_labels=int, feats=(), device=None, **kw):
+        assert truncate_final_batch and batch_size == B
+        for x, t in ((x0, z["target0"]), (x1, z["target1"])):
+            yield {"target": torch.from_numpy(t.astype(np.int64)).to(dev), "avgpool_512": torch.from_numpy(x).to(dev)}
+    monkeypatch.setattr(model, "load_hdf5", fake_load_hdf5)
+    conf_path = str(tmp_path / "conf.txt")
+    acc, extra = model.eval_dev("dev", B, 0, False, 2, game, torch.from_numpy(desc).to(dev), int, conf_path, dev)
+    assert acc == pytest.approx(float(z["accuracy"]), abs=1e-12)
+    for k in ("conversation_lengths_mean", "conversation_lengths_std"):
+        assert float(extra[k]) == pytest.approx(float(z[k]), abs=1e-9), k
+    for k in ("hamming_sen_mean", "hamming_rec_mean"):
+        assert float(extra[k]) == pytest.approx(float(z[k]), abs=1e-6), k
+    np.testing.assert_array_equal(np.loadtxt(conf_path, delimiter=",", dtype=np.int64, ndmin=2), z["conf_mat"])
+    _flags.FLAGS.Reset()
+
+
+@pytest.mark.gpu
+def test_eval_dev_matches_reference(tmp_path, monkeypatch):
+    _eval_dev_vs_reference(tmp_path, monkeypatch, "cuda:0")
+
+
+def test_eval_dev_host_logic_matches_reference_cpu(tmp_path, monkeypatch):
+    """The same comparison without a GPU: the host side of eval_dev (nominal-batch denominator, conversation lengths, Hamming
+    means, sklearn-style confusion matrix) over the oracle-backed engine stand-in (tests/oracle_engine.py, swapped in here)."""
+    from multimodalgame_amd import game
+    from tests import oracle_engine
+    monkeypatch.setattr(game, "Engine", oracle_engine.OracleEngine)
+    _eval_dev_vs_reference(tmp_path, monkeypatch, "cpu")
