@@ -76,9 +76,38 @@ namespace mmg {
 // sample, so they run concurrently with the rest of the recurrence instead of after it.
 // (Rejected, measured: every sample role deriving the coefficients itself from the score partials -- in waves 0-3:
 //  +64 live registers, AGPR spills, +4 us; in a dedicated fifth wave: +8 us, it outlasts the weight prologue.)
+// dbar = softmax(y) . desc (model.py:442-449) for 16 (step, sample) rows, on the matrix cores: [16, 32] x [32, V].  The forward
+// kernel of kernels_fast3.h folds the description product onto the classes (Dd) and never forms dbar; only the weight-gradient job
+// of w_d reads it, so it is made HERE, by workgroups the backward launch carries along on idle CUs (nothing in this launch depends
+// on them; k_wgrad is the next launch).  Dead rows hold stale softmax rows (finite): their dgpre is zero / they are not in the row list.
+template <int V>
+__device__ __forceinline__ void dbar_role(const Dims& dm, const Tape& tp, int tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+    const int rows = dm.T * dm.B, r0 = tile * 16, Dr = dm.D;
+    const float* prow = tp.pi + (size_t)min(r0 + i, rows - 1) * 32;
+    float a[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) a[ks] = prow[4 * ks + q];
+    constexpr int NTILE = (V + 15) / 16;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int nt = wave + 4 * u;
+        if (nt >= NTILE) break;                                              // (wave-uniform)
+        const int n = nt * 16 + i;
+        float bv[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { const int d = 4 * ks + q; bv[ks] = (d < Dr && n < V) ? tp.descc[(size_t)min(d, Dr - 1) * V + min(n, V - 1)] : 0.f; }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc = mfma16(a[ks], bv[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = r0 + 4 * q + r; if (row < rows && n < V) tp.dbar[(size_t)row * V + n] = acc[r]; }
+    }
+}
+
 template <int H, int W, int R, int V, int D, bool MERGED, bool MERGE_DC>
 __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int n_stats,
-                                                          int zero_dead) {
+                                                          int zero_dead, int n_dbar) {
     constexpr int NT = 256, K4 = NT / R;          // 4 lanes per output unit of the R-wide transposed products
     constexpr int TMAX = 16;
     static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
@@ -105,6 +134,10 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
 #ifdef MMG_TIMING
         if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[128 + 50] = (long long)wall_clock64();
 #endif
+        return;
+    }
+    if ((int)blockIdx.x >= (int)gridDim.x - n_dbar) {      // trailing workgroups: dbar tiles (k_conversation_fast3 left softmax rows only)
+        dbar_role<V>(dm, tp, (int)blockIdx.x - ((int)gridDim.x - n_dbar));
         return;
     }
     if (MERGE_DC && (int)blockIdx.x >= n_stats + dm.B) {
@@ -495,6 +528,9 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     const bool binary = dm.use_binary != 0, train = ar.train != 0;
     const bool inject = ar.u_s != nullptr;
     MMG_STAMP(0);
+#ifdef MMG_TIMING
+    if (b == 0 && tid == 0) tp.dbg[4] = (long long)__builtin_readcyclecounter();      // s_memtime: shader cycles on gfx950
+#endif
     const uint32_t mb_counter = tp.counter[0];
     const uint32_t gb = (uint32_t)(dm.boff + b);
     if (train && inject) {
@@ -786,6 +822,9 @@ __global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P
     }
     __syncthreads();
     MMG_STAMP(3);
+#ifdef MMG_TIMING
+    if (b == 0 && tid == 0) tp.dbg[5] = (long long)__builtin_readcyclecounter();
+#endif
     // ------------------------------------------------------------ log-likelihood / neg-entropy sums of all steps (model.py:908-922)
     {
         const int tt = tid >> 5, j = tid & 31;                              // one (step, bit) per thread

@@ -41,6 +41,25 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         const float* by1 = P.p[R_Y1_B];
         const bool vec = ((ld & 3) == 0) && ((R & 3) == 0) && ((V & 3) == 0);
         float cy_part = 0.f;
+        // threads [R, 2R) (when the block has them): Dd[d, r] = sum_v w_d[r, v] desc[d, v] -- the query head's description
+        // product folded onto the classes, formed beside Cd (kernels_fast3.h: g = tanh(w_h h + b_h + softmax(y) . Dd))
+        for (int rr = tid; rr < 2 * R; rr += blockDim.x) {
+            if (rr < R) continue;
+            const int r = rr - R;
+            const float* wrow = P.p[R_WD_W] + (size_t)r * V;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            if ((V & 3) == 0) {
+#pragma unroll 8
+                for (int v = 0; v < V; v += 4) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wrow + v);
+                    const float4 dv = *reinterpret_cast<const float4*>(s_desc + v);
+                    a0 = fmaf(wv.x, dv.x, a0); a1 = fmaf(wv.y, dv.y, a1); a2 = fmaf(wv.z, dv.z, a2); a3 = fmaf(wv.w, dv.w, a3);
+                }
+            } else {
+                for (int v = 0; v < V; ++v) a0 = fmaf(wrow[v], s_desc[v], a0);
+            }
+            tp.Dd[(size_t)d * R + r] = (a0 + a1) + (a2 + a3);
+        }
         for (int r = tid; r < R; r += blockDim.x) {
             const float* wrow = P.p[R_Y1_W] + (size_t)r * ld + R;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;

@@ -87,6 +87,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(hx, float, 0, 2, B, H, 1)          /* image_layer(x)            model.py:195 */ \
     X(Cd, float, 0, 2, D, R, 1)          /* desc . W_y1[:,R:]^T + b_y1 (App. A.2)  */ \
     X(descc, float, 0, 2, D, V, 1)       /* copy of the description matrix (GEMM operand inside the workspace) */ \
+    X(Dd, float, 0, 2, D, R, 1)          /* desc . w_d^T: W_d (softmax(y) . desc) = softmax(y) . Dd (kernels_fast3.h)    */ \
     X(CdT, float, 0, 2, R, D, 1)         /* -Cd transposed: class index contiguous (kernels_tile.h, many-class y head) */ \
     X(cy, float, 0, 1, D, 1, 1)          /* b_y2 + sum_r w_y2[r] Cd[d][r]                                              */ \
     X(mstate, float, 0, 1, B, 1, 1)      /* running stop mask m_t between the per-step launches of one conversation */ \
@@ -116,6 +117,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(sprod, float, 0, 1, B, 1, 1)       /* eval: running product of stop probs    */ \
     X(y, float, 0, 3, T, B, D)           /* class logits per step            :859  */ \
     X(dbar, float, 0, 3, T, B, V)        /* softmax(y) . desc                :449  */ \
+    X(pi, float, 0, 3, T, B, 32)         /* softmax(y_t), <= 32 classes (kernels_fast3.h): dbar = pi . desc is formed by roles of the backward launch */ \
     X(g, float, 0, 3, T, B, R)           /* receiver.h_w                     :452  */ \
     X(w, float, 0, 3, T, B, W)           /* receiver message (rec_feats)     :857  */ \
     X(pw, float, 0, 3, T, B, W)          /* receiver probs (rec_probs)       :858  */ \

@@ -15,6 +15,7 @@
 #include "kernels_fwd.h"
 #include "kernels_bwd.h"
 #include "kernels_fast.h"
+#include "kernels_fast3.h"
 #include "kernels_tile.h"
 #include "kernels_mc.h"
 
@@ -45,6 +46,7 @@ struct mmg_handle {
     int conv_smem, conv_smem_agent, conv_threads, bwd_smem, prep_smem;
     bool profiling;
     bool scores_in_parts;      // the last forward left baseline scores as partials (k_baselines2)
+    bool use_fast3;            // one-wave-per-SIMD forward kernel of the small agents (kernels_fast3.h); MMG_FAST2=1: the 512-thread one
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
     bool basehx_ready;         // this forward pass formed tape.basehx inside the conversation launch
     bool merge_roles;          // MMG_NO_MERGE=1 keeps k_stats / k_dC / basehx as separate launches / in-kernel work
@@ -332,6 +334,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         if (hipHostGetDevicePointer((void**)&h->d_err, h->h_err, 0) != hipSuccess) h->d_err = nullptr;
     } else h->h_err = nullptr;
     h->use_fast = !getenv("MMG_NO_FAST"); h->merge_roles = !getenv("MMG_NO_MERGE");
+    h->use_fast3 = !getenv("MMG_FAST2");
     h->sw_rsample = !getenv("MMG_NO_RSAMPLE"); h->sw_rmsg = !getenv("MMG_NO_RMSG"); h->sw_fused_s = !getenv("MMG_NO_FUSED_S");
     h->sw_xcd_map = getenv("MMG_XCD_MAP") != nullptr;
     h->mc_ok = h->use_fast && mc_shape(h->dm.H, h->dm.W, h->dm.R, h->dm.V, h->dm.D, h->dm.T) && !getenv("MMG_NO_MC");
@@ -458,6 +461,8 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         if (mc_budget < 128) h->mc_xcd = 0;
         if (mc_budget < 16) h->mc_ok = false;
     }
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
     if (h->conv_smem > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
@@ -708,7 +713,9 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
         const bool fast = fast_shape(h);
         base_ready = fast && bas && !run_all_steps && h->merge_roles;
         const int base_tiles = base_ready ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
-        if (fast)
+        if (fast && h->use_fast3)
+            hipLaunchKernelGGL((k_conversation_fast3<256, 32, 64, 100>), dim3(d.B + base_tiles), dim3(256), fast3_lds_bytes(), st, h->dm, h->P, h->tp, ar);
+        else if (fast)
             if (d.D == 30) hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
             else hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 32>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
         else
@@ -818,16 +825,18 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         const bool fast = fast_shape(h);
         const bool merge_dc = fast && h->merge_roles;
         row_map = merge_dc && d.T * d.B <= 2048;         // class role 0 lists the live (step, sample) rows for k_wgrad
+        // k_conversation_fast3 stores softmax rows, not dbar = softmax(y) . desc: trailing workgroups form it (16 rows each)
+        const int n_dbar = (fast && h->use_fast3 && d.use_binary) ? (d.T * d.B + 15) / 16 : 0;
         if (fast && with_stats) {
             const int n_stats = (5 * d.T + 2 + 3) / 4;       // statistics roles: one (stream, step) pair per wave
-            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1);
-            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, true, true>), dim3(n_stats + d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1);
+            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1, n_dbar);
+            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, true, true>), dim3(n_stats + d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1, n_dbar);
         } else if (merge_dc)
-            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1);
-            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, true>), dim3(d.B + d.D), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1);
+            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1, n_dbar);
+            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, true>), dim3(d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1, n_dbar);
         else if (fast)      // (a 512-thread variant of this kernel measured slower: 31.8 vs 28.8 us -- it is not issue-bound)
-            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1);
-            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, false>), dim3(d.B), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1);
+            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1, n_dbar);
+            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, false>), dim3(d.B + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1, n_dbar);
         else
             if (d.B > 512)
                 hipLaunchKernelGGL(k_bwd_conv<true>, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);

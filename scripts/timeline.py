@@ -22,6 +22,8 @@ tick = 10.0  # wall_clock64: 100 MHz -> 10 ns
 t0 = dbg[0]
 print("tstar[0] =", int(eng.tape["tstar"][0]), " prologue(weights->regs) %.2f us, state init %.2f us" % ((dbg[1]-t0)*tick/1e3, (dbg[2]-dbg[1])*tick/1e3))
 names = ["(1)sender a", "(2)logits+sample", "(3)gates", "(4)h", "(5)heads", "(6)y", "(7)softmax.desc", "(8)g", "(9)w"]
+if not os.environ.get("MMG_FAST2"):      # k_conversation_fast3: seven phases
+    names = ["P1 code->a", "P2 bin->z", "P3 GRU", "P4 A|w_h h", "P5 y+stop+gh_r", "P6 softmax->g+gh_u", "P7 w+gh_n"]
 for st in range(int(eng.tape["tstar"][0]) + 1):
     base = 8 + 10 * st
     prev = dbg[base + 9]
@@ -32,6 +34,10 @@ for st in range(int(eng.tape["tstar"][0]) + 1):
         parts.append("%s %.2f" % (names[k], (cur - prev) * tick / 1e3)); prev = cur
     print("step %d: total %.2f us | " % (st, (prev - dbg[base + 9]) * tick / 1e3) + " | ".join(parts))
 
+if dbg[122] > dbg[3]:
+    print("   loads + output selection %.2f | log-likelihood sums %.2f | tape flush %.2f | dbar %.2f" % tuple((dbg[x] - dbg[y]) * tick / 1e3 for x, y in ((120, 3), (121, 120), (122, 121), (6, 122))))
+if dbg[6] > dbg[3]:
+    print("after the loop (log-likelihood sums, dbar, tape flush, output selection): %.2f us" % ((dbg[6] - dbg[3]) * tick / 1e3))
 wall_us = (dbg[3] - dbg[0]) * tick / 1e3
 print("kernel body %.2f us, shader cycles %d -> shader clock %.0f MHz" % (wall_us, dbg[5] - dbg[4], (dbg[5] - dbg[4]) / wall_us))
 
