@@ -20,12 +20,14 @@ namespace mmg {
 // model.py:870)  <=>  t < t*(b).  Fixed exchange has t* = T-1 for every sample, which reproduces the
 // unmasked sums over T (T-1 for the receiver messages, rec_feats[:-1] at model.py:1286).
 // ---------------------------------------------------------------------------------------------
+// CC: the partials were written by other workgroups of THIS launch (write-through stores): agent-scope loads
+template <bool CC = false>
 __device__ __forceinline__ float combine_score(const float* part, size_t row, int npb, float b2) {
     float v = 0.f;
     if (npb <= 8) {                                                     // all partial loads in flight at once
         float p[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) p[j] = (j < npb) ? part[row * npb + j] : 0.f;
+        for (int j = 0; j < 8; ++j) p[j] = (j < npb) ? (CC ? __hip_atomic_load(&part[row * npb + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : part[row * npb + j]) : 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v += p[j];
     } else {
@@ -39,7 +41,7 @@ __device__ __forceinline__ float combine_score(const float* part, size_t row, in
 // one wave reduces the (stream, step) pairs first, first + stride, ...
 // WT: results go out as device-scope (write-through) stores, so a role of a larger launch can publish them with a plain
 // counter increment instead of a device-scope release (= L2 write-back); see role_signal_wt.
-template <bool WT = false>
+template <bool WT = false, bool CC = false>
 __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, const Tape& tp, int from_parts, int first, int stride) {
     auto put_d = [](double* p, double v) { if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
     auto put_f = [](float* p, float v) { if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
@@ -72,7 +74,7 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
                 const float* lp_ptr = (kind == 0) ? tp.lp_s : (kind == 1) ? tp.lp_w : tp.lp_z;
                 const float* ne_ptr = (kind == 0) ? tp.ne_s : (kind == 1) ? tp.ne_w : tp.ne_z;
                 const float lp_raw = lp_ptr[row], ne_raw = ne_ptr[row];
-                const float beta_all = from_parts ? combine_score(sen_side ? tp.bs_part : tp.br_part, row, npb, sen_side ? b2s : b2r)
+                const float beta_all = from_parts ? combine_score<CC>(sen_side ? tp.bs_part : tp.br_part, row, npb, sen_side ? b2s : b2r)
                                                   : (sen_side ? tp.bs : tp.br)[row];
                 const float lp_all = (kind < 3) ? lp_raw : 0.f;
                 const float ne_all = (kind < 3) ? ne_raw : 0.f;

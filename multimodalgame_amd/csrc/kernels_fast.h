@@ -107,7 +107,7 @@ __device__ __forceinline__ void dbar_role(const Dims& dm, const Tape& tp, int ti
 
 template <int H, int W, int R, int V, int D, bool MERGED, bool MERGE_DC>
 __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int n_stats,
-                                                          int zero_dead, int n_dbar) {
+                                                          int zero_dead, int n_dbar, int n_bas) {
     constexpr int NT = 256, K4 = NT / R;          // 4 lanes per output unit of the R-wide transposed products
     constexpr int TMAX = 16;
     static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
@@ -122,17 +122,50 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     float* t_w = t_msg; float* t_pw = t_msg + TMAX * W; float* t_z = t_msg + 2 * TMAX * W; float* t_pz = t_msg + 3 * TMAX * W;
     static_assert(2 * TMAX * W == TMAX * R, "a pair of message arrays holds one [16][R] tile");
     __shared__ float t_gru[TMAX * 4 * R], t_h[(TMAX + 1) * R], t_a[TMAX * H];
-    if (MERGED && (int)blockIdx.x < n_stats) {          // four pairs per workgroup (one per wave): few releasing workgroups
+    // Workgroup roles.  n_bas == 0: [statistics n_stats][samples B][classes D][dbar n_dbar].
+    // n_bas > 0 (the baselines' forward pass rides in this launch, kernels_fwd.h: baselines3_body): [samples B][statistics n_stats]
+    // [baselines n_bas][classes D][dbar n_dbar] -- the sample roles start at once (their first ~10 us need no statistics), the
+    // baseline roles fill the other CUs, the statistics roles wait for them.  (Consumers ahead of producers: the host only selects
+    // this layout when B + n_stats workgroups leave CUs free for the producers.)
+    int vbx = (int)blockIdx.x;                          // index in the n_bas == 0 layout
+    if (MERGED && n_bas > 0) {
+        const int bx = (int)blockIdx.x, B0 = dm.B;
+        if (bx < B0) vbx = n_stats + bx;
+        else if (bx < B0 + n_stats) vbx = bx - B0;
+        else if (bx < B0 + n_stats + n_bas) {
+            const int idx = bx - B0 - n_stats, npb = (dm.K + 63) / 64;
+            const int window = idx / (2 * npb), rem = idx - window * 2 * npb, which = rem / npb, byi = rem - which * npb;
+            baselines3_body<true>(dm, P, tp, window, byi, which, npb, tp.pflags + (size_t)(which * npb + byi) * 64);
+            return;
+        } else vbx = bx - n_bas;
+    }
+    if (MERGED && vbx < n_stats) {                      // four pairs per workgroup (one per wave): few releasing workgroups
 #ifdef MMG_TIMING
-        if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[128 + 48] = (long long)wall_clock64();
+        if (vbx == 0 && threadIdx.x == 0) tp.dbg[128 + 48] = (long long)wall_clock64();
 #endif
-        stats_pairs<true>(dm, P, tp, 1, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
+        if (n_bas > 0) {
+            // the baseline roles of the live windows count themselves on 2 * npb counters (zeroed by k_prep); windows = ceil(live rows / 16)
+            const int ln = threadIdx.x & 63;
+            const float live = dpp_wave_sum((ln < dm.B) ? (float)(tp.tstar[min(ln, dm.B - 1)] + 1) : 0.f);
+            const uint32_t windows = (uint32_t)(((int)live + 15) / 16);
+            const int ncnt = 2 * ((dm.K + 63) / 64);
+            if ((int)threadIdx.x < ncnt) {
+                int spins = 0;
+                while (__hip_atomic_load(tp.pflags + (size_t)threadIdx.x * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < windows) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+            }
+            __syncthreads();
+            stats_pairs<true, true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
+        } else
+            stats_pairs<true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
 #ifdef MMG_TIMING
-        if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[128 + 49] = (long long)wall_clock64();
+        if (vbx == 0 && threadIdx.x == 0) tp.dbg[128 + 49] = (long long)wall_clock64();
 #endif
         role_signal_wt(tp.sync, 0);
 #ifdef MMG_TIMING
-        if (blockIdx.x == 0 && threadIdx.x == 0) tp.dbg[128 + 50] = (long long)wall_clock64();
+        if (vbx == 0 && threadIdx.x == 0) tp.dbg[128 + 50] = (long long)wall_clock64();
 #endif
         return;
     }
@@ -140,14 +173,14 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         dbar_role<V>(dm, tp, (int)blockIdx.x - ((int)gridDim.x - n_dbar));
         return;
     }
-    if (MERGE_DC && (int)blockIdx.x >= n_stats + dm.B) {
+    if (MERGE_DC && vbx >= n_stats + dm.B) {
         float* s_c = t_a; float* s_p = t_a + 256;
-        if ((int)blockIdx.x == n_stats + dm.B && threadIdx.x < 64) build_row_map(dm, tp);   // while waiting: rows k_wgrad will reduce over
+        if (vbx == n_stats + dm.B && threadIdx.x < 64) build_row_map(dm, tp);   // while waiting: rows k_wgrad will reduce over
         role_wait<8, false>(tp.sync, 1, (uint32_t)dm.B, (uint32_t)dm.D);
-        dC_class<true>(dm, P, tp, (int)blockIdx.x - n_stats - dm.B, s_c, s_p);
+        dC_class<true>(dm, P, tp, vbx - n_stats - dm.B, s_c, s_p);
         return;
     }
-    const int b = blockIdx.x - n_stats, tid = threadIdx.x, lane = tid & 63;
+    const int b = vbx - n_stats, tid = threadIdx.x, lane = tid & 63;
     const int B = dm.B, T = dm.T;
     const int Dr = dm.D;                                // classes of this run (<= D, the compile-time capacity)
     const bool binary = dm.use_binary != 0;

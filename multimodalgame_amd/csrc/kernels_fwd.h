@@ -879,11 +879,16 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
 // Needs B <= 64 (one lane per sample when listing rows), W and R multiples of 16 up to 64, tape.basehx.
 // Same operand order as k_baselines2, so hidden tiles and partial scores are bit-identical to it.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MMG_BLOCK) void k_baselines3(Dims dm, Params P, Tape tp) {
+// ROLE: the body runs as a workgroup role of the backward launch (kernels_fast.h): partial scores go out as write-through
+// stores and the role counts itself on the (baseline, hidden block) counter `done` -- only windows inside the live rows do;
+// the statistics roles derive the number of such windows from t* themselves.
+template <bool ROLE>
+__device__ __forceinline__ void baselines3_body(const Dims& dm, const Params& P, const Tape& tp, int window, int byi, int which, int npb,
+                                                uint32_t* done) {
     __shared__ int s_rid[16];
     __shared__ float s_part[4][16];
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, K = dm.K, T = dm.T;
-    const int which = blockIdx.z, lo = blockIdx.x * 16, byi = blockIdx.y, npb = gridDim.y;
+    const int lo = window * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int ts = tp.tstar[min(lane, B - 1)];           // (first: the row list depends on it)
@@ -936,9 +941,19 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines3(Dims dm, Params P, Tap
     __syncthreads();
     if (threadIdx.x < 16 && s_rid[threadIdx.x] >= 0) {
         float* part = which ? tp.bs_part : tp.br_part;
-        part[(size_t)s_rid[threadIdx.x] * npb + byi] =
-            (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+        const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+        if (ROLE) __hip_atomic_store(&part[(size_t)s_rid[threadIdx.x] * npb + byi], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else part[(size_t)s_rid[threadIdx.x] * npb + byi] = v;
     }
+    if (ROLE) {                                          // (device_utils.h: role_signal_wt, on this role's own counter)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_baselines3(Dims dm, Params P, Tape tp) {
+    baselines3_body<false>(dm, P, tp, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.y, nullptr);
 }
 
 }  // namespace mmg

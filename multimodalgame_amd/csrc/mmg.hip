@@ -46,6 +46,9 @@ struct mmg_handle {
     int conv_smem, conv_smem_agent, conv_threads, bwd_smem, prep_smem;
     bool profiling;
     bool scores_in_parts;      // the last forward left baseline scores as partials (k_baselines2)
+    bool sw_merge_bas;         // MMG_NO_MERGE_BAS=1: the baselines' forward pass stays its own launch in the fused step
+    bool defer_bas;            // set by mmg_train_step around its forward call: the baselines may ride in the backward launch
+    bool bas_deferred;         // ... and this forward pass left them to it (k_bwd_conv_fast: baseline roles)
     bool use_fast3;            // one-wave-per-SIMD forward kernel of the small agents (kernels_fast3.h); MMG_FAST2=1: the 512-thread one
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
     bool basehx_ready;         // this forward pass formed tape.basehx inside the conversation launch
@@ -335,6 +338,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     } else h->h_err = nullptr;
     h->use_fast = !getenv("MMG_NO_FAST"); h->merge_roles = !getenv("MMG_NO_MERGE");
     h->use_fast3 = !getenv("MMG_FAST2");
+    h->sw_merge_bas = !getenv("MMG_NO_MERGE_BAS"); h->defer_bas = false; h->bas_deferred = false;
     h->sw_rsample = !getenv("MMG_NO_RSAMPLE"); h->sw_rmsg = !getenv("MMG_NO_RMSG"); h->sw_fused_s = !getenv("MMG_NO_FUSED_S");
     h->sw_xcd_map = getenv("MMG_XCD_MAP") != nullptr;
     h->mc_ok = h->use_fast && mc_shape(h->dm.H, h->dm.W, h->dm.R, h->dm.V, h->dm.D, h->dm.T) && !getenv("MMG_NO_MC");
@@ -699,6 +703,7 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
     bool base_ready = false;
     h->basehx_ready = false;
+    h->bas_deferred = false;
     if (tile_path(h)) {
         if (launch_conv_tile(h, st, ar)) return -1;
     } else if (mc_path(h)) {
@@ -729,6 +734,16 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     if (bas) {
         if (run_all_steps) {                         // exchange(): every row, scores materialised directly
             if (launch_baselines_fused(h, st)) return -1;
+        } else if (h->defer_bas && base_ready && d.B <= 64 && (d.K + 63) / 64 <= 8 && h->sw_merge_bas && !d.fixed &&
+                   h->n_cu >= 2 * (d.B + (5 * d.T + 2 + 3) / 4)) {
+            // fused step, register-resident kernels: the baselines' live-row pass (k_baselines3's body) runs as workgroup roles of
+            // the backward launch, beside the sample roles' statistics-independent prologue (kernels_fast.h) -- one launch less.
+            // (The sample and statistics roles of that launch sit ahead of these producers and spin: only with CUs to spare.
+            //  Adaptive conversations only: with early stopping ~140 of the 640 (step, sample) rows are live = ~144 baseline roles;
+            //  Fixed mode keeps all 640 rows live and the backward kernel holds ONE workgroup per CU -- measured at config 3:
+            //  101.3 us per minibatch with the roles against 94.6 with k_baselines3 as its own launch; config 2: 66.0 against 72.1.)
+            h->bas_deferred = true;
+            h->scores_in_parts = true;
         } else {
             Scope sc(h, st, "k_baselines");
             const bool live_rows = base_ready && d.B <= 64;      // k_baselines3: live (step, sample) rows only
@@ -829,14 +844,15 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         const int n_dbar = (fast && h->use_fast3 && d.use_binary) ? (d.T * d.B + 15) / 16 : 0;
         if (fast && with_stats) {
             const int n_stats = (5 * d.T + 2 + 3) / 4;       // statistics roles: one (stream, step) pair per wave
-            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1, n_dbar);
-            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, true, true>), dim3(n_stats + d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1, n_dbar);
+            const int n_bas = h->bas_deferred ? ((d.T * d.B + 15) / 16) * 2 * ((d.K + 63) / 64) : 0;     // baseline roles: 16 live rows x 64 hidden units each
+            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, true, true>), dim3(n_stats + d.B + d.D + n_dbar + n_bas), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1, n_dbar, n_bas);
+            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, true, true>), dim3(n_stats + d.B + d.D + n_dbar + n_bas), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, n_stats, row_map ? 0 : 1, n_dbar, n_bas);
         } else if (merge_dc)
-            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1, n_dbar);
-            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, true>), dim3(d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1, n_dbar);
+            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, true>), dim3(d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1, n_dbar, 0);
+            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, true>), dim3(d.B + d.D + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, row_map ? 0 : 1, n_dbar, 0);
         else if (fast)      // (a 512-thread variant of this kernel measured slower: 31.8 vs 28.8 us -- it is not issue-bound)
-            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1, n_dbar);
-            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, false>), dim3(d.B + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1, n_dbar);
+            if (d.D == 30) hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 30, false, false>), dim3(d.B + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1, n_dbar, 0);
+            else hipLaunchKernelGGL((k_bwd_conv_fast<256, 32, 64, 100, 32, false, false>), dim3(d.B + n_dbar), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, 0, 1, n_dbar, 0);
         else
             if (d.B > 512)
                 hipLaunchKernelGGL(k_bwd_conv<true>, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
@@ -929,8 +945,12 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
     if (h->cfg.global_batch != h->cfg.batch) return fail("mmg_train_step is single-GPU; with several ranks all-reduce between the phases");
     if (!d_target) return fail("target must not be NULL");
     if (sticky_error(h)) return -1;
-    if (mmg_exchange_forward(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, 2, stream)) return -1;
+    h->defer_bas = true;
+    const int frc = mmg_exchange_forward(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, 2, stream);
+    h->defer_bas = false;
+    if (frc) return -1;
     const bool merged = merge_stats(h);
+    if (h->bas_deferred && !merged) return fail("internal: deferred baselines without the merged backward launch");
     if (!merged && mmg_loss_stats(h, stream)) return -1;
     if (backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, merged)) return -1;
     return clip_step_impl(h, (hipStream_t)stream, true);

@@ -15,7 +15,10 @@ feats, target, desc = bench.synthetic_dataset(3000, 30, 512, 100)
 dev = eng.device
 x = torch.from_numpy(feats[:64]).to(dev); t = torch.from_numpy(target[:64]).to(dev); d = torch.from_numpy(desc).to(dev)
 for it in range(6):
-    eng.train_step(x, t, d, seed=0)
+    if os.environ.get("FWD_ONLY"):       # forward launches only (k_prep, conversation, baselines): the conversation kernel's code stays in the I-cache
+        eng.forward(x, t, d, seed=0, train=True, run_all=False, minimal=True)
+    else:
+        eng.train_step(x, t, d, seed=0)
 torch.cuda.synchronize()
 dbg = eng.tape["dbg"].view(torch.int64).cpu().numpy()
 tick = 10.0  # wall_clock64: 100 MHz -> 10 ns
