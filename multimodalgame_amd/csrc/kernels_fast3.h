@@ -55,19 +55,28 @@ __device__ __forceinline__ float dot4p(const float* __restrict__ w, const float*
     return s.x + s.y;
 }
 
-// 16 parked weights of this lane (four float4 slots of the LDS park, written by this lane itself) times 16 floats of h
-__device__ __forceinline__ float park_dot(const float4* park, int gate, int tid, const float* hq) {
+// 16 parked weights of this lane (four float4 slots of the LDS park, written by this lane itself) times 16 floats of h:
+// the loads (issued at the top of a phase) and the products (wherever the scheduler finds room)
+__device__ __forceinline__ void park_load(float4 (&w)[4], float4 (&v)[4], const float4* park, int gate, int tid, const float* hq) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[i] = park[(gate * 4 + i) * 256 + tid]; v[i] = *reinterpret_cast<const float4*>(hq + 4 * i); }
+}
+__device__ __forceinline__ float park_fma(const float4 (&w)[4], const float4 (&v)[4]) {
     f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float4 w = park[(gate * 4 + i) * 256 + tid];
-        const float4 v = *reinterpret_cast<const float4*>(hq + 4 * i);
-        const f32x2 w01 = {w.x, w.y}, w23 = {w.z, w.w}, v01 = {v.x, v.y}, v23 = {v.z, v.w};
-        a01 = __builtin_elementwise_fma(w01, v01, a01);
-        a23 = __builtin_elementwise_fma(w23, v23, a23);
+        a01 = __builtin_elementwise_fma(f32x2{w[i].x, w[i].y}, f32x2{v[i].x, v[i].y}, a01);
+        a23 = __builtin_elementwise_fma(f32x2{w[i].z, w[i].w}, f32x2{v[i].z, v[i].w}, a23);
     }
     const f32x2 s = a01 + a23;
     return s.x + s.y;
+}
+// max of two finite values as ONE v_max_f32 (fmaxf / fmed3 make the compiler canonicalise both operands first: three v_max per
+// relu on the dependent chain of the class logits)
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // LDS plan of k_conversation_fast3 (floats); the host asks for fast3_lds_bytes() of dynamic shared memory
@@ -222,6 +231,12 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
 
     int t_done = T, w_done = T;                         // steps executed / steps whose receiver message was formed
     MMG_STAMP(2);
+    // Every phase below is written as  [all LDS loads] [branch-free arithmetic: uniform mode flags become selects] [stores]:
+    // a predicated store or a mode branch in the middle of a phase splits the basic block, and the scheduler then issues the
+    // loads of the next independent chain only after the previous chain has drained (measured in P5: the stop head's h read
+    // waited for the class chain's store).
+    const float fixedm = dm.fixed ? 1.f : 0.f;
+    const bool sprodm = dm.s_prob_prod != 0;
     for (int t = 0; t < T; ++t) {
         MMG_STAMP(8 + 10 * t + 9);
         // ===== P1 sender: a = tanh(h_x + code_layer(c))
@@ -232,23 +247,28 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
         __syncthreads(); MMG_STAMP(8 + 10 * t + 0);
         // ===== P2 sender logits + sample
         {
-            const float acc = dpp_group_sum<8>(dot4p<8>(wb, s_a + t * H + k2 * 4, 32));
-            const float lz = acc + bb;
-            float zz = lz, pp = 0.f;
-            if (binary) {
-                pp = fsigmoid(lz);
-                zz = train ? ((s_uz[t * W + m2] < pp) ? 1.f : 0.f) : rintf(pp);
-            }
+            const float uz = s_uz[t * W + m2];
+            const float lz = dpp_group_sum<8>(dot4p<8>(wb, s_a + t * H + k2 * 4, 32)) + bb;
+            const float ps = fsigmoid(lz);
+            const float pp = binary ? ps : 0.f;
+            const float zz = binary ? (train ? ((uz < ps) ? 1.f : 0.f) : rintf(ps)) : lz;
             if (k2 == 0) { s_z[t * W + m2] = zz; s_pz[t * W + m2] = pp; }
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 1);
         // ===== P3 GRU cell: gate pre-activations of this lane's quarter, 4-lane sums, state update
         {
             const float* zq = s_z + t * W + q3 * 8;
+            const float4 z0 = *reinterpret_cast<const float4*>(zq), z1 = *reinterpret_cast<const float4*>(zq + 4);
             const float h_old = s_h[t * R + u3];
-            const float xr = dpp_group_sum<4>(dot4p<2>(wih, zq, 4) + ghp_r) + b_r;
-            const float xu = dpp_group_sum<4>(dot4p<2>(wih + 8, zq, 4) + ghp_u) + b_u;
-            const float gin = dpp_group_sum<4>(dot4p<2>(wih + 16, zq, 4)) + b_in;
+            auto gate = [&](const float* wg) {
+                const f32x2 a = __builtin_elementwise_fma(f32x2{wg[0], wg[1]}, f32x2{z0.x, z0.y}, f32x2{wg[4], wg[5]} * f32x2{z1.x, z1.y});
+                const f32x2 c = __builtin_elementwise_fma(f32x2{wg[2], wg[3]}, f32x2{z0.z, z0.w}, f32x2{wg[6], wg[7]} * f32x2{z1.z, z1.w});
+                const f32x2 sm = a + c;
+                return sm.x + sm.y;
+            };
+            const float xr = dpp_group_sum<4>(gate(wih) + ghp_r) + b_r;
+            const float xu = dpp_group_sum<4>(gate(wih + 8) + ghp_u) + b_u;
+            const float gin = dpp_group_sum<4>(gate(wih + 16)) + b_in;
             const float rr = fsigmoid(xr), uu = fsigmoid(xu);
             const float nn = ftanh(gin + rr * ghn);
             const float hv = nn + uu * (h_old - nn);
@@ -263,65 +283,70 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
             if (half4 == 0) { if (row4 < R) s_A[row4] = acc; else s_gh[row4 - R] = acc; }
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 3);
-        // ===== P5 class logits (+ stop head on lanes 240..255, + hidden-side product of the r gate for the next step)
+        // ===== P5 class logits | stop head (every wave computes it; lane 240 -- row 3 of wave 3, whose 16 lanes cover h -- keeps it) |
+        //       hidden-side product of the r gate for the next step
         {
-            const float us_t = s_us[t];
             const float4 a0 = *reinterpret_cast<const float4*>(s_A + r5 * 8), a1 = *reinterpret_cast<const float4*>(s_A + r5 * 8 + 4);
-            float acc = w2[0] * fmax_nn(a0.x, ncd[0]);
-            acc = fmaf(w2[1], fmax_nn(a0.y, ncd[1]), acc); acc = fmaf(w2[2], fmax_nn(a0.z, ncd[2]), acc); acc = fmaf(w2[3], fmax_nn(a0.w, ncd[3]), acc);
-            acc = fmaf(w2[4], fmax_nn(a1.x, ncd[4]), acc); acc = fmaf(w2[5], fmax_nn(a1.y, ncd[5]), acc);
-            acc = fmaf(w2[6], fmax_nn(a1.z, ncd[6]), acc); acc = fmaf(w2[7], fmax_nn(a1.w, ncd[7]), acc);
-            acc = dpp_group_sum<8>(acc);
-            if (r5 == 0) s_y[t * 32 + d5] = (d5 < Dr) ? acc + cy5 : -3.0e38f;
-            // stop head, branch-free on every wave (the arithmetic interleaves with the class chain above; only lane 240 -- row 3 of
-            // wave 3, whose 16 lanes cover h -- keeps the result).  Running mask / output step / eval product live in registers.
-            {
-                const float4 hv = *reinterpret_cast<const float4*>(hn + (tid & 15) * 4);
-                const float sv = dpp_group_sum<16>(fmaf(ws4.x, hv.x, fmaf(ws4.y, hv.y, fmaf(ws4.z, hv.z, ws4.w * hv.w))));
-                const float p = fsigmoid(sv + bs);
-                float sbit;
-                if (train) sbit = (us_t < p) ? 1.f : 0.f;
-                else { sprod = dm.s_prob_prod ? sprod * p : p; sbit = rintf(sprod); }
-                const float m_next = fminf(m_run, sbit);
-                const bool first_stop = (m_next == 0.f) && (t_out < 0);
-                if (dm.fixed ? (t == T - 1) : (first_stop || ((t == T - 1) && (t_out < 0)))) t_out = t;
-                m_run = m_next;
-                if (tid == 240) { s_ps[t] = p; s_sb[t] = sbit; s_mask[t + 1] = m_next; }
-            }
-            ghp_r = park_dot(s_park, 0, tid, hn + q3 * 16);
+            const float4 hv = *reinterpret_cast<const float4*>(hn + (tid & 15) * 4);
+            const float us_t = s_us[t];
+            float4 pk[4], hq[4];
+            park_load(pk, hq, s_park, 0, tid, hn + q3 * 16);
+            float acc0 = w2[0] * vmax_raw(a0.x, ncd[0]), acc1 = w2[1] * vmax_raw(a0.y, ncd[1]);
+            acc0 = fmaf(w2[2], vmax_raw(a0.z, ncd[2]), acc0); acc1 = fmaf(w2[3], vmax_raw(a0.w, ncd[3]), acc1);
+            acc0 = fmaf(w2[4], vmax_raw(a1.x, ncd[4]), acc0); acc1 = fmaf(w2[5], vmax_raw(a1.y, ncd[5]), acc1);
+            acc0 = fmaf(w2[6], vmax_raw(a1.z, ncd[6]), acc0); acc1 = fmaf(w2[7], vmax_raw(a1.w, ncd[7]), acc1);
+            const float yv = dpp_group_sum<8>(acc0 + acc1) + cy5;
+            const float sv = dpp_group_sum<16>(fmaf(ws4.x, hv.x, fmaf(ws4.y, hv.y, fmaf(ws4.z, hv.z, ws4.w * hv.w))));
+            const float p = fsigmoid(sv + bs);
+            const float prod = sprodm ? sprod * p : p;
+            sprod = train ? sprod : prod;
+            const float sbit = train ? ((us_t < p) ? 1.f : 0.f) : rintf(prod);
+            const float m_next = fminf(m_run, sbit);
+            const bool last = (t == T - 1);
+            const bool take = (fixedm != 0.f) ? last : (t_out < 0 && (m_next == 0.f || last));
+            t_out = take ? t : t_out;
+            m_run = m_next;
+            ghp_r = park_fma(pk, hq);
+            if (r5 == 0) s_y[t * 32 + d5] = (d5 < Dr) ? yv : -3.0e38f;
+            if (tid == 240) { s_ps[t] = p; s_sb[t] = sbit; s_mask[t + 1] = m_next; }
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 4);
         if (!ar.run_all && !dm.fixed && train && s_mask[t + 1] == 0.f) { t_done = t + 1; w_done = t; break; }
         // ===== P6 softmax of the wave's own copy of y (lanes 0..31), then g = tanh(w_h h + b_h + softmax(y) . Dd)
         {
-            const float yv = (lane < 32) ? s_y[t * 32 + lane] : -3.0e38f;
-            float mx = fmaxf(yv, dpp_f<MMG_DPP_QUAD_1032>(yv)); mx = fmaxf(mx, dpp_f<MMG_DPP_QUAD_2301>(mx));
-            mx = fmaxf(mx, dpp_f<MMG_DPP_ROW_HALF_MIRROR>(mx)); mx = fmaxf(mx, dpp_f<MMG_DPP_ROW_MIRROR>(mx));   // per 16-lane row
+            const float yv = s_y[t * 32 + (lane & 31)];
+            const float ghu = s_gh[u3];
+            float4 pk[4], hq[4];
+            park_load(pk, hq, s_park, 1, tid, hn + q3 * 16);
+            float mx = vmax_raw(yv, dpp_f<MMG_DPP_QUAD_1032>(yv)); mx = vmax_raw(mx, dpp_f<MMG_DPP_QUAD_2301>(mx));
+            mx = vmax_raw(mx, dpp_f<MMG_DPP_ROW_HALF_MIRROR>(mx)); mx = vmax_raw(mx, dpp_f<MMG_DPP_ROW_MIRROR>(mx));   // per 16-lane row
             const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 0));
             const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 16));
-            const float e = (lane < Dr) ? __expf(yv - fmaxf(m0, m1)) : 0.f;
+            const float e = __expf(yv - fmaxf(m0, m1));                      // (classes beyond Dr hold -3e38: e = 0; lanes 32..63 mirror 0..31)
             const float rs = dpp_group_sum<16>(e);
             const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 0));
             const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 16));
             const float inv = __builtin_amdgcn_rcpf(s0 + s1);
-            if (lane < 32) { s_e[wave * 32 + lane] = e; if (wave == 0) s_pi[t * 32 + lane] = e * inv; }
+            if (lane < 32) s_e[wave * 32 + lane] = e;
             __builtin_amdgcn_wave_barrier();
             const float mix = dpp_group_sum<4>(dot4p<2>(dd, s_e + wave * 32 + q3 * 8, 4));
-            const float gv = ftanh(fmaf(mix, inv, s_gh[u3]));
+            const float gv = ftanh(fmaf(mix, inv, ghu));
+            ghp_u = park_fma(pk, hq);
             if (q3 == 0) s_g[t * R + u3] = gv;
-            ghp_u = park_dot(s_park, 1, tid, hn + q3 * 16);
+            if (tid < 32) s_pi[t * 32 + tid] = e * inv;
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 5);
         // ===== P7 receiver message
         {
+            const float uw = s_uw[t * W + m2];
+            float4 pk[4], hq[4];
+            park_load(pk, hq, s_park, 2, tid, hn + q3 * 16);
             const float lw = dpp_group_sum<8>(dot4p<2>(ww, s_g + t * R + k2 * 8, 4)) + bw;
-            float wv = lw, pp = 0.f;
-            if (binary) {
-                pp = fsigmoid(lw);
-                wv = train ? ((s_uw[t * W + m2] < pp) ? 1.f : 0.f) : rintf(pp);
-            }
+            const float ps = fsigmoid(lw);
+            const float pp = binary ? ps : 0.f;
+            const float wv = binary ? (train ? ((uw < ps) ? 1.f : 0.f) : rintf(ps)) : lw;
+            ghn = dpp_group_sum<4>(park_fma(pk, hq)) + b_hn;
             if (k2 == 0) { s_w[(t + 1) * W + m2] = wv; s_pw[t * W + m2] = pp; }
-            ghn = dpp_group_sum<4>(park_dot(s_park, 2, tid, hn + q3 * 16)) + b_hn;
         }
         __syncthreads(); MMG_STAMP(8 + 10 * t + 6);
     }
