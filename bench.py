@@ -85,13 +85,17 @@ def algorithmic_work(kernel, d, B, t_steps, lean=False):
             # g / w and no per-step y
             tape = rows * 4 * (W + 5 * R + 8) + B * 4 * 4 * D
         else:
-            tape = rows * 4 * (H + 4 * W + 5 * R + R + D + V + 12)      # floats written per (step, sample)
+            # floats written per live (step, sample) row: a [H]; z, pz, w, pw, zr, c [6 W]; GRU gates [4 R], h [R], g [R]; the class
+            # logits [D]; softmax(y) [32] (k_conversation_fast3; the generic kernels write dbar [V] instead) and ~12 scalars
+            tape = rows * 4 * (H + 6 * W + 6 * R + D + min(V, 32) + 12)
         return "hbm", 4 * (p_sender + p_recv) + tape + 4 * B * H
     if kernel == "k_bwd_mc":                  # continuous many-class backward: softmax in, dy out, class tables once, GRU tape in, gate gradients out
         return "hbm", 4 * (2 * B * D + 3 * D * R + rows * 11 * R + 3 * R * R)
     if kernel == "k_bwd_conv":
-        tape = rows * 4 * (2 * H + 6 * W + 13 * R + 2 * K + D + V + 16)  # read fwd tape + write delta tape
-        return "hbm", 4 * (p_sender + p_recv) + tape
+        # read the forward tape + write the delta tape; with the register-resident kernels the launch also carries the
+        # baselines' forward pass over the live rows (their weights once, hidden tiles [2 K] out) and dbar = softmax(y) . desc [V]
+        tape = rows * 4 * (2 * H + 6 * W + 13 * R + 2 * K + D + V + 16)
+        return "hbm", 4 * (p_sender + p_recv) + tape + 4 * (K * (W + R) + K * (H + W) + 4 * K)
     if kernel == "k_conv_tile":               # sample-tile recurrence on the matrix cores (kernels_tile.h)
         sender = 2 * H * W if H * W < 65536 else 0                      # large sender MLPs run in k_send_s1 / k_send_s2
         return "mfma", 2 * rows * (mac_recv + sender)
