@@ -71,14 +71,6 @@ __device__ __forceinline__ float park_fma(const float4 (&w)[4], const float4 (&v
     const f32x2 s = a01 + a23;
     return s.x + s.y;
 }
-// max of two finite values as ONE v_max_f32 (fmaxf / fmed3 make the compiler canonicalise both operands first: three v_max per
-// relu on the dependent chain of the class logits)
-__device__ __forceinline__ float vmax_raw(float a, float b) {
-    float r;
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // LDS plan of k_conversation_fast3 (floats); the host asks for fast3_lds_bytes() of dynamic shared memory
 struct Fast3Lds {
     static constexpr int TMAX = 16, H = 256, W = 32, R = 64;
@@ -291,10 +283,10 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
             const float us_t = s_us[t];
             float4 pk[4], hq[4];
             park_load(pk, hq, s_park, 0, tid, hn + q3 * 16);
-            float acc0 = w2[0] * vmax_raw(a0.x, ncd[0]), acc1 = w2[1] * vmax_raw(a0.y, ncd[1]);
-            acc0 = fmaf(w2[2], vmax_raw(a0.z, ncd[2]), acc0); acc1 = fmaf(w2[3], vmax_raw(a0.w, ncd[3]), acc1);
-            acc0 = fmaf(w2[4], vmax_raw(a1.x, ncd[4]), acc0); acc1 = fmaf(w2[5], vmax_raw(a1.y, ncd[5]), acc1);
-            acc0 = fmaf(w2[6], vmax_raw(a1.z, ncd[6]), acc0); acc1 = fmaf(w2[7], vmax_raw(a1.w, ncd[7]), acc1);
+            float acc0 = w2[0] * fmax_nn(a0.x, ncd[0]), acc1 = w2[1] * fmax_nn(a0.y, ncd[1]);
+            acc0 = fmaf(w2[2], fmax_nn(a0.z, ncd[2]), acc0); acc1 = fmaf(w2[3], fmax_nn(a0.w, ncd[3]), acc1);
+            acc0 = fmaf(w2[4], fmax_nn(a1.x, ncd[4]), acc0); acc1 = fmaf(w2[5], fmax_nn(a1.y, ncd[5]), acc1);
+            acc0 = fmaf(w2[6], fmax_nn(a1.z, ncd[6]), acc0); acc1 = fmaf(w2[7], fmax_nn(a1.w, ncd[7]), acc1);
             const float yv = dpp_group_sum<8>(acc0 + acc1) + cy5;
             const float sv = dpp_group_sum<16>(fmaf(ws4.x, hv.x, fmaf(ws4.y, hv.y, fmaf(ws4.z, hv.z, ws4.w * hv.w))));
             const float p = fsigmoid(sv + bs);
@@ -318,8 +310,8 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
             const float ghu = s_gh[u3];
             float4 pk[4], hq[4];
             park_load(pk, hq, s_park, 1, tid, hn + q3 * 16);
-            float mx = vmax_raw(yv, dpp_f<MMG_DPP_QUAD_1032>(yv)); mx = vmax_raw(mx, dpp_f<MMG_DPP_QUAD_2301>(mx));
-            mx = vmax_raw(mx, dpp_f<MMG_DPP_ROW_HALF_MIRROR>(mx)); mx = vmax_raw(mx, dpp_f<MMG_DPP_ROW_MIRROR>(mx));   // per 16-lane row
+            float mx = fmax_nn(yv, dpp_f<MMG_DPP_QUAD_1032>(yv)); mx = fmax_nn(mx, dpp_f<MMG_DPP_QUAD_2301>(mx));
+            mx = fmax_nn(mx, dpp_f<MMG_DPP_ROW_HALF_MIRROR>(mx)); mx = fmax_nn(mx, dpp_f<MMG_DPP_ROW_MIRROR>(mx));   // per 16-lane row
             const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 0));
             const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 16));
             const float e = __expf(yv - fmaxf(m0, m1));                      // (classes beyond Dr hold -3e38: e = 0; lanes 32..63 mirror 0..31)

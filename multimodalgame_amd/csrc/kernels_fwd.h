@@ -21,16 +21,61 @@ __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__
 
 // blocks [0, D]: parameter-only constants; blocks (D, D + hx_tiles]: tiles of h_x = image_layer(x)
 // (model.py:195) -- independent work sharing one launch.
+// cpb > 1 (many classes): a class block owns `cpb` consecutive classes and keeps its y1 / w_d weight row in registers across
+// them -- one block per class re-reads all 2 R weight rows (51 KB) from L2 per class: 51 MB per launch at D = 1000.
 __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, const float* __restrict__ desc,
-                                                    const float* __restrict__ x) {
+                                                    const float* __restrict__ x, int cpb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int HB = (dm.H + 63) / 64;                 // blocks [D, D + HB): 64 rows of hw0 each
-    if ((int)blockIdx.x >= dm.D + HB) {
-        gemm_nt_tile(blockIdx.x - dm.D - HB, x, dm.F, P.p[S_IMG_W], dm.F, P.p[S_IMG_B], tp.hx, dm.H, dm.B, dm.H, dm.F);
+    const int HB = (dm.H + 63) / 64;                 // blocks [nC, nC + HB): 64 rows of hw0 each
+    const int nC = (dm.D + cpb - 1) / cpb;           // class blocks
+    if ((int)blockIdx.x >= nC + HB) {
+        gemm_nt_tile(blockIdx.x - nC - HB, x, dm.F, P.p[S_IMG_W], dm.F, P.p[S_IMG_B], tp.hx, dm.H, dm.B, dm.H, dm.F);
         return;
     }
-    if ((int)blockIdx.x < dm.D) {
+    if ((int)blockIdx.x < nC && cpb > 1) {
+        // (host: cpb > 1 only with R <= 64, V <= 128, V % 4 == 0) threads [0, R): Cd rows, [R, 2R): Dd rows
+        const int R = dm.R, V = dm.V, ld = dm.R + dm.V, D = dm.D;
+        const int d0 = blockIdx.x * cpb, nd = min(cpb, D - d0);
+        float* s_desc = smem;                       // [cpb][V]
+        float* s_cd = smem + cpb * V;               // [cpb][R]
+        for (int i = tid; i < nd * V; i += blockDim.x) { const float dv = desc[(size_t)d0 * V + i]; s_desc[i] = dv; tp.descc[(size_t)d0 * V + i] = dv; }
+        const bool isC = tid < R, isD = tid >= R && tid < 2 * R;
+        const int r = isC ? tid : (isD ? tid - R : 0);
+        const float* wrow = isD ? P.p[R_WD_W] + (size_t)r * V : P.p[R_Y1_W] + (size_t)r * ld + R;
+        float4 wreg[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wreg[j] = (4 * j < V) ? *reinterpret_cast<const float4*>(wrow + 4 * min(j, V / 4 - 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float by = isC ? P.p[R_Y1_B][r] : 0.f;
+        __syncthreads();
+        if (isC || isD) {
+            for (int c = 0; c < nd; ++c) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    if (4 * j < V) {
+                        const float4 dv = *reinterpret_cast<const float4*>(s_desc + c * V + 4 * j);
+                        a0 = fmaf(wreg[j].x, dv.x, a0); a1 = fmaf(wreg[j].y, dv.y, a1); a2 = fmaf(wreg[j].z, dv.z, a2); a3 = fmaf(wreg[j].w, dv.w, a3);
+                    }
+                }
+                const float v = (a0 + a1) + (a2 + a3) + by;
+                const int d = d0 + c;
+                if (isC) { tp.Cd[(size_t)d * R + r] = v; tp.CdT[(size_t)r * D + d] = -v; s_cd[c * R + r] = v; }
+                else tp.Dd[(size_t)d * R + r] = v;
+            }
+        }
+        __syncthreads();
+        {   // cy[d] = b_y2 + sum_r w2[r] Cd[d][r]: wave w takes the classes w, w + 4, ...
+            const int lane = tid & 63, wave = tid >> 6;
+            const float w2 = (lane < R) ? P.p[R_Y2_W][lane] : 0.f;
+            for (int c = wave; c < nd; c += 4) {
+                const float t = dpp_wave_sum((lane < R) ? w2 * s_cd[c * R + lane] : 0.f);
+                if (lane == 0) tp.cy[d0 + c] = t + P.p[R_Y2_B][0];
+            }
+        }
+        return;
+    }
+    if ((int)blockIdx.x < nC) {
         // Cd[d, r] = b_y1[r] + sum_v W_y1[r, R+v] * desc[d, v]: thread r owns output r and issues all of its
         // row loads at once (one memory round trip per block instead of one per row pass)
         const int d = blockIdx.x;
@@ -87,9 +132,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         for (int j = tid; j < W; j += blockDim.x) {
             const float sg = sigmoidf_(cb[j]);
             s_sig[j] = sg;
-            if ((int)blockIdx.x == dm.D) tp.dsig[j] = sg * (1.f - sg);
+            if ((int)blockIdx.x == nC) tp.dsig[j] = sg * (1.f - sg);
         }
-        const bool first = (int)blockIdx.x == dm.D;
+        const bool first = (int)blockIdx.x == nC;
         if (first && tid < dm.T + 2) tp.alive[tid] = (tid == 0) ? 1 : 0;     // per-step live-tile counts (kernels_tile.h)
         if (first) for (int i = tid; i < 4 * 64; i += blockDim.x) tp.pflags[(size_t)i * 64] = 0u;   // role counters of k_conv_persist
         if (first && mc_shape(dm.H, dm.W, dm.R, dm.V, dm.D, dm.T))                                    // ... and of k_conversation_mc
@@ -102,7 +147,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         // hw0 = code_layer(sigmoid(code_bias)): four lanes per row, interleaved float4 slices (64 contiguous bytes per row step),
         // 8 loads in flight per lane
         const float* bc = P.p[S_CODE_B];
-        const int n = ((int)blockIdx.x - dm.D) * 64 + (tid >> 2), p4 = tid & 3;
+        const int n = ((int)blockIdx.x - nC) * 64 + (tid >> 2), p4 = tid & 3;
         const int nc = min(n, dm.H - 1);
         const float* wrow = P.p[S_CODE_W] + (size_t)nc * W;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;

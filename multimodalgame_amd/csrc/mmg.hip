@@ -18,6 +18,7 @@
 #include "kernels_fast3.h"
 #include "kernels_tile.h"
 #include "kernels_mc.h"
+#include "kernels_mc3.h"
 
 using namespace mmg;
 
@@ -43,7 +44,7 @@ struct mmg_handle {
     void* ws;
     JobTable* d_jt;
     JobTable jt;
-    int conv_smem, conv_smem_agent, conv_threads, bwd_smem, prep_smem;
+    int conv_smem, conv_smem_agent, conv_threads, bwd_smem, prep_smem, prep_cpb;
     bool profiling;
     bool scores_in_parts;      // the last forward left baseline scores as partials (k_baselines2)
     bool sw_merge_bas;         // MMG_NO_MERGE_BAS=1: the baselines' forward pass stays its own launch in the fused step
@@ -71,6 +72,7 @@ struct mmg_handle {
     bool sw_rsample, sw_rmsg, sw_fused_s, sw_xcd_map, rs_capable;
     bool mc_ok;                // many-class register-resident conversation (kernels_mc.h); MMG_NO_MC=1: off
     bool mc_never_big, mc_bwd_ok;
+    bool mc3_ok;               // continuous messages: the one-wave-per-SIMD many-class kernel (kernels_mc3.h); MMG_MC_OLD=1: k_conversation_mc
     bool any_split;            // some k_wgrad job splits its rows over workgroups (k_wreduce adds the partial tiles)
     bool wgrad_small_split;    // jobs with few output tiles split their (step, sample) rows further (layout.h: wgrad_job_nsplit)
     int mc_per, mc_xcd;        // classes per member of a tile; MMG_MC_XCD=1: a tile's 16 workgroups on one XCD
@@ -346,6 +348,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->mc_xcd = (getenv("MMG_MC_XCD") && atoi(getenv("MMG_MC_XCD")) == 0) ? 0 : 1;     // (measured at config 5, 256 samples: 192 us per minibatch against 201)
     h->mc_never_big = getenv("MMG_MC_SMALL_ONLY") != nullptr;
     h->mc_bwd_ok = !getenv("MMG_NO_MC_BWD");
+    h->mc3_ok = false;
     h->wgrad_small_split = !getenv("MMG_NO_SMALL_SPLIT");
     int n_cu = 0;
     {
@@ -369,6 +372,10 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->conv_smem_agent = conv_smem_floats(h->dm, MMG_BLOCK) * 4;
     h->bwd_smem = bwd_smem_floats(h->dm) * 4;
     h->prep_smem = ((h->dm.V > h->dm.W ? h->dm.V : h->dm.W) + 16) * 4;
+    // hundreds of classes: 8 per class block of k_prep (weight rows in registers across them); few classes: one per block (latency)
+    h->prep_cpb = (h->dm.D >= 256 && h->dm.R <= 64 && h->dm.V <= 128 && !(h->dm.V & 3) && 2 * h->dm.R <= MMG_BLOCK) ? 2 : 1;
+    if (h->prep_cpb > 1 && getenv("MMG_PREP_CPB")) h->prep_cpb = atoi(getenv("MMG_PREP_CPB")) > 0 ? atoi(getenv("MMG_PREP_CPB")) : 1;
+    if (h->prep_cpb > 1 && (int)(h->prep_cpb * (h->dm.V + h->dm.R) * 4) > h->prep_smem) h->prep_smem = h->prep_cpb * (h->dm.V + h->dm.R) * 4;
     if (h->conv_smem > 160 * 1024 || h->bwd_smem > 160 * 1024) { fail("dimensions need more than 160 KB of LDS per sample"); delete h; return nullptr; }
     hipError_t e = hipSuccess;
     {
@@ -464,6 +471,12 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         const int mc_budget = budget_of((const void*)(k_conversation_mc<256, 32, 64, 100, 64>), 512, 0);
         if (mc_budget < 128) h->mc_xcd = 0;
         if (mc_budget < 16) h->mc_ok = false;
+        h->mc3_ok = h->mc_ok && !h->dm.use_binary && !getenv("MMG_MC_OLD");
+        if (h->mc3_ok) {
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k_conversation_mc3<256, 32, 64, 100, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, mc3_lds_bytes());
+            const int b3 = budget_of((const void*)(k_conversation_mc3<256, 32, 64, 100, 64>), 256, mc3_lds_bytes());
+            if (b3 < (h->mc_xcd ? 128 : 16)) h->mc3_ok = false;
+        }
     }
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
@@ -556,7 +569,8 @@ static int launch_prep(mmg_handle* h, hipStream_t st, const float* desc, const f
     Scope sc(h, st, x ? "k_prep+h_x" : "k_prep");
     const Dims& d = h->dm;
     const int hx_tiles = x ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0;
-    hipLaunchKernelGGL(k_prep, dim3(d.D + (d.H + 63) / 64 + hx_tiles), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc, x);
+    const int cpb = h->prep_cpb, nC = (d.D + cpb - 1) / cpb;
+    hipLaunchKernelGGL(k_prep, dim3(nC + (d.H + 63) / 64 + hx_tiles), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc, x, cpb);
     return launch_check("k_prep");
 }
 
@@ -711,7 +725,10 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
         const int ntile = (d.B + 15) / 16;
         ar.per = h->mc_per;
         const int grid = h->mc_xcd ? ((ntile + 7) / 8) * 128 : ntile * 16;     // (mc_xcd assumes the 8 XCDs of an unpartitioned MI355X; mmg_create clears it otherwise)
-        hipLaunchKernelGGL((k_conversation_mc<256, 32, 64, 100, 64>), dim3(grid), dim3(512), 0, st, h->dm, h->P, h->tp, ar, ntile, h->mc_xcd, y_last_only);
+        if (h->mc3_ok)
+            hipLaunchKernelGGL((k_conversation_mc3<256, 32, 64, 100, 64>), dim3(grid), dim3(256), mc3_lds_bytes(), st, h->dm, h->P, h->tp, ar, ntile, h->mc_xcd, y_last_only);
+        else
+            hipLaunchKernelGGL((k_conversation_mc<256, 32, 64, 100, 64>), dim3(grid), dim3(512), 0, st, h->dm, h->P, h->tp, ar, ntile, h->mc_xcd, y_last_only);
         if (launch_check("k_conversation_mc")) return -1;
     } else {
         Scope sc(h, st, "k_conversation");
@@ -1011,7 +1028,7 @@ extern "C" int mmg_sender_forward(mmg_handle* h, const float* d_x, const float* 
         Scope sc(h, st, "k_prep(sender)");
         Dims d1 = h->dm; d1.D = 0;
         hipLaunchKernelGGL(k_prep, dim3((d1.H + 63) / 64), dim3(MMG_BLOCK), h->prep_smem, st, d1, h->P, h->tp, (const float*)nullptr,
-                           (const float*)nullptr);
+                           (const float*)nullptr, 1);
         if (launch_check("k_prep")) return -1;
     }
     if (launch_gemm_nt(h, st, "k_gemm_nt(h_x)", d_x, d.F, h->P.p[S_IMG_W], d.F, h->P.p[S_IMG_B], h->tp.hx, d.H, d.B, d.H, d.F)) return -1;
