@@ -139,7 +139,10 @@ int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_targe
  * than one rank the caller all-reduces (sum) that array between this call and mmg_backward
  * (model.py:912-915, 947-961: the REINFORCE weights are normalised by statistics of the WHOLE minibatch).
  * Continuous mode (use_binary == 0; model.py:1297-1305: loss = NLL mean) has no such coupling: the call and the
- * all-reduce may be skipped, mmg_backward forms the two logged sums itself (see mmg_grad_floats). */
+ * all-reduce may be skipped, mmg_backward forms the two logged sums itself (see mmg_grad_floats).
+ * Binary mode: the call is REQUIRED between mmg_exchange_forward(train, run_all_steps != 1) and mmg_backward -- on the
+ * register-resident path it also carries the baselines' forward pass over the live rows (model.py:835-843; one launch for the
+ * baselines and the statistics that consume their scores); mmg_backward fails if it was skipped. */
 int mmg_loss_stats(mmg_handle* h, void* stream);
 
 /* Gradient of the four losses (model.py:1296-1305) w.r.t. all parameters into d_grads (the whole

@@ -50,6 +50,7 @@ struct mmg_handle {
     bool sw_merge_bas;         // MMG_NO_MERGE_BAS=1: the baselines' forward pass stays its own launch in the fused step
     bool defer_bas;            // set by mmg_train_step around its forward call: the baselines may ride in the backward launch
     bool bas_deferred;         // ... and this forward pass left them to it (k_bwd_conv_fast: baseline roles)
+    bool bas_pending;          // phased step: the forward pass left the baselines to mmg_loss_stats (k_bas_stats: one launch for both)
     bool use_fast3;            // one-wave-per-SIMD forward kernel of the small agents (kernels_fast3.h); MMG_FAST2=1: the 512-thread one
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
     bool basehx_ready;         // this forward pass formed tape.basehx inside the conversation launch
@@ -718,6 +719,7 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     bool base_ready = false;
     h->basehx_ready = false;
     h->bas_deferred = false;
+    h->bas_pending = false;
     if (tile_path(h)) {
         if (launch_conv_tile(h, st, ar)) return -1;
     } else if (mc_path(h)) {
@@ -761,6 +763,12 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
             //  101.3 us per minibatch with the roles against 94.6 with k_baselines3 as its own launch; config 2: 66.0 against 72.1.)
             h->bas_deferred = true;
             h->scores_in_parts = true;
+        } else if (!h->defer_bas && base_ready && d.B <= 64 && (d.K + 63) / 64 <= 8 && h->sw_merge_bas &&
+                   h->n_cu >= 2 * ((5 * d.T + 2 + 3) / 4)) {
+            // phased (data-parallel) step, register-resident kernels: the baselines run in mmg_loss_stats' launch, as roles beside
+            // the statistics roles that consume their scores (k_bas_stats) -- one launch instead of two before the statistics all-reduce
+            h->bas_pending = true;
+            h->scores_in_parts = true;
         } else {
             Scope sc(h, st, "k_baselines");
             const bool live_rows = base_ready && d.B <= 64;      // k_baselines3: live (step, sample) rows only
@@ -788,6 +796,14 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
 extern "C" int mmg_loss_stats(mmg_handle* h, void* stream) {
     if (!h) return fail("NULL handle");
     hipStream_t st = (hipStream_t)stream;
+    if (h->bas_pending) {
+        Scope sc(h, st, "k_bas_stats");
+        const Dims& d = h->dm;
+        const int n_stats = (5 * d.T + 2 + 3) / 4, n_bas = ((d.T * d.B + 15) / 16) * 2 * ((d.K + 63) / 64);
+        hipLaunchKernelGGL(k_bas_stats, dim3(n_stats + n_bas), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, n_stats);
+        h->bas_pending = false;
+        return launch_check("k_bas_stats");
+    }
     Scope sc(h, st, "k_stats");
     hipLaunchKernelGGL(k_stats, dim3(5 * h->dm.T + 2), dim3(64), 0, st, h->dm, h->P, h->tp, h->scores_in_parts ? 1 : 0);
     return launch_check("k_stats");
@@ -911,6 +927,7 @@ extern "C" int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_ta
     if (!h) return fail("NULL handle");
     if (!d_x || !d_target || !d_desc) return fail("x / target / desc must not be NULL");
     if (sticky_error(h)) return -1;
+    if (h->bas_pending) return fail("mmg_loss_stats must run between mmg_exchange_forward(train) and mmg_backward (it carries the baselines' forward pass)");
     // continuous messages: the statistics are this rank's sum of rewards and hit count only, nothing a gradient depends on
     // (model.py:1297-1305) -- the call forms them itself (as a workgroup of the backward launch where the path has one, else as
     // k_stats) and no mmg_loss_stats / statistics all-reduce is needed; they reach the other ranks in the gradient tail
