@@ -145,7 +145,8 @@ def traffic_lookup(workload, kernel, strong, profiles_dir=None):
     pat = re.compile(r"^r(\d+)_%sconfig%s_pmc_hbm_traffic\.json$" % ("strong_" if strong else "", num))
     files = sorted((int(pat.match(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(pdir, "r*_pmc_hbm_traffic.json"))
                    if pat.match(os.path.basename(f)))
-    alias = {"k_conversation": ("k_conversation_fast2", "k_conversation_mc", "k_conversation"), "k_bwd_conv": ("k_bwd_conv_fast", "k_bwd_conv"),
+    alias = {"k_conversation": ("k_conversation_fast3", "k_conversation_fast2", "k_conversation_mc3", "k_conversation_mc", "k_conversation"),
+             "k_conversation_mc": ("k_conversation_mc3", "k_conversation_mc"), "k_bwd_conv": ("k_bwd_conv_fast", "k_bwd_conv"),
              "k_baselines": ("k_baselines3", "k_baselines4", "k_baselines2", "k_baselines")}
     for _, f in reversed(files):
         try:
