@@ -2410,6 +2410,8 @@ __device__ __forceinline__ void nfrag_mma(const NFrag<MAXKG>& f, const float* A,
     }
 }
 
+// UR: g values a thread holds per step: 16 * R <= UR * NT (host: 8 up to R = 128, 16 up to R = 256)
+template <int UR>
 __device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, const Tape& tp, const int zero_dead, const int blk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = MMG_BLOCK, nw = NT / 64;
@@ -2430,7 +2432,7 @@ __device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, co
     const float r_ts = (float)tp.tstar[bm], r_L = tp.logs[bm];
     const float r_br = tp.br[rowb + bm], r_bs = tp.bs[rowb + bm];
     const float r_s = dm.fixed ? 0.f : tp.s[rowb + bm], r_ps = dm.fixed ? 0.5f : tp.ps[rowb + bm];
-    constexpr int UW = 16, UR = 8;                                      // 16 * W <= UW * NT (W <= 256), 16 * R <= UR * NT (R <= 128)
+    constexpr int UW = 16;                                              // 16 * W <= UW * NT (W <= 256); 16 * R <= UR * NT
     F2 rw[UW]; float rg[UR];
 #pragma unroll
     for (int u = 0; u < UW; ++u) {
@@ -2509,16 +2511,18 @@ __device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, co
     }
 }
 
+template <int UR>
 __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre(Dims dm, Params P, Tape tp, int zero_dead) {
-    bwd_pre_body(dm, P, tp, zero_dead, (int)blockIdx.x);
+    bwd_pre_body<UR>(dm, P, tp, zero_dead, (int)blockIdx.x);
 }
 __device__ __forceinline__ void send_bwd_body(const Dims& dm, const Params& P, const Tape& tp, const int* __restrict__ rmap, const int bx, const int by);
 // k_bwd_pre and the sender's backward (k_send_bwd over all T * B rows, dead row blocks return) in ONE launch: neither depends
 // on the other, both are "statistics -> seeds -> one or two products" latency chains of ~20 us -- side by side instead of
 // one after the other.  Blocks [0, npre): bwd_pre_body; then nbands blocks per 16-row block: send_bwd_body.
+template <int UR>
 __global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre_send(Dims dm, Params P, Tape tp, int zero_dead, int npre, int nbands) {
     const int blk = blockIdx.x;
-    if (blk < npre) { bwd_pre_body(dm, P, tp, zero_dead, blk); return; }
+    if (blk < npre) { bwd_pre_body<UR>(dm, P, tp, zero_dead, blk); return; }
     const int sb = blk - npre;
     send_bwd_body(dm, P, tp, nullptr, sb / nbands, sb % nbands);
 }

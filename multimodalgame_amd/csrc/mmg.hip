@@ -445,19 +445,24 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         }
         h->tile_bwd_smem = bwd_tile_lds(d, 512 / 64).total * 4;
         h->send_bwd_smem = (MMG_TM * ld16(d.W) + 7 * 64 + 16 + tile_raw_floats_nn(64, MMG_BLOCK / 64)) * 4;
-        if (h->tile_bwd_smem > 160 * 1024 || d.W > 256 || d.R > 128) h->tile_ok = false;     // (k_bwd_tile keeps a step's GRU tape in 4 registers per thread per 32 hidden units)
+        if (h->tile_bwd_smem > 160 * 1024 || d.W > 256 || d.R > 256) h->tile_ok = false;     // (k_bwd_tile keeps a step's GRU tape in 4 registers per thread per 32 hidden units)
         if (h->tile_ok && e == hipSuccess && h->tile_bwd_smem > 48 * 1024)
         {
             e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_tile<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_bwd_smem);
         }
         if (h->tile_ok && e == hipSuccess && bwd_pre_lds_floats(d) * 4 > 48 * 1024)
-            e = hipFuncSetAttribute((const void*)k_bwd_pre, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_pre_lds_floats(d) * 4);
+        {
+            e = hipFuncSetAttribute((const void*)k_bwd_pre<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_pre_lds_floats(d) * 4);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_pre<16>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_pre_lds_floats(d) * 4);
+        }
         if (h->tile_ok && e == hipSuccess && h->send_bwd_smem > 48 * 1024)
             e = hipFuncSetAttribute((const void*)k_send_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, h->send_bwd_smem);
         if (h->tile_ok && e == hipSuccess) {
             const int smem = bwd_pre_lds_floats(d) * 4 > h->send_bwd_smem ? bwd_pre_lds_floats(d) * 4 : h->send_bwd_smem;
-            if (smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_pre_send, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_pre_send<8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (smem > 48 * 1024 && e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_pre_send<16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         }
         if (h->tile_ok && h->tile_smem > 48 * 1024) {
             e = hipFuncSetAttribute((const void*)k_conv_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
@@ -481,6 +486,10 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     }
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
+    if (getenv("MMG_DEBUG"))
+        fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d\n",
+                (int)h->tile_ok, h->tile_nt, h->tile_smem, (int)h->tile_ext, (int)h->tile_persist, h->persist_smem, h->resident_budget, h->tile_bwd_smem,
+                bwd_pre_lds_floats(h->dm) * 4, h->send_bwd_smem, (int)h->tile_split, (int)h->mc_ok, (int)h->use_fast);
     if (h->conv_smem > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
@@ -834,9 +843,12 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             if (d.use_binary && merged_send) {
                 const int nbands = (d.H + 63) / 64, nrb = (d.T * d.B + MMG_TM - 1) / MMG_TM;
                 const int smem = bwd_pre_lds_floats(d) * 4 > h->send_bwd_smem ? bwd_pre_lds_floats(d) * 4 : h->send_bwd_smem;
-                hipLaunchKernelGGL(k_bwd_pre_send, dim3(d.T * tiles + nrb * nbands), dim3(MMG_BLOCK), smem, st, h->dm, h->P, h->tp, zero_dead, d.T * tiles, nbands);
-            } else if (d.use_binary)
-                hipLaunchKernelGGL(k_bwd_pre, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
+                if (d.R <= 128) hipLaunchKernelGGL(k_bwd_pre_send<8>, dim3(d.T * tiles + nrb * nbands), dim3(MMG_BLOCK), smem, st, h->dm, h->P, h->tp, zero_dead, d.T * tiles, nbands);
+                else hipLaunchKernelGGL(k_bwd_pre_send<16>, dim3(d.T * tiles + nrb * nbands), dim3(MMG_BLOCK), smem, st, h->dm, h->P, h->tp, zero_dead, d.T * tiles, nbands);
+            } else if (d.use_binary) {
+                if (d.R <= 128) hipLaunchKernelGGL(k_bwd_pre<8>, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
+                else hipLaunchKernelGGL(k_bwd_pre<16>, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
+            }
             if (h->rs_capable) {
                 // receiver shape of the register-resident kernels: one workgroup per sample (+ one for the live-row list)
                 // (+ k_dhx's blocks when the sender's backward already ran: its dpre is complete)
@@ -846,8 +858,10 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
                 else hipLaunchKernelGGL((k_bwd_sample<64, 100, 32>), dim3(d.B + 1 + ndhx), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0, nblk);
             } else if (d.R <= 64)
                 hipLaunchKernelGGL((k_bwd_tile<512, 2>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
-            else
+            else if (d.R <= 128)
                 hipLaunchKernelGGL((k_bwd_tile<512, 4>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
+            else
+                hipLaunchKernelGGL((k_bwd_tile<512, 8>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             if (launch_check("k_bwd_tile")) return -1;
         }
         if (d.use_binary) {
