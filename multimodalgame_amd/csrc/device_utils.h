@@ -361,6 +361,45 @@ __device__ __forceinline__ void role_wait(uint32_t* sync, int dep, uint32_t prod
     if (ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale cache lines before reading what the producers wrote
 }
 
+// agent-scope (write-through) store: payload another workgroup of the same launch reads after a counter hand-off
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... 16 bytes at once (p 16-byte aligned): the agent-scope store of gfx942 / gfx950 is a global store with sc1 set
+__device__ __forceinline__ void st_wt4(float* p, float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+}
+// agent-scope (sc1) loads of such a payload: coherent across the XCDs' L2s by themselves, so the consumer needs NO acquire fence
+// (an agent-scope acquire is a buffer_inv of the whole L2: everything the role reads afterwards comes from memory again)
+__device__ __forceinline__ float ld_cc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float2 ld_cc2(const float* p) {
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__builtin_bit_cast(float, (unsigned)u), __builtin_bit_cast(float, (unsigned)(u >> 32)));
+}
+__device__ __forceinline__ float4 ld_cc4(const float* p) { const float2 a = ld_cc2(p), b = ld_cc2(p + 2); return make_float4(a.x, a.y, b.x, b.y); }
+
+// (value, epoch) pairs: ONE aligned 8-byte write-through store / agent-scope load each, so a reader of the same launch sees the
+// value together with its tag or not at all -- the consumer spins on the payload itself (one memory round trip once it has
+// landed; no counter, no store-completion wait at the producer, nothing to re-arm: an epoch is used by one launch only)
+__device__ __forceinline__ void st_ll(float* ll, size_t i, float v, uint32_t epoch) {
+    const unsigned long long u = ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(ll) + i, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_ll(const float* ll, size_t i) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(ll) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ll_value(unsigned long long u) { return __builtin_bit_cast(float, (unsigned)u); }
+__device__ __forceinline__ bool ll_fresh(unsigned long long u, uint32_t epoch) { return (uint32_t)(u >> 32) == epoch; }
+
+// four consecutive pairs as one float4, spinning (bounded) until all four carry this launch's epoch
+__device__ __forceinline__ float4 ll_wait4(const float* ll, size_t i, uint32_t epoch) {
+    unsigned long long u0, u1, u2, u3;
+    int spins = 0;
+    do {
+        u0 = ld_ll(ll, i); u1 = ld_ll(ll, i + 1); u2 = ld_ll(ll, i + 2); u3 = ld_ll(ll, i + 3);
+    } while (!(ll_fresh(u0, epoch) && ll_fresh(u1, epoch) && ll_fresh(u2, epoch) && ll_fresh(u3, epoch)) && ++spins < (1 << 16));
+    return make_float4(ll_value(u0), ll_value(u1), ll_value(u2), ll_value(u3));
+}
+
 // one 16x16x4 fp32 MFMA step:  D += A(16x4) * B(4x16);  lane l holds A[l&15][l>>4], B[l>>4][l&15],
 // D[(l>>4)*4 + reg][l&15]   (cdna_hip_programming.md §3)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {

@@ -99,11 +99,36 @@ template <int H, int W, int R, int V>
 __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P, Tape tp, ConvArgs ar) {
     constexpr int NT = 256, TMAX = Fast3Lds::TMAX;
     static_assert(H == 256 && W == 32 && R == 64 && V % 4 == 0 && V <= 128, "lane maps of k_conversation_fast3");
-    if ((int)blockIdx.x >= dm.B) {                         // trailing workgroups: tiles of basehx for the baselines' launch
-        gemm_nt_tile((int)blockIdx.x - dm.B, tp.hx, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // Roles of the launch, in workgroup order (producers before their consumers, device_utils.h):
+    //   [0, nprep)            k_prep's blocks (parameter constants Cd / cy / Dd / hw0, tiles of h_x): nothing they need comes from
+    //                         this launch, and the sample roles spend their first ~5 us loading weights -- a launch of its own
+    //                         (5.5 us + the boundary) hidden behind that prologue; hand-off by counters (prep_body<true>)
+    //   [nprep, nprep + B)    one conversation per sample
+    //   then                  tiles of basehx for the baselines' launch (they wait for the h_x row tile they multiply)
+    const int merged = ar.nprep > 0;
+    const uint32_t n_consumers = (uint32_t)(dm.B + ar.nbase);
+    if ((int)blockIdx.x < ar.nprep) {
+        prep_body<true>(dm, P, tp, ar.desc, ar.x, ar.prep_cpb, (int)blockIdx.x, lds);
+#ifdef MMG_TIMING
+        {   // when the first class block, the first hw0 block and the first / last h_x tile are through (scripts/timeline.py)
+            const int nC = (dm.D + ar.prep_cpb - 1) / ar.prep_cpb, HB = (dm.H + 63) / 64, blk = (int)blockIdx.x;
+            const int slot = blk == 0 ? 123 : blk == nC ? 127 : blk == nC + HB ? 124 : blk == ar.nprep - 1 ? 125 : -1;
+            if (slot >= 0 && threadIdx.x == 0) tp.dbg[slot] = (long long)wall_clock64();
+        }
+#endif
         return;
     }
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= ar.nprep + dm.B) {
+        const int tile = (int)blockIdx.x - ar.nprep - dm.B;
+        if (!merged) { gemm_nt_tile(tile, tp.hx, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H); return; }
+        // (A operand = the h_x pairs of this launch's prep roles: the loads spin until they carry this launch's epoch)
+        gemm_nt_tile<false, true>(tile, tp.prepll, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H, nullptr, tp.counter[0] + 1u);
+        uint32_t passed = 0;
+        if (threadIdx.x == 0) passed = prep_consumer_arrive(tp);
+        if (threadIdx.x == 0) prep_consumer_done(dm, tp, passed, n_consumers);
+        return;
+    }
     typedef Fast3Lds L;
     float* const s_a = lds + L::a; float* const s_gru = lds + L::gru; float* const s_h = lds + L::h; float* const s_g = lds + L::g;
     float* const s_z = lds + L::z; float* const s_pz = lds + L::pz; float* const s_w = lds + L::w; float* const s_pw = lds + L::pw;
@@ -113,14 +138,14 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
     float* const s_misc = s_us + 65; float* const s_sig = s_us + 80;
     float4* const s_park = reinterpret_cast<float4*>(lds + L::park);
 
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (int)blockIdx.x - ar.nprep, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = dm.B, T = dm.T, Dr = dm.D;
     const bool binary = dm.use_binary != 0, train = ar.train != 0, inject = ar.u_s != nullptr;
     MMG_STAMP(0);
 #ifdef MMG_TIMING
     if (b == 0 && tid == 0) tp.dbg[4] = (long long)__builtin_readcyclecounter();
 #endif
-    const uint32_t mb_counter = tp.counter[0];
+    const uint32_t mb_counter = tp.counter[0] + (merged ? 1u : 0u);      // (merged: bumped by the last consumer to arrive, below)
     const uint32_t gb = (uint32_t)(dm.boff + b);
     const int tgt = ar.target ? (int)ar.target[b] : -1;     // (read here: no dependent memory round trip after the conversation)
     if (train && inject) {
@@ -139,7 +164,9 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
         const float4 v = *reinterpret_cast<const float4*>(P.p[S_CODE_W] + (size_t)tid * W + 4 * j);
         wc[4 * j] = v.x; wc[4 * j + 1] = v.y; wc[4 * j + 2] = v.z; wc[4 * j + 3] = v.w;
     }
-    const float bc = P.p[S_CODE_B][tid], hw0 = tp.hw0[tid], hx = tp.hx[(size_t)b * H + tid];
+    const float bc = P.p[S_CODE_B][tid];
+    float hw0 = 0.f, hx = 0.f;
+    if (!merged) { hw0 = tp.hw0[tid]; hx = tp.hx[(size_t)b * H + tid]; }
     // P2 binary_layer (m2, k2): float4 index j * 8 + k2 of row m2;  P7 w: floats k2 * 8 .. + 7 of row m2
     const int m2 = tid >> 3, k2 = tid & 7;
     float wb[32], ww[8];
@@ -188,18 +215,19 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
     float ncd[8], w2[8];
     {
         const float* crow = tp.Cd + (size_t)min(d5, Dr - 1) * R + r5 * 8;
-        const float4 c0 = *reinterpret_cast<const float4*>(crow), c1 = *reinterpret_cast<const float4*>(crow + 4);
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+        if (!merged) { c0 = *reinterpret_cast<const float4*>(crow); c1 = *reinterpret_cast<const float4*>(crow + 4); }
         ncd[0] = -c0.x; ncd[1] = -c0.y; ncd[2] = -c0.z; ncd[3] = -c0.w; ncd[4] = -c1.x; ncd[5] = -c1.y; ncd[6] = -c1.z; ncd[7] = -c1.w;
         const float4 q0 = *reinterpret_cast<const float4*>(P.p[R_Y2_W] + r5 * 8), q1 = *reinterpret_cast<const float4*>(P.p[R_Y2_W] + r5 * 8 + 4);
         w2[0] = q0.x; w2[1] = q0.y; w2[2] = q0.z; w2[3] = q0.w; w2[4] = q1.x; w2[5] = q1.y; w2[6] = q1.z; w2[7] = q1.w;
     }
-    const float cy5 = tp.cy[min(d5, Dr - 1)];           // b_y2 + sum_r w2[r] Cd[d][r]  (k_prep)
+    float cy5 = merged ? 0.f : tp.cy[min(d5, Dr - 1)];  // b_y2 + sum_r w2[r] Cd[d][r]  (k_prep)
     const float4 ws4 = *reinterpret_cast<const float4*>(P.p[R_S_W] + (tid & 15) * 4);
     const float bs = P.p[R_S_B][0];
     // P6 (u3, q3): Dd[q3 * 8 + k][u3]
     float dd[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int d = q3 * 8 + k; dd[k] = (d < Dr) ? tp.Dd[(size_t)d * R + u3] : 0.f; }
+    for (int k = 0; k < 8; ++k) { const int d = q3 * 8 + k; dd[k] = (d < Dr && !merged) ? tp.Dd[(size_t)d * R + u3] : 0.f; }
     if (tid < W) s_sig[tid] = fsigmoid(P.p[S_CODE_BIAS][tid]);
     if (train && !inject) {                        // Philox draws of the whole conversation, while the weight loads are in flight
         for (int i = tid; i < T * W; i += NT) {
@@ -212,6 +240,37 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) s_park[i * NT + tid] = whh_tmp[i];
+    uint32_t arrived = 0;
+    if (merged) {
+        // what the prep roles of this launch produced, as (value, epoch) pairs: issued once the weights are in (the producers
+        // need ~3.5 us, the weight loads ~4.5), one more memory round trip; a pair of another epoch -> load again
+        const size_t i_hw = prepll_hw0(dm) + tid, i_hx = prepll_hx(dm) + (size_t)b * H + tid;
+        const size_t i_cd = prepll_cd(dm) + (size_t)min(d5, Dr - 1) * R + r5 * 8, i_dd = prepll_dd(dm) + u3;
+        unsigned long long u[18];
+        int spins = 0;
+        bool fresh;
+        do {
+            u[0] = ld_ll(tp.prepll, i_hw); u[1] = ld_ll(tp.prepll, i_hx);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[2 + k] = ld_ll(tp.prepll, i_cd + k);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[10 + k] = ld_ll(tp.prepll, i_dd + (size_t)min(q3 * 8 + k, Dr - 1) * R);
+            fresh = true;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) fresh = fresh && ll_fresh(u[k], mb_counter);
+            if (++spins > (1 << 16)) { if (lane == 0) __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        } while (__any(!fresh));
+        MMG_STAMP(126);
+        hw0 = ll_value(u[0]); hx = ll_value(u[1]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ncd[k] = -ll_value(u[2 + k]); dd[k] = (q3 * 8 + k < Dr) ? ll_value(u[10 + k]) : 0.f; }
+        // cy[d] = b_y2 + sum_r w2[r] Cd[d][r] from this lane group's own eighths (k_prep's value reaches later launches only)
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) part = fmaf(w2[k], -ncd[k], part);
+        cy5 = dpp_group_sum<8>(part) + P.p[R_Y2_B][0];
+        if (tid == 0) arrived = prep_consumer_arrive(tp);
+    }
     MMG_STAMP(1);
     // ------------------------------------------------------------ conversation state
     if (tid < R) s_h[tid] = 0.f;
@@ -447,6 +506,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
             if (t < t_done && d < Dr) tp.y[((size_t)t * B + b) * Dr + d] = yv;
         }
     }
+    if (merged && tid == 0) prep_consumer_done(dm, tp, arrived, n_consumers);
     MMG_STAMP(122);
     MMG_STAMP(6);
 }

@@ -16,27 +16,43 @@ namespace mmg {
 // build_inp, model.py:412/432 -- SURVEY.md Appendix A.2).  Block D: hw0 = code_layer(sigmoid(
 // code_bias)) (model.py:199-200) and dsig = sigmoid'(code_bias).
 // ---------------------------------------------------------------------------------------------
+// LLO: the output ALSO goes out as (value, epoch) pairs at ll[m * ldo + n] (consumer roles of the SAME launch spin on them);
+// LLA: the X operand is such a pair array written by other roles of this launch (X = the pair array, ldx in pairs)
+template <bool LLO = false, bool LLA = false>
 __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__ X, int ldx, const float* __restrict__ Wm, int ldw,
-                                             const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K);
+                                             const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K,
+                                             float* ll = nullptr, uint32_t epoch = 0u);
 
 // blocks [0, D]: parameter-only constants; blocks (D, D + hx_tiles]: tiles of h_x = image_layer(x)
 // (model.py:195) -- independent work sharing one launch.
 // cpb > 1 (many classes): a class block owns `cpb` consecutive classes and keeps its y1 / w_d weight row in registers across
 // them -- one block per class re-reads all 2 R weight rows (51 KB) from L2 per class: 51 MB per launch at D = 1000.
-__global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, const float* __restrict__ desc,
-                                                    const float* __restrict__ x, int cpb) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// ROLE: the blocks are workgroup roles of the conversation's launch (k_conversation_fast3): what the sample roles read (h_x, hw0,
+// Cd, Dd) ALSO goes out as (value, launch epoch) pairs (tape.prepll, device_utils.h: st_ll) the consumers spin on; the epoch is
+// the minibatch counter of this launch, which the LAST consumer to arrive bumps (prep_consumer_done) -- every role has read it
+// by then -- instead of the first hw0 block; only the counters of the backward launch's roles are zeroed here.
+#define PREP_CTR_ARRIVE 193
+#define PREP_CTR(tp, k) ((tp).pflags + (size_t)(k) * 64)
+// pair offsets inside tape.prepll
+__host__ __device__ inline size_t prepll_hx(const Dims&) { return 0; }
+__host__ __device__ inline size_t prepll_hw0(const Dims& d) { return (size_t)d.B * d.H; }
+__host__ __device__ inline size_t prepll_cd(const Dims& d) { return (size_t)d.B * d.H + d.H; }
+__host__ __device__ inline size_t prepll_dd(const Dims& d) { return (size_t)d.B * d.H + d.H + (size_t)d.D * d.R; }
+template <bool ROLE>
+__device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const Tape& tp, const float* __restrict__ desc,
+                                          const float* __restrict__ x, const int cpb, const int blk, float* smem) {
     const int tid = threadIdx.x;
+    const uint32_t epoch = ROLE ? tp.counter[0] + 1u : 0u;
     const int HB = (dm.H + 63) / 64;                 // blocks [nC, nC + HB): 64 rows of hw0 each
     const int nC = (dm.D + cpb - 1) / cpb;           // class blocks
-    if ((int)blockIdx.x >= nC + HB) {
-        gemm_nt_tile(blockIdx.x - nC - HB, x, dm.F, P.p[S_IMG_W], dm.F, P.p[S_IMG_B], tp.hx, dm.H, dm.B, dm.H, dm.F);
+    if (blk >= nC + HB) {
+        gemm_nt_tile<ROLE, false>(blk - nC - HB, x, dm.F, P.p[S_IMG_W], dm.F, P.p[S_IMG_B], tp.hx, dm.H, dm.B, dm.H, dm.F, tp.prepll, epoch);
         return;
     }
-    if ((int)blockIdx.x < nC && cpb > 1) {
+    if (blk < nC && cpb > 1) {
         // (host: cpb > 1 only with R <= 64, V <= 128, V % 4 == 0) threads [0, R): Cd rows, [R, 2R): Dd rows
         const int R = dm.R, V = dm.V, ld = dm.R + dm.V, D = dm.D;
-        const int d0 = blockIdx.x * cpb, nd = min(cpb, D - d0);
+        const int d0 = blk * cpb, nd = min(cpb, D - d0);
         float* s_desc = smem;                       // [cpb][V]
         float* s_cd = smem + cpb * V;               // [cpb][R]
         for (int i = tid; i < nd * V; i += blockDim.x) { const float dv = desc[(size_t)d0 * V + i]; s_desc[i] = dv; tp.descc[(size_t)d0 * V + i] = dv; }
@@ -60,8 +76,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
                 }
                 const float v = (a0 + a1) + (a2 + a3) + by;
                 const int d = d0 + c;
-                if (isC) { tp.Cd[(size_t)d * R + r] = v; tp.CdT[(size_t)r * D + d] = -v; s_cd[c * R + r] = v; }
-                else tp.Dd[(size_t)d * R + r] = v;
+                if (isC) { tp.Cd[(size_t)d * R + r] = v; if (ROLE) st_ll(tp.prepll, prepll_cd(dm) + (size_t)d * R + r, v, epoch); tp.CdT[(size_t)r * D + d] = -v; s_cd[c * R + r] = v; }
+                else { tp.Dd[(size_t)d * R + r] = v; if (ROLE) st_ll(tp.prepll, prepll_dd(dm) + (size_t)d * R + r, v, epoch); }
             }
         }
         __syncthreads();
@@ -75,10 +91,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         }
         return;
     }
-    if ((int)blockIdx.x < nC) {
+    if (blk < nC) {
         // Cd[d, r] = b_y1[r] + sum_v W_y1[r, R+v] * desc[d, v]: thread r owns output r and issues all of its
         // row loads at once (one memory round trip per block instead of one per row pass)
-        const int d = blockIdx.x;
+        const int d = blk;
         const int R = dm.R, V = dm.V, ld = dm.R + dm.V;
         float* s_desc = smem;                       // [V]
         for (int v = tid; v < V; v += blockDim.x) { const float dv = desc[(size_t)d * V + v]; s_desc[v] = dv; tp.descc[(size_t)d * V + v] = dv; }
@@ -104,6 +120,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
                 for (int v = 0; v < V; ++v) a0 = fmaf(wrow[v], s_desc[v], a0);
             }
             tp.Dd[(size_t)d * R + r] = (a0 + a1) + (a2 + a3);
+            if (ROLE) st_ll(tp.prepll, prepll_dd(dm) + (size_t)d * R + r, (a0 + a1) + (a2 + a3), epoch);
         }
         for (int r = tid; r < R; r += blockDim.x) {
             const float* wrow = P.p[R_Y1_W] + (size_t)r * ld + R;
@@ -120,6 +137,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
             }
             const float cdv = (a0 + a1) + (a2 + a3) + by1[r];
             tp.Cd[(size_t)d * R + r] = cdv;
+            if (ROLE) st_ll(tp.prepll, prepll_cd(dm) + (size_t)d * R + r, cdv, epoch);
             tp.CdT[(size_t)r * dm.D + d] = -cdv;      // NEGATED: relu(A + c) = max(A, -c) + c (kernels_tile.h, many-class y head)
             cy_part = fmaf(P.p[R_Y2_W][r], cdv, cy_part);
         }
@@ -132,22 +150,22 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
         for (int j = tid; j < W; j += blockDim.x) {
             const float sg = sigmoidf_(cb[j]);
             s_sig[j] = sg;
-            if ((int)blockIdx.x == nC) tp.dsig[j] = sg * (1.f - sg);
+            if (blk == nC) tp.dsig[j] = sg * (1.f - sg);
         }
-        const bool first = (int)blockIdx.x == nC;
+        const bool first = blk == nC;
         if (first && tid < dm.T + 2) tp.alive[tid] = (tid == 0) ? 1 : 0;     // per-step live-tile counts (kernels_tile.h)
-        if (first) for (int i = tid; i < 4 * 64; i += blockDim.x) tp.pflags[(size_t)i * 64] = 0u;   // role counters of k_conv_persist
+        if (first) for (int i = tid; i < (ROLE ? 128 : 4 * 64); i += blockDim.x) tp.pflags[(size_t)i * 64] = 0u;   // role counters of k_conv_persist / the backward launch
         if (first && mc_shape(dm.H, dm.W, dm.R, dm.V, dm.D, dm.T))                                    // ... and of k_conversation_mc
             for (int i = tid; i < 2 * ((dm.B + 15) / 16); i += blockDim.x) tp.mcflags[(size_t)i * 64] = 0u;
         if (first && tid == 0) {
-            tp.counter[0] += 1u;                    // minibatch counter: the Philox stream of this conversation
+            if (!ROLE) tp.counter[0] += 1u;         // minibatch counter: the Philox stream of this conversation
             if (tp.counter[2] > tp.counter[1]) tp.counter[1] = tp.counter[2];   // optimizer step bumped by k_opt
         }
         __syncthreads();
         // hw0 = code_layer(sigmoid(code_bias)): four lanes per row, interleaved float4 slices (64 contiguous bytes per row step),
         // 8 loads in flight per lane
         const float* bc = P.p[S_CODE_B];
-        const int n = ((int)blockIdx.x - nC) * 64 + (tid >> 2), p4 = tid & 3;
+        const int n = (blk - nC) * 64 + (tid >> 2), p4 = tid & 3;
         const int nc = min(n, dm.H - 1);
         const float* wrow = P.p[S_CODE_W] + (size_t)nc * W;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -169,9 +187,30 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
             for (int k = p4; k < W; k += 4) a0 = fmaf(wrow[k], s_sig[k], a0);
         }
         const float tot = dpp_group_sum<4>((a0 + a1) + (a2 + a3));
-        if (p4 == 0 && n < dm.H) tp.hw0[n] = tot + bc[n];
+        if (p4 == 0 && n < dm.H) { tp.hw0[n] = tot + bc[n]; if (ROLE) st_ll(tp.prepll, prepll_hw0(dm) + n, tot + bc[n], epoch); }
     }
 }
+// consumers of a launch with prep roles count themselves once they hold what they waited for; the last one bumps the minibatch
+// counter (every role of the launch has read it by then) and re-arms the arrival counter.  `passed`: the consumer's own arrival index.
+__device__ __forceinline__ uint32_t prep_consumer_arrive(const Tape& tp) {
+    return __hip_atomic_fetch_add(PREP_CTR(tp, PREP_CTR_ARRIVE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void prep_consumer_done(const Dims& dm, const Tape& tp, const uint32_t passed, const uint32_t consumers) {
+    if (passed + 1 != consumers) return;
+    __hip_atomic_store(PREP_CTR(tp, PREP_CTR_ARRIVE), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tp.counter[0] += 1u;
+}
+__host__ __device__ inline int prep_blocks(const Dims& d, int cpb, bool with_hx) {
+    return (d.D + cpb - 1) / cpb + (d.H + 63) / 64 + (with_hx ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0);
+}
+
+__global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, const float* __restrict__ desc,
+                                                    const float* __restrict__ x, int cpb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    prep_body<false>(dm, P, tp, desc, x, cpb, (int)blockIdx.x, smem);
+}
+
+
 
 // ---------------------------------------------------------------------------------------------
 // k_gemm_nt: out[m, n] = sum_k X[m*ldx + k] * Wm[n*ldw + k] + bias[n].  One workgroup per 16x16
@@ -180,10 +219,11 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, 
 // per operand per four MFMAs (the k index inside the group of 16 is permuted identically for A
 // and B, which leaves the sum unchanged).
 // ---------------------------------------------------------------------------------------------
+template <bool LLO, bool LLA>
 __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__ X, int ldx,
                                                        const float* __restrict__ Wm, int ldw,
                                                        const float* __restrict__ bias,
-                                                       float* __restrict__ out, int ldo, int M, int N, int K) {
+                                                       float* __restrict__ out, int ldo, int M, int N, int K, float* ll, uint32_t epoch) {
     __shared__ float s_acc[4][16][17];
     const int tiles_n = (N + 15) >> 4;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -206,7 +246,7 @@ __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__
             for (int u = 0; u < 8; ++u) {
                 const int k = (cb0 + u) * 16 + q * 4;
                 const bool kv = (cb0 + u) < c1;
-                a[u] = (mv && kv) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[u] = (mv && kv) ? (LLA ? ll_wait4(X, (size_t)(mv ? m : 0) * ldx + k, epoch) : *reinterpret_cast<const float4*>(xr + k)) : make_float4(0.f, 0.f, 0.f, 0.f);
                 b[u] = (nv && kv) ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -236,7 +276,9 @@ __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__
         const int mo = tm * 16 + r, no = tn * 16 + cidx;
         if (mo < M && no < N) {
             float v = s_acc[0][r][cidx] + s_acc[1][r][cidx] + s_acc[2][r][cidx] + s_acc[3][r][cidx];
-            out[(size_t)mo * ldo + no] = v + (bias ? bias[no] : 0.f);
+            v += bias ? bias[no] : 0.f;
+            out[(size_t)mo * ldo + no] = v;
+            if (LLO) st_ll(ll, (size_t)mo * ldo + no, v, epoch);
         }
     }
 }
@@ -274,6 +316,8 @@ struct ConvArgs {
     int nhelp, per;            // kernels_tile.h, k_conv_split: class helpers per sample tile, classes per slice
     int y_last_only;           // Fixed-mode training step (mmg_train_step): tape.y keeps the output step's logits only
     int lean;                  // training-minimal call in continuous mode: tape arrays the receiver-only backward never reads are not stored
+    int nprep, prep_cpb;       // k_conversation_fast3: leading workgroups that run k_prep's blocks as roles of the launch (0: k_prep ran before), classes per class block
+    int nbase;                 // ... and trailing basehx tiles
 };
 
 struct ConvSmem {

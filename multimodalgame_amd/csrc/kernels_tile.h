@@ -24,21 +24,7 @@
 namespace mmg {
 
 #define MMG_TM 16                                   // samples per tile = MFMA M
-// agent-scope (write-through) store: payload another workgroup of the same launch reads after a counter hand-off
-__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// ... 16 bytes at once (p 16-byte aligned): the agent-scope store of gfx942 / gfx950 is a global store with sc1 set
-__device__ __forceinline__ void st_wt4(float* p, float4 v) {
-    const f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
-}
-// agent-scope (sc1) loads of such a payload: coherent across the XCDs' L2s by themselves, so the consumer needs NO acquire fence
-// (an agent-scope acquire is a buffer_inv of the whole L2: everything the role reads afterwards comes from memory again)
-__device__ __forceinline__ float ld_cc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float2 ld_cc2(const float* p) {
-    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__builtin_bit_cast(float, (unsigned)u), __builtin_bit_cast(float, (unsigned)(u >> 32)));
-}
-__device__ __forceinline__ float4 ld_cc4(const float* p) { const float2 a = ld_cc2(p), b = ld_cc2(p + 2); return make_float4(a.x, a.y, b.x, b.y); }
+// (st_wt / st_wt4 / ld_cc / ld_cc2 / ld_cc4: device_utils.h)
 // values of lanes l, l + 2, l + 4, l + 6 (the results of four neighbouring 2-lane groups) as one float4 in lane l
 __device__ __forceinline__ float4 gather4_even(float v) {
     return make_float4(v, __shfl_down(v, 2), __shfl_down(v, 4), __shfl_down(v, 6));

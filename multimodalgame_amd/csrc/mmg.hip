@@ -51,6 +51,7 @@ struct mmg_handle {
     bool defer_bas;            // set by mmg_train_step around its forward call: the baselines may ride in the backward launch
     bool bas_deferred;         // ... and this forward pass left them to it (k_bwd_conv_fast: baseline roles)
     bool bas_pending;          // phased step: the forward pass left the baselines to mmg_loss_stats (k_bas_stats: one launch for both)
+    bool sw_merge_prep;        // k_prep's blocks as roles of k_conversation_fast3's launch (MMG_NO_MERGE_PREP=1: a launch of their own)
     bool use_fast3;            // one-wave-per-SIMD forward kernel of the small agents (kernels_fast3.h); MMG_FAST2=1: the 512-thread one
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
     bool basehx_ready;         // this forward pass formed tape.basehx inside the conversation launch
@@ -341,6 +342,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     } else h->h_err = nullptr;
     h->use_fast = !getenv("MMG_NO_FAST"); h->merge_roles = !getenv("MMG_NO_MERGE");
     h->use_fast3 = !getenv("MMG_FAST2");
+    h->sw_merge_prep = !getenv("MMG_NO_MERGE_PREP");
     h->sw_merge_bas = !getenv("MMG_NO_MERGE_BAS"); h->defer_bas = false; h->bas_deferred = false;
     h->sw_rsample = !getenv("MMG_NO_RSAMPLE"); h->sw_rmsg = !getenv("MMG_NO_RMSG"); h->sw_fused_s = !getenv("MMG_NO_FUSED_S");
     h->sw_xcd_map = getenv("MMG_XCD_MAP") != nullptr;
@@ -714,7 +716,10 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     if (train && sticky_error(h)) return -1;
     hipStream_t st = (hipStream_t)stream;
     const Dims& d = h->dm;
-    if (launch_prep(h, st, d_desc, d_x)) return -1;
+    // register-resident forward (k_conversation_fast3): k_prep's blocks run as leading roles of the conversation's launch
+    const bool merge_prep = h->sw_merge_prep && !tile_path(h) && !mc_path(h) && fast_shape(h) && h->use_fast3 && d.B <= 512 &&
+                            h->prep_smem <= fast3_lds_bytes();
+    if (!merge_prep && launch_prep(h, st, d_desc, d_x)) return -1;
     const bool bas = train && d.use_binary;
     ConvArgs ar;
     memset(&ar, 0, sizeof(ar));
@@ -746,8 +751,10 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
         const bool fast = fast_shape(h);
         base_ready = fast && bas && !run_all_steps && h->merge_roles;
         const int base_tiles = base_ready ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
-        if (fast && h->use_fast3)
-            hipLaunchKernelGGL((k_conversation_fast3<256, 32, 64, 100>), dim3(d.B + base_tiles), dim3(256), fast3_lds_bytes(), st, h->dm, h->P, h->tp, ar);
+        if (fast && h->use_fast3) {
+            ar.nprep = merge_prep ? prep_blocks(d, h->prep_cpb, true) : 0; ar.prep_cpb = h->prep_cpb; ar.nbase = base_tiles;
+            hipLaunchKernelGGL((k_conversation_fast3<256, 32, 64, 100>), dim3(ar.nprep + d.B + base_tiles), dim3(256), fast3_lds_bytes(), st, h->dm, h->P, h->tp, ar);
+        }
         else if (fast)
             if (d.D == 30) hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
             else hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 32>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
