@@ -67,11 +67,12 @@ def conversation_flops(d, B, t_steps):
     return B * t_steps * per_row
 
 
-def algorithmic_work(kernel, d, B, t_steps, lean=False):
+def algorithmic_work(kernel, d, B, t_steps, lean=False, prep_inside=False):
     """Algorithmic (minimal) work of ALL launches of `kernel` in one minibatch: (bound, amount) with amount in bytes for
     HBM-bound kernels and flops for MFMA-bound ones.  B samples, t_steps = exchange steps a sample takes on average
     (B * t_steps live (step, sample) rows).  Formulas: DESIGN.md §3.
-    lean: the fused continuous-mode step (include/mmg.h: run_all_steps == 2) stores only what its backward reads."""
+    lean: the fused continuous-mode step (include/mmg.h: run_all_steps == 2) stores only what its backward reads.
+    prep_inside: the conversation launch carries k_prep's blocks as roles: their operands count as its bytes."""
     F, H, W, R, V, K, D, T = (d[k] for k in ("feat_dim", "h_dim", "w_dim", "rec_hidden", "wv_dim", "bas_hidden",
                                              "n_classes", "max_exchange"))
     rows = B * t_steps
@@ -88,7 +89,8 @@ def algorithmic_work(kernel, d, B, t_steps, lean=False):
             # floats written per live (step, sample) row: a [H]; z, pz, w, pw, zr, c [6 W]; GRU gates [4 R], h [R], g [R]; the class
             # logits [D]; softmax(y) [32] (k_conversation_fast3; the generic kernels write dbar [V] instead) and ~12 scalars
             tape = rows * 4 * (H + 6 * W + 6 * R + D + min(V, 32) + 12)
-        return "hbm", 4 * (p_sender + p_recv) + tape + 4 * B * H
+        prep = 4 * (B * F + H * F + H + D * V + 2 * R * V + 2 * D * R + H * W) if prep_inside else 0   # x, W_i, desc, y1 / w_d rows in; Cd, Dd out
+        return "hbm", 4 * (p_sender + p_recv) + tape + 4 * B * H + prep
     if kernel == "k_bwd_mc":                  # continuous many-class backward: softmax in, dy out, class tables once, GRU tape in, gate gradients out
         return "hbm", 4 * (2 * B * D + 3 * D * R + rows * 11 * R + 3 * R * R)
     if kernel == "k_bwd_conv":
@@ -279,7 +281,8 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
         dom = max(avg, key=avg.get)
         tstar = eng.tape["tstar"].float().mean().item() + 1.0      # live steps per sample (B * tstar live rows)
         lean = not CFG["use_binary"]                                # (mmg_train_step and the phased DP step both run the lean tape)
-        bound, amount = algorithmic_work(dom, CFG, B, tstar, lean=lean)
+        prep_inside = not any(k.startswith("k_prep") for k in avg)         # (the register-resident path with a CU per role)
+        bound, amount = algorithmic_work(dom, CFG, B, tstar, lean=lean, prep_inside=prep_inside)
         secs = avg[dom] * 1e-3
         if bound == "hbm":
             achieved, peak, unit = amount / secs / 1e9, HBM_PEAK_GBS, "GB/s"
@@ -290,7 +293,7 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
         traffic, traffic_source = traffic_lookup(workload, dom, strong)
         per_kernel = {}
         for k, ms in avg.items():
-            bk, amt = algorithmic_work(k, CFG, B, tstar, lean=lean)
+            bk, amt = algorithmic_work(k, CFG, B, tstar, lean=lean, prep_inside=prep_inside)
             if amt:
                 a_k = amt / (ms * 1e-3) / (1e9 if bk == "hbm" else 1e12)
                 per_kernel[k] = dict(bound=bk, achieved=round(a_k, 3), unit="GB/s" if bk == "hbm" else "TFLOP/s",

@@ -155,8 +155,9 @@ int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const
 int mmg_clip_step(mmg_handle* h, void* stream);
 
 /* forward(train, run_all_steps = 2) + stats + backward + clip_step for a single-GPU minibatch; nothing returns to the
- * host.  Equivalent to the four calls above in sequence.  Launches per minibatch depend on the shape: 6 for the agents of
- * BASELINE configs 1-3 (k_prep, k_conversation_fast2, k_baselines3, k_bwd_conv_fast, k_wgrad, k_opt), 7 for config 5's
+ * host.  Equivalent to the four calls above in sequence.  Launches per minibatch depend on the shape: 4 for the agents of
+ * BASELINE configs 1-2 (k_conversation_fast3 with k_prep's blocks as roles, k_bwd_conv_fast with the baselines / statistics
+ * as roles, k_wgrad, k_opt), 5 for config 3's shard (+ k_baselines3; + k_prep with more samples than CUs), 7 for config 5's
  * shard (k_prep, k_conversation_mc, k_bwd_mc1, k_bwd_mc2, k_wgrad, k_wreduce, k_opt), 10-11 for config 4 (k_prep,
  * k_conv_persist, [k_gemm_nt], k_baselines4, k_stats, k_bwd_pre_send, k_bwd_sample, k_dC_tile, k_wgrad, k_opt). */
 int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,

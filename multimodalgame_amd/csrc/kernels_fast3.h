@@ -95,38 +95,42 @@ struct Fast3Lds {
 };
 __host__ __device__ inline int fast3_lds_bytes() { return Fast3Lds::total * 4; }
 
-template <int H, int W, int R, int V>
+// MERGED: the launch carries k_prep's blocks as leading roles (ar.nprep of them); a compile-time switch -- a runtime branch
+// around the prologue's loads makes hipcc drain them at the join
+template <int H, int W, int R, int V, bool MERGED>
 __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P, Tape tp, ConvArgs ar) {
     constexpr int NT = 256, TMAX = Fast3Lds::TMAX;
     static_assert(H == 256 && W == 32 && R == 64 && V % 4 == 0 && V <= 128, "lane maps of k_conversation_fast3");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // Roles of the launch, in workgroup order (producers before their consumers, device_utils.h):
-    //   [0, nprep)            k_prep's blocks (parameter constants Cd / cy / Dd / hw0, tiles of h_x): nothing they need comes from
-    //                         this launch, and the sample roles spend their first ~5 us loading weights -- a launch of its own
-    //                         (5.5 us + the boundary) hidden behind that prologue; hand-off by counters (prep_body<true>)
-    //   [nprep, nprep + B)    one conversation per sample
-    //   then                  tiles of basehx for the baselines' launch (they wait for the h_x row tile they multiply)
-    const int merged = ar.nprep > 0;
+    // Roles of the launch, in workgroup order:
+    //   [0, B)                one conversation per sample
+    //   [B, B + nprep)        (MERGED) k_prep's blocks (parameter constants Cd / cy / Dd / hw0, tiles of h_x): nothing they need
+    //                         comes from this launch, and the sample roles spend their first ~4.5 us loading weights -- a launch
+    //                         of its own (5.5 us + the boundary) behind that prologue; hand-off by (value, epoch) pairs
+    //                         (prep_body<true>).  The consumers sit AHEAD of their producers here, so that they start first: the
+    //                         host merges only when every sample and prep role has a CU of its own, and the spin is bounded.
+    //   then                  tiles of basehx for the baselines' launch (they spin on the h_x pairs they multiply)
+    //   last                  (MERGED) the closing role: bumps the minibatch counter once every consumer holds its pairs
+    constexpr bool merged = MERGED;
     const uint32_t n_consumers = (uint32_t)(dm.B + ar.nbase);
-    if ((int)blockIdx.x < ar.nprep) {
-        prep_body<true>(dm, P, tp, ar.desc, ar.x, ar.prep_cpb, (int)blockIdx.x, lds);
+    if (merged && (int)blockIdx.x >= dm.B && (int)blockIdx.x < dm.B + ar.nprep) {
+        prep_body<true>(dm, P, tp, ar.desc, ar.x, ar.prep_cpb, (int)blockIdx.x - dm.B, lds);
 #ifdef MMG_TIMING
         {   // when the first class block, the first hw0 block and the first / last h_x tile are through (scripts/timeline.py)
-            const int nC = (dm.D + ar.prep_cpb - 1) / ar.prep_cpb, HB = (dm.H + 63) / 64, blk = (int)blockIdx.x;
+            const int nC = (dm.D + ar.prep_cpb - 1) / ar.prep_cpb, HB = (dm.H + 63) / 64, blk = (int)blockIdx.x - dm.B;
             const int slot = blk == 0 ? 123 : blk == nC ? 127 : blk == nC + HB ? 124 : blk == ar.nprep - 1 ? 125 : -1;
             if (slot >= 0 && threadIdx.x == 0) tp.dbg[slot] = (long long)wall_clock64();
         }
 #endif
         return;
     }
+    if (merged && (int)blockIdx.x == ar.nprep + dm.B + ar.nbase) { prep_closing_role(tp, n_consumers); return; }
     if ((int)blockIdx.x >= ar.nprep + dm.B) {
         const int tile = (int)blockIdx.x - ar.nprep - dm.B;
         if (!merged) { gemm_nt_tile(tile, tp.hx, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H); return; }
         // (A operand = the h_x pairs of this launch's prep roles: the loads spin until they carry this launch's epoch)
         gemm_nt_tile<false, true>(tile, tp.prepll, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H, nullptr, tp.counter[0] + 1u);
-        uint32_t passed = 0;
-        if (threadIdx.x == 0) passed = prep_consumer_arrive(tp);
-        if (threadIdx.x == 0) prep_consumer_done(dm, tp, passed, n_consumers);
+        if (threadIdx.x == 0) prep_consumer_arrive(tp);
         return;
     }
     typedef Fast3Lds L;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
     float* const s_misc = s_us + 65; float* const s_sig = s_us + 80;
     float4* const s_park = reinterpret_cast<float4*>(lds + L::park);
 
-    const int b = (int)blockIdx.x - ar.nprep, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = dm.B, T = dm.T, Dr = dm.D;
     const bool binary = dm.use_binary != 0, train = ar.train != 0, inject = ar.u_s != nullptr;
     MMG_STAMP(0);
@@ -229,6 +233,20 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int d = q3 * 8 + k; dd[k] = (d < Dr && !merged) ? tp.Dd[(size_t)d * R + u3] : 0.f; }
     if (tid < W) s_sig[tid] = fsigmoid(P.p[S_CODE_BIAS][tid]);
+    // What the prep roles of this launch produce, as (value, epoch) pairs (device_utils.h: st_ll): loaded once this role's
+    // weights are in (below) -- the producers need ~3.5 us, the ~400 KB of weight loads ~4.5 -- one more memory round trip; a pair
+    // of another epoch -> load again.  (Issued behind the weight loads instead, 18 agent-scope loads per lane in the middle of
+    // that stream: prologue 8.8 us against 6.2.)
+    const size_t i_hw = prepll_hw0(dm) + tid, i_hx = prepll_hx(dm) + (size_t)b * H + tid;
+    const size_t i_cd = prepll_cd(dm) + (size_t)min(d5, Dr - 1) * R + r5 * 8, i_dd = prepll_dd(dm) + u3;
+    unsigned long long u[18];
+    auto load_pairs = [&]() {
+        u[0] = ld_ll(tp.prepll, i_hw); u[1] = ld_ll(tp.prepll, i_hx);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[2 + k] = ld_ll(tp.prepll, i_cd + k);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[10 + k] = ld_ll(tp.prepll, i_dd + (size_t)min(q3 * 8 + k, Dr - 1) * R);
+    };
     if (train && !inject) {                        // Philox draws of the whole conversation, while the weight loads are in flight
         for (int i = tid; i < T * W; i += NT) {
             const int t = i / W, j = i - t * W;
@@ -240,27 +258,20 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) s_park[i * NT + tid] = whh_tmp[i];
-    uint32_t arrived = 0;
     if (merged) {
-        // what the prep roles of this launch produced, as (value, epoch) pairs: issued once the weights are in (the producers
-        // need ~3.5 us, the weight loads ~4.5), one more memory round trip; a pair of another epoch -> load again
-        const size_t i_hw = prepll_hw0(dm) + tid, i_hx = prepll_hx(dm) + (size_t)b * H + tid;
-        const size_t i_cd = prepll_cd(dm) + (size_t)min(d5, Dr - 1) * R + r5 * 8, i_dd = prepll_dd(dm) + u3;
-        unsigned long long u[18];
         int spins = 0;
-        bool fresh;
-        do {
-            u[0] = ld_ll(tp.prepll, i_hw); u[1] = ld_ll(tp.prepll, i_hx);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) u[2 + k] = ld_ll(tp.prepll, i_cd + k);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) u[10 + k] = ld_ll(tp.prepll, i_dd + (size_t)min(q3 * 8 + k, Dr - 1) * R);
-            fresh = true;
+        for (;;) {
+            load_pairs();
+            bool fresh = true;
 #pragma unroll
             for (int k = 0; k < 18; ++k) fresh = fresh && ll_fresh(u[k], mb_counter);
+            if (!__any(!fresh)) break;
             if (++spins > (1 << 16)) { if (lane == 0) __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        } while (__any(!fresh));
+        }
         MMG_STAMP(126);
+#ifdef MMG_TIMING
+        if (lane == 0) atomicAdd((unsigned long long*)&tp.dbg[118], (unsigned long long)spins);      // reloads of the pairs, summed over waves (scripts/timeline.py)
+#endif
         hw0 = ll_value(u[0]); hx = ll_value(u[1]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ncd[k] = -ll_value(u[2 + k]); dd[k] = (q3 * 8 + k < Dr) ? ll_value(u[10 + k]) : 0.f; }
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
 #pragma unroll
         for (int k = 0; k < 8; ++k) part = fmaf(w2[k], -ncd[k], part);
         cy5 = dpp_group_sum<8>(part) + P.p[R_Y2_B][0];
-        if (tid == 0) arrived = prep_consumer_arrive(tp);
+        if (tid == 0) prep_consumer_arrive(tp);
     }
     MMG_STAMP(1);
     // ------------------------------------------------------------ conversation state
@@ -506,7 +517,6 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
             if (t < t_done && d < Dr) tp.y[((size_t)t * B + b) * Dr + d] = yv;
         }
     }
-    if (merged && tid == 0) prep_consumer_done(dm, tp, arrived, n_consumers);
     MMG_STAMP(122);
     MMG_STAMP(6);
 }

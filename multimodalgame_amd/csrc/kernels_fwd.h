@@ -29,8 +29,8 @@ __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__
 // them -- one block per class re-reads all 2 R weight rows (51 KB) from L2 per class: 51 MB per launch at D = 1000.
 // ROLE: the blocks are workgroup roles of the conversation's launch (k_conversation_fast3): what the sample roles read (h_x, hw0,
 // Cd, Dd) ALSO goes out as (value, launch epoch) pairs (tape.prepll, device_utils.h: st_ll) the consumers spin on; the epoch is
-// the minibatch counter of this launch, which the LAST consumer to arrive bumps (prep_consumer_done) -- every role has read it
-// by then -- instead of the first hw0 block; only the counters of the backward launch's roles are zeroed here.
+// the minibatch counter of this launch, which the launch's closing role bumps (prep_closing_role) once every consumer has
+// arrived -- every role has read it by then -- instead of the first hw0 block; only the counters of the backward launch's roles are zeroed here.
 #define PREP_CTR_ARRIVE 193
 #define PREP_CTR(tp, k) ((tp).pflags + (size_t)(k) * 64)
 // pair offsets inside tape.prepll
@@ -190,13 +190,20 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
         if (p4 == 0 && n < dm.H) { tp.hw0[n] = tot + bc[n]; if (ROLE) st_ll(tp.prepll, prepll_hw0(dm) + n, tot + bc[n], epoch); }
     }
 }
-// consumers of a launch with prep roles count themselves once they hold what they waited for; the last one bumps the minibatch
-// counter (every role of the launch has read it by then) and re-arms the arrival counter.  `passed`: the consumer's own arrival index.
-__device__ __forceinline__ uint32_t prep_consumer_arrive(const Tape& tp) {
-    return __hip_atomic_fetch_add(PREP_CTR(tp, PREP_CTR_ARRIVE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Consumers of a launch with prep roles count themselves once they hold what they waited for (a fire-and-forget increment);
+// the launch's LAST workgroup is the closing role: it waits for all of them -- every role has read the minibatch counter by
+// then -- bumps it and re-arms the arrival counter.  (Done by the last consumer to arrive instead, through a returning atomic:
+// the closing work lands at the end of a conversation, on the launch's critical path when that one is the longest.)
+__device__ __forceinline__ void prep_consumer_arrive(const Tape& tp) {
+    __hip_atomic_fetch_add(PREP_CTR(tp, PREP_CTR_ARRIVE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void prep_consumer_done(const Dims& dm, const Tape& tp, const uint32_t passed, const uint32_t consumers) {
-    if (passed + 1 != consumers) return;
+__device__ __forceinline__ void prep_closing_role(const Tape& tp, const uint32_t consumers) {
+    if (threadIdx.x != 0) return;
+    int spins = 0;
+    while (__hip_atomic_load(PREP_CTR(tp, PREP_CTR_ARRIVE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < consumers) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
     __hip_atomic_store(PREP_CTR(tp, PREP_CTR_ARRIVE), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tp.counter[0] += 1u;
 }

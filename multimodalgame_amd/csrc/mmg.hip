@@ -487,7 +487,9 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         }
     }
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
+        e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
     if (getenv("MMG_DEBUG"))
         fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d\n",
                 (int)h->tile_ok, h->tile_nt, h->tile_smem, (int)h->tile_ext, (int)h->tile_persist, h->persist_smem, h->resident_budget, h->tile_bwd_smem,
@@ -716,9 +718,12 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     if (train && sticky_error(h)) return -1;
     hipStream_t st = (hipStream_t)stream;
     const Dims& d = h->dm;
-    // register-resident forward (k_conversation_fast3): k_prep's blocks run as leading roles of the conversation's launch
-    const bool merge_prep = h->sw_merge_prep && !tile_path(h) && !mc_path(h) && fast_shape(h) && h->use_fast3 && d.B <= 512 &&
-                            h->prep_smem <= fast3_lds_bytes();
+    // register-resident forward (k_conversation_fast3): k_prep's blocks run as leading roles of the conversation's launch -- when
+    // every prep and sample role has a CU of its own (the launch holds ONE workgroup per CU: with 512 samples the 531 prep roles would be two
+    // more rounds of workgroups ahead of the conversations: 318 us per minibatch against 306 with k_prep as its own launch)
+    const bool merge_prep = h->sw_merge_prep && !tile_path(h) && !mc_path(h) && fast_shape(h) && h->use_fast3 &&
+                            h->prep_smem <= fast3_lds_bytes() &&
+                            prep_blocks(d, h->prep_cpb, true) + d.B <= h->n_cu;
     if (!merge_prep && launch_prep(h, st, d_desc, d_x)) return -1;
     const bool bas = train && d.use_binary;
     ConvArgs ar;
@@ -753,7 +758,8 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
         const int base_tiles = base_ready ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
         if (fast && h->use_fast3) {
             ar.nprep = merge_prep ? prep_blocks(d, h->prep_cpb, true) : 0; ar.prep_cpb = h->prep_cpb; ar.nbase = base_tiles;
-            hipLaunchKernelGGL((k_conversation_fast3<256, 32, 64, 100>), dim3(ar.nprep + d.B + base_tiles), dim3(256), fast3_lds_bytes(), st, h->dm, h->P, h->tp, ar);
+            if (merge_prep) hipLaunchKernelGGL((k_conversation_fast3<256, 32, 64, 100, true>), dim3(ar.nprep + d.B + base_tiles + 1), dim3(256), fast3_lds_bytes(), st, h->dm, h->P, h->tp, ar);
+            else hipLaunchKernelGGL((k_conversation_fast3<256, 32, 64, 100, false>), dim3(d.B + base_tiles), dim3(256), fast3_lds_bytes(), st, h->dm, h->P, h->tp, ar);
         }
         else if (fast)
             if (d.D == 30) hipLaunchKernelGGL((k_conversation_fast2<256, 32, 64, 100, 30>), dim3(d.B + base_tiles), dim3(512), 0, st, h->dm, h->P, h->tp, ar);
