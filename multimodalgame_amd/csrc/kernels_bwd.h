@@ -36,13 +36,42 @@ __device__ __forceinline__ float combine_score(const float* part, size_t row, in
     return v + b2;                                                      // model.py:515
 }
 
+// the partials as (value, epoch) pairs written by baseline roles of THIS launch (tape.partll): the wave spins until every lane
+// that needs its row (live rows only are ever written) holds npb <= 8 fresh pairs
+__host__ __device__ inline size_t partll_at(const Dims& d, int sen_side, size_t row, int npb) { return ((size_t)(sen_side ? 0 : 1) * d.T * d.B + row) * npb; }
+__device__ __forceinline__ float combine_score_ll(const Dims& dm, const Tape& tp, int sen_side, size_t row, int npb, float b2, uint32_t epoch, bool need) {
+    const size_t at = partll_at(dm, sen_side, row, npb);
+    unsigned long long u[8];
+    for (int spins = 0;; ) {
+        bool fresh = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { u[j] = ld_ll(tp.partll, at + min(j, npb - 1)); fresh = fresh && ll_fresh(u[j], epoch); }
+        if (!__any(need && !fresh)) break;
+        if (++spins > (1 << 16)) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += (j < npb) ? ll_value(u[j]) : 0.f;
+    return v + b2;
+}
+
 // from_parts: baseline scores arrive as per-64-hidden-unit partials (k_baselines2); the blocks of the
 // two baseline kinds also materialise bs / br on the tape (exchange() returns them, k_bwd_conv reads them).
 // one wave reduces the (stream, step) pairs first, first + stride, ...
 // WT: results go out as device-scope (write-through) stores, so a role of a larger launch can publish them with a plain
 // counter increment instead of a device-scope release (= L2 write-back); see role_signal_wt.
-template <bool WT = false, bool CC = false>
-__device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, const Tape& tp, int from_parts, int first, int stride) {
+// ... and what the sample roles of the same launch need of them ALSO goes out as (value, epoch) pairs (tape.statll; device_utils.h:
+// st_ll): the consumer spins on the payload -- one trip through memory instead of counter poll + loads (statll_* give the pair index)
+__host__ __device__ inline size_t statll_stream(int T, int k, int t) { return (size_t)(k * T + t) * 9; }      // n | lo, hi of sums 1..4
+__host__ __device__ inline size_t statll_bs(const Dims& d) { return (size_t)27 * d.T; }
+__host__ __device__ inline size_t statll_br(const Dims& d) { return (size_t)27 * d.T + (size_t)d.T * d.B; }
+__device__ __forceinline__ void st_ll_d(float* ll, size_t i, double v, uint32_t epoch) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    st_ll(ll, i, __builtin_bit_cast(float, (unsigned)u), epoch); st_ll(ll, i + 1, __builtin_bit_cast(float, (unsigned)(u >> 32)), epoch);
+}
+// PLL: the partial baseline scores are pairs of this launch's baseline roles (combine_score_ll; npb <= 8)
+template <bool WT = false, bool CC = false, bool PLL = false>
+__device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, const Tape& tp, int from_parts, int first, int stride, uint32_t epoch = 0u) {
     auto put_d = [](double* p, double v) { if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
     auto put_f = [](float* p, float v) { if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
     const int T = dm.T, B = dm.B;
@@ -74,13 +103,15 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
                 const float* lp_ptr = (kind == 0) ? tp.lp_s : (kind == 1) ? tp.lp_w : tp.lp_z;
                 const float* ne_ptr = (kind == 0) ? tp.ne_s : (kind == 1) ? tp.ne_w : tp.ne_z;
                 const float lp_raw = lp_ptr[row], ne_raw = ne_ptr[row];
-                const float beta_all = from_parts ? combine_score<CC>(sen_side ? tp.bs_part : tp.br_part, row, npb, sen_side ? b2s : b2r)
+                const float beta_all = PLL ? combine_score_ll(dm, tp, sen_side, row, npb, sen_side ? b2s : b2r, epoch, t <= ts)
+                                     : from_parts ? combine_score<CC>(sen_side ? tp.bs_part : tp.br_part, row, npb, sen_side ? b2s : b2r)
                                                   : (sen_side ? tp.bs : tp.br)[row];
                 const float lp_all = (kind < 3) ? lp_raw : 0.f;
                 const float ne_all = (kind < 3) ? ne_raw : 0.f;
                 const bool act = (kind == 1) ? (t < ts) : (t <= ts);
                 if (from_parts && kind >= 3 && t <= ts) {
                     put_f(kind == 3 ? &tp.br[row] : &tp.bs[row], beta_all);
+                    if (WT) st_ll(tp.statll, (kind == 3 ? statll_br(dm) : statll_bs(dm)) + row, beta_all, epoch);
                 }
                 if (!act) continue;
                 if (kind < 3) {
@@ -98,6 +129,12 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
             if (kind < 3) {
                 double* st = tp.stats + stat_stream(T, kind, t, 0);
                 put_d(st, a0); put_d(st + 1, a1); put_d(st + 2, a2); put_d(st + 3, a3); put_d(st + 4, a4);
+                if (WT) {
+                    const size_t i = statll_stream(T, kind, t);
+                    st_ll(tp.statll, i, (float)a0, epoch);              // a count: exact in fp32
+                    st_ll_d(tp.statll, i + 1, a1, epoch); st_ll_d(tp.statll, i + 3, a2, epoch);
+                    st_ll_d(tp.statll, i + 5, a3, epoch); st_ll_d(tp.statll, i + 7, a4, epoch);
+                }
             } else {
                 put_d(&tp.stats[stat_bas(T, kind - 3, t)], a0);
             }
@@ -221,33 +258,61 @@ __device__ __forceinline__ CoefRegs coef_load(const Dims& dm, const double* __re
     return c;
 }
 
+// The same share from the VALUES of the statistics roles' (value, epoch) pair table, staged in LDS by the workgroup
+// (layout statll_stream: per (stream, step) the count as a float, then the four f64 sums as low / high halves)
+__device__ __forceinline__ CoefRegs coef_lds_regs(const Dims& dm, const float* sv) {
+    CoefRegs r;
+    const int T = dm.T;
+    const int i = min((int)threadIdx.x, 4 * T - 1);
+    const int k = i / T, t = i - k * T;
+    const int ks = (k < 3) ? k : 2;
+    const float* e = sv + (ks * T + t) * 9;
+    r.s5[0] = (double)e[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        r.s5[1 + j] = __builtin_bit_cast(double, (unsigned long long)__builtin_bit_cast(unsigned, e[1 + 2 * j]) |
+                                                 ((unsigned long long)__builtin_bit_cast(unsigned, e[2 + 2 * j]) << 32));
+    float nsum = 0.f;                                    // (counts: exact in fp32)
+    const float* e0 = sv + ks * T * 9;
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) { const float v = e0[min(tt, T - 1) * 9]; nsum += (tt < T) ? v : 0.f; }
+    r.nsum = (double)nsum;
+    return r;
+}
+
+// (on the recurrence's critical path in the register-resident backward: f64 only where it matters -- the variance's cancellation;
+//  the counts are small integers and the results are fp32 coefficients, so their reciprocals, the square root and the quotient run
+//  in fp32: four f64 divisions and an f64 sqrt -- software sequences of ~20 dependent f64 instructions each -- were 0.6 us here)
 __device__ __forceinline__ void coef_compute(const Dims& dm, const CoefRegs& c, LossCoef lc) {
     const int T = dm.T, i = threadIdx.x;
     if (i < 4 * T) {
         const int k = i / T, t = i - k * T;
         const double n = c.s5[0];
+        const float nf = (float)n, nsf = (float)c.nsum;
         if (k < 3) {
             const int len = (k == 1) ? T - 1 : T;
             const float lam = (k == 0) ? dm.es : (k == 1) ? dm.erec : dm.esen;
             const bool has = (k == 0) ? dm.has_es : (k == 1) ? dm.has_erec : dm.has_esen;
             float cw = 0.f, ce = 0.f;
             if (n > 0 && c.nsum > 0) {
-                const double c_over_n = dm.fixed ? 1.0 / ((double)len * n) : 1.0 / c.nsum;
-                double denom = 1.0;
+                const float c_over_n = dm.fixed ? 1.f / ((float)len * nf) : 1.f / nsf;
+                float denom = 1.f;
                 if (n > 1) {                                            // model.py:914-915
-                    const double mean = c.s5[1] / n;
-                    double var = (c.s5[2] - n * mean * mean) / (n - 1.0);
+                    double rn = (double)(1.f / nf);
+                    rn = rn * (2.0 - n * rn);                           // one Newton step: 1 / n to f64 precision (n is a count)
+                    const double mean = c.s5[1] * rn;
+                    double var = (c.s5[2] - n * mean * mean) * (double)(1.f / (nf - 1.f));
                     if (var < 0) var = 0;
-                    const double sd = sqrt(var);
-                    denom = sd > 1.0 ? sd : 1.0;
+                    const float sd = sqrtf((float)var);
+                    denom = sd > 1.f ? sd : 1.f;
                 }
-                cw = (float)(c_over_n / denom);
-                ce = has ? (float)(c_over_n * (double)lam) : 0.f;
+                cw = c_over_n / denom;
+                ce = has ? c_over_n * lam : 0.f;
             }
             lc.cw[k * T + t] = cw; lc.ce[k * T + t] = ce;
         } else {
             float cb = 0.f;
-            if (n > 0 && c.nsum > 0) cb = (float)(2.0 * (dm.fixed ? 1.0 / ((double)T * n) : 1.0 / c.nsum));
+            if (n > 0 && c.nsum > 0) cb = 2.f * (dm.fixed ? 1.f / ((float)T * nf) : 1.f / nsf);
             lc.cb[t] = cb;
         }
     }

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     float* t_w = t_msg; float* t_pw = t_msg + TMAX * W; float* t_z = t_msg + 2 * TMAX * W; float* t_pz = t_msg + 3 * TMAX * W;
     static_assert(2 * TMAX * W == TMAX * R, "a pair of message arrays holds one [16][R] tile");
     __shared__ float t_gru[TMAX * 4 * R], t_h[(TMAX + 1) * R], t_a[TMAX * H];
+    __shared__ float s_statv[27 * TMAX];                 // the statistics roles' pair table, values only (MERGED)
     // Workgroup roles.  n_bas == 0: [statistics n_stats][samples B][classes D][dbar n_dbar].
     // n_bas > 0 (the baselines' forward pass rides in this launch, kernels_fwd.h: baselines3_body): [samples B][statistics n_stats]
     // [baselines n_bas][classes D][dbar n_dbar] -- the sample roles start at once (their first ~10 us need no statistics), the
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         else if (bx < B0 + n_stats + n_bas) {
             const int idx = bx - B0 - n_stats, npb = (dm.K + 63) / 64;
             const int window = idx / (2 * npb), rem = idx - window * 2 * npb, which = rem / npb, byi = rem - which * npb;
-            baselines3_body<true>(dm, P, tp, window, byi, which, npb, tp.pflags + (size_t)(which * npb + byi) * 64);
+            baselines3_body<true>(dm, P, tp, window, byi, which, npb, nullptr);       // (done == nullptr: pairs, no counter)
             return;
         } else vbx = bx - n_bas;
     }
@@ -176,14 +177,13 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         if (vbx == 0 && threadIdx.x == 0) tp.dbg[128 + 48] = (long long)wall_clock64();
 #endif
         if (n_bas > 0) {
-            wait_baseline_roles(dm, tp);
-            stats_pairs<true, true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
+            stats_pairs<true, true, true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4, tp.counter[0]);
         } else
-            stats_pairs<true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
+            stats_pairs<true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4, tp.counter[0]);
 #ifdef MMG_TIMING
         if (vbx == 0 && threadIdx.x == 0) tp.dbg[128 + 49] = (long long)wall_clock64();
 #endif
-        role_signal_wt(tp.sync, 0);
+        // (no counter: the sample roles spin on the (value, epoch) pairs stats_pairs wrote beside the statistics)
 #ifdef MMG_TIMING
         if (vbx == 0 && threadIdx.x == 0) tp.dbg[128 + 50] = (long long)wall_clock64();
 #endif
@@ -397,6 +397,18 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     for (int r = 0; r < 4; ++r) { t_g[(4 * fq + r) * R + unit] = g1[r]; s_G2[(4 * fq + r) * R + unit] = g2[r]; }
     __syncthreads();
     MMG_BSTAMP(10);
+    // The statistics roles of this launch are normally through by now (8 us after the start): their (value, epoch) pairs are
+    // asked for HERE, a sweep ahead of their use -- the answer arrives while the matrix cores work.  Stale pairs: again, below.
+    // The workgroup fetches the table of 27 T pairs ONCE (two per thread; every thread loading its own 25: 64 x 256 x 25 requests
+    // for the same twenty cache lines) and the coefficient threads assemble their share from LDS.
+    const uint32_t epoch = MERGED ? tp.counter[0] : 0u;
+    const int i_st0 = min(tid, 27 * T - 1), i_st1 = min(tid + NT, 27 * T - 1);
+    unsigned long long u_st0 = 0, u_st1 = 0, u_bs = 0, u_br = 0;
+    auto load_stat_pairs = [&]() {
+        u_st0 = ld_ll(tp.statll, i_st0); u_st1 = ld_ll(tp.statll, i_st1);
+        u_bs = ld_ll(tp.statll, statll_bs(dm) + so); u_br = ld_ll(tp.statll, statll_br(dm) + so);
+    };
+    if (MERGED) { load_stat_pairs(); asm volatile("" ::: "memory"); }      // (the loads stay ahead of the sweep's LDS reads)
     {
         f32x4 h1 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -409,10 +421,18 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     }
     MMG_BSTAMP(11);
     if (MERGED) {                                       // the statistics roles of this launch publish stats, bs, br
-        role_wait<1, false, false>(tp.sync, 0, (uint32_t)n_stats, (uint32_t)B);     // (re-armed at the end of the role)
-        creg = coef_load<true>(dm, tp.stats);
-        rbs_ = __hip_atomic_load(&tp.bs[so], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rbr_ = __hip_atomic_load(&tp.br[so], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool need_b = binary && min(tid, Tm1) <= tstar;       // (the statistics roles write the baseline scores of live rows only)
+        for (int spins = 0;; ) {
+            const bool fresh = ll_fresh(u_st0, epoch) && ll_fresh(u_st1, epoch) && (!need_b || (ll_fresh(u_bs, epoch) && ll_fresh(u_br, epoch)));
+            if (!__any(!fresh)) break;
+            if (++spins > (1 << 16)) { if (lane == 0) __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            load_stat_pairs();
+        }
+        s_statv[i_st0] = ll_value(u_st0); s_statv[i_st1] = ll_value(u_st1);
+        __syncthreads();
+        MMG_BSTAMP(12);
+        creg = coef_lds_regs(dm, s_statv);
+        rbs_ = ll_value(u_bs); rbr_ = ll_value(u_br);
         coef_compute(dm, creg, lc);
     }
     MMG_BSTAMP(2);
@@ -524,7 +544,6 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         __syncthreads();
     }
     MMG_BSTAMP(4);
-    if (MERGED && tid == 0) role_rearm(tp.sync, 0, (uint32_t)B);
     // (code_bias: k_wgrad's special column job forms dsig * W_c^T (sum_b dpre_0) once, instead of W_c^T dpre_0 per sample here)
 }
 

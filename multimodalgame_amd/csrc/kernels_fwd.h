@@ -1038,10 +1038,13 @@ __device__ __forceinline__ void baselines3_body(const Dims& dm, const Params& P,
     if (threadIdx.x < 16 && s_rid[threadIdx.x] >= 0) {
         float* part = which ? tp.bs_part : tp.br_part;
         const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
-        if (ROLE) __hip_atomic_store(&part[(size_t)s_rid[threadIdx.x] * npb + byi], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ROLE && !done) {       // roles of the backward launch: the statistics roles spin on (value, epoch) pairs (kernels_bwd.h: combine_score_ll)
+            part[(size_t)s_rid[threadIdx.x] * npb + byi] = v;
+            st_ll(tp.partll, ((size_t)(which ? 0 : 1) * T * B + (size_t)s_rid[threadIdx.x]) * npb + byi, v, tp.counter[0]);
+        } else if (ROLE) __hip_atomic_store(&part[(size_t)s_rid[threadIdx.x] * npb + byi], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else part[(size_t)s_rid[threadIdx.x] * npb + byi] = v;
     }
-    if (ROLE) {                                          // (device_utils.h: role_signal_wt, on this role's own counter)
+    if (ROLE && done) {                                          // (device_utils.h: role_signal_wt, on this role's own counter)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -142,6 +142,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(sm, float, 0, 2, B, D, 1)          /* softmax(outp)                          */ \
     X(logs, float, 0, 1, B, 1, 1)        /* loglikelihood(dist, target)      :1274 */ \
     X(hit, int32_t, 2, 1, B, 1, 1)       /* target within top-k              :1333 */ \
+    X(partll, float, 0, 1, 2 * 2 * T * B * NPB, 1, 1) /* (value, epoch) pairs of the baselines' partial scores [bs | br][T B][NPB]: hand-off from the baseline roles to the statistics roles of the backward launch */ \
+    X(statll, float, 0, 1, 2 * (27 * T + 2 * T * B), 1, 1) /* (value, epoch) pairs of the stream statistics (per (stream, step): n | four f64 sums as 2 halves each) and of bs | br: hand-off from the statistics roles to the sample roles of the backward launch (kernels_fast.h) */ \
     X(stats, double, 3, 1, NSTAT, 1, 1)  /* batch statistics (all-reduced in DP)   */ \
     X(losses, float, 0, 1, 8, 1, 1)      /* nll, bin_s, bin_rec, bin_sen, bas_rec, bas_sen, n_steps, hits */ \
     X(counter, uint32_t, 2, 1, 4, 1, 1)  /* [0] minibatch counter (Philox), [1] optimizer step */ \

@@ -51,9 +51,11 @@ bd = dbg[128:]
 u = lambda a, b: (bd[b] - bd[a]) * tick / 1e3
 print("== k_bwd_conv_fast (sample 0): tape preload %.2f us | staging + output step %.2f | seed bases %.2f | dgpre / dpre bases (MFMA) %.2f | dgpre W_h bases (MFMA) %.2f | wait for the statistics roles + coefficients %.2f | per-step scalars %.2f | tape stores + recurrence %.2f" % (
     u(0, 1), u(1, 8), u(8, 9), u(9, 10), u(10, 11), u(11, 2), u(2, 3), u(3, 4)))
+if bd[12]:
+    print("   of the wait: until the statistics pairs are fresh %.2f us | coefficients (f64) %.2f us" % (u(11, 12), u(12, 2)))
 if bd[48]:
-    print("   statistics role 0 (same launch): starts %+.2f us relative to sample role 0 | pairs %.2f us | signal %.2f us | done %.2f us after sample role 0 started" % (
-        (bd[48] - bd[0]) * tick / 1e3, u(48, 49), u(49, 50), (bd[50] - bd[0]) * tick / 1e3))
+    print("   statistics role 0 (same launch): starts %+.2f us relative to sample role 0 | wait for the baseline roles %.2f us | pairs %.2f us | done %.2f us after sample role 0 started" % (
+        (bd[48] - bd[0]) * tick / 1e3, u(48, 51) if bd[51] else 0.0, u(51, 49) if bd[51] else u(48, 49), (bd[50] - bd[0]) * tick / 1e3))
 ts0 = int(eng.tape["tstar"][0])
 for st in range(ts0, -1, -1):
     base = 16 + 2 * st
