@@ -105,36 +105,18 @@ __device__ __forceinline__ void dbar_role(const Dims& dm, const Tape& tp, int ti
     }
 }
 
-// wait of a statistics role for the baseline roles of its launch: they count themselves on 2 * npb counters (tape.pflags, zeroed
-// by k_prep), one per (baseline, hidden block); only windows inside the live rows do, windows = ceil(live rows / 16) from t*
-__device__ __forceinline__ void wait_baseline_roles(const Dims& dm, const Tape& tp) {
-    const int ln = threadIdx.x & 63;
-    const float live = dpp_wave_sum((ln < dm.B) ? (float)(tp.tstar[min(ln, dm.B - 1)] + 1) : 0.f);
-    const uint32_t windows = (uint32_t)(((int)live + 15) / 16);
-    const int ncnt = 2 * ((dm.K + 63) / 64);
-    if ((int)threadIdx.x < ncnt) {
-        int spins = 0;
-        while (__hip_atomic_load(tp.pflags + (size_t)threadIdx.x * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < windows) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-    }
-    __syncthreads();
-}
-
 // k_bas_stats: the phased (data-parallel) step's baselines AND batch statistics in one launch -- mmg_loss_stats of the
 // register-resident path.  [n_stats statistics roles (4 (stream, step) pairs each, k_stats' pairs)] [baseline roles: k_baselines3's
-// body per (16 live rows, 64 hidden units, baseline)]; the statistics roles wait for the baseline roles as in the fused step's
-// backward launch.  13 spinning workgroups ahead of their producers: the host selects it with CUs to spare only.
+// body per (16 live rows, 64 hidden units, baseline)]; the statistics roles spin on the baseline roles' partial-score pairs as in the
+// fused step's backward launch.  13 spinning workgroups ahead of their producers: the host selects it with CUs to spare only.
 __global__ __launch_bounds__(MMG_BLOCK) void k_bas_stats(Dims dm, Params P, Tape tp, int n_stats) {
-    if ((int)blockIdx.x < n_stats) {
-        wait_baseline_roles(dm, tp);
-        stats_pairs<false, true>(dm, P, tp, 1, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_stats * 4);
+    if ((int)blockIdx.x < n_stats) {            // (the partial scores arrive as (value, epoch) pairs: combine_score_ll spins on them)
+        stats_pairs<false, true, true>(dm, P, tp, 1, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_stats * 4, tp.counter[0]);
         return;
     }
     const int idx = (int)blockIdx.x - n_stats, npb = (dm.K + 63) / 64;
     const int window = idx / (2 * npb), rem = idx - window * 2 * npb, which = rem / npb, byi = rem - which * npb;
-    baselines3_body<true>(dm, P, tp, window, byi, which, npb, tp.pflags + (size_t)(which * npb + byi) * 64);
+    baselines3_body<true>(dm, P, tp, window, byi, which, npb);
 }
 
 template <int H, int W, int R, int V, int D, bool MERGED, bool MERGE_DC>
@@ -168,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         else if (bx < B0 + n_stats + n_bas) {
             const int idx = bx - B0 - n_stats, npb = (dm.K + 63) / 64;
             const int window = idx / (2 * npb), rem = idx - window * 2 * npb, which = rem / npb, byi = rem - which * npb;
-            baselines3_body<true>(dm, P, tp, window, byi, which, npb, nullptr);       // (done == nullptr: pairs, no counter)
+            baselines3_body<true>(dm, P, tp, window, byi, which, npb);
             return;
         } else vbx = bx - n_bas;
     }

@@ -979,8 +979,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_baselines2(Dims dm, Params P, Tap
 // stores and the role counts itself on the (baseline, hidden block) counter `done` -- only windows inside the live rows do;
 // the statistics roles derive the number of such windows from t* themselves.
 template <bool ROLE>
-__device__ __forceinline__ void baselines3_body(const Dims& dm, const Params& P, const Tape& tp, int window, int byi, int which, int npb,
-                                                uint32_t* done) {
+__device__ __forceinline__ void baselines3_body(const Dims& dm, const Params& P, const Tape& tp, int window, int byi, int which, int npb) {
     __shared__ int s_rid[16];
     __shared__ float s_part[4][16];
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, K = dm.K, T = dm.T;
@@ -1038,21 +1037,15 @@ __device__ __forceinline__ void baselines3_body(const Dims& dm, const Params& P,
     if (threadIdx.x < 16 && s_rid[threadIdx.x] >= 0) {
         float* part = which ? tp.bs_part : tp.br_part;
         const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
-        if (ROLE && !done) {       // roles of the backward launch: the statistics roles spin on (value, epoch) pairs (kernels_bwd.h: combine_score_ll)
+        if (ROLE) {                // roles of a larger launch: its statistics roles spin on (value, epoch) pairs (kernels_bwd.h: combine_score_ll)
             part[(size_t)s_rid[threadIdx.x] * npb + byi] = v;
             st_ll(tp.partll, ((size_t)(which ? 0 : 1) * T * B + (size_t)s_rid[threadIdx.x]) * npb + byi, v, tp.counter[0]);
-        } else if (ROLE) __hip_atomic_store(&part[(size_t)s_rid[threadIdx.x] * npb + byi], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else part[(size_t)s_rid[threadIdx.x] * npb + byi] = v;
-    }
-    if (ROLE && done) {                                          // (device_utils.h: role_signal_wt, on this role's own counter)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else part[(size_t)s_rid[threadIdx.x] * npb + byi] = v;
     }
 }
 
 __global__ __launch_bounds__(MMG_BLOCK) void k_baselines3(Dims dm, Params P, Tape tp) {
-    baselines3_body<false>(dm, P, tp, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.y, nullptr);
+    baselines3_body<false>(dm, P, tp, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.y);
 }
 
 }  // namespace mmg

@@ -9,8 +9,16 @@
 //     gradient (every message input is detached, model.py:810, 1297-1305);
 //   * W_hh (and code_layer) parked in LDS as per-lane spill slots; the hidden-side GRU product of the NEXT step runs between the
 //     publication of A and the poll for the tile's rows, i.e. inside the first hand-off's wait.
-// Same hand-off protocol (write-through stores + one counter increment per member, agent-scope loads), tape contract and
-// sampling streams as k_conversation_mc; binary messages with many classes stay on k_conversation_mc (their w_d gradient needs dbar).
+// Hand-offs: the payload itself, as (value, epoch) pairs -- one aligned 8-byte write-through store / agent-scope load each
+// (device_utils.h: st_ll), epoch = (minibatch counter, step).  A consumer loads the pairs it needs and loads again while any carries
+// another epoch: one trip through memory once the data has landed.  k_conversation_mc's protocol (write-through payload, wait for
+// the stores to complete, one counter increment per member; poll the counter, then agent-scope loads of the payload) is three
+// dependent trips, ~1.5 us more per hand-off, two hand-offs per step.  The buffers are reused every step: a member's step t + 1
+// rows go out only after it has passed the second hand-off of step t, i.e. after every member has read the step-t rows.
+// ONE counter hand-off remains, after the last step: a slice owner's write-through stores of the selected logits (tape.outp) must
+// have completed before the sample's owner reads them.
+// Same tape contract and sampling streams as k_conversation_mc; binary messages with many classes stay on k_conversation_mc (their
+// w_d gradient needs dbar).
 #pragma once
 #include "device_utils.h"
 #include "kernels_fast3.h"
@@ -169,10 +177,15 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
     const bool sprodm = dm.s_prob_prod != 0;
     __syncthreads();
     MMG_MSTAMP(2);
-    uint32_t* cA = mc_ctr(tp, 0, tile, ntile); uint32_t* cP = mc_ctr(tp, 1, tile, ntile);
-    float* pubA = tp.mcA + (size_t)tile * TM * LDA;
-    float* part_mine = tp.mcpart + ((size_t)(tile * TM + member) * TM) * LDP;      // [16 samples][LDP] written by this member
-    const float* part_tile = tp.mcpart + ((size_t)tile * TM * TM) * LDP;            // [16 members][16 samples][LDP]
+    uint32_t* cA = mc_ctr(tp, 0, tile, ntile);
+    float* llA = tp.mc3A + (size_t)tile * TM * LDA * 2;                              // pairs [16 members][LDA]
+    float* llP = tp.mc3P + ((size_t)tile * TM * TM) * LDP * 2;                       // pairs [16 members][16 samples][LDP]
+    const size_t p_mine = (size_t)member * TM * LDP;                                 // ... this member's [16 samples][LDP]
+    auto spin_expired = [&](int& spins) {
+        if (++spins <= (1 << 16)) return false;
+        if (lane == 0) __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    };
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)t * B + b;
         float* const hcur = s_h + (t & 1) * R;
@@ -253,21 +266,26 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
             tp.hstar[(size_t)b * R + tid] = hn[tid];
         }
         // ----- hand-off 1: publish A (17 x 16 bytes); the hidden-side GRU product of the next step fills the wait
-        if (tid < LDA / 4) st_wt4(pubA + member * LDA + 4 * tid, *reinterpret_cast<const float4*>(s_Aown + 4 * tid));
-        pf_signal(cA);
+        const uint32_t ep = mb_counter * 32u + (uint32_t)t + 1u;
+        if (tid < LDA) st_ll(llA, (size_t)member * LDA + tid, s_Aown[tid], ep);
         {
             float4 pk[4], hq[4];
             park_load(pk, hq, s_park, 0, tid, hn + q3 * 16); ghp_r = park_fma(pk, hq);
             park_load(pk, hq, s_park, 1, tid, hn + q3 * 16); ghp_u = park_fma(pk, hq);
             park_load(pk, hq, s_park, 2, tid, hn + q3 * 16); ghn = dpp_group_sum<4>(park_fma(pk, hq)) + b_hn;
         }
-        mc_wait(cA, (uint32_t)(TM * (t + 1)), tp.sync);
-        MMG_MSTAMP(16 + 8 * t + 1);
+        {
+            constexpr int NA = (TM * LDA + NT - 1) / NT;                     // pairs of the tile's 16 rows per thread
+            unsigned long long ua[NA];
+            for (int spins = 0;; ) {
+                bool fresh = true;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int i = min(tid + NT * r, TM * LDA / 2 - 1);
-            const float2 v = ld_cc2(pubA + 2 * i);
-            if (tid + NT * r < TM * LDA / 2) *reinterpret_cast<float2*>(s_At + 2 * i) = v;
+                for (int r = 0; r < NA; ++r) { ua[r] = ld_ll(llA, min(tid + NT * r, TM * LDA - 1)); fresh = fresh && ll_fresh(ua[r], ep); }
+                if (!__any(!fresh) || spin_expired(spins)) break;
+            }
+            MMG_MSTAMP(16 + 8 * t + 1);
+#pragma unroll
+            for (int r = 0; r < NA; ++r) if (tid + NT * r < TM * LDA) s_At[tid + NT * r] = ll_value(ua[r]);
         }
         __syncthreads();
         MMG_MSTAMP(16 + 8 * t + 2);
@@ -331,19 +349,31 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
         __syncthreads();
         MMG_MSTAMP(16 + 8 * t + 3);
         // ----- hand-off 2: this slice's partials out (16 x 17 x 16 bytes), the 16 slices of this sample in
-        st_wt4(part_mine + 4 * tid, *reinterpret_cast<const float4*>(s_P + 4 * tid));
-        if (tid < TM * (LDP / 4) - NT) st_wt4(part_mine + 4 * (tid + NT), *reinterpret_cast<const float4*>(s_P + 4 * (tid + NT)));
-        pf_signal(cP);
-        mc_wait(cP, (uint32_t)(TM * (t + 1)), tp.sync);
-        MMG_MSTAMP(16 + 8 * t + 4);
+        {
+            constexpr int NP = (TM * LDP + NT - 1) / NT;                     // pairs per thread, out and in
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int i = min(tid + NT * r, TM * LDP / 2 - 1);
-            const int k = i / (LDP / 2), q = i % (LDP / 2);
-            const float2 v = ld_cc2(part_tile + ((size_t)(k * TM + member)) * LDP + 2 * q);
-            if (tid + NT * r < TM * LDP / 2) {
-                *reinterpret_cast<float2*>(s_in + k * LDP + 2 * q) = v;
-                if (q == R / 2) { s_m[k] = v.x; s_s[k] = v.y; }
+            for (int r = 0; r < NP; ++r) if (tid + NT * r < TM * LDP) st_ll(llP, p_mine + tid + NT * r, s_P[tid + NT * r], ep);
+            unsigned long long up[NP];
+            int kq[NP];
+#pragma unroll
+            for (int r = 0; r < NP; ++r) { const int i = min(tid + NT * r, TM * LDP - 1); kq[r] = ((i / LDP) * TM + member) * LDP + i % LDP; }
+            for (int spins = 0;; ) {
+                bool fresh = true;
+#pragma unroll
+                for (int r = 0; r < NP; ++r) { up[r] = ld_ll(llP, (size_t)kq[r]); fresh = fresh && ll_fresh(up[r], ep); }
+                if (!__any(!fresh) || spin_expired(spins)) break;
+            }
+            MMG_MSTAMP(16 + 8 * t + 4);
+#pragma unroll
+            for (int r = 0; r < NP; ++r) {
+                const int i = tid + NT * r;
+                if (i < TM * LDP) {
+                    const int k = i / LDP, q = i % LDP;
+                    const float v = ll_value(up[r]);
+                    s_in[i] = v;
+                    if (q == R) s_m[k] = v;
+                    if (q == R + 1) s_s[k] = v;
+                }
             }
         }
         __syncthreads();
@@ -375,6 +405,8 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
         MMG_MSTAMP(16 + 8 * t + 6);
     }
     MMG_MSTAMP(3);
+    // the one counter hand-off: every slice owner's selected-logit stores (tape.outp, write-through) have completed
+    pf_signal(cA);
     if (!have) return;
     // ------------------------------------------------------------ the sample's tape, coalesced
     for (int i4 = tid; i4 < T * (4 * R / 4); i4 += NT) {
@@ -411,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
     // ------------------------------------------------------------ output selection / reward / top-k (model.py:1264-1275, 1333-1339)
     // every slice owner stored this sample's selected logits (write-through) before its partial hand-off of that step
     if (tid == 240) { s_red[8] = (float)t_out; s_red[9] = sprod; }
-    __syncthreads();
+    mc_wait(cA, (uint32_t)TM, tp.sync);                 // (the tape flush above went out in its shadow)
     const int tstar = dm.fixed ? (T - 1) : (int)s_red[8];
     constexpr int NY = 4;                               // classes per thread: D <= 16 * CAP = NT * NY
     float o[NY];

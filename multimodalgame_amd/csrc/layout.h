@@ -98,6 +98,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(pflags, uint32_t, 2, 1, 4 * 64 * 64, 1, 1) /* k_conv_persist: per (kind, sample tile) counters, one per 256-byte block */ \
     X(mcA, float, 0, 3, NMC, 16, R + 4)  /* k_conversation_mc: A rows (+ take flag) published by the 16 members of a tile       */ \
     X(mcpart, float, 0, 3, NMC * 16, 16, 104) /* k_conversation_mc: per (tile, class slice): [16 samples][V mixture terms | m | s | pad] */ \
+    X(mc3A, float, 0, 3, NMC, 16, 2 * (R + 4)) /* k_conversation_mc3: (value, epoch) pairs of the A rows (+ take flag) of a tile's 16 members */ \
+    X(mc3P, float, 0, 3, NMC * 16, 16, 2 * 68) /* k_conversation_mc3: (value, epoch) pairs per (tile, class slice): [16 samples][R mixture terms | m | s | pad] */ \
     X(mcflags, uint32_t, 2, 1, 2 * NMC * 64, 1, 1) /* k_conversation_mc: per (kind, tile) hand-off counters, one per 256-byte block (zeroed by k_prep) */ \
     X(mcdA, float, 0, 3, NMCB, B, R)     /* k_bwd_mc1: per class block: partial dA of every sample                        */ \
     X(mcdys, float, 0, 2, NMCB, B, 1)    /* k_bwd_mc1: per class block: partial sum_d dy                                  */ \
@@ -227,7 +229,7 @@ __host__ __device__ inline int dc_slices(int B) { return B >= 1024 ? 4 : 1; }
 
 struct TapeLayout {
     int n;
-    mmg_tape_entry e[96];
+    mmg_tape_entry e[128];
     int64_t total;
 };
 
@@ -255,6 +257,9 @@ inline TapeLayout tape_layout(const mmg_config& c) {
         o += (bytes + 255) & ~(int64_t)255;                                         \
     }
     MMG_TAPE_LIST(X)
+#undef X
+#define X(name_, ctype, code, nd, d0, d1, d2) +1
+    static_assert(0 MMG_TAPE_LIST(X) <= (int)(sizeof(L.e) / sizeof(L.e[0])), "TapeLayout::e is too small for MMG_TAPE_LIST");
 #undef X
     L.total = o;
     return L;
