@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
         __syncthreads();
         MMG_MSTAMP(16 + 8 * t + 2);
         // ===== C1 slice logits for the 16 samples of the tile
-#pragma unroll 4
+#pragma unroll 8
         for (int i = 0; i < TM; ++i) {
             const float* ar_ = s_At + i * LDA + 16 * e4;
             const float4 a0 = *reinterpret_cast<const float4*>(ar_), a1 = *reinterpret_cast<const float4*>(ar_ + 4);
@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
             if (e4 == 0) s_y[i * LDY + cls] = tot + cyv;
         }
         __syncthreads();
+        MMG_MSTAMP(16 + 8 * t + 7);
         // logits -> tape (every step: exchange() returns them; y_last_only: the output step's) and the selected rows -> outp;
         // slice softmax numerators: 16 lanes per sample, 4 classes per lane
         {
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
             if (l == 0) { s_P[i * LDP + R] = m; s_P[i * LDP + R + 1] = s; s_P[i * LDP + R + 2] = 0.f; s_P[i * LDP + R + 3] = 0.f; }
         }
         __syncthreads();
+        MMG_MSTAMP(200 + t);
         // ===== C3 unnormalised mixture of the slice on the matrix cores: [16, CAP] x Dd_k [CAP, 16 columns of this wave]
         {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};

@@ -34,3 +34,7 @@ for st in range(T):
     tot += np.array(seg)
     print("step %d: %s = %.2f" % (st, " | ".join("%.2f" % v for v in seg), sum(seg)))
 print("mean per step: " + " | ".join("%s %.2f" % (n, v / T) for n, v in zip(names, tot)) + " = %.2f us" % (tot.sum() / T))
+if dbg[16 + 7]:
+    c1 = np.mean([us(16 + 8 * st + 2, 16 + 8 * st + 7) for st in range(T)]); c2 = np.mean([us(16 + 8 * st + 7, 200 + st) for st in range(T)])
+    c3 = np.mean([us(200 + st, 16 + 8 * st + 3) for st in range(T)])
+    print("   of logits+softmax+mixture: class logits %.2f | tape / selected logits / softmax numerators %.2f | mixture MFMA %.2f" % (c1, c2, c3))
