@@ -79,3 +79,40 @@ def test_remote_rank_error_reaches_this_rank_through_the_gradient_all_reduce():
     torch.testing.assert_close(eng.flat_params, before, rtol=0, atol=0)
     with pytest.raises(_lib.MmgError, match="another rank"):
         eng.forward(xd, td, dd, seed=3, train=True)
+
+
+def test_prep_roles_inside_the_conversation_launch_equal_k_prep_as_a_launch(monkeypatch):
+    """mmg_exchange_forward runs k_prep's blocks as roles of k_conversation_fast3's launch when every role has a CU (kernels_fast3.h,
+    MERGED; hand-off by (value, epoch) pairs, the minibatch counter bumped by the closing role).  MMG_NO_MERGE_PREP=1 (read by
+    mmg_create) keeps k_prep a launch of its own: same constants bit for bit, same Philox streams (the counter arithmetic), the
+    same training trajectory within rounding of the one value the consumers re-form themselves (cy)."""
+    z, meta = common.load_golden("g2_adaptive_c1")
+    x, target, desc, _ = common.case_inputs(meta, 0)
+    eng_a = common.make_engine(meta)
+    monkeypatch.setenv("MMG_NO_MERGE_PREP", "1")
+    eng_b = common.make_engine(meta)
+    monkeypatch.delenv("MMG_NO_MERGE_PREP")
+    eng_b.flat_params.copy_(eng_a.flat_params); eng_b.opt_state.copy_(eng_a.opt_state)
+    names = [[], []]
+    first = [{}, {}]
+    for k, eng in enumerate((eng_a, eng_b)):
+        xd, td, dd = [torch.from_numpy(a).to(eng.device) for a in (x, target, desc)]
+        for step in range(6):                                  # in-kernel Philox: the streams depend on the minibatch counter
+            if step == 5:
+                eng.set_profiling(True)
+            eng.train_step(xd, td, dd, seed=11)
+            if step == 0:                                      # same parameters: the constants and the draws must agree exactly
+                torch.cuda.synchronize()
+                first[k] = {key: eng.tape[key].clone() for key in ("hx", "Cd", "Dd", "hw0", "tstar", "z", "s")}
+        torch.cuda.synchronize()
+        names[k] = [n for n, _ in eng.kernel_times()]
+        eng.set_profiling(False)
+        eng.check_sync()
+    assert not any(n.startswith("k_prep") for n in names[0]) and any(n.startswith("k_prep") for n in names[1]), names
+    for key in first[0]:
+        assert torch.equal(first[0][key], first[1][key]), key
+    assert torch.equal(eng_a.tape["counter"], eng_b.tape["counter"]) and int(eng_a.tape["counter"][0]) == 6
+    # five more updates: RMSprop turns a rounding-level difference of a near-zero gradient into a visible step of that element, so
+    # the trajectories are compared in bulk -- all but a handful of the 384 k parameters within 2e-5, none further than 1e-2
+    diff = (eng_a.flat_params - eng_b.flat_params).abs()
+    assert float((diff > 2e-5).float().mean()) < 1e-4 and float(diff.max()) < 1e-2, (float((diff > 2e-5).float().mean()), float(diff.max()))
