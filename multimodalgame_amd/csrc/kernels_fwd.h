@@ -55,14 +55,14 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
         const int d0 = blk * cpb, nd = min(cpb, D - d0);
         float* s_desc = smem;                       // [cpb][V]
         float* s_cd = smem + cpb * V;               // [cpb][R]
-        for (int i = tid; i < nd * V; i += blockDim.x) { const float dv = desc[(size_t)d0 * V + i]; s_desc[i] = dv; tp.descc[(size_t)d0 * V + i] = dv; }
         const bool isC = tid < R, isD = tid >= R && tid < 2 * R;
         const int r = isC ? tid : (isD ? tid - R : 0);
         const float* wrow = isD ? P.p[R_WD_W] + (size_t)r * V : P.p[R_Y1_W] + (size_t)r * ld + R;
-        float4 wreg[32];
+        float4 wreg[32];                            // (issued BEFORE the description rows: their copy loop waits for its loads)
 #pragma unroll
         for (int j = 0; j < 32; ++j) wreg[j] = (4 * j < V) ? *reinterpret_cast<const float4*>(wrow + 4 * min(j, V / 4 - 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float by = isC ? P.p[R_Y1_B][r] : 0.f;
+        for (int i = tid; i < nd * V; i += blockDim.x) { const float dv = desc[(size_t)d0 * V + i]; s_desc[i] = dv; tp.descc[(size_t)d0 * V + i] = dv; }
         __syncthreads();
         if (isC || isD) {
             for (int c = 0; c < nd; ++c) {
