@@ -111,7 +111,7 @@ __device__ __forceinline__ void dbar_role(const Dims& dm, const Tape& tp, int ti
 // fused step's backward launch.  13 spinning workgroups ahead of their producers: the host selects it with CUs to spare only.
 __global__ __launch_bounds__(MMG_BLOCK) void k_bas_stats(Dims dm, Params P, Tape tp, int n_stats) {
     if ((int)blockIdx.x < n_stats) {            // (the partial scores arrive as (value, epoch) pairs: combine_score_ll spins on them)
-        stats_pairs<false, true, true>(dm, P, tp, 1, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_stats * 4, tp.counter[0]);
+        stats_pairs<false, true, true>(dm, P, tp, 1, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_stats * 4, tp.counter[3]);
         return;
     }
     const int idx = (int)blockIdx.x - n_stats, npb = (dm.K + 63) / 64;
@@ -159,9 +159,9 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         if (vbx == 0 && threadIdx.x == 0) tp.dbg[128 + 48] = (long long)wall_clock64();
 #endif
         if (n_bas > 0) {
-            stats_pairs<true, true, true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4, tp.counter[0]);
+            stats_pairs<true, true, true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4, tp.counter[3]);
         } else
-            stats_pairs<true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4, tp.counter[0]);
+            stats_pairs<true>(dm, P, tp, 1, vbx * 4 + (int)(threadIdx.x >> 6), n_stats * 4, tp.counter[3]);
 #ifdef MMG_TIMING
         if (vbx == 0 && threadIdx.x == 0) tp.dbg[128 + 49] = (long long)wall_clock64();
 #endif
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     // asked for HERE, a sweep ahead of their use -- the answer arrives while the matrix cores work.  Stale pairs: again, below.
     // The workgroup fetches the table of 27 T pairs ONCE (two per thread; every thread loading its own 25: 64 x 256 x 25 requests
     // for the same twenty cache lines) and the coefficient threads assemble their share from LDS.
-    const uint32_t epoch = MERGED ? tp.counter[0] : 0u;
+    const uint32_t epoch = MERGED ? tp.counter[3] : 0u;
     const int i_st0 = min(tid, 27 * T - 1), i_st1 = min(tid + NT, 27 * T - 1);
     unsigned long long u_st0 = 0, u_st1 = 0, u_bs = 0, u_br = 0;
     auto load_stat_pairs = [&]() {

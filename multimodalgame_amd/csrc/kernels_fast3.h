@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
         const int tile = (int)blockIdx.x - ar.nprep - dm.B;
         if (!merged) { gemm_nt_tile(tile, tp.hx, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H); return; }
         // (A operand = the h_x pairs of this launch's prep roles: the loads spin until they carry this launch's epoch)
-        gemm_nt_tile<false, true>(tile, tp.prepll, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H, nullptr, tp.counter[0] + 1u);
+        gemm_nt_tile<false, true>(tile, tp.prepll, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H, nullptr, tp.counter[3] + 1u);
         if (threadIdx.x == 0) prep_consumer_arrive(tp);
         return;
     }
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
 #ifdef MMG_TIMING
     if (b == 0 && tid == 0) tp.dbg[4] = (long long)__builtin_readcyclecounter();
 #endif
-    const uint32_t mb_counter = tp.counter[0] + (merged ? 1u : 0u);      // (merged: bumped by the last consumer to arrive, below)
+    const uint32_t mb_counter = tp.counter[0] + (merged ? 1u : 0u);      // (merged: bumped by the launch's closing role)
+    const uint32_t ll_epoch = tp.counter[3] + 1u;                         // epoch of this launch's (value, epoch) pairs
     const uint32_t gb = (uint32_t)(dm.boff + b);
     const int tgt = ar.target ? (int)ar.target[b] : -1;     // (read here: no dependent memory round trip after the conversation)
     if (train && inject) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
             load_pairs();
             bool fresh = true;
 #pragma unroll
-            for (int k = 0; k < 18; ++k) fresh = fresh && ll_fresh(u[k], mb_counter);
+            for (int k = 0; k < 18; ++k) fresh = fresh && ll_fresh(u[k], ll_epoch);
             if (!__any(!fresh)) break;
             if (++spins > (1 << 16)) { if (lane == 0) __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }

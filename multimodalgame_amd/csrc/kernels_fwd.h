@@ -42,7 +42,7 @@ template <bool ROLE>
 __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const Tape& tp, const float* __restrict__ desc,
                                           const float* __restrict__ x, const int cpb, const int blk, float* smem) {
     const int tid = threadIdx.x;
-    const uint32_t epoch = ROLE ? tp.counter[0] + 1u : 0u;
+    const uint32_t epoch = ROLE ? tp.counter[3] + 1u : 0u;
     const int HB = (dm.H + 63) / 64;                 // blocks [nC, nC + HB): 64 rows of hw0 each
     const int nC = (dm.D + cpb - 1) / cpb;           // class blocks
     if (blk >= nC + HB) {
@@ -158,7 +158,7 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
         if (first && mc_shape(dm.H, dm.W, dm.R, dm.V, dm.D, dm.T))                                    // ... and of k_conversation_mc
             for (int i = tid; i < 2 * ((dm.B + 15) / 16); i += blockDim.x) tp.mcflags[(size_t)i * 64] = 0u;
         if (first && tid == 0) {
-            if (!ROLE) tp.counter[0] += 1u;         // minibatch counter: the Philox stream of this conversation
+            if (!ROLE) { tp.counter[0] += 1u; tp.counter[3] += 1u; }   // minibatch counter: the Philox stream of this conversation; launch epoch
             if (tp.counter[2] > tp.counter[1]) tp.counter[1] = tp.counter[2];   // optimizer step bumped by k_opt
         }
         __syncthreads();
@@ -205,7 +205,7 @@ __device__ __forceinline__ void prep_closing_role(const Tape& tp, const uint32_t
         if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
     __hip_atomic_store(PREP_CTR(tp, PREP_CTR_ARRIVE), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tp.counter[0] += 1u;
+    tp.counter[0] += 1u; tp.counter[3] += 1u;
 }
 __host__ __device__ inline int prep_blocks(const Dims& d, int cpb, bool with_hx) {
     return (d.D + cpb - 1) / cpb + (d.H + 63) / 64 + (with_hx ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0);
@@ -1039,7 +1039,7 @@ __device__ __forceinline__ void baselines3_body(const Dims& dm, const Params& P,
         const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
         if (ROLE) {                // roles of a larger launch: its statistics roles spin on (value, epoch) pairs (kernels_bwd.h: combine_score_ll)
             part[(size_t)s_rid[threadIdx.x] * npb + byi] = v;
-            st_ll(tp.partll, ((size_t)(which ? 0 : 1) * T * B + (size_t)s_rid[threadIdx.x]) * npb + byi, v, tp.counter[0]);
+            st_ll(tp.partll, ((size_t)(which ? 0 : 1) * T * B + (size_t)s_rid[threadIdx.x]) * npb + byi, v, tp.counter[3]);
         } else part[(size_t)s_rid[threadIdx.x] * npb + byi] = v;
     }
 }

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
     const bool train = ar.train != 0, inject = ar.u_s != nullptr;
     const int per = ar.per, c0 = member * per;
     const uint32_t mb_counter = tp.counter[0];
+    const uint32_t ll_base = tp.counter[3] * 32u;          // epochs of this launch's pair hand-offs: launch epoch, step
     const uint32_t gb = (uint32_t)(dm.boff + b);
     const int tgt = ar.target ? (int)ar.target[b] : -1;
     MMG_MSTAMP(0);
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
             tp.hstar[(size_t)b * R + tid] = hn[tid];
         }
         // ----- hand-off 1: publish A (17 x 16 bytes); the hidden-side GRU product of the next step fills the wait
-        const uint32_t ep = mb_counter * 32u + (uint32_t)t + 1u;
+        const uint32_t ep = ll_base + (uint32_t)t + 1u;
         if (tid < LDA) st_ll(llA, (size_t)member * LDA + tid, s_Aown[tid], ep);
         {
             float4 pk[4], hq[4];

@@ -148,7 +148,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(statll, float, 0, 1, 2 * (27 * T + 2 * T * B), 1, 1) /* (value, epoch) pairs of the stream statistics (per (stream, step): n | four f64 sums as 2 halves each) and of bs | br: hand-off from the statistics roles to the sample roles of the backward launch (kernels_fast.h) */ \
     X(stats, double, 3, 1, NSTAT, 1, 1)  /* batch statistics (all-reduced in DP)   */ \
     X(losses, float, 0, 1, 8, 1, 1)      /* nll, bin_s, bin_rec, bin_sen, bas_rec, bas_sen, n_steps, hits */ \
-    X(counter, uint32_t, 2, 1, 4, 1, 1)  /* [0] minibatch counter (Philox), [1] optimizer step */ \
+    X(counter, uint32_t, 2, 1, 4, 1, 1)  /* [0] minibatch counter (Philox), [1] optimizer step, [3] launch epoch of the (value, epoch) pair hand-offs: bumped with [0], never copied between engines (game.py), never reset */ \
     X(rmap, int32_t, 2, 1, T * B, 1, 1)  /* compacted list of the (step, sample) rows with t <= t*(b), in (t, b) order   */ \
     X(rcount, int32_t, 2, 1, 4, 1, 1)    /* [0] its length (k_wgrad reduces over these rows only)                          */ \
     X(sync, uint32_t, 2, 1, 512, 1, 1)    /* in-launch dependency counters between workgroup roles (device_utils.h: role_signal) */ \

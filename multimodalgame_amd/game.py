@@ -202,7 +202,7 @@ class Game(object):
         # them over when the batch size / class count -- hence the engine -- changes between steps
         last = getattr(self, "_train_engine", None)
         if last is not None and last is not eng:
-            eng.tape["counter"].copy_(last.tape["counter"])
+            eng.tape["counter"][:3].copy_(last.tape["counter"][:3])      # ([3]: the engine's own launch epoch, never handed over)
         self._train_engine = eng
         if self.world > 1:
             dp = self._dp.get(id(eng))
