@@ -201,9 +201,9 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     const float L = tp.logs[b];
     // transposed fragments: output unit k4 = tid/4, reduction slice p4 = tid%4 (n = p4 + 4*i)
     const int k4 = tid / K4, p4 = tid % K4;
+    // (the five transposed weight fragments below: 30 lane-consecutive float4 loads from k_prep's repacked copy, tape.wrep --
+    //  kernels_fwd.h: prep_repack -- instead of 120 strided dword loads from the parameter buffer)
     float whhT[3 * R / K4];
-#pragma unroll
-    for (int i = 0; i < 3 * R / K4; ++i) whhT[i] = P.p[R_WHH][(size_t)(p4 * (3 * R / K4) + i) * R + k4];
     const float wsk = P.p[R_S_W][k4];
     // the three dh-independent transposed products run for all steps at once on the matrix cores ([16 steps, K] x [K, N],
     // v_mfma_f32_16x16x4_f32): B fragments, lane (i = lane & 15, q = lane >> 4) holds Wm[4 ks + q][n0 + i] per k-step ks.
@@ -211,17 +211,25 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     static_assert(R == 64 && H == 256 && NT == 256, "one n-tile of the R-wide products and four of the H-wide product per wave");
     const int wv = tid >> 6, fi = lane & 15, fq = lane >> 4;
     float wwF[W / 4], whF[R / 4], wbF[4][W / 4];
-#pragma unroll
-    for (int ks = 0; ks < W / 4; ++ks) wwF[ks] = P.p[R_W_W][(size_t)(4 * ks + fq) * R + 16 * wv + fi];
-#pragma unroll
-    for (int ks = 0; ks < R / 4; ++ks) whF[ks] = P.p[R_WH_W][(size_t)(4 * ks + fq) * R + 16 * wv + fi];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < W / 4; ++ks) wbF[nt][ks] = P.p[S_BIN_W][(size_t)(4 * ks + fq) * H + 64 * wv + 16 * nt + fi];
     float y1T[R / K4];                             // y1[:, :R]^T fragment (output step only)
+    {
+        static_assert(3 * R / K4 == 48 && R / K4 == 16 && W / 4 == 8 && R / 4 == 16 && MMG_REPACK_F4 == 30, "layout of tape.wrep");
+        const float4* wr = reinterpret_cast<const float4*>(tp.wrep) + tid;
+        float4 q[MMG_REPACK_F4];
 #pragma unroll
-    for (int i = 0; i < R / K4; ++i) y1T[i] = P.p[R_Y1_W][(size_t)(p4 * (R / K4) + i) * (R + V) + k4];
+        for (int j = 0; j < MMG_REPACK_F4; ++j) q[j] = wr[j * NT];
+        auto put = [](float* dst, const float4& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; };
+#pragma unroll
+        for (int j = 0; j < 12; ++j) put(whhT + 4 * j, q[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put(y1T + 4 * j, q[12 + j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) put(wwF + 4 * j, q[16 + j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put(whF + 4 * j, q[18 + j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) put(&wbF[j >> 1][4 * (j & 1)], q[22 + j]);
+    }
     float y1r[R / K4];                             // y1[:, :R] row k4 fragment (forward product A = y1h . h*)
 #pragma unroll
     for (int i = 0; i < R / K4; ++i) y1r[i] = P.p[R_Y1_W][(size_t)k4 * (R + V) + p4 * (R / K4) + i];

@@ -38,6 +38,37 @@ __host__ __device__ inline size_t prepll_hx(const Dims&) { return 0; }
 __host__ __device__ inline size_t prepll_hw0(const Dims& d) { return (size_t)d.B * d.H; }
 __host__ __device__ inline size_t prepll_cd(const Dims& d) { return (size_t)d.B * d.H + d.H; }
 __host__ __device__ inline size_t prepll_dd(const Dims& d) { return (size_t)d.B * d.H + d.H + (size_t)d.D * d.R; }
+// Trailing blocks of k_prep on the agents of BASELINE configs 1-3 / 5 (H = 256, W = 32, R = 64): the transposed weight fragments
+// k_bwd_conv_fast keeps in registers, repacked so that each lane finds ITS values as 30 consecutive-by-lane float4s -- as the matrices
+// lie in the parameter buffer they are 120 strided dword loads per thread, and a wave holds at most 63 loads in flight (the backward's
+// prologue is ~230 loads: 3.7 memory latencies).  wrep[(j * 256 + tid) * 4 + c]:
+//   j  0..11  W_hh^T   [(p4 * 48 + i) * R + k4]          i = 4 j + c          (k4 = tid / 4, p4 = tid % 4)
+//   j 12..15  y1[:, :R]^T [(p4 * 16 + i) * (R + V) + k4]  i = 4 (j - 12) + c
+//   j 16..17  W_w      [(4 ks + fq) * R + 16 wv + fi]     ks = 4 (j - 16) + c  (wv = tid / 64, fi = lane % 16, fq = lane / 16)
+//   j 18..21  W_h      [(4 ks + fq) * R + 16 wv + fi]     ks = 4 (j - 18) + c
+//   j 22..29  binary_layer [(4 ks + fq) * H + 64 wv + 16 nt + fi]   nt * 8 + ks = 4 (j - 22) + c
+#define MMG_REPACK_BLOCKS 8
+#define MMG_REPACK_F4 30
+__host__ __device__ inline bool prep_has_repack(const Dims& d) { return d.H == 256 && d.W == 32 && d.R == 64; }
+__device__ __forceinline__ void prep_repack(const Dims& dm, const Params& P, const Tape& tp, const int rb) {
+    constexpr int H = 256, W = 32, R = 64, NTH = 256;
+    const int ldy = R + dm.V;
+    for (int idx = rb * NTH + (int)threadIdx.x; idx < MMG_REPACK_F4 * NTH; idx += MMG_REPACK_BLOCKS * NTH) {
+        const int j = idx / NTH, t = idx % NTH;
+        const int k4 = t >> 2, p4 = t & 3, wv = t >> 6, fi = t & 15, fq = (t & 63) >> 4;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (j < 12) v[c] = P.p[R_WHH][(size_t)(p4 * 48 + 4 * j + c) * R + k4];
+            else if (j < 16) v[c] = P.p[R_Y1_W][(size_t)(p4 * 16 + 4 * (j - 12) + c) * ldy + k4];
+            else if (j < 18) v[c] = P.p[R_W_W][(size_t)(4 * (4 * (j - 16) + c) + fq) * R + 16 * wv + fi];
+            else if (j < 22) v[c] = P.p[R_WH_W][(size_t)(4 * (4 * (j - 18) + c) + fq) * R + 16 * wv + fi];
+            else { const int f = 4 * (j - 22) + c, nt = f >> 3, ks = f & 7; v[c] = P.p[S_BIN_W][(size_t)(4 * ks + fq) * H + 64 * wv + 16 * nt + fi]; }
+        }
+        *reinterpret_cast<float4*>(tp.wrep + (size_t)idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    (void)W;
+}
 template <bool ROLE>
 __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const Tape& tp, const float* __restrict__ desc,
                                           const float* __restrict__ x, const int cpb, const int blk, float* smem) {
@@ -46,6 +77,8 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
     const int HB = (dm.H + 63) / 64;                 // blocks [nC, nC + HB): 64 rows of hw0 each
     const int nC = (dm.D + cpb - 1) / cpb;           // class blocks
     if (blk >= nC + HB) {
+        const int nhx = x ? ((dm.B + 15) / 16) * ((dm.H + 15) / 16) : 0;
+        if (blk >= nC + HB + nhx) { prep_repack(dm, P, tp, blk - nC - HB - nhx); return; }
         gemm_nt_tile<ROLE, false>(blk - nC - HB, x, dm.F, P.p[S_IMG_W], dm.F, P.p[S_IMG_B], tp.hx, dm.H, dm.B, dm.H, dm.F, tp.prepll, epoch);
         return;
     }
@@ -208,7 +241,7 @@ __device__ __forceinline__ void prep_closing_role(const Tape& tp, const uint32_t
     tp.counter[0] += 1u; tp.counter[3] += 1u;
 }
 __host__ __device__ inline int prep_blocks(const Dims& d, int cpb, bool with_hx) {
-    return (d.D + cpb - 1) / cpb + (d.H + 63) / 64 + (with_hx ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0);
+    return (d.D + cpb - 1) / cpb + (d.H + 63) / 64 + (with_hx ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0) + (prep_has_repack(d) ? MMG_REPACK_BLOCKS : 0);
 }
 
 __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, const float* __restrict__ desc,

@@ -584,7 +584,8 @@ static int launch_prep(mmg_handle* h, hipStream_t st, const float* desc, const f
     const Dims& d = h->dm;
     const int hx_tiles = x ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0;
     const int cpb = h->prep_cpb, nC = (d.D + cpb - 1) / cpb;
-    hipLaunchKernelGGL(k_prep, dim3(nC + (d.H + 63) / 64 + hx_tiles), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc, x, cpb);
+    (void)nC; (void)hx_tiles;
+    hipLaunchKernelGGL(k_prep, dim3(prep_blocks(d, cpb, x != nullptr)), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc, x, cpb);
     return launch_check("k_prep");
 }
 
