@@ -237,7 +237,16 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     const float w2_mine = (tid < R) ? P.p[R_Y2_W][tid] : 0.f;
     float cdcol[D];                                // Cd[:, tid] for tid < R
 #pragma unroll
-    for (int d = 0; d < D; ++d) cdcol[d] = (tid < R) ? tp.Cd[(size_t)min(d, Dr - 1) * R + tid] : 0.f;   // (dy is zero beyond Dr)
+    for (int d = 0; d < D; ++d) cdcol[d] = 0.f;
+    {   // k_prep's [8 float4][R] copy, tape.cd32 (classes beyond Dr: dy is zero there); every thread loads (clamped): no branch
+        // around the loads of the prologue
+        static_assert(D <= 32, "tape.cd32 holds the first 32 classes");
+#pragma unroll
+        for (int j = 0; j < (D + 3) / 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(tp.cd32 + ((size_t)j * R + min(tid, R - 1)) * 4);
+            cdcol[4 * j] = v.x; if (4 * j + 1 < D) cdcol[4 * j + 1] = v.y; if (4 * j + 2 < D) cdcol[4 * j + 2] = v.z; if (4 * j + 3 < D) cdcol[4 * j + 3] = v.w;
+        }
+    }
     // forward tape of this sample -> registers for ALL T steps (no dependence on tstar: every load of the prologue is
     // in flight at once; indices are clamped instead of guarded so the compiler keeps counted waits), LDS stores below
     constexpr int NW_ = TMAX * W / NT, NG_ = TMAX * R / NT, NU_ = TMAX * 4 * R / NT, NH_ = ((TMAX + 1) * R + NT - 1) / NT, NA_ = TMAX * H / NT;

@@ -109,7 +109,7 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
                 }
                 const float v = (a0 + a1) + (a2 + a3) + by;
                 const int d = d0 + c;
-                if (isC) { tp.Cd[(size_t)d * R + r] = v; if (ROLE) st_ll(tp.prepll, prepll_cd(dm) + (size_t)d * R + r, v, epoch); tp.CdT[(size_t)r * D + d] = -v; s_cd[c * R + r] = v; }
+                if (isC) { tp.Cd[(size_t)d * R + r] = v; if (ROLE) st_ll(tp.prepll, prepll_cd(dm) + (size_t)d * R + r, v, epoch); tp.CdT[(size_t)r * D + d] = -v; s_cd[c * R + r] = v; if (d < 32) tp.cd32[((size_t)(d >> 2) * R + r) * 4 + (d & 3)] = v; }
                 else { tp.Dd[(size_t)d * R + r] = v; if (ROLE) st_ll(tp.prepll, prepll_dd(dm) + (size_t)d * R + r, v, epoch); }
             }
         }
@@ -171,6 +171,7 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
             const float cdv = (a0 + a1) + (a2 + a3) + by1[r];
             tp.Cd[(size_t)d * R + r] = cdv;
             if (ROLE) st_ll(tp.prepll, prepll_cd(dm) + (size_t)d * R + r, cdv, epoch);
+            if (d < 32) tp.cd32[((size_t)(d >> 2) * R + r) * 4 + (d & 3)] = cdv;
             tp.CdT[(size_t)r * dm.D + d] = -cdv;      // NEGATED: relu(A + c) = max(A, -c) + c (kernels_tile.h, many-class y head)
             cy_part = fmaf(P.p[R_Y2_W][r], cdv, cy_part);
         }

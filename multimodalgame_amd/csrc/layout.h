@@ -106,6 +106,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(mcdC, float, 0, 3, NMCB, 2 * D, R) /* k_bwd_mc1: per sample group: partial dC | Py2                                 */ \
     X(prepll, float, 0, 1, 2 * (B * H + H + 2 * D * R), 1, 1) /* (value, launch epoch) pairs of h_x | hw0 | Cd | Dd: hand-off from the prep roles to the sample roles of ONE launch (kernels_fast3.h) */ \
     X(wrep, float, 0, 1, 30 * 256 * 4, 1, 1) /* the register-resident backward's transposed weight fragments, repacked per lane by k_prep's blocks: [30 float4][256 threads] (kernels_fwd.h: prep_repack) */ \
+    X(cd32, float, 0, 1, 8 * R * 4, 1, 1) /* Cd of the first 32 classes as [8 float4][R] (class 4 j + c of unit r at ((j R + r) 4 + c)): the register-resident backward's column of Cd in 8 lane-consecutive loads */ \
     X(alive, int32_t, 2, 1, T + 2, 1, 1) /* [t]: sample tiles with a live sample when step t starts (kernels_tile.h)  */ \
     X(hw0, float, 0, 1, H, 1, 1)         /* code_layer(sigmoid(code_bias)) :199-200*/ \
     X(dsig, float, 0, 1, W, 1, 1)        /* sigmoid'(code_bias)                    */ \
