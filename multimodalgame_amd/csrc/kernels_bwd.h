@@ -589,7 +589,7 @@ struct ColJob { const float* src; float* dst; const float* scale; const float* v
 struct NormPlan { int64_t begin[MMG_GN_BLOCKS], end[MMG_GN_BLOCKS]; int agent[MMG_GN_BLOCKS]; };
 #define MMG_MAX_WBLOCKS 16384
 struct JobTable {
-    int n_gemm, n_col, gemm_tiles, gemm_blocks, col_blocks, pad0, pad1, pad2;
+    int n_gemm, n_col, gemm_tiles, gemm_blocks, col_blocks, special_block, special_job, pad2;   // special_*: the code_bias job's workgroup / entry of c[] (-1: none)
     GemmJob g[MMG_MAX_GEMM];
     ColJob c[MMG_MAX_COL];
     NormPlan np;
@@ -643,6 +643,56 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     float (*s_acc)[16][33] = reinterpret_cast<float (*)[16][33]>(&s_b[0][0][0]);   // [4][16][33] reused after the row loop
     float* s_part = &s_b[0][0][0];                                                   // column-sum staging
     __shared__ float s_red[8];
+    if ((int)blockIdx.x == jt->special_block) {
+        // (found by ONE scalar load, ahead of the live-row list and the job lookup every other block starts with: this is the launch's
+        //  longest block -- 9.0 us next to ~7 -- and those were a dependent memory round trip in front of its two)
+        const ColJob& C = jt->c[jt->special_job];
+        // code_bias gradient: dst[j] = scale[j] * sum_h wrow[h*cols + j] * v[h],  v[h] = sum_{b < rows} src[b*ld + h]
+        // (src = dpre rows of step 0, wrow = code_layer.weight [ld, cols], scale = sigmoid'(code_bias))
+        float* s_v = &s_b[0][0][0];                        // ld <= 4224 floats of staging
+        const int Hh = C.ld, Wc = C.cols, nb = C.rows;
+        const int p8 = threadIdx.x & 7, jj = threadIdx.x >> 3;
+        // this runs in ONE workgroup next to ~1000 short ones: every load that does not depend on v is issued first
+        // (the weight slice of the first 32 output columns), then the rows in batches of 64 -- two memory round trips
+        float wreg[32];
+        const bool wfast = (Hh == 256) && (Wc <= 32);
+        if (wfast) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) wreg[i] = C.wrow[(size_t)(p8 + 8 * i) * Wc + min(jj, Wc - 1)];
+        }
+        for (int h0 = threadIdx.x; h0 < Hh; h0 += MMG_BLOCK) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int b0 = 0; b0 < nb; b0 += 64) {
+                float v[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) v[u] = C.src[(size_t)min(b0 + u, nb - 1) * Hh + h0];
+#pragma unroll
+                for (int u = 0; u < 64; u += 4) {
+                    a0 += (b0 + u < nb) ? v[u] : 0.f; a1 += (b0 + u + 1 < nb) ? v[u + 1] : 0.f;
+                    a2 += (b0 + u + 2 < nb) ? v[u + 2] : 0.f; a3 += (b0 + u + 3 < nb) ? v[u + 3] : 0.f;
+                }
+            }
+            s_v[h0] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        float sq = 0.f;
+        for (int j0 = 0; j0 < Wc; j0 += MMG_BLOCK / 8) {   // 8 lanes per output column
+            const int j = j0 + jj;
+            float acc = 0.f;
+            if (wfast) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) acc = fmaf(wreg[i], s_v[p8 + 8 * i], acc);
+            } else if (j < Wc) {
+                for (int h0 = p8; h0 < Hh; h0 += 8) acc = fmaf(C.wrow[(size_t)h0 * Wc + j], s_v[h0], acc);
+            }
+            acc = dpp_group_sum<8>(acc);
+            if (j < Wc && p8 == 0) { const float gsum = acc * C.scale[j]; C.dst[j] = gsum; sq = fmaf(gsum, gsum, sq); }
+        }
+        sq = block_sum(sq, s_red);
+        if (threadIdx.x == 0) part[blockIdx.x] = sq;
+        MMG_WG_END();
+        return;
+    }
     // rmap != NULL: jobs whose rows are (step, sample) rows reduce over the compacted list of live rows only
     // (build_row_map); the list is copied to LDS first thing, in the shadow of the job lookup below.
     constexpr int MAXMAP = 2048;
@@ -835,53 +885,6 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     const ColJob& C = jt->c[j];
     const bool ccmp = use_map && C.compact;
     if (use_map) __syncthreads();                          // s_map is complete
-    if (C.special) {
-        // code_bias gradient: dst[j] = scale[j] * sum_h wrow[h*cols + j] * v[h],  v[h] = sum_{b < rows} src[b*ld + h]
-        // (src = dpre rows of step 0, wrow = code_layer.weight [ld, cols], scale = sigmoid'(code_bias))
-        float* s_v = &s_b[0][0][0];                        // ld <= 4224 floats of staging
-        const int Hh = C.ld, Wc = C.cols, nb = C.rows;
-        const int p8 = threadIdx.x & 7, jj = threadIdx.x >> 3;
-        // this runs in ONE workgroup next to ~1000 short ones: every load that does not depend on v is issued first
-        // (the weight slice of the first 32 output columns), then the rows in batches of 64 -- two memory round trips
-        float wreg[32];
-        const bool wfast = (Hh == 256) && (Wc <= 32);
-        if (wfast) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) wreg[i] = C.wrow[(size_t)(p8 + 8 * i) * Wc + min(jj, Wc - 1)];
-        }
-        for (int h0 = threadIdx.x; h0 < Hh; h0 += MMG_BLOCK) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int b0 = 0; b0 < nb; b0 += 64) {
-                float v[64];
-#pragma unroll
-                for (int u = 0; u < 64; ++u) v[u] = C.src[(size_t)min(b0 + u, nb - 1) * Hh + h0];
-#pragma unroll
-                for (int u = 0; u < 64; u += 4) {
-                    a0 += (b0 + u < nb) ? v[u] : 0.f; a1 += (b0 + u + 1 < nb) ? v[u + 1] : 0.f;
-                    a2 += (b0 + u + 2 < nb) ? v[u + 2] : 0.f; a3 += (b0 + u + 3 < nb) ? v[u + 3] : 0.f;
-                }
-            }
-            s_v[h0] = (a0 + a1) + (a2 + a3);
-        }
-        __syncthreads();
-        float sq = 0.f;
-        for (int j0 = 0; j0 < Wc; j0 += MMG_BLOCK / 8) {   // 8 lanes per output column
-            const int j = j0 + jj;
-            float acc = 0.f;
-            if (wfast) {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) acc = fmaf(wreg[i], s_v[p8 + 8 * i], acc);
-            } else if (j < Wc) {
-                for (int h0 = p8; h0 < Hh; h0 += 8) acc = fmaf(C.wrow[(size_t)h0 * Wc + j], s_v[h0], acc);
-            }
-            acc = dpp_group_sum<8>(acc);
-            if (j < Wc && p8 == 0) { const float gsum = acc * C.scale[j]; C.dst[j] = gsum; sq = fmaf(gsum, gsum, sq); }
-        }
-        sq = block_sum(sq, s_red);
-        if (threadIdx.x == 0) part[blockIdx.x] = sq;
-        MMG_WG_END();
-        return;
-    }
     const int c0 = (cb - C.blk_begin) * 16;
     const int cc = threadIdx.x & 15, g = threadIdx.x >> 4;
     const bool cv = (c0 + cc) < C.cols;

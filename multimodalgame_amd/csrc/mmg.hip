@@ -271,6 +271,8 @@ static int build_jobs(mmg_handle* h) {
     for (int g = 0; g < ng; ++g) h->any_split = h->any_split || jt.g[g].nsplit > 1;
     jt.n_gemm = ng; jt.n_col = nc; jt.gemm_tiles = tiles; jt.gemm_blocks = tiles; jt.col_blocks = cblocks;
     jt.n_wblocks = tiles + cblocks;
+    jt.special_block = -1; jt.special_job = -1;
+    for (int c = 0; c < nc; ++c) if (jt.c[c].special) { jt.special_job = c; jt.special_block = tiles + jt.c[c].blk_begin; }
     for (int k = 0; k < 64; ++k) {
         jt.g_begin[k] = k < ng ? jt.g[k].tile_begin : 0x7fffffff;
         jt.c_begin[k] = k < nc ? jt.c[k].blk_begin : 0x7fffffff;
