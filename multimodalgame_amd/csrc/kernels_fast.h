@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     constexpr int TMAX = 16;
     static_assert(FastDims<H, W, R, V, D>::ok, "unsupported fast shape");
     __shared__ float s_coef[7 * 64];
-    __shared__ __attribute__((aligned(16))) float s_dh[R], s_dgh[3 * R];
+    __shared__ __attribute__((aligned(16))) float s_dgh[2][3 * R];   // gate gradients of a step, double-buffered (ONE barrier per reverse step)
     __shared__ __attribute__((aligned(16))) float s_dy[32], s_A[R], s_dA[R];
     __shared__ float s_dls[TMAX], s_cf[4 * TMAX], s_dAy[R];
     __shared__ __attribute__((aligned(16))) float s_dhin[TMAX * R];
@@ -451,7 +451,6 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
             tp.dbr[row] = binary ? lc.cb[t] * (rbr_ - L) : 0.f;
         }
     }
-    if (tid < R) s_dh[tid] = 0.f;
 
     // ---- zero the gradient tapes of steps this sample never took -- unless k_wgrad reduces over the live rows only
     // (build_row_map) and never looks at them: ~1.7 MB of stores per minibatch at config 2
@@ -500,47 +499,50 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         }
     }
 
-    // ---- the recurrence: two phases per step
+    // ---- the recurrence: two phases and ONE barrier per step.  The carried dh of unit k4 lives in a register of each of the unit's
+    // four lanes (the 4-lane sum leaves W_hh^T dgh in all of them: no LDS hop, no barrier before the next cell backward), and the gate
+    // gradients are double-buffered: a wave that runs ahead writes the OTHER buffer and stops at the next step's barrier, which the
+    // slowest wave reaches only after it has read this one.
     auto step_in = [&](int t) {                                        // what step t adds to dh besides the recurrence
         float v = fmaf(s_cf[t], s_dhin[t * R + k4], s_cf[TMAX + t] * s_H2[t * R + k4]) + wsk * s_dls[t];
         if (t == tstar) v += s_dAy[k4];
         return v;
     };
+    float dh_c = 0.f;
     for (int t = tstar; t >= 0; --t) {
         const size_t row = (size_t)t * B + b;
+        float* const dgb = s_dgh[t & 1];
         MMG_BSTAMP(16 + 2 * t);
+        // ===== (4) GRU cell backward: all K4 lanes of unit k4 form the gate gradients, lane p4 stores the p4-th of them
+        const float dh = dh_c + step_in(t);
+        const float* gr = t_gru + t * 4 * R;
+        const float rr = gr[k4], uu = gr[R + k4], nn = gr[2 * R + k4], ghn = gr[3 * R + k4];
         {
-            // ===== (4) GRU cell backward: all K4 lanes of unit k4 form the gate gradients, lane p4 stores the p4-th of them
-            const float dh = s_dh[k4] + step_in(t);
-            const float* gr = t_gru + t * 4 * R;
-            const float rr = gr[k4], uu = gr[R + k4], nn = gr[2 * R + k4], ghn = gr[3 * R + k4];
             const float hp = t_h[t * R + k4];
             const float dn = dh * (1.f - uu), du = dh * (hp - nn);
             const float dnp = dn * (1.f - nn * nn), dup = du * uu * (1.f - uu);
             const float drp = dnp * ghn * rr * (1.f - rr);
             float* gi = tp.dgi + row * 3 * R; float* gh = tp.dgh + row * 3 * R;
             static_assert(K4 == 4, "four lanes per unit share the stores");
-            if (p4 == 0)      { gi[k4] = drp; gh[k4] = drp; s_dgh[k4] = drp; }
-            else if (p4 == 1) { gi[R + k4] = dup; gh[R + k4] = dup; s_dgh[R + k4] = dup; }
-            else if (p4 == 2) { gi[2 * R + k4] = dnp; gh[2 * R + k4] = dnp * rr; s_dgh[2 * R + k4] = dnp * rr; }
+            // (selects, then ONE predicated region: three divergent branches each with their own stores split the phase)
+            const float vi = (p4 == 0) ? drp : (p4 == 1) ? dup : dnp;
+            const float vh = (p4 == 2) ? dnp * rr : vi;
+            const int idx = p4 * R + k4;
+            if (p4 < 3) { gi[idx] = vi; gh[idx] = vh; dgb[idx] = vh; }
         }
         __syncthreads(); MMG_BSTAMP(16 + 2 * t + 1);
-        // ===== (5) dh_{t-1} = dh * u + W_hh^T dgh      (lane p4 == 3 of the unit re-forms dh * u: s_dh is rewritten here only)
+        // ===== (5) dh_{t-1} = dh * u + W_hh^T dgh
         {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
             for (int i = 0; i < 3 * R / K4; i += 4) {
-                const float4 dv = *reinterpret_cast<const float4*>(s_dgh + p4 * (3 * R / K4) + i);
+                const float4 dv = *reinterpret_cast<const float4*>(dgb + p4 * (3 * R / K4) + i);
                 a0 = fmaf(whhT[i], dv.x, a0); a1 = fmaf(whhT[i + 1], dv.y, a1);
                 a2 = fmaf(whhT[i + 2], dv.z, a2); a3 = fmaf(whhT[i + 3], dv.w, a3);
             }
             const float acc = lane_group_sum<K4>((a0 + a1) + (a2 + a3));
-            if (p4 == 0) {
-                const float dh = s_dh[k4] + step_in(t);
-                s_dh[k4] = __fmul_rn(dh, t_gru[t * 4 * R + R + k4]) + acc;
-            }
+            dh_c = __fmul_rn(dh, uu) + acc;
         }
-        __syncthreads();
     }
     MMG_BSTAMP(4);
     // (code_bias: k_wgrad's special column job forms dsig * W_c^T (sum_b dpre_0) once, instead of W_c^T dpre_0 per sample here)
