@@ -2101,6 +2101,24 @@ __host__ __device__ inline BwdLds bwd_tile_lds(const Dims& d, int nw) {
     L.dy = take(hh ? (dysz > hhsz ? dysz : hhsz) : dysz);
     if (hh) L.whh = L.dy;
     L.total = o;
+    if (L.total > budget && !((3 * d.R) & 15) && 3 * MMG_TM * L.ldR >= MMG_TM * L.ld3R) {
+        // wide receivers (R = 256: 204 KB): the gate-gradient tile dgh lives in the reverse-time loop only, the dA | A | h* tiles
+        // (contiguous) in the output-step prelude only -- they share their space.  Every element of dgh's K = 3R columns is
+        // rewritten each step before the product reads it, and 3R is a multiple of 16 (no K padding to keep zero).
+        BwdLds M = L;
+        int o2 = 0;
+        auto take2 = [&](int n) { const int at = o2; o2 += (n + 3) & ~3; return at; };
+        M.dh = take2(MMG_TM * L.ldR);
+        M.dAm = take2(MMG_TM * L.ldR); M.dA = take2(MMG_TM * L.ldR); M.A = take2(MMG_TM * L.ldR); M.hs = take2(MMG_TM * L.ldR);
+        M.dgh = M.dA;
+        M.ws = take2(L.ldR); M.w2 = take2(L.ldR);
+        M.raw0 = take2(r); M.raw1 = take2(r);
+        M.misc = take2(128);
+        M.dy = take2(dysz);
+        M.whh = -1;
+        M.total = o2;
+        return M;
+    }
     return L;
 }
 #define BL_TSTAR 0      // [0,16) t* of the tile's samples   [16,32) reward L   [32,48) dls of this step   [48,64) live this step

@@ -95,6 +95,10 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(cpart, float, 0, 3, NTILE * NHLP, 16, V + 2) /* k_conv_split: per helper: unnormalised mixture partial | slice max | slice sum */ \
     X(gip, float, 0, 3, NS2P, B, 3 * R)  /* per-sender-role partials of the GRU input product (k_conv_persist)           */ \
     X(zpart, float, 0, 3, NZP, 16, W)    /* per-SA-role partial message logits of a tile (k_conv_persist, fused sender roles) */ \
+    X(rcgw, float, 0, 2, NRCB, R, 1)     /* wide receiver (kernels_rc.h): w_h h + b_h of the step, written per 16-unit slice by k_rc_heads */ \
+    X(rcyp, float, 0, 3, NRCJ, NRCB, D)  /* ... per-slice partial class logits [R/16][B][D], added in slice order by k_rc_query              */ \
+    X(rclw, float, 0, 3, NRCW, NRCB, 2)  /* ... per-16-bit-slice partial (log-likelihood, neg-entropy) of the receiver's message            */ \
+    X(rcst, float, 0, 2, 4, B, 1)        /* ... [0..1] running stop mask m_t, double-buffered by step parity; [2] take-output flag of the step */ \
     X(pflags, uint32_t, 2, 1, 4 * 64 * 64, 1, 1) /* k_conv_persist: per (kind, sample tile) counters, one per 256-byte block */ \
     X(mcA, float, 0, 3, NMC, 16, R + 4)  /* k_conversation_mc: A rows (+ take flag) published by the 16 members of a tile       */ \
     X(mcpart, float, 0, 3, NMC * 16, 16, 104) /* k_conversation_mc: per (tile, class slice): [16 samples][V mixture terms | m | s | pad] */ \
@@ -227,6 +231,13 @@ __host__ __device__ inline int split_helpers(int B) { const int tiles = (B + 15)
 // own workgroup holds, up to 16 slices x 64 classes
 __host__ __device__ inline bool mc_shape(int H, int W, int R, int V, int D, int T) { return H == 256 && W == 32 && R == 64 && V == 100 && D > 32 && D <= 1024 && T <= 16; }
 
+// wide receiver (kernels_rc.h): rec_hidden beyond the one-workgroup-per-tile forward (its LDS plan stops at R = 128 with a
+// 256-bit message), beside the large sender / few samples of the per-step sender launches
+__host__ __device__ inline bool rc_shape(int B, int H, int W, int R, int V, int D) {
+    return R > 128 && R <= 256 && !(R & 15) && !(W & 15) && W <= 256 && (B + 15) / 16 < 64 && (long long)H * W >= 65536 &&
+           D <= 64 && V <= 128 && !(V & 3) && !(H & 3);
+}
+
 __host__ __device__ inline int dc_slices(int B) { return B >= 1024 ? 4 : 1; }
 
 struct TapeLayout {
@@ -242,9 +253,12 @@ inline TapeLayout tape_layout(const mmg_config& c) {
                   V = c.wv_dim, K = c.bas_hidden, T = c.max_exchange, T1 = T + 1,
                   NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B), NS2P = (W + 15) / 16, NTILE = (B + 15) / 16, NZP = ((B + 15) / 16) * ((H + 63) / 64), NHLP = split_helpers((int)B) > 0 ? split_helpers((int)B) : 1,
                   NMC = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) ? (B + 15) / 16 : 1,
+                  NRCB = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? B : 1,
+                  NRCJ = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? R / 16 : 1,
+                  NRCW = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? W / 16 : 1,
                   NMCB = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) && !c.use_binary ? 16 : 0,
                   NWP = wgrad_any_split((int)(T * B), param_layout(c).total) ? (int64_t)16 * (param_layout(c).total + 512 * 64) : 4;   /* (every job splits <= 16 ways) */
-    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB;
+    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \

@@ -19,6 +19,7 @@
 #include "kernels_tile.h"
 #include "kernels_mc.h"
 #include "kernels_mc3.h"
+#include "kernels_rc.h"
 
 using namespace mmg;
 
@@ -58,6 +59,8 @@ struct mmg_handle {
     bool merge_roles;          // MMG_NO_MERGE=1 keeps k_stats / k_dC / basehx as separate launches / in-kernel work
     // sample-tile MFMA path (kernels_tile.h): every shape the register-resident kernels do not cover
     bool tile_ok;              // its LDS plan fits (MMG_NO_TILE=1: never use it)
+    bool rc_fwd;               // wide receiver (kernels_rc.h): the tile's receiver step as three chip-wide launches over 16-unit slices -- the
+                               // one-workgroup-per-tile forward does not fit its LDS plan (R > 128 with a 256-bit message); MMG_NO_RC=1: off
     bool tile_force;           // MMG_TILE=1: use it even where the register-resident kernels apply (cross-checks)
     bool tile_ext;             // the sender MLP of a step runs as its own chip-wide launches (k_send_s1 / k_send_s2)
     int tile_nt, tile_smem;    // threads per tile workgroup, dynamic LDS bytes
@@ -403,7 +406,8 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         }
         // 16-byte aligned weight rows (float4 fragments): every BASELINE shape; odd dimensions take the per-sample kernels
         const bool aligned = !(d.H & 3) && !(d.W & 3) && !(d.R & 3) && !(d.V & 3);
-        h->tile_ok = aligned && h->tile_smem <= 160 * 1024 && !getenv("MMG_NO_TILE");
+        h->rc_fwd = aligned && h->tile_ext && h->tile_smem > 160 * 1024 && rc_shape(d.B, d.H, d.W, d.R, d.V, d.D) && !getenv("MMG_NO_RC");
+        h->tile_ok = aligned && (h->tile_smem <= 160 * 1024 || h->rc_fwd) && !getenv("MMG_NO_TILE");
         h->tile_force = getenv("MMG_TILE") != nullptr;
         // many classes, small agents, fewer than 64 tiles: a workgroup per SAMPLE fills the chip (256 samples = 256 CUs) and
         // beats 16 tiles + class helpers (measured at D = 1000, B = 256: 557 us against 1 010 us per minibatch; B = 2048:
@@ -468,7 +472,8 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
             if (smem > 48 * 1024) e = hipFuncSetAttribute((const void*)k_bwd_pre_send<8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (smem > 48 * 1024 && e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_pre_send<16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         }
-        if (h->tile_ok && h->tile_smem > 48 * 1024) {
+        if (!h->tile_ok) h->rc_fwd = false;
+        if (h->tile_ok && h->tile_smem > 48 * 1024 && !h->rc_fwd) {
             e = hipFuncSetAttribute((const void*)k_conv_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
@@ -493,9 +498,9 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
     if (getenv("MMG_DEBUG"))
-        fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d\n",
+        fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d rc %d\n",
                 (int)h->tile_ok, h->tile_nt, h->tile_smem, (int)h->tile_ext, (int)h->tile_persist, h->persist_smem, h->resident_budget, h->tile_bwd_smem,
-                bwd_pre_lds_floats(h->dm) * 4, h->send_bwd_smem, (int)h->tile_split, (int)h->mc_ok, (int)h->use_fast);
+                bwd_pre_lds_floats(h->dm) * 4, h->send_bwd_smem, (int)h->tile_split, (int)h->mc_ok, (int)h->use_fast, (int)h->rc_fwd);
     if (h->conv_smem > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
@@ -694,6 +699,21 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
     // per-step launches: no co-residency needed (any device, any batch)
     ar.persist = 0; ar.rsample = 0;
     const int skip = (!ar.run_all && !d.fixed && ar.train) ? 1 : 0;
+    if (h->rc_fwd) {
+        // wide receiver: the receiver step of a tile as three launches over 16-unit / 16-bit slices (kernels_rc.h)
+        Scope sc(h, st, "k_conv_rc");
+        const int nj = d.R / 16, njw = d.W / 16;
+        ar.phases = 2;
+        for (int t = 0; t < d.T; ++t) {
+            hipLaunchKernelGGL(k_send_s1, dim3(tiles * ((d.H + 15) / 16)), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, t, skip);
+            hipLaunchKernelGGL(k_send_s2, dim3(tiles * ((d.W + 15) / 16)), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, ar, t, skip);
+            hipLaunchKernelGGL(k_rc_gru, dim3(tiles * nj), dim3(256), 0, st, h->dm, h->P, h->tp, ar, t, skip);
+            hipLaunchKernelGGL(k_rc_heads, dim3(tiles * nj), dim3(256), 0, st, h->dm, h->P, h->tp, ar, t, skip);
+            hipLaunchKernelGGL(k_rc_query, dim3(tiles * njw), dim3(256), 0, st, h->dm, h->P, h->tp, ar, t, skip);
+        }
+        hipLaunchKernelGGL(k_rc_tail, dim3(tiles), dim3(256), 0, st, h->dm, h->P, h->tp, ar);
+        return launch_check("k_conv_rc");
+    }
     for (int t = 0; t < d.T; ++t) {
         {
             Scope sc(h, st, "k_send_s1");

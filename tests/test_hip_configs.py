@@ -60,9 +60,22 @@ def test_config4_shape_vs_oracle(switch, monkeypatch):
 
 
 def test_config4_with_rec_hidden_256_vs_oracle():
-    """'rec_w_dim 256 / img_h_dim 1024 ... use R = 64 and additionally report R = 256'.  R = 256 is beyond the
-    sample-tile kernels (R <= 128): the generic per-sample kernels run it; same gate against the oracle."""
-    _compare(_meta(dict(C4, rec_hidden=256, batch_size=64), 30, 64, 2), skip=("y2.bias",), label="config4-R256")
+    """'rec_w_dim 256 / img_h_dim 1024 ... use R = 64 and additionally report R = 256'.  At R = 256 the
+    one-workgroup-per-tile forward does not fit its LDS plan: the receiver step runs as launches over 16-unit slices on the
+    matrix cores (kernels_rc.h: k_rc_gru / k_rc_heads / k_rc_query), the backward on the tile kernels; B = 64 as the bench times it."""
+    meta = _meta(dict(C4, rec_hidden=256, batch_size=64), 30, 64, 2)
+    got, eng = common.hip_train_case(None, meta)
+    flips = []
+    want = common.oracle_train_case(None, meta, flips=flips)
+    common.assert_parity(got, want, flips, eng, "config4-R256", skip=("y2.bias",))
+    names = _kernel_names(eng, meta)
+    assert "k_conv_rc" in names and "k_bwd_tile" in names, names
+
+
+def test_config4_with_rec_hidden_256_generic_fallback(monkeypatch):
+    """MMG_NO_RC=1: the same shape on the generic per-sample kernels (what a device without the tile path's alignment runs)."""
+    monkeypatch.setenv("MMG_NO_RC", "1")
+    _compare(_meta(dict(C4, rec_hidden=256, batch_size=16), 30, 16, 2), skip=("y2.bias",), label="config4-R256-generic")
 
 
 def test_config4_shape_consecutive_role_launches():
