@@ -26,11 +26,23 @@ namespace mmg {
 #define RC_MAXG 4                                   // k-groups of 16 per wave: K <= 256 over four waves
 struct RcFrag { float4 v[RC_MAXG]; };
 
+// PS (persistent launch, k_rc_persist): what another workgroup of the SAME launch wrote is read with agent-scope loads and
+// written with write-through stores (device_utils.h: ld_cc / st_wt); the per-step kernels use plain accesses
+template <bool PS> __device__ __forceinline__ float rc_ld(const float* p) { return PS ? ld_cc(p) : *p; }
+template <bool PS> __device__ __forceinline__ float4 rc_ld4(const float* p) { return PS ? ld_cc4(p) : *reinterpret_cast<const float4*>(p); }
+template <bool PS> __device__ __forceinline__ void rc_st(float* p, float v) { if (PS) st_wt(p, v); else *p = v; }
+
 // this wave's k-groups [g0, g0 + RC_MAXG) of one operand row (clamped, branch-free: all loads of a phase go out together)
 __device__ __forceinline__ void rc_load(RcFrag& f, const float* __restrict__ row, int K, int g0, int q) {
     const int kgroups = K >> 4;
 #pragma unroll
     for (int u = 0; u < RC_MAXG; ++u) f.v[u] = *reinterpret_cast<const float4*>(row + min(g0 + u, kgroups - 1) * 16 + q * 4);
+}
+template <bool PS>
+__device__ __forceinline__ void rc_load_act(RcFrag& f, const float* row, int K, int g0, int q) {      // activation rows (hand-off payload when PS)
+    const int kgroups = K >> 4;
+#pragma unroll
+    for (int u = 0; u < RC_MAXG; ++u) f.v[u] = rc_ld4<PS>(row + min(g0 + u, kgroups - 1) * 16 + q * 4);
 }
 __device__ __forceinline__ f32x4 rc_mma(const RcFrag& a, const RcFrag& b, int n, f32x4 acc) {
 #pragma unroll
@@ -50,40 +62,43 @@ __device__ __forceinline__ void rc_share(int K, int wave, int& g0, int& n) {
 }
 
 // rows of step t that are stored: valid sample, still in its conversation (k_conv_tile's TL_LIVE)
+template <bool PS>
 __device__ __forceinline__ bool rc_live(const Tape& tp, int B, int t, int b, bool valid, bool may_stop) {
-    return valid && (!may_stop || t == 0 || tp.rcst[(size_t)(t & 1) * B + b] != 0.f);
+    return valid && (!may_stop || t == 0 || rc_ld<PS>(&tp.rcst[(size_t)(t & 1) * B + b]) != 0.f);
 }
 
 // lp_w / ne_w of step tp_ from the per-role partials k_rc_query left (fixed summation tree: deterministic)
+template <bool PS>
 __device__ __forceinline__ void rc_sum_lw(const Dims& dm, const Tape& tp, int tp_, int b0, int nb, bool may_stop) {
     const int B = dm.B, NJW = dm.W >> 4, tid = threadIdx.x, m = tid >> 4, l16 = tid & 15, b = min(b0 + m, B - 1);
     float lpv = 0.f, nev = 0.f;
     for (int jw = l16; jw < NJW; jw += 16) {
         const float* p = tp.rclw + ((size_t)jw * B + b) * 2;
-        lpv += p[0]; nev += p[1];
+        lpv += rc_ld<PS>(p); nev += rc_ld<PS>(p + 1);
     }
     lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
-    const bool live = rc_live(tp, B, tp_, b, m < nb, may_stop);
-    const bool live2 = live && (!may_stop || tp.rcst[(size_t)((tp_ + 1) & 1) * B + b] != 0.f);
+    const bool live = rc_live<PS>(tp, B, tp_, b, m < nb, may_stop);
+    const bool live2 = live && (!may_stop || rc_ld<PS>(&tp.rcst[(size_t)((tp_ + 1) & 1) * B + b]) != 0.f);
     if (l16 == 0 && live2) { tp.lp_w[(size_t)tp_ * B + b] = lpv; tp.ne_w[(size_t)tp_ * B + b] = nev; }
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rc_gru(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
+// PS = false: returns early (false) when the tile's conversations are over; PS = true: always runs through (its signals must go out)
+template <bool PS>
+__device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int j) {
     __shared__ float s_acc[6][4][16][17];
     __shared__ float s_live[16];
-    if (skip && tp.alive[t] == 0) return;
-    const int B = dm.B, W = dm.W, R = dm.R, NJ = R >> 4;
-    const int tile = blockIdx.x / NJ, j = blockIdx.x - tile * NJ;
+    const int B = dm.B, W = dm.W, R = dm.R;
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
-    if (tid < MMG_TM) s_live[tid] = rc_live(tp, B, t, min(b0 + tid, B - 1), tid < nb, may_stop) ? 1.f : 0.f;
+    __syncthreads();                                                    // (PS: the LDS of the phase before is free)
+    if (tid < MMG_TM) s_live[tid] = rc_live<PS>(tp, B, t, min(b0 + tid, B - 1), tid < nb, may_stop) ? 1.f : 0.f;
     __syncthreads();
-    if (may_stop) {
+    if (!PS && may_stop) {
         bool any = false;
         for (int m = 0; m < MMG_TM; ++m) any = any || (s_live[m] != 0.f);
-        if (!any) return;                                               // the tile's conversations are over
+        if (!any) return false;                                         // the tile's conversations are over
     }
     const size_t rowb = (size_t)t * B;
     {
@@ -91,13 +106,13 @@ __global__ __launch_bounds__(256) void k_rc_gru(Dims dm, Params P, Tape tp, Conv
         int gw0, nw_, gr0, nr_;
         rc_share(W, wave, gw0, nw_); rc_share(R, wave, gr0, nr_);
         RcFrag az, ah, wi0, wi1, wi2, wh0, wh1, wh2;
-        rc_load(az, tp.z + (rowb + bx) * W, W, gw0, q);
+        rc_load_act<PS>(az, tp.z + (rowb + bx) * W, W, gw0, q);
         rc_load(wi0, P.p[R_WIH] + (size_t)(unit) * W, W, gw0, q);
         rc_load(wi1, P.p[R_WIH] + (size_t)(R + unit) * W, W, gw0, q);
         rc_load(wi2, P.p[R_WIH] + (size_t)(2 * R + unit) * W, W, gw0, q);
         // (t == 0: h_0 = 0 is being written by this very launch -- the hidden-side product is b_hh alone)
         const int nh = (t > 0) ? nr_ : 0;
-        rc_load(ah, tp.h + (rowb + bx) * R, R, gr0, q);
+        rc_load_act<PS>(ah, tp.h + (rowb + bx) * R, R, gr0, q);
         rc_load(wh0, P.p[R_WHH] + (size_t)(unit) * R, R, gr0, q);
         rc_load(wh1, P.p[R_WHH] + (size_t)(R + unit) * R, R, gr0, q);
         rc_load(wh2, P.p[R_WHH] + (size_t)(2 * R + unit) * R, R, gr0, q);
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(256) void k_rc_gru(Dims dm, Params P, Tape tp, Conv
         const int m = tid >> 4, c = tid & 15, unit = 16 * j + c, b = min(b0 + m, B - 1);
         auto S = [&](int p) { return (s_acc[p][0][m][c] + s_acc[p][1][m][c]) + (s_acc[p][2][m][c] + s_acc[p][3][m][c]); };
         const float* bih = P.p[R_BIH]; const float* bhh = P.p[R_BHH];
-        const float hprev = (t > 0) ? tp.h[(rowb + b) * R + unit] : 0.f;
+        const float hprev = (t > 0) ? rc_ld<PS>(&tp.h[(rowb + b) * R + unit]) : 0.f;
         const float gir = S(0) + bih[unit], giu = S(1) + bih[R + unit], gin = S(2) + bih[2 * R + unit];
         const float ghr = S(3) + bhh[unit], ghu = S(4) + bhh[R + unit], ghn = S(5) + bhh[2 * R + unit];
         const float rr = fsigmoid(gir + ghr), uu = fsigmoid(giu + ghu);
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(256) void k_rc_gru(Dims dm, Params P, Tape tp, Conv
         if (s_live[m] != 0.f) {
             float* gr = tp.gru + (rowb + b) * 4 * R;
             gr[unit] = rr; gr[R + unit] = uu; gr[2 * R + unit] = nn; gr[3 * R + unit] = ghn;
-            tp.h[((size_t)(t + 1) * B + b) * R + unit] = hv;
+            rc_st<PS>(&tp.h[((size_t)(t + 1) * B + b) * R + unit], hv);
         }
     }
     if (j == 0) {
@@ -134,34 +149,41 @@ __global__ __launch_bounds__(256) void k_rc_gru(Dims dm, Params P, Tape tp, Conv
             const int m = tid >> 4, l16 = tid & 15, b = min(b0 + m, B - 1);
             float lpv = 0.f, nev = 0.f;
             for (int k = l16; k < W; k += 16) {
-                const float p = tp.pz[(rowb + b) * W + k], zz = tp.z[(rowb + b) * W + k];
+                const float p = rc_ld<PS>(&tp.pz[(rowb + b) * W + k]), zz = rc_ld<PS>(&tp.z[(rowb + b) * W + k]);
                 const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
                 lpv += zz * l1 + (1.f - zz) * l0; nev += p * l1 + (1.f - p) * l0;
             }
             lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
             if (l16 == 0 && s_live[m] != 0.f) { tp.lp_z[rowb + b] = lpv; tp.ne_z[rowb + b] = nev; }
-            if (t > 0) rc_sum_lw(dm, tp, t - 1, b0, nb, may_stop);       // the receiver's message of the step before
+            if (t > 0) rc_sum_lw<PS>(dm, tp, t - 1, b0, nb, may_stop);   // the receiver's message of the step before
         }
     }
+    return true;
+}
+__global__ __launch_bounds__(256) void k_rc_gru(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
+    if (skip && tp.alive[t] == 0) return;
+    const int NJ = dm.R >> 4;
+    rc_gru_body<false>(dm, P, tp, ar, t, blockIdx.x / NJ, blockIdx.x % NJ);
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rc_heads(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
+// returns (role 0 only; true elsewhere): a sample of the tile goes on after this step
+template <bool PS>
+__device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int j) {
     __shared__ float s_acc[2][4][16][17];
     __shared__ __attribute__((aligned(16))) float s_A[16][20];
     __shared__ float s_live[16], s_mn[16];
-    if (skip && tp.alive[t] == 0) return;
-    const int B = dm.B, R = dm.R, V = dm.V, D = dm.D, T = dm.T, NJ = R >> 4;
-    const int tile = blockIdx.x / NJ, j = blockIdx.x - tile * NJ;
+    const int B = dm.B, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train, train = ar.train != 0;
-    if (tid < MMG_TM) s_live[tid] = rc_live(tp, B, t, min(b0 + tid, B - 1), tid < nb, may_stop) ? 1.f : 0.f;
     __syncthreads();
-    if (may_stop) {
+    if (tid < MMG_TM) s_live[tid] = rc_live<PS>(tp, B, t, min(b0 + tid, B - 1), tid < nb, may_stop) ? 1.f : 0.f;
+    __syncthreads();
+    if (!PS && may_stop) {
         bool any = false;
         for (int m = 0; m < MMG_TM; ++m) any = any || (s_live[m] != 0.f);
-        if (!any) return;
+        if (!any) return false;
     }
     const size_t rowb = (size_t)t * B, rowh = (size_t)(t + 1) * B;
     {
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(256) void k_rc_heads(Dims dm, Params P, Tape tp, Co
         int g0, n;
         rc_share(R, wave, g0, n);
         RcFrag ah, wa, wg;
-        rc_load(ah, tp.h + (rowh + bx) * R, R, g0, q);
+        rc_load_act<PS>(ah, tp.h + (rowh + bx) * R, R, g0, q);
         rc_load(wa, P.p[R_Y1_W] + (size_t)unit * (R + V), R, g0, q);
         rc_load(wg, P.p[R_WH_W] + (size_t)unit * R, R, g0, q);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -182,7 +204,7 @@ __global__ __launch_bounds__(256) void k_rc_heads(Dims dm, Params P, Tape tp, Co
         const int m = tid >> 4, c = tid & 15, unit = 16 * j + c;
         auto S = [&](int p) { return (s_acc[p][0][m][c] + s_acc[p][1][m][c]) + (s_acc[p][2][m][c] + s_acc[p][3][m][c]); };
         s_A[m][c] = S(0);                                               // A (App. A.2)
-        if (m < nb) tp.rcgw[(size_t)(b0 + m) * R + unit] = S(1) + P.p[R_WH_B][unit];     // w_h h + b_h
+        if (m < nb) rc_st<PS>(&tp.rcgw[(size_t)(b0 + m) * R + unit], S(1) + P.p[R_WH_B][unit]);     // w_h h + b_h
     }
     __syncthreads();
     {   // this slice's share of y[m][d] = b_y2 + sum_r w_y2[r] relu(A[m][r] + Cd[d][r])     (model.py:432-433)
@@ -203,17 +225,17 @@ __global__ __launch_bounds__(256) void k_rc_heads(Dims dm, Params P, Tape tp, Co
             s0 = fmaf(wq2.z, fmax_nn(aq2.z + cq2.z, 0.f), s0); s1 = fmaf(wq2.w, fmax_nn(aq2.w + cq2.w, 0.f), s1);
             s0 = fmaf(wq3.x, fmax_nn(aq3.x + cq3.x, 0.f), s0); s1 = fmaf(wq3.y, fmax_nn(aq3.y + cq3.y, 0.f), s1);
             s0 = fmaf(wq3.z, fmax_nn(aq3.z + cq3.z, 0.f), s0); s1 = fmaf(wq3.w, fmax_nn(aq3.w + cq3.w, 0.f), s1);
-            if (m < nb) tp.rcyp[((size_t)j * B + b0 + m) * D + d] = s0 + s1;
+            if (m < nb) rc_st<PS>(&tp.rcyp[((size_t)j * B + b0 + m) * D + d], s0 + s1);
         }
     }
-    if (j != 0) return;
+    if (j != 0) return true;
     {   // stop bit (model.py:414-427) and the stop-mask bookkeeping (model.py:852) -- per sample
         const int m = tid >> 4, l16 = tid & 15, b = min(b0 + m, B - 1);
         const float* hr = tp.h + (rowh + b) * R;
         const float* ws = P.p[R_S_W];
         float acc = 0.f;
         for (int r = l16 * 4; r < R; r += 64) {
-            const float4 hq = *reinterpret_cast<const float4*>(hr + r), wq = *reinterpret_cast<const float4*>(ws + r);
+            const float4 hq = rc_ld4<PS>(hr + r), wq = *reinterpret_cast<const float4*>(ws + r);
             acc = fmaf(wq.x, hq.x, acc); acc = fmaf(wq.y, hq.y, acc); acc = fmaf(wq.z, hq.z, acc); acc = fmaf(wq.w, hq.w, acc);
         }
         acc = dpp_group_sum<16>(acc);
@@ -225,21 +247,22 @@ __global__ __launch_bounds__(256) void k_rc_heads(Dims dm, Params P, Tape tp, Co
                 const float u = ar.u_s ? ar.u_s[rowb + b] : philox_uniform(ar.seed, (uint32_t)(t * dm.Bg + dm.boff + b), tp.counter[0], 1u);
                 sv = (u < p) ? 1.f : 0.f;                                                   // model.py:420
             } else {
-                const float before = (t == 0) ? 1.f : tp.sprod[b];
+                const float before = (t == 0) ? 1.f : rc_ld<PS>(&tp.sprod[b]);
                 prod = dm.s_prob_prod ? before * p : p;                                     // model.py:423-426
                 sv = rintf(prod);                                                           // model.py:427
             }
-            const float m_t = (t == 0) ? 1.f : tp.rcst[(size_t)(t & 1) * B + b];
+            const float m_t = (t == 0) ? 1.f : rc_ld<PS>(&tp.rcst[(size_t)(t & 1) * B + b]);
             const float m_next = fminf(m_t, sv);
-            const int ts_before = (t == 0) ? -1 : tp.tstar[b];
+            const int ts_before = (t == 0) ? -1 : (PS ? __hip_atomic_load(&tp.tstar[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tp.tstar[b]);
             const bool take = dm.fixed ? (t == T - 1) : (ts_before < 0 && (m_next == 0.f || t == T - 1));
             s_mn[m] = valid ? m_next : 0.f;
             if (valid) {
-                tp.rcst[(size_t)((t + 1) & 1) * B + b] = m_next;
-                tp.rcst[(size_t)2 * B + b] = take ? 1.f : 0.f;
-                tp.tstar[b] = take ? t : ts_before;
+                rc_st<PS>(&tp.rcst[(size_t)((t + 1) & 1) * B + b], m_next);
+                rc_st<PS>(&tp.rcst[(size_t)2 * B + b], take ? 1.f : 0.f);
+                if (PS) __hip_atomic_store(&tp.tstar[b], take ? t : ts_before, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else tp.tstar[b] = take ? t : ts_before;
                 tp.mstate[b] = m_next;
-                if (!train) tp.sprod[b] = prod;
+                if (!train) rc_st<PS>(&tp.sprod[b], prod);
             }
             if (live) {
                 tp.s[rowb + b] = sv; tp.ps[rowb + b] = p;
@@ -250,37 +273,41 @@ __global__ __launch_bounds__(256) void k_rc_heads(Dims dm, Params P, Tape tp, Co
             }
         }
         __syncthreads();
-        if (tid == 0 && t + 1 < T) {
-            bool alive = false;
-            for (int mm = 0; mm < nb; ++mm) alive = alive || (s_mn[mm] != 0.f);
-            if (alive) atomicAdd(&tp.alive[t + 1], 1);
-        }
+        bool alive = false;
+        for (int mm = 0; mm < nb; ++mm) alive = alive || (s_mn[mm] != 0.f);
+        if (tid == 0 && t + 1 < T && alive) atomicAdd(&tp.alive[t + 1], 1);
+        return alive;
     }
+}
+__global__ __launch_bounds__(256) void k_rc_heads(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
+    if (skip && tp.alive[t] == 0) return;
+    const int NJ = dm.R >> 4;
+    rc_heads_body<false>(dm, P, tp, ar, t, blockIdx.x / NJ, blockIdx.x % NJ);
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
+template <bool PS>
+__device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int jw) {
     __shared__ __attribute__((aligned(16))) float s_y[16][68];
     __shared__ __attribute__((aligned(16))) float s_dbar[16][132];
     __shared__ __attribute__((aligned(16))) float s_g[16][260];
     __shared__ float s_acc[4][16][17];
     __shared__ float s_live[16], s_live2[16], s_take[16];
-    if (skip && tp.alive[t] == 0) return;
-    const int B = dm.B, W = dm.W, R = dm.R, V = dm.V, D = dm.D, NJ = R >> 4, NJW = W >> 4;
-    const int tile = blockIdx.x / NJW, jw = blockIdx.x - tile * NJW;
+    const int B = dm.B, W = dm.W, R = dm.R, V = dm.V, D = dm.D, NJ = R >> 4;
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train, train = ar.train != 0, binary = dm.use_binary != 0;
+    __syncthreads();
     if (tid < MMG_TM) {
         const int b = min(b0 + tid, B - 1);
-        const bool live = rc_live(tp, B, t, b, tid < nb, may_stop);
+        const bool live = rc_live<PS>(tp, B, t, b, tid < nb, may_stop);
         s_live[tid] = live ? 1.f : 0.f;
-        s_live2[tid] = (live && (!may_stop || tp.rcst[(size_t)((t + 1) & 1) * B + b] != 0.f)) ? 1.f : 0.f;
-        s_take[tid] = (tid < nb && tp.rcst[(size_t)2 * B + b] != 0.f) ? 1.f : 0.f;
+        s_live2[tid] = (live && (!may_stop || rc_ld<PS>(&tp.rcst[(size_t)((t + 1) & 1) * B + b]) != 0.f)) ? 1.f : 0.f;
+        s_take[tid] = (tid < nb && rc_ld<PS>(&tp.rcst[(size_t)2 * B + b]) != 0.f) ? 1.f : 0.f;
     }
     for (int idx = tid; idx < 16 * 132; idx += 256) (&s_dbar[0][0])[idx] = 0.f;        // K padding of the w_d product
     __syncthreads();
-    if (may_stop) {
+    if (!PS && may_stop) {
         bool any = false;
         for (int m = 0; m < MMG_TM; ++m) any = any || (s_live[m] != 0.f);
         if (!any) return;
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(256) void k_rc_query(Dims dm, Params P, Tape tp, Co
         for (int jj = 0; jj < NJ; jj += 8) {
             float pv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pv[u] = tp.rcyp[((size_t)min(jj + u, NJ - 1) * B + b) * D + d];
+            for (int u = 0; u < 8; ++u) pv[u] = rc_ld<PS>(&tp.rcyp[((size_t)min(jj + u, NJ - 1) * B + b) * D + d]);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += (jj + u < NJ) ? pv[u] : 0.f;
         }
@@ -302,7 +329,7 @@ __global__ __launch_bounds__(256) void k_rc_query(Dims dm, Params P, Tape tp, Co
         s_y[m][d] = yv;
         if (jw == 0 && m < nb) {
             if ((ar.y_last_only ? s_take[m] : s_live[m]) != 0.f) tp.y[(rowb + b) * D + d] = yv;
-            if (s_take[m] != 0.f) tp.outp[(size_t)b * D + d] = yv;       // the output step, model.py:1261-1264
+            if (s_take[m] != 0.f) rc_st<PS>(&tp.outp[(size_t)b * D + d], yv);       // the output step, model.py:1261-1264
         }
     }
     __syncthreads();
@@ -340,7 +367,7 @@ __global__ __launch_bounds__(256) void k_rc_query(Dims dm, Params P, Tape tp, Co
             for (int u = 0; u < 8; ++u) bq[u] = ldrow4c<true>(wrow, min(u, kg - 1) * 16 + q * 4, V);
             float gwv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gwv[r] = tp.rcgw[(size_t)min(b0 + q * 4 + r, B - 1) * R + tn * 16 + i];
+            for (int r = 0; r < 4; ++r) gwv[r] = rc_ld<PS>(&tp.rcgw[(size_t)min(b0 + q * 4 + r, B - 1) * R + tn * 16 + i]);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -391,30 +418,36 @@ __global__ __launch_bounds__(256) void k_rc_query(Dims dm, Params P, Tape tp, Co
             const float l1 = flog(pp + MMG_EPS), l0 = flog(1.f - pp + MMG_EPS);
             lpv = wv * l1 + (1.f - wv) * l0; nev = pp * l1 + (1.f - pp) * l0;
         }
-        if (st) tp.w[(rowb + b) * W + n] = wv;
+        if (st) rc_st<PS>(&tp.w[(rowb + b) * W + n], wv);
         if (binary) {
             lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
-            if (c == 0 && m < nb) { float* pl = tp.rclw + ((size_t)jw * B + b) * 2; pl[0] = lpv; pl[1] = nev; }
+            if (c == 0 && m < nb) { float* pl = tp.rclw + ((size_t)jw * B + b) * 2; rc_st<PS>(pl, lpv); rc_st<PS>(pl + 1, nev); }
         }
     }
 }
+__global__ __launch_bounds__(256) void k_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
+    if (skip && tp.alive[t] == 0) return;
+    const int NJW = dm.W >> 4;
+    rc_query_body<false>(dm, P, tp, ar, t, blockIdx.x / NJW, blockIdx.x % NJW);
+}
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rc_tail(Dims dm, Params P, Tape tp, ConvArgs ar) {
+template <bool PS>
+__device__ __forceinline__ void rc_tail_body(const Dims& dm, const Tape& tp, const ConvArgs& ar, const int tile, const bool last_lw) {
     const int B = dm.B, D = dm.D, T = dm.T;
-    const int b0 = blockIdx.x * MMG_TM, nb = min(MMG_TM, B - b0);
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
-    if (dm.use_binary) rc_sum_lw(dm, tp, T - 1, b0, nb, may_stop);
+    if (dm.use_binary && last_lw) rc_sum_lw<PS>(dm, tp, T - 1, b0, nb, may_stop);
     // output selection, log-softmax, reward, top-k (model.py:1264-1275, 1333-1339): wave per sample, D <= 64
     for (int m = wave; m < nb; m += 4) {
         const int b = b0 + m;
-        const float v = (lane < D) ? tp.outp[(size_t)b * D + lane] : -3.0e38f;
+        const float v = (lane < D) ? rc_ld<PS>(&tp.outp[(size_t)b * D + lane]) : -3.0e38f;
         const float mx = dpp_wave_max(v);
         const float se = dpp_wave_sum((lane < D) ? __expf(v - mx) : 0.f);
         const float lse = mx + flog(se);
         const int tgt = ar.target ? (int)ar.target[b] : -1;
-        const float dt = (tgt >= 0) ? (tp.outp[(size_t)b * D + max(tgt, 0)] - lse) : 0.f;
+        const float dt = (tgt >= 0) ? (rc_ld<PS>(&tp.outp[(size_t)b * D + max(tgt, 0)]) - lse) : 0.f;
         const float ld = v - lse;
         float above = 0.f;
         if (lane < D) {
@@ -428,6 +461,168 @@ __global__ __launch_bounds__(256) void k_rc_tail(Dims dm, Params P, Tape tp, Con
             tp.hit[b] = (tgt >= 0 && above < (float)dm.top_k) ? 1 : 0;
         }
     }
+}
+__global__ __launch_bounds__(256) void k_rc_tail(Dims dm, Params P, Tape tp, ConvArgs ar) {
+    rc_tail_body<false>(dm, tp, ar, blockIdx.x, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rc_persist: the same conversation as ONE launch of co-resident workgroup roles that hand their results on through memory
+// + counters (kernels_tile.h: pf_signal / pf_wait; write-through payload stores, agent-scope payload loads, bounded spins ->
+// error word) instead of 5 T + 1 launches.  Per tile of 16 samples:
+//   S1 roles (H / 64)              64 units of a_t = tanh(h_x + w_{t-1} W_c^T + b_c)   (model.py:195-216), weight fragments in registers
+//   S2 roles (W / 16)              16 bits of z_t ~ Bernoulli(sigmoid(a_t W_b^T + b_b)) (model.py:218-236), weight fragments in registers
+//   RC roles (max(R, W) / 16)      GRU slice -> heads slice -> message slice (the three bodies above), two in-cluster hand-offs
+// Counters (tape.pflags, zeroed by k_prep; (kind * 40 + tile) x 256 bytes): 0 w_t out (RC -> S1), 1 a_t out (S1 -> S2), 2 z_t out
+// (S2 -> RC), 3 h_{t+1} out, 4 partial logits / w_h h / stop masks out, 5 the tile's conversations are over.
+// ---------------------------------------------------------------------------------------------
+#define RC_MAXTILES 40
+__device__ __forceinline__ uint32_t* rc_ctr(const Tape& tp, int kind, int tile) { return tp.pflags + ((size_t)kind * RC_MAXTILES + tile) * 64; }
+
+__device__ __forceinline__ void rc_s1_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int sidx, const int nrc) {
+    __shared__ float s_acc[4][4][16][17];
+    const int B = dm.B, H = dm.H, W = dm.W, T = dm.T;
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0), n0 = sidx * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    uint32_t* cW = rc_ctr(tp, 0, tile); uint32_t* cA = rc_ctr(tp, 1, tile); uint32_t* done = rc_ctr(tp, 5, tile);
+    int g0, n;
+    rc_share(W, wave, g0, n);
+    RcFrag wc[4];                                                       // this wave's K share of the role's 4 x 16 rows of W_c: loaded once
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rc_load(wc[u], P.p[S_CODE_W] + (size_t)min(n0 + u * 16 + i, H - 1) * W, W, g0, q);
+    const int m = tid >> 4, c = tid & 15, b = min(b0 + m, B - 1);
+    float hxv[4], bcv[4], hw0v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int hn = min(n0 + u * 16 + c, H - 1);
+        hxv[u] = tp.hx[(size_t)b * H + hn]; bcv[u] = P.p[S_CODE_B][hn]; hw0v[u] = tp.hw0[hn];
+    }
+    for (int t = 0; t < T; ++t) {
+        const size_t rowb = (size_t)t * B;
+        if (t > 0) {
+            if (!pf_wait<false>(cW, (uint32_t)(nrc * t), done, tp.sync)) return;
+            RcFrag aw;
+            rc_load_act<true>(aw, tp.w + ((size_t)(t - 1) * B + min(b0 + i, B - 1)) * W, W, g0, q);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 a = rc_mma(aw, wc[u], n, z4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_acc[u][wave][q * 4 + r][i] = a[r];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int hn = n0 + u * 16 + c;
+            const float hw = (t == 0) ? hw0v[u] : (s_acc[u][0][m][c] + s_acc[u][1][m][c]) + (s_acc[u][2][m][c] + s_acc[u][3][m][c]) + bcv[u];
+            if (m < nb && hn < H) st_wt(&tp.a[(rowb + b) * H + hn], ftanh(hxv[u] + hw));      // model.py:216
+        }
+        if (sidx == 0) {                                                // code input rows of the tile (tapes c, zr)
+            for (int idx = tid; idx < nb * W; idx += 256) {
+                const int mm = idx / W, jj = idx - mm * W;
+                const float cv = (t == 0) ? dm.first_rec : ld_cc(&tp.w[((size_t)(t - 1) * B + b0 + mm) * W + jj]);
+                tp.zr[(rowb + b0 + mm) * W + jj] = cv;                  // z_r of baseline_sen, model.py:836
+                tp.c[(rowb + b0 + mm) * W + jj] = (t == 0) ? fsigmoid(P.p[S_CODE_BIAS][jj]) : cv;
+            }
+        }
+        pf_signal(cA);
+    }
+}
+
+__device__ __forceinline__ void rc_s2_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int k, const int ns1) {
+    __shared__ float s_acc[4][16][17];
+    const int B = dm.B, H = dm.H, W = dm.W, T = dm.T;
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0), n0 = k * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    uint32_t* cA = rc_ctr(tp, 1, tile); uint32_t* cZ = rc_ctr(tp, 2, tile); uint32_t* done = rc_ctr(tp, 5, tile);
+    // K = H over the four waves: up to 16 k-groups each (H <= 1024), the role's W_b rows as register fragments
+    const int kg = H >> 4, per = (kg + 3) >> 2, g0 = wave * per, n = max(0, min(kg, g0 + per) - g0);
+    float4 wb[16];
+    const float* wrow = P.p[S_BIN_W] + (size_t)(n0 + i) * H;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wb[u] = *reinterpret_cast<const float4*>(wrow + min(g0 + u, kg - 1) * 16 + q * 4);
+    const int m = tid >> 4, c = tid & 15, b = min(b0 + m, B - 1), col = n0 + c;
+    const float bb = P.p[S_BIN_B][col];
+    const uint32_t mb_counter = tp.counter[0];
+    for (int t = 0; t < T; ++t) {
+        const size_t rowb = (size_t)t * B;
+        float uz = 0.f;                                                 // the uniform of this thread's bit does not depend on the step's data: drawn before the wait
+        if (dm.use_binary && ar.train)
+            uz = ar.u_z ? ar.u_z[(rowb + b) * W + col] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + dm.boff + b) * W + col), mb_counter, 0u);
+        if (!pf_wait<false>(cA, (uint32_t)(ns1 * (t + 1)), done, tp.sync)) return;
+        const float* arow = tp.a + (rowb + min(b0 + i, B - 1)) * H;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h8 = 0; h8 < 16; h8 += 8) {
+            float4 av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = ld_cc4(arow + min(g0 + h8 + u, kg - 1) * 16 + q * 4);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                if (h8 + u < n) {
+                    acc0 = mfma16(av[u].x, wb[h8 + u].x, acc0); acc0 = mfma16(av[u].y, wb[h8 + u].y, acc0);
+                    acc0 = mfma16(av[u].z, wb[h8 + u].z, acc0); acc0 = mfma16(av[u].w, wb[h8 + u].w, acc0);
+                }
+                if (h8 + u + 1 < n) {
+                    acc1 = mfma16(av[u + 1].x, wb[h8 + u + 1].x, acc1); acc1 = mfma16(av[u + 1].y, wb[h8 + u + 1].y, acc1);
+                    acc1 = mfma16(av[u + 1].z, wb[h8 + u + 1].z, acc1); acc1 = mfma16(av[u + 1].w, wb[h8 + u + 1].w, acc1);
+                }
+            }
+        }
+        const f32x4 acc = acc0 + acc1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = acc[r];
+        __syncthreads();
+        {
+            const float lz = (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]) + bb;
+            float zz = lz;
+            if (dm.use_binary) {
+                const float pp = fsigmoid(lz);
+                zz = ar.train ? ((uz < pp) ? 1.f : 0.f) : rintf(pp);    // model.py:227 / 229
+                if (m < nb) st_wt(&tp.pz[(rowb + b) * W + col], pp);
+            }
+            if (m < nb) st_wt(&tp.z[(rowb + b) * W + col], zz);
+        }
+        pf_signal(cZ);                                                  // (its barrier also frees s_acc for the next step)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles) {
+    const int T = dm.T, NJ = dm.R >> 4, NJW = dm.W >> 4, nrc = NJ > NJW ? NJ : NJW, ns1 = (dm.H + 63) >> 6, ns2 = NJW;
+    const int per_tile = nrc + ns1 + ns2;
+    // roles of a tile sit side by side in the grid (consecutive workgroups go round the XCDs)
+    const int tile = blockIdx.x / per_tile, slot = blockIdx.x - tile * per_tile;
+    if (tile >= tiles) return;
+    if (slot >= nrc + ns2) { rc_s1_role(dm, P, tp, ar, tile, slot - nrc - ns2, nrc); return; }
+    if (slot >= nrc) { rc_s2_role(dm, P, tp, ar, tile, slot - nrc, ns1); return; }
+    const int k = slot;
+    uint32_t* cW = rc_ctr(tp, 0, tile); uint32_t* cZ = rc_ctr(tp, 2, tile); uint32_t* cH = rc_ctr(tp, 3, tile);
+    uint32_t* cY = rc_ctr(tp, 4, tile); uint32_t* done = rc_ctr(tp, 5, tile);
+    const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
+    bool whole = true;
+    for (int t = 0; t < T; ++t) {
+        if (!pf_wait<false>(cZ, (uint32_t)(ns2 * (t + 1)), done, tp.sync)) return;
+        if (k < NJ) rc_gru_body<true>(dm, P, tp, ar, t, tile, k);
+        pf_signal(cH);
+        if (!pf_wait<false>(cH, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
+        bool alive = true;
+        if (k < NJ) alive = rc_heads_body<true>(dm, P, tp, ar, t, tile, k);
+        pf_signal(cY);
+        if (!pf_wait<false>(cY, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
+        if (k < NJW) rc_query_body<true>(dm, P, tp, ar, t, tile, k);
+        pf_signal(cW);
+        if (k == 0 && may_stop && !alive) {                            // every conversation of the tile has ended: the other roles stop at their next wait
+            if (threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            whole = false;
+            break;
+        }
+    }
+    if (k != 0) return;
+    if (whole && !pf_wait<false>(cW, (uint32_t)(nrc * T), nullptr, tp.sync)) return;       // the last message's partial sums
+    __syncthreads();
+    rc_tail_body<true>(dm, tp, ar, tile, whole);
+    if (threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace mmg

@@ -59,6 +59,8 @@ struct mmg_handle {
     bool merge_roles;          // MMG_NO_MERGE=1 keeps k_stats / k_dC / basehx as separate launches / in-kernel work
     // sample-tile MFMA path (kernels_tile.h): every shape the register-resident kernels do not cover
     bool tile_ok;              // its LDS plan fits (MMG_NO_TILE=1: never use it)
+    bool rc_persist;           // ... as ONE launch of co-resident roles (k_rc_persist) when they all fit on the device; MMG_NO_RC_PERSIST=1: per-step launches
+    int rc_budget;
     bool rc_fwd;               // wide receiver (kernels_rc.h): the tile's receiver step as three chip-wide launches over 16-unit slices -- the
                                // one-workgroup-per-tile forward does not fit its LDS plan (R > 128 with a 256-bit message); MMG_NO_RC=1: off
     bool tile_force;           // MMG_TILE=1: use it even where the register-resident kernels apply (cross-checks)
@@ -473,6 +475,12 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
             if (smem > 48 * 1024 && e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_pre_send<16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         }
         if (!h->tile_ok) h->rc_fwd = false;
+        h->rc_persist = false; h->rc_budget = 0;
+        if (h->rc_fwd && e == hipSuccess) {
+            const int nj = d.R / 16, njw = d.W / 16, per_tile = (nj > njw ? nj : njw) + njw + (d.H + 63) / 64;
+            h->rc_budget = budget_of((const void*)k_rc_persist, 256, 0);
+            h->rc_persist = !(d.H & 15) && d.H <= 1024 && tiles <= RC_MAXTILES && tiles * per_tile <= h->rc_budget && !getenv("MMG_NO_RC_PERSIST");
+        }
         if (h->tile_ok && h->tile_smem > 48 * 1024 && !h->rc_fwd) {
             e = hipFuncSetAttribute((const void*)k_conv_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
@@ -498,9 +506,9 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
     if (getenv("MMG_DEBUG"))
-        fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d rc %d\n",
+        fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d rc %d rc_persist %d rc_budget %d\n",
                 (int)h->tile_ok, h->tile_nt, h->tile_smem, (int)h->tile_ext, (int)h->tile_persist, h->persist_smem, h->resident_budget, h->tile_bwd_smem,
-                bwd_pre_lds_floats(h->dm) * 4, h->send_bwd_smem, (int)h->tile_split, (int)h->mc_ok, (int)h->use_fast, (int)h->rc_fwd);
+                bwd_pre_lds_floats(h->dm) * 4, h->send_bwd_smem, (int)h->tile_split, (int)h->mc_ok, (int)h->use_fast, (int)h->rc_fwd, (int)h->rc_persist, h->rc_budget);
     if (h->conv_smem > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
@@ -699,6 +707,14 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
     // per-step launches: no co-residency needed (any device, any batch)
     ar.persist = 0; ar.rsample = 0;
     const int skip = (!ar.run_all && !d.fixed && ar.train) ? 1 : 0;
+    if (h->rc_fwd && h->rc_persist) {
+        // wide receiver, all roles co-resident: one launch for the whole conversation (kernels_rc.h: k_rc_persist)
+        Scope sc(h, st, "k_conv_rc");
+        const int nj = d.R / 16, njw = d.W / 16, per_tile = (nj > njw ? nj : njw) + njw + (d.H + 63) / 64;
+        ar.phases = 2;
+        hipLaunchKernelGGL(k_rc_persist, dim3(tiles * per_tile), dim3(256), 0, st, h->dm, h->P, h->tp, ar, tiles);
+        return launch_check("k_rc_persist");
+    }
     if (h->rc_fwd) {
         // wide receiver: the receiver step of a tile as three launches over 16-unit / 16-bit slices (kernels_rc.h)
         Scope sc(h, st, "k_conv_rc");
