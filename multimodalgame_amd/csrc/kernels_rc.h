@@ -625,4 +625,92 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
     if (threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_rc_bwd: the reverse-time loop of k_bwd_tile (same math and tape contract) with a tile's hidden units split over R/16
+// co-resident roles.  A role keeps ITS 16 columns of W_hh (3R x 16 = 48 KB) as MFMA B fragments in registers and the carried
+// dh of its units in a register per thread; per reverse step it gathers the tile's gate gradients dgh_{t+1} (16 x 3R, published
+// by all roles: ONE counter hand-off per step), forms dgh_{t+1} W_hh for its columns, runs the GRU cell backward of its units
+// (model.py:340) and publishes its slice of dgh_t.  The output-step prelude (dy, h*, A*, dA, dA W_y1h) stays k_bwd_tile's
+// (make_map & 2), which also zeroes the tile's counter.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, int zero_dead) {
+    __shared__ float s_acc[4][16][17];
+    const int B = dm.B, R = dm.R, T = dm.T, NJ = R >> 4, R3 = 3 * R;
+    const int tile = blockIdx.x / NJ, j = blockIdx.x - tile * NJ;
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0), u0 = 16 * j;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    const int m = tid >> 4, c = tid & 15, b = min(b0 + m, B - 1), unit = u0 + c;
+    const bool binary = dm.use_binary != 0;
+    uint32_t* ctr = tp.rcflags + (size_t)tile * 64;
+    int tmax = 0;
+    for (int mm = 0; mm < nb; ++mm) tmax = max(tmax, tp.tstar[b0 + mm]);
+    const int ts = (m < nb) ? tp.tstar[b] : -1;                         // padded rows: never live
+    const float dam = tp.rcdam[(size_t)b * R + unit];
+    // this wave's K share of the role's 16 columns of W_hh ("NN" form: the PyTorch [out, in] matrix IS [K, N])
+    const int kg = R3 >> 4, per = (kg + 3) >> 2, g0 = wave * per, n = max(0, min(kg, g0 + per) - g0);
+    float4 wf[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+        const float* w = P.p[R_WHH] + (size_t)(min(g0 + u, kg - 1) * 16 + q * 4) * R + u0 + i;
+        wf[u] = make_float4(w[0], w[R], w[2 * R], w[3 * R]);
+    }
+    float carry = 0.f;
+    bool have = false;
+    int step = 0;
+    for (int t = zero_dead ? T - 1 : tmax; t >= 0; --t) {
+        const size_t rowb = (size_t)t * B;
+        // this step's forward tape (GRU gates, h_{t-1}) and dhin: in flight while the hand-off is awaited
+        const float* gr = tp.gru + (rowb + b) * 4 * R;
+        const float rr = gr[unit], uu = gr[R + unit], nn = gr[2 * R + unit], ghn = gr[3 * R + unit];
+        const float fh = tp.h[(rowb + b) * R + unit];
+        const float fin = binary ? tp.dhin[(rowb + b) * R + unit] : 0.f;
+        float prod = 0.f;
+        if (have) {
+            if (!pf_wait<false>(ctr, (uint32_t)(NJ * step), nullptr, tp.sync)) return;
+            const float* xrow = tp.rcx + ((size_t)(tile * 2 + ((t + 1) & 1)) * 16 + i) * R3;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            float4 av[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) av[u] = ld_cc4(xrow + min(g0 + u, kg - 1) * 16 + q * 4);
+#pragma unroll
+            for (int u = 0; u < 12; u += 2) {
+                if (u < n) {
+                    acc0 = mfma16(av[u].x, wf[u].x, acc0); acc0 = mfma16(av[u].y, wf[u].y, acc0);
+                    acc0 = mfma16(av[u].z, wf[u].z, acc0); acc0 = mfma16(av[u].w, wf[u].w, acc0);
+                }
+                if (u + 1 < n) {
+                    acc1 = mfma16(av[u + 1].x, wf[u + 1].x, acc1); acc1 = mfma16(av[u + 1].y, wf[u + 1].y, acc1);
+                    acc1 = mfma16(av[u + 1].z, wf[u + 1].z, acc1); acc1 = mfma16(av[u + 1].w, wf[u + 1].w, acc1);
+                }
+            }
+            const f32x4 acc = acc0 + acc1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = acc[r];
+            __syncthreads();
+            prod = (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]);
+        }
+        // dh_t = dh_{t+1} u_{t+1} + dgh_{t+1} W_hh + dhin_t (+ dA W_y1h at the output step); GRU cell backward (model.py:340)
+        const bool live = t <= ts;
+        float dh = carry + prod;
+        dh += (t == ts) ? dam : 0.f;
+        dh += (binary && live) ? fin : 0.f;                             // (rows of steps a sample never took hold no dhin)
+        if (!live) dh = 0.f;
+        const float dn = dh * (1.f - uu), du = dh * (fh - nn);
+        const float dnp = dn * (1.f - nn * nn), dup = du * uu * (1.f - uu);
+        const float drp = dnp * ghn * rr * (1.f - rr);
+        const float g0v = live ? drp : 0.f, g1v = live ? dup : 0.f, g2v = live ? dnp * rr : 0.f;
+        carry = live ? dh * uu : 0.f;
+        if (t > 0) {                                                    // dh_{t-1} receives dgh_t W_hh: the slice goes out to the tile's roles
+            float* xw = tp.rcx + ((size_t)(tile * 2 + (t & 1)) * 16 + m) * R3;
+            st_wt(xw + unit, g0v); st_wt(xw + R + unit, g1v); st_wt(xw + 2 * R + unit, g2v);
+        }
+        if (m < nb && (live || zero_dead)) {
+            float* gi = tp.dgi + (rowb + b) * R3; float* gh = tp.dgh + (rowb + b) * R3;
+            gi[unit] = g0v; gi[R + unit] = g1v; gi[2 * R + unit] = live ? dnp : 0.f;
+            gh[unit] = g0v; gh[R + unit] = g1v; gh[2 * R + unit] = g2v;
+        }
+        if (t > 0) { pf_signal(ctr); ++step; have = true; }             // (its barrier also frees s_acc)
+    }
+}
+
 }  // namespace mmg

@@ -2143,7 +2143,7 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
         const int tid = threadIdx.x;
         for (int i = tid; i < L.total; i += NT) smem[i] = 0.f;
         __syncthreads();
-        if (make_map && blockIdx.x == 0 && tid < 64) build_row_map(dm, tp);       // live (step, sample) rows for k_wgrad / k_send_bwd
+        if ((make_map & 1) && blockIdx.x == 0 && tid < 64) build_row_map(dm, tp);       // live (step, sample) rows for k_wgrad / k_send_bwd
         if (tid < MMG_TM) {
             const int b = min(b0 + tid, B - 1);
             misc[BL_TSTAR + tid] = (tid < nb) ? (float)tp.tstar[b] : -1.f;          // padded rows: never live
@@ -2289,9 +2289,13 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
         for (int idx = tid; idx < MMG_TM * R; idx += NT) {
             const int m = idx / R, i = idx - m * R;
             s_dAm[m * L.ldR + i] = raw_sum(raw0, L.ldR, kp, m, i);
+            // (make_map & 2: the reverse-time loop runs as k_rc_bwd's roles, kernels_rc.h -- dAy and a zeroed hand-off counter go out)
+            if ((make_map & 2) && m < nb) tp.rcdam[(size_t)(b0 + m) * R + i] = s_dAm[m * L.ldR + i];
         }
+        if ((make_map & 2) && tid == 0) tp.rcflags[(size_t)blockIdx.x * 64] = 0u;
         __syncthreads();
     }
+    if (make_map & 2) return;
     // ---------------- W_hh in [K][N + 4] layout in LDS (the dy tile is dead now): the loop's only product reads no weight from L2
     if (L.whh >= 0) {
         const int stride = R + 4, n4 = R >> 2;

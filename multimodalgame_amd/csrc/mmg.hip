@@ -59,6 +59,7 @@ struct mmg_handle {
     bool merge_roles;          // MMG_NO_MERGE=1 keeps k_stats / k_dC / basehx as separate launches / in-kernel work
     // sample-tile MFMA path (kernels_tile.h): every shape the register-resident kernels do not cover
     bool tile_ok;              // its LDS plan fits (MMG_NO_TILE=1: never use it)
+    bool rc_bwd;               // ... and the reverse-time loop of its backward as co-resident roles over 16-unit slices (k_rc_bwd); MMG_NO_RC_BWD=1: k_bwd_tile's loop
     bool rc_persist;           // ... as ONE launch of co-resident roles (k_rc_persist) when they all fit on the device; MMG_NO_RC_PERSIST=1: per-step launches
     int rc_budget;
     bool rc_fwd;               // wide receiver (kernels_rc.h): the tile's receiver step as three chip-wide launches over 16-unit slices -- the
@@ -475,7 +476,9 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
             if (smem > 48 * 1024 && e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_pre_send<16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         }
         if (!h->tile_ok) h->rc_fwd = false;
-        h->rc_persist = false; h->rc_budget = 0;
+        h->rc_persist = false; h->rc_budget = 0; h->rc_bwd = false;
+        if (h->rc_fwd && e == hipSuccess)
+            h->rc_bwd = tiles <= 64 && tiles * (d.R / 16) <= budget_of((const void*)k_rc_bwd, 256, 0) && !getenv("MMG_NO_RC_BWD");
         if (h->rc_fwd && e == hipSuccess) {
             const int nj = d.R / 16, njw = d.W / 16, per_tile = (nj > njw ? nj : njw) + njw + (d.H + 63) / 64;
             h->rc_budget = budget_of((const void*)k_rc_persist, 256, 0);
@@ -506,9 +509,9 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
     if (getenv("MMG_DEBUG"))
-        fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d rc %d rc_persist %d rc_budget %d\n",
+        fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d rc %d rc_persist %d rc_budget %d rc_bwd %d\n",
                 (int)h->tile_ok, h->tile_nt, h->tile_smem, (int)h->tile_ext, (int)h->tile_persist, h->persist_smem, h->resident_budget, h->tile_bwd_smem,
-                bwd_pre_lds_floats(h->dm) * 4, h->send_bwd_smem, (int)h->tile_split, (int)h->mc_ok, (int)h->use_fast, (int)h->rc_fwd, (int)h->rc_persist, h->rc_budget);
+                bwd_pre_lds_floats(h->dm) * 4, h->send_bwd_smem, (int)h->tile_split, (int)h->mc_ok, (int)h->use_fast, (int)h->rc_fwd, (int)h->rc_persist, h->rc_budget, (int)h->rc_bwd);
     if (h->conv_smem > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
@@ -912,7 +915,11 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
                 hipLaunchKernelGGL((k_bwd_tile<512, 2>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             else if (d.R <= 128)
                 hipLaunchKernelGGL((k_bwd_tile<512, 4>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
-            else
+            else if (h->rc_fwd && h->rc_bwd) {
+                // wide receiver: k_bwd_tile's output-step prelude, then the reverse-time loop as roles over 16-unit slices (kernels_rc.h)
+                hipLaunchKernelGGL((k_bwd_tile<512, 8>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, (row_map ? 1 : 0) | 2);
+                hipLaunchKernelGGL(k_rc_bwd, dim3(tiles * (d.R / 16)), dim3(256), 0, st, h->dm, h->P, h->tp, zero_dead);
+            } else
                 hipLaunchKernelGGL((k_bwd_tile<512, 8>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             if (launch_check("k_bwd_tile")) return -1;
         }

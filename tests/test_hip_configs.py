@@ -59,12 +59,13 @@ def test_config4_shape_vs_oracle(switch, monkeypatch):
     _compare_cached(_meta(C4, 30, 64, 2), skip=("y2.bias",), label="config4" + ("-" + switch if switch else ""), key="c4")
 
 
-@pytest.mark.parametrize("switch", [None, "MMG_NO_RC_PERSIST"])
+@pytest.mark.parametrize("switch", [None, "MMG_NO_RC_PERSIST", "MMG_NO_RC_BWD"])
 def test_config4_with_rec_hidden_256_vs_oracle(switch, monkeypatch):
     """'rec_w_dim 256 / img_h_dim 1024 ... use R = 64 and additionally report R = 256'.  At R = 256 the
     one-workgroup-per-tile forward does not fit its LDS plan: the receiver of a tile is split over workgroups by 16-unit slices on
     the matrix cores (kernels_rc.h) -- one launch of co-resident roles (k_rc_persist), or with the switch k_rc_gru / k_rc_heads /
-    k_rc_query between the per-step sender launches; the backward on the tile kernels; B = 64 as the bench times it."""
+    k_rc_query between the per-step sender launches; the backward on the tile kernels, its reverse-time loop as roles over
+    16-unit slices (k_rc_bwd; MMG_NO_RC_BWD: inside k_bwd_tile); B = 64 as the bench times it."""
     if switch:
         monkeypatch.setenv(switch, "1")
     meta = _meta(dict(C4, rec_hidden=256, batch_size=64), 30, 64, 2)
