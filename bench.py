@@ -101,7 +101,7 @@ def algorithmic_work(kernel, d, B, t_steps, lean=False, prep_inside=False):
     if kernel == "k_conv_tile":               # sample-tile recurrence on the matrix cores (kernels_tile.h)
         sender = 2 * H * W if H * W < 65536 else 0                      # large sender MLPs run in k_send_s1 / k_send_s2
         return "mfma", 2 * rows * (mac_recv + sender)
-    if kernel in ("k_conv_persist", "k_conv_split"):   # all roles of the conversation in one launch: receiver + whole sender
+    if kernel in ("k_conv_persist", "k_conv_split", "k_conv_rc"):   # all roles of the conversation in one launch: receiver + whole sender
         return "mfma", 2 * rows * (mac_recv + 2 * H * W)
     if kernel == "k_send_s1":
         return "mfma", 2 * rows * H * W

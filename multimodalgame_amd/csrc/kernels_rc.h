@@ -73,12 +73,13 @@ __device__ __forceinline__ void rc_sum_lw(const Dims& dm, const Tape& tp, int tp
     const int B = dm.B, NJW = dm.W >> 4, tid = threadIdx.x, m = tid >> 4, l16 = tid & 15, b = min(b0 + m, B - 1);
     float lpv = 0.f, nev = 0.f;
     for (int jw = l16; jw < NJW; jw += 16) {
-        const float* p = tp.rclw + ((size_t)jw * B + b) * 2;
+        const float* p = tp.rclw + (((size_t)(tp_ & 1) * NJW + jw) * B + b) * 2;
         lpv += rc_ld<PS>(p); nev += rc_ld<PS>(p + 1);
     }
     lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
-    const bool live = rc_live<PS>(tp, B, tp_, b, m < nb, may_stop);
-    const bool live2 = live && (!may_stop || rc_ld<PS>(&tp.rcst[(size_t)((tp_ + 1) & 1) * B + b]) != 0.f);
+    // stored rows of the message of step tp_: the conversation goes on after it (m_{tp_+1} != 0 implies m_{tp_} != 0; only
+    // the slot of m_{tp_+1} is read -- the other one may already hold m_{tp_+2})
+    const bool live2 = (m < nb) && (!may_stop || rc_ld<PS>(&tp.rcst[(size_t)((tp_ + 1) & 1) * B + b]) != 0.f);
     if (l16 == 0 && live2) { tp.lp_w[(size_t)tp_ * B + b] = lpv; tp.ne_w[(size_t)tp_ * B + b] = nev; }
 }
 
@@ -92,15 +93,14 @@ __device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, con
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
-    __syncthreads();                                                    // (PS: the LDS of the phase before is free)
-    if (tid < MMG_TM) s_live[tid] = rc_live<PS>(tp, B, t, min(b0 + tid, B - 1), tid < nb, may_stop) ? 1.f : 0.f;
-    __syncthreads();
-    if (!PS && may_stop) {
-        bool any = false;
-        for (int m = 0; m < MMG_TM; ++m) any = any || (s_live[m] != 0.f);
-        if (!any) return false;                                         // the tile's conversations are over
-    }
+    const float live_in = rc_live<PS>(tp, B, t, min(b0 + (tid & 15), B - 1), (tid & 15) < nb, may_stop) ? 1.f : 0.f;
     const size_t rowb = (size_t)t * B;
+    // operands of the epilogue (biases, h_{t-1} of this thread's unit): in flight with the product's operands
+    const int m = tid >> 4, c = tid & 15, unit_e = 16 * j + c, b = min(b0 + m, B - 1);
+    const float* bih = P.p[R_BIH]; const float* bhh = P.p[R_BHH];
+    const float bir = bih[unit_e], biu = bih[R + unit_e], bin_ = bih[2 * R + unit_e];
+    const float bhr = bhh[unit_e], bhu = bhh[R + unit_e], bhn = bhh[2 * R + unit_e];
+    const float hprev = (t > 0) ? rc_ld<PS>(&tp.h[(rowb + b) * R + unit_e]) : 0.f;
     {
         const int bx = min(b0 + i, B - 1), unit = 16 * j + i;
         int gw0, nw_, gr0, nr_;
@@ -119,6 +119,9 @@ __device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, con
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         const f32x4 a0 = rc_mma(az, wi0, nw_, z4), a1 = rc_mma(az, wi1, nw_, z4), a2 = rc_mma(az, wi2, nw_, z4);
         const f32x4 a3 = rc_mma(ah, wh0, nh, z4), a4 = rc_mma(ah, wh1, nh, z4), a5 = rc_mma(ah, wh2, nh, z4);
+        MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 160);
+        __syncthreads();                                                // (PS: the LDS of the phase before is free)
+        if (tid < MMG_TM) s_live[tid] = live_in;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             s_acc[0][wave][q * 4 + r][i] = a0[r]; s_acc[1][wave][q * 4 + r][i] = a1[r]; s_acc[2][wave][q * 4 + r][i] = a2[r];
@@ -126,44 +129,60 @@ __device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, con
         }
     }
     __syncthreads();
+    if (!PS && may_stop) {
+        bool any = false;
+        for (int mm = 0; mm < MMG_TM; ++mm) any = any || (s_live[mm] != 0.f);
+        if (!any) return false;                                         // the tile's conversations are over
+    }
     {   // GRUCell (model.py:340); gate order r, u, n
-        const int m = tid >> 4, c = tid & 15, unit = 16 * j + c, b = min(b0 + m, B - 1);
+        MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 161);
         auto S = [&](int p) { return (s_acc[p][0][m][c] + s_acc[p][1][m][c]) + (s_acc[p][2][m][c] + s_acc[p][3][m][c]); };
-        const float* bih = P.p[R_BIH]; const float* bhh = P.p[R_BHH];
-        const float hprev = (t > 0) ? rc_ld<PS>(&tp.h[(rowb + b) * R + unit]) : 0.f;
-        const float gir = S(0) + bih[unit], giu = S(1) + bih[R + unit], gin = S(2) + bih[2 * R + unit];
-        const float ghr = S(3) + bhh[unit], ghu = S(4) + bhh[R + unit], ghn = S(5) + bhh[2 * R + unit];
+        const float gir = S(0) + bir, giu = S(1) + biu, gin = S(2) + bin_;
+        const float ghr = S(3) + bhr, ghu = S(4) + bhu, ghn = S(5) + bhn;
         const float rr = fsigmoid(gir + ghr), uu = fsigmoid(giu + ghu);
         const float nn = ftanh(gin + rr * ghn);
         const float hv = nn + uu * (hprev - nn);
-        if (t == 0 && m < nb) tp.h[(size_t)b * R + unit] = 0.f;         // h_{-1} = 0
+        if (t == 0 && m < nb) tp.h[(size_t)b * R + unit_e] = 0.f;       // h_{-1} = 0
         if (s_live[m] != 0.f) {
             float* gr = tp.gru + (rowb + b) * 4 * R;
-            gr[unit] = rr; gr[R + unit] = uu; gr[2 * R + unit] = nn; gr[3 * R + unit] = ghn;
-            rc_st<PS>(&tp.h[((size_t)(t + 1) * B + b) * R + unit], hv);
-        }
-    }
-    if (j == 0) {
-        if (t == 0 && tid < nb) tp.mask[b0 + tid] = 1;                  // stop_mask[0] = ones   model.py:775
-        if (dm.use_binary) {                                            // log-likelihood / neg-entropy of the sender's bits, model.py:908-922
-            const int m = tid >> 4, l16 = tid & 15, b = min(b0 + m, B - 1);
-            float lpv = 0.f, nev = 0.f;
-            for (int k = l16; k < W; k += 16) {
-                const float p = rc_ld<PS>(&tp.pz[(rowb + b) * W + k]), zz = rc_ld<PS>(&tp.z[(rowb + b) * W + k]);
-                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                lpv += zz * l1 + (1.f - zz) * l0; nev += p * l1 + (1.f - p) * l0;
-            }
-            lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
-            if (l16 == 0 && s_live[m] != 0.f) { tp.lp_z[rowb + b] = lpv; tp.ne_z[rowb + b] = nev; }
-            if (t > 0) rc_sum_lw<PS>(dm, tp, t - 1, b0, nb, may_stop);   // the receiver's message of the step before
+            gr[unit_e] = rr; gr[R + unit_e] = uu; gr[2 * R + unit_e] = nn; gr[3 * R + unit_e] = ghn;
+            rc_st<PS>(&tp.h[((size_t)(t + 1) * B + b) * R + unit_e], hv);
         }
     }
     return true;
 }
+// role 0 of a tile, off the hand-off's critical path (PS: after h_{t+1} has been signalled): stop_mask[0], the log-likelihood /
+// neg-entropy of the sender's bits (model.py:908-922) and the sums of the receiver's message of the step before
+template <bool PS>
+__device__ __forceinline__ void rc_gru_extras(const Dims& dm, const Tape& tp, const ConvArgs& ar, const int t, const int tile) {
+    const int B = dm.B, W = dm.W;
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0), tid = threadIdx.x;
+    const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
+    const size_t rowb = (size_t)t * B;
+    if (t == 0 && tid < nb) tp.mask[b0 + tid] = 1;                      // stop_mask[0] = ones   model.py:775
+    if (dm.use_binary) {
+        const int m = tid >> 4, l16 = tid & 15, b = min(b0 + m, B - 1);
+        const bool live = rc_live<PS>(tp, B, t, b, m < nb, may_stop);
+        float lpv = 0.f, nev = 0.f;
+        for (int k0 = l16 * 4; k0 < W; k0 += 64) {
+            const float4 pq = rc_ld4<PS>(&tp.pz[(rowb + b) * W + k0]), zq = rc_ld4<PS>(&tp.z[(rowb + b) * W + k0]);
+            const float pv[4] = {pq.x, pq.y, pq.z, pq.w}, zv[4] = {zq.x, zq.y, zq.z, zq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float l1 = flog(pv[e] + MMG_EPS), l0 = flog(1.f - pv[e] + MMG_EPS);
+                lpv += zv[e] * l1 + (1.f - zv[e]) * l0; nev += pv[e] * l1 + (1.f - pv[e]) * l0;
+            }
+        }
+        lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
+        if (l16 == 0 && live) { tp.lp_z[rowb + b] = lpv; tp.ne_z[rowb + b] = nev; }
+        if (t > 0) rc_sum_lw<PS>(dm, tp, t - 1, b0, nb, may_stop);       // the receiver's message of the step before
+    }
+}
 __global__ __launch_bounds__(256) void k_rc_gru(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
     if (skip && tp.alive[t] == 0) return;
     const int NJ = dm.R >> 4;
-    rc_gru_body<false>(dm, P, tp, ar, t, blockIdx.x / NJ, blockIdx.x % NJ);
+    if (rc_gru_body<false>(dm, P, tp, ar, t, blockIdx.x / NJ, blockIdx.x % NJ) && blockIdx.x % NJ == 0)
+        rc_gru_extras<false>(dm, tp, ar, t, blockIdx.x / NJ);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -176,84 +195,115 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
     const int B = dm.B, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    const int m = tid >> 4, c = tid & 15, b = min(b0 + m, B - 1);
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train, train = ar.train != 0;
-    __syncthreads();
-    if (tid < MMG_TM) s_live[tid] = rc_live<PS>(tp, B, t, min(b0 + tid, B - 1), tid < nb, may_stop) ? 1.f : 0.f;
+    const size_t rowb = (size_t)t * B, rowh = (size_t)(t + 1) * B;
+    // ---- every operand of the phase goes out in ONE round trip: the products' fragments, the class rows / w_y2 slice of the
+    //      partial logits, and (role 0) the stop head's h rows and the bookkeeping state
+    const float live_in = rc_live<PS>(tp, B, t, min(b0 + (tid & 15), B - 1), (tid & 15) < nb, may_stop) ? 1.f : 0.f;
+    const int bx = min(b0 + i, B - 1);
+    int g0, n;
+    rc_share(R, wave, g0, n);
+    RcFrag ah, wa, wg;
+    rc_load_act<PS>(ah, tp.h + (rowh + bx) * R, R, g0, q);
+    rc_load(wa, P.p[R_Y1_W] + (size_t)(16 * j + i) * (R + V), R, g0, q);
+    rc_load(wg, P.p[R_WH_W] + (size_t)(16 * j + i) * R, R, g0, q);
+    const float bh = P.p[R_WH_B][16 * j + c];
+    const float4* w4 = reinterpret_cast<const float4*>(P.p[R_Y2_W] + 16 * j);
+    const float4 wq0 = w4[0], wq1 = w4[1], wq2 = w4[2], wq3 = w4[3];
+    float4 cq[2][4];                                                    // Cd[d][slice] of this thread's first two classes (d = c, c + 16)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float4* c4 = reinterpret_cast<const float4*>(tp.Cd + (size_t)min(c + 16 * e, D - 1) * R + 16 * j);
+        cq[e][0] = c4[0]; cq[e][1] = c4[1]; cq[e][2] = c4[2]; cq[e][3] = c4[3];
+    }
+    float4 hq[4], sq[4];                                                // role 0: s.weight and h_{t+1} of sample m, 16 lanes x 4 floats x 4
+    float m_t = 1.f, sp_before = 1.f, u_s = 0.f;
+    int ts_before = -1;
+    if (j == 0) {
+        const float* hr = tp.h + (rowh + b) * R;
+        const float* ws = P.p[R_S_W];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = min(c * 4 + 64 * e, R - 4);
+            hq[e] = rc_ld4<PS>(hr + r); sq[e] = *reinterpret_cast<const float4*>(ws + r);
+        }
+        if (t > 0) {
+            m_t = rc_ld<PS>(&tp.rcst[(size_t)(t & 1) * B + b]);
+            ts_before = PS ? __hip_atomic_load(&tp.tstar[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tp.tstar[b];
+            if (!train) sp_before = rc_ld<PS>(&tp.sprod[b]);
+        }
+        if (train) u_s = ar.u_s ? ar.u_s[rowb + b] : philox_uniform(ar.seed, (uint32_t)(t * dm.Bg + dm.boff + b), tp.counter[0], 1u);
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 a0 = rc_mma(ah, wa, n, z4), a1 = rc_mma(ah, wg, n, z4);
+    MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 165);
+    __syncthreads();                                                    // (PS: the LDS of the phase before is free)
+    if (tid < MMG_TM) s_live[tid] = live_in;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s_acc[0][wave][q * 4 + r][i] = a0[r]; s_acc[1][wave][q * 4 + r][i] = a1[r]; }
     __syncthreads();
     if (!PS && may_stop) {
         bool any = false;
-        for (int m = 0; m < MMG_TM; ++m) any = any || (s_live[m] != 0.f);
+        for (int mm = 0; mm < MMG_TM; ++mm) any = any || (s_live[mm] != 0.f);
         if (!any) return false;
     }
-    const size_t rowb = (size_t)t * B, rowh = (size_t)(t + 1) * B;
     {
-        const int bx = min(b0 + i, B - 1), unit = 16 * j + i;
-        int g0, n;
-        rc_share(R, wave, g0, n);
-        RcFrag ah, wa, wg;
-        rc_load_act<PS>(ah, tp.h + (rowh + bx) * R, R, g0, q);
-        rc_load(wa, P.p[R_Y1_W] + (size_t)unit * (R + V), R, g0, q);
-        rc_load(wg, P.p[R_WH_W] + (size_t)unit * R, R, g0, q);
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 a0 = rc_mma(ah, wa, n, z4), a1 = rc_mma(ah, wg, n, z4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s_acc[0][wave][q * 4 + r][i] = a0[r]; s_acc[1][wave][q * 4 + r][i] = a1[r]; }
-    }
-    __syncthreads();
-    {
-        const int m = tid >> 4, c = tid & 15, unit = 16 * j + c;
+        const int unit = 16 * j + c;
         auto S = [&](int p) { return (s_acc[p][0][m][c] + s_acc[p][1][m][c]) + (s_acc[p][2][m][c] + s_acc[p][3][m][c]); };
         s_A[m][c] = S(0);                                               // A (App. A.2)
-        if (m < nb) rc_st<PS>(&tp.rcgw[(size_t)(b0 + m) * R + unit], S(1) + P.p[R_WH_B][unit]);     // w_h h + b_h
+        if (m < nb) rc_st<PS>(&tp.rcgw[(size_t)(b0 + m) * R + unit], S(1) + bh);     // w_h h + b_h
     }
     __syncthreads();
     {   // this slice's share of y[m][d] = b_y2 + sum_r w_y2[r] relu(A[m][r] + Cd[d][r])     (model.py:432-433)
-        const int m = tid >> 4, c = tid & 15;
-        const float4* w4 = reinterpret_cast<const float4*>(P.p[R_Y2_W] + 16 * j);
-        const float4 wq0 = w4[0], wq1 = w4[1], wq2 = w4[2], wq3 = w4[3];
+        MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 166);
         const float4* a4 = reinterpret_cast<const float4*>(&s_A[m][0]);
         const float4 aq0 = a4[0], aq1 = a4[1], aq2 = a4[2], aq3 = a4[3];
-        for (int d = c; d < D; d += 16) {
-            const float4* c4 = reinterpret_cast<const float4*>(tp.Cd + (size_t)d * R + 16 * j);
-            const float4 cq0 = c4[0], cq1 = c4[1], cq2 = c4[2], cq3 = c4[3];
+        auto part = [&](const float4& c0, const float4& c1, const float4& c2, const float4& c3) {
             float s0 = 0.f, s1 = 0.f;
-            s0 = fmaf(wq0.x, fmax_nn(aq0.x + cq0.x, 0.f), s0); s1 = fmaf(wq0.y, fmax_nn(aq0.y + cq0.y, 0.f), s1);
-            s0 = fmaf(wq0.z, fmax_nn(aq0.z + cq0.z, 0.f), s0); s1 = fmaf(wq0.w, fmax_nn(aq0.w + cq0.w, 0.f), s1);
-            s0 = fmaf(wq1.x, fmax_nn(aq1.x + cq1.x, 0.f), s0); s1 = fmaf(wq1.y, fmax_nn(aq1.y + cq1.y, 0.f), s1);
-            s0 = fmaf(wq1.z, fmax_nn(aq1.z + cq1.z, 0.f), s0); s1 = fmaf(wq1.w, fmax_nn(aq1.w + cq1.w, 0.f), s1);
-            s0 = fmaf(wq2.x, fmax_nn(aq2.x + cq2.x, 0.f), s0); s1 = fmaf(wq2.y, fmax_nn(aq2.y + cq2.y, 0.f), s1);
-            s0 = fmaf(wq2.z, fmax_nn(aq2.z + cq2.z, 0.f), s0); s1 = fmaf(wq2.w, fmax_nn(aq2.w + cq2.w, 0.f), s1);
-            s0 = fmaf(wq3.x, fmax_nn(aq3.x + cq3.x, 0.f), s0); s1 = fmaf(wq3.y, fmax_nn(aq3.y + cq3.y, 0.f), s1);
-            s0 = fmaf(wq3.z, fmax_nn(aq3.z + cq3.z, 0.f), s0); s1 = fmaf(wq3.w, fmax_nn(aq3.w + cq3.w, 0.f), s1);
-            if (m < nb) rc_st<PS>(&tp.rcyp[((size_t)j * B + b0 + m) * D + d], s0 + s1);
+            s0 = fmaf(wq0.x, fmax_nn(aq0.x + c0.x, 0.f), s0); s1 = fmaf(wq0.y, fmax_nn(aq0.y + c0.y, 0.f), s1);
+            s0 = fmaf(wq0.z, fmax_nn(aq0.z + c0.z, 0.f), s0); s1 = fmaf(wq0.w, fmax_nn(aq0.w + c0.w, 0.f), s1);
+            s0 = fmaf(wq1.x, fmax_nn(aq1.x + c1.x, 0.f), s0); s1 = fmaf(wq1.y, fmax_nn(aq1.y + c1.y, 0.f), s1);
+            s0 = fmaf(wq1.z, fmax_nn(aq1.z + c1.z, 0.f), s0); s1 = fmaf(wq1.w, fmax_nn(aq1.w + c1.w, 0.f), s1);
+            s0 = fmaf(wq2.x, fmax_nn(aq2.x + c2.x, 0.f), s0); s1 = fmaf(wq2.y, fmax_nn(aq2.y + c2.y, 0.f), s1);
+            s0 = fmaf(wq2.z, fmax_nn(aq2.z + c2.z, 0.f), s0); s1 = fmaf(wq2.w, fmax_nn(aq2.w + c2.w, 0.f), s1);
+            s0 = fmaf(wq3.x, fmax_nn(aq3.x + c3.x, 0.f), s0); s1 = fmaf(wq3.y, fmax_nn(aq3.y + c3.y, 0.f), s1);
+            s0 = fmaf(wq3.z, fmax_nn(aq3.z + c3.z, 0.f), s0); s1 = fmaf(wq3.w, fmax_nn(aq3.w + c3.w, 0.f), s1);
+            return s0 + s1;
+        };
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int d = c + 16 * e;
+            if (d < D && m < nb) rc_st<PS>(&tp.rcyp[((size_t)j * B + b0 + m) * D + d], part(cq[e][0], cq[e][1], cq[e][2], cq[e][3]));
+        }
+        for (int d = c + 32; d < D; d += 16) {                          // (more than 32 classes: rows fetched here)
+            const float4* c4 = reinterpret_cast<const float4*>(tp.Cd + (size_t)d * R + 16 * j);
+            const float4 c0 = c4[0], c1 = c4[1], c2 = c4[2], c3 = c4[3];
+            if (m < nb) rc_st<PS>(&tp.rcyp[((size_t)j * B + b0 + m) * D + d], part(c0, c1, c2, c3));
         }
     }
     if (j != 0) return true;
+    MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 167);
     {   // stop bit (model.py:414-427) and the stop-mask bookkeeping (model.py:852) -- per sample
-        const int m = tid >> 4, l16 = tid & 15, b = min(b0 + m, B - 1);
-        const float* hr = tp.h + (rowh + b) * R;
-        const float* ws = P.p[R_S_W];
         float acc = 0.f;
-        for (int r = l16 * 4; r < R; r += 64) {
-            const float4 hq = rc_ld4<PS>(hr + r), wq = *reinterpret_cast<const float4*>(ws + r);
-            acc = fmaf(wq.x, hq.x, acc); acc = fmaf(wq.y, hq.y, acc); acc = fmaf(wq.z, hq.z, acc); acc = fmaf(wq.w, hq.w, acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c * 4 + 64 * e < R) {
+                acc = fmaf(sq[e].x, hq[e].x, acc); acc = fmaf(sq[e].y, hq[e].y, acc);
+                acc = fmaf(sq[e].z, hq[e].z, acc); acc = fmaf(sq[e].w, hq[e].w, acc);
+            }
         }
         acc = dpp_group_sum<16>(acc);
-        if (l16 == 0) {
+        if (c == 0) {
             const bool valid = m < nb, live = s_live[m] != 0.f;
             const float p = fsigmoid(acc + P.p[R_S_B][0]);
             float sv, prod = 1.f;
-            if (train) {
-                const float u = ar.u_s ? ar.u_s[rowb + b] : philox_uniform(ar.seed, (uint32_t)(t * dm.Bg + dm.boff + b), tp.counter[0], 1u);
-                sv = (u < p) ? 1.f : 0.f;                                                   // model.py:420
-            } else {
-                const float before = (t == 0) ? 1.f : rc_ld<PS>(&tp.sprod[b]);
-                prod = dm.s_prob_prod ? before * p : p;                                     // model.py:423-426
+            if (train) sv = (u_s < p) ? 1.f : 0.f;                                          // model.py:420
+            else {
+                prod = dm.s_prob_prod ? sp_before * p : p;                                  // model.py:423-426
                 sv = rintf(prod);                                                           // model.py:427
             }
-            const float m_t = (t == 0) ? 1.f : rc_ld<PS>(&tp.rcst[(size_t)(t & 1) * B + b]);
             const float m_next = fminf(m_t, sv);
-            const int ts_before = (t == 0) ? -1 : (PS ? __hip_atomic_load(&tp.tstar[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tp.tstar[b]);
             const bool take = dm.fixed ? (t == T - 1) : (ts_before < 0 && (m_next == 0.f || t == T - 1));
             s_mn[m] = valid ? m_next : 0.f;
             if (valid) {
@@ -274,6 +324,7 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
         }
         __syncthreads();
         bool alive = false;
+        MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 168);
         for (int mm = 0; mm < nb; ++mm) alive = alive || (s_mn[mm] != 0.f);
         if (tid == 0 && t + 1 < T && alive) atomicAdd(&tp.alive[t + 1], 1);
         return alive;
@@ -291,40 +342,60 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
     __shared__ __attribute__((aligned(16))) float s_y[16][68];
     __shared__ __attribute__((aligned(16))) float s_dbar[16][132];
     __shared__ __attribute__((aligned(16))) float s_g[16][260];
+    __shared__ __attribute__((aligned(16))) float s_desc[64 * 128];       // the description matrix: read once per launch (PS) instead of once per step
     __shared__ float s_acc[4][16][17];
     __shared__ float s_live[16], s_live2[16], s_take[16];
     const int B = dm.B, W = dm.W, R = dm.R, V = dm.V, D = dm.D, NJ = R >> 4;
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    const int m = tid >> 4, c = tid & 15, b = min(b0 + m, B - 1), ncol = 16 * jw + c;
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train, train = ar.train != 0, binary = dm.use_binary != 0;
-    __syncthreads();
+    const size_t rowb = (size_t)t * B;
+    // ---- operands that do not wait for anything this phase computes: row flags, the partial logits, this role's rows of W_w,
+    //      its bias and Bernoulli uniforms -- one round trip
+    float f_live = 0.f, f_next = 0.f, f_take = 0.f;
     if (tid < MMG_TM) {
-        const int b = min(b0 + tid, B - 1);
-        const bool live = rc_live<PS>(tp, B, t, b, tid < nb, may_stop);
-        s_live[tid] = live ? 1.f : 0.f;
-        s_live2[tid] = (live && (!may_stop || rc_ld<PS>(&tp.rcst[(size_t)((t + 1) & 1) * B + b]) != 0.f)) ? 1.f : 0.f;
-        s_take[tid] = (tid < nb && rc_ld<PS>(&tp.rcst[(size_t)2 * B + b]) != 0.f) ? 1.f : 0.f;
+        const int bb = min(b0 + tid, B - 1);
+        f_live = rc_live<PS>(tp, B, t, bb, tid < nb, may_stop) ? 1.f : 0.f;
+        f_next = may_stop ? rc_ld<PS>(&tp.rcst[(size_t)((t + 1) & 1) * B + bb]) : 1.f;
+        f_take = (tid < nb) ? rc_ld<PS>(&tp.rcst[(size_t)2 * B + bb]) : 0.f;
     }
+    float pv[2][16];                                                    // thread (m, d = c) and (m, d = c + 16): the partials of its first two classes
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int d = min(c + 16 * e, D - 1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pv[e][u] = rc_ld<PS>(&tp.rcyp[((size_t)min(u, NJ - 1) * B + b) * D + d]);
+    }
+    int gm0, nm;
+    rc_share(R, wave, gm0, nm);
+    RcFrag ww;
+    rc_load(ww, P.p[R_W_W] + (size_t)(16 * jw + i) * R, R, gm0, q);
+    const float bw = P.p[R_W_B][ncol], b2 = P.p[R_Y2_B][0];
+    float u_w = 0.f;
+    if (binary && train)
+        u_w = ar.u_w ? ar.u_w[(rowb + b) * W + ncol] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + dm.boff + b) * W + ncol), tp.counter[0], 2u);
+    __syncthreads();                                                    // (PS: the LDS of the phase before is free)
+    if (tid < MMG_TM) { s_live[tid] = f_live; s_live2[tid] = (f_live != 0.f && f_next != 0.f) ? 1.f : 0.f; s_take[tid] = f_take; }
+    if (!PS || t == 0) for (int idx = tid; idx < D * V; idx += 256) s_desc[idx] = ar.desc[idx];
     for (int idx = tid; idx < 16 * 132; idx += 256) (&s_dbar[0][0])[idx] = 0.f;        // K padding of the w_d product
     __syncthreads();
     if (!PS && may_stop) {
         bool any = false;
-        for (int m = 0; m < MMG_TM; ++m) any = any || (s_live[m] != 0.f);
+        for (int mm = 0; mm < MMG_TM; ++mm) any = any || (s_live[mm] != 0.f);
         if (!any) return;
     }
-    const size_t rowb = (size_t)t * B;
-    const float b2 = P.p[R_Y2_B][0];
     // ---- class logits: the R/16 partials in role order
-    for (int idx = tid; idx < MMG_TM * D; idx += 256) {
-        const int m = idx / D, d = idx - m * D, b = min(b0 + m, B - 1);
+    MMG_RSTAMP(PS && tile == 0 && jw == 0 && t == 3, 170);
+    for (int d = c, e = 0; d < D; d += 16, ++e) {
         float acc = 0.f;
-        for (int jj = 0; jj < NJ; jj += 8) {
-            float pv[8];
+        float pw_[16];
+        if (e >= 2) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pv[u] = rc_ld<PS>(&tp.rcyp[((size_t)min(jj + u, NJ - 1) * B + b) * D + d]);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += (jj + u < NJ) ? pv[u] : 0.f;
+            for (int u = 0; u < 16; ++u) pw_[u] = rc_ld<PS>(&tp.rcyp[((size_t)min(u, NJ - 1) * B + b) * D + d]);
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += (u < NJ) ? (e == 0 ? pv[0][u] : (e == 1 ? pv[1][u] : pw_[u])) : 0.f;
         const float yv = acc + b2;
         s_y[m][d] = yv;
         if (jw == 0 && m < nb) {
@@ -334,94 +405,114 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
     }
     __syncthreads();
     // ---- softmax(y) (detached, model.py:441): wave per sample row, in place (D <= 64: one class per lane)
-    for (int m = wave; m < MMG_TM; m += 4) {
-        const float v = (lane < D) ? s_y[m][lane] : -3.0e38f;
+    MMG_RSTAMP(PS && tile == 0 && jw == 0 && t == 3, 171);
+    for (int mm = wave; mm < MMG_TM; mm += 4) {
+        const float v = (lane < D) ? s_y[mm][lane] : -3.0e38f;
         const float mx = dpp_wave_max(v);
         const float e = (lane < D) ? __expf(v - mx) : 0.f;
         const float se = dpp_wave_sum(e);
-        if (lane < D) s_y[m][lane] = e * __builtin_amdgcn_rcpf(se);
+        s_y[mm][lane] = (lane < D) ? e * __builtin_amdgcn_rcpf(se) : 0.f;      // (columns D..63 zero: K padding of the mixture product)
     }
     __syncthreads();
-    // ---- description mixture (model.py:442-449)
-    for (int idx = tid; idx < MMG_TM * V; idx += 256) {
-        const int m = idx / V, v = idx - m * V;
-        float acc = 0.f;
-        for (int d0 = 0; d0 < D; d0 += 8) {
-            float dv[8];
+    MMG_RSTAMP(PS && tile == 0 && jw == 0 && t == 3, 172);
+    // ---- description mixture softmax(y) . desc (model.py:442-449) on the matrix cores, both operands in LDS: K = D in steps of
+    //      4 (lane (i, q): A[i][4 s + q], B[4 s + q][16 vt + i]), the 16-column tiles of V round-robin over the waves
+    {
+        const int ks = (D + 3) >> 2, nv = (V + 15) >> 4;
+        for (int vt = wave; vt < nv; vt += 4) {
+            const int col = vt * 16 + i;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int sk = 0; sk < ks; ++sk) {
+                const int kk = 4 * sk + q;
+                const float bv = (kk < D && col < V) ? s_desc[kk * V + col] : 0.f;
+                acc = mfma16(s_y[i][kk], bv, acc);
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dv[u] = ar.desc[(size_t)min(d0 + u, D - 1) * V + v];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf((d0 + u < D) ? s_y[m][min(d0 + u, D - 1)] : 0.f, dv[u], acc);
+            for (int r = 0; r < 4; ++r) {
+                const int mm = q * 4 + r;
+                if (col < V) {
+                    s_dbar[mm][col] = acc[r];
+                    if (jw == 0 && s_live2[mm] != 0.f) tp.dbar[(rowb + b0 + mm) * V + col] = acc[r];
+                }
+            }
         }
-        s_dbar[m][v] = acc;
-        if (jw == 0 && s_live2[m] != 0.f) tp.dbar[(rowb + b0 + m) * V + v] = acc;
     }
     __syncthreads();
-    // ---- h_w = tanh(w_h h + b_h + w_d dbar)   (model.py:452): all R columns, four 16-column tiles per wave
+    MMG_RSTAMP(PS && tile == 0 && jw == 0 && t == 3, 173);
+    // ---- h_w = tanh(w_h h + b_h + w_d dbar)   (model.py:452): all R columns, 16-column tiles round-robin over the waves, two
+    //      tiles' weight fragments and w_h h values in flight together
     {
         const int kg = (V + 15) >> 4;                                   // <= 8
-        for (int tn = wave; tn < NJ; tn += 4) {
-            const float* wrow = P.p[R_WD_W] + (size_t)(tn * 16 + i) * V;
-            float4 bq[8];
+        for (int tn0 = wave; tn0 < NJ; tn0 += 8) {
+            const int tn1 = min(tn0 + 4, NJ - 1);
+            const bool has1 = tn0 + 4 < NJ;
+            const float* wr0 = P.p[R_WD_W] + (size_t)(tn0 * 16 + i) * V;
+            const float* wr1 = P.p[R_WD_W] + (size_t)(tn1 * 16 + i) * V;
+            float4 bq0[8], bq1[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bq[u] = ldrow4c<true>(wrow, min(u, kg - 1) * 16 + q * 4, V);
-            float gwv[4];
+            for (int u = 0; u < 8; ++u) { bq0[u] = ldrow4c<true>(wr0, min(u, kg - 1) * 16 + q * 4, V); bq1[u] = ldrow4c<true>(wr1, min(u, kg - 1) * 16 + q * 4, V); }
+            float gw0[4], gw1[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gwv[r] = rc_ld<PS>(&tp.rcgw[(size_t)min(b0 + q * 4 + r, B - 1) * R + tn * 16 + i]);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) {
+                const size_t ro = (size_t)min(b0 + q * 4 + r, B - 1) * R;
+                gw0[r] = rc_ld<PS>(&tp.rcgw[ro + tn0 * 16 + i]); gw1[r] = rc_ld<PS>(&tp.rcgw[ro + tn1 * 16 + i]);
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (u < kg) {
                     const float4 a = *reinterpret_cast<const float4*>(&s_dbar[i][u * 16 + q * 4]);
-                    acc = mfma16(a.x, bq[u].x, acc); acc = mfma16(a.y, bq[u].y, acc);
-                    acc = mfma16(a.z, bq[u].z, acc); acc = mfma16(a.w, bq[u].w, acc);
+                    acc0 = mfma16(a.x, bq0[u].x, acc0); acc0 = mfma16(a.y, bq0[u].y, acc0);
+                    acc0 = mfma16(a.z, bq0[u].z, acc0); acc0 = mfma16(a.w, bq0[u].w, acc0);
+                    acc1 = mfma16(a.x, bq1[u].x, acc1); acc1 = mfma16(a.y, bq1[u].y, acc1);
+                    acc1 = mfma16(a.z, bq1[u].z, acc1); acc1 = mfma16(a.w, bq1[u].w, acc1);
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = q * 4 + r, n = tn * 16 + i;
-                const float gv = ftanh(gwv[r] + acc[r]);
-                s_g[m][n] = gv;
-                if (jw == 0 && s_live2[m] != 0.f) tp.g[(rowb + b0 + m) * R + n] = gv;
+                const int mm = q * 4 + r;
+                const float gv0 = ftanh(gw0[r] + acc0[r]);
+                s_g[mm][tn0 * 16 + i] = gv0;
+                if (jw == 0 && s_live2[mm] != 0.f) tp.g[(rowb + b0 + mm) * R + tn0 * 16 + i] = gv0;
+                if (has1) {
+                    const float gv1 = ftanh(gw1[r] + acc1[r]);
+                    s_g[mm][tn1 * 16 + i] = gv1;
+                    if (jw == 0 && s_live2[mm] != 0.f) tp.g[(rowb + b0 + mm) * R + tn1 * 16 + i] = gv1;
+                }
             }
         }
     }
     __syncthreads();
+    MMG_RSTAMP(PS && tile == 0 && jw == 0 && t == 3, 174);
     // ---- this role's 16 bits of the receiver's message (model.py:454-475)
     {
-        int g0, n;
-        rc_share(R, wave, g0, n);
-        RcFrag ag, ww;
-        rc_load(ww, P.p[R_W_W] + (size_t)(16 * jw + i) * R, R, g0, q);
+        RcFrag ag;
         const int kgr = R >> 4;
 #pragma unroll
-        for (int u = 0; u < RC_MAXG; ++u) ag.v[u] = *reinterpret_cast<const float4*>(&s_g[i][min(g0 + u, kgr - 1) * 16 + q * 4]);
+        for (int u = 0; u < RC_MAXG; ++u) ag.v[u] = *reinterpret_cast<const float4*>(&s_g[i][min(gm0 + u, kgr - 1) * 16 + q * 4]);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 a0 = rc_mma(ag, ww, n, z4);
+        const f32x4 a0 = rc_mma(ag, ww, nm, z4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = a0[r];
     }
     __syncthreads();
+    MMG_RSTAMP(PS && tile == 0 && jw == 0 && t == 3, 175);
     {
-        const int m = tid >> 4, c = tid & 15, n = 16 * jw + c, b = min(b0 + m, B - 1);
-        const float lw = (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]) + P.p[R_W_B][n];
+        const float lw = (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]) + bw;
         float wv = lw, lpv = 0.f, nev = 0.f;
         const bool st = s_live2[m] != 0.f;
         if (binary) {
             const float pp = fsigmoid(lw);
-            if (train) {
-                const float u = ar.u_w ? ar.u_w[(rowb + b) * W + n]
-                                       : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + dm.boff + b) * W + n), tp.counter[0], 2u);
-                wv = (u < pp) ? 1.f : 0.f;                                                  // model.py:460
-            } else wv = rintf(pp);                                                          // model.py:462
-            if (st) tp.pw[(rowb + b) * W + n] = pp;
+            wv = train ? ((u_w < pp) ? 1.f : 0.f) : rintf(pp);                              // model.py:460 / 462
+            if (st) tp.pw[(rowb + b) * W + ncol] = pp;
             const float l1 = flog(pp + MMG_EPS), l0 = flog(1.f - pp + MMG_EPS);
             lpv = wv * l1 + (1.f - wv) * l0; nev = pp * l1 + (1.f - pp) * l0;
         }
-        if (st) rc_st<PS>(&tp.w[(rowb + b) * W + n], wv);
+        if (st) rc_st<PS>(&tp.w[(rowb + b) * W + ncol], wv);
         if (binary) {
             lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
-            if (c == 0 && m < nb) { float* pl = tp.rclw + ((size_t)jw * B + b) * 2; rc_st<PS>(pl, lpv); rc_st<PS>(pl + 1, nev); }
+            if (c == 0 && m < nb) { float* pl = tp.rclw + (((size_t)(t & 1) * (W >> 4) + jw) * B + b) * 2; rc_st<PS>(pl, lpv); rc_st<PS>(pl + 1, nev); }
         }
     }
 }
@@ -500,7 +591,9 @@ __device__ __forceinline__ void rc_s1_role(const Dims& dm, const Params& P, cons
     for (int t = 0; t < T; ++t) {
         const size_t rowb = (size_t)t * B;
         if (t > 0) {
+            MMG_RSTAMP(tile == 0 && sidx == 0 && t == 3, 100);
             if (!pf_wait<false>(cW, (uint32_t)(nrc * t), done, tp.sync)) return;
+            MMG_RSTAMP(tile == 0 && sidx == 0 && t == 3, 101);
             RcFrag aw;
             rc_load_act<true>(aw, tp.w + ((size_t)(t - 1) * B + min(b0 + i, B - 1)) * W, W, g0, q);
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -511,6 +604,7 @@ __device__ __forceinline__ void rc_s1_role(const Dims& dm, const Params& P, cons
                 for (int r = 0; r < 4; ++r) s_acc[u][wave][q * 4 + r][i] = a[r];
             }
             __syncthreads();
+            MMG_RSTAMP(tile == 0 && sidx == 0 && t == 3, 102);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -518,15 +612,20 @@ __device__ __forceinline__ void rc_s1_role(const Dims& dm, const Params& P, cons
             const float hw = (t == 0) ? hw0v[u] : (s_acc[u][0][m][c] + s_acc[u][1][m][c]) + (s_acc[u][2][m][c] + s_acc[u][3][m][c]) + bcv[u];
             if (m < nb && hn < H) st_wt(&tp.a[(rowb + b) * H + hn], ftanh(hxv[u] + hw));      // model.py:216
         }
-        if (sidx == 0) {                                                // code input rows of the tile (tapes c, zr)
-            for (int idx = tid; idx < nb * W; idx += 256) {
-                const int mm = idx / W, jj = idx - mm * W;
-                const float cv = (t == 0) ? dm.first_rec : ld_cc(&tp.w[((size_t)(t - 1) * B + b0 + mm) * W + jj]);
-                tp.zr[(rowb + b0 + mm) * W + jj] = cv;                  // z_r of baseline_sen, model.py:836
-                tp.c[(rowb + b0 + mm) * W + jj] = (t == 0) ? fsigmoid(P.p[S_CODE_BIAS][jj]) : cv;
+        MMG_RSTAMP(tile == 0 && sidx == 0 && t == 3, 103);
+        pf_signal(cA);
+        MMG_RSTAMP(tile == 0 && sidx == 0 && t == 3, 104);
+        if (sidx == 0) {                                                // code input rows of the tile (tapes c, zr): off the hand-off's critical path
+            for (int idx = tid * 4; idx < nb * W; idx += 1024) {
+                const int mm = idx / W, jj = idx - mm * W;              // (W is a multiple of 16: a quad never straddles rows)
+                const float4 cv = (t == 0) ? make_float4(dm.first_rec, dm.first_rec, dm.first_rec, dm.first_rec)
+                                           : ld_cc4(&tp.w[((size_t)(t - 1) * B + b0 + mm) * W + jj]);
+                *reinterpret_cast<float4*>(&tp.zr[(rowb + b0 + mm) * W + jj]) = cv;        // z_r of baseline_sen, model.py:836
+                const float4 cb = *reinterpret_cast<const float4*>(P.p[S_CODE_BIAS] + jj);
+                *reinterpret_cast<float4*>(&tp.c[(rowb + b0 + mm) * W + jj]) =
+                    (t == 0) ? make_float4(fsigmoid(cb.x), fsigmoid(cb.y), fsigmoid(cb.z), fsigmoid(cb.w)) : cv;
             }
         }
-        pf_signal(cA);
     }
 }
 
@@ -550,23 +649,24 @@ __device__ __forceinline__ void rc_s2_role(const Dims& dm, const Params& P, cons
         float uz = 0.f;                                                 // the uniform of this thread's bit does not depend on the step's data: drawn before the wait
         if (dm.use_binary && ar.train)
             uz = ar.u_z ? ar.u_z[(rowb + b) * W + col] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + dm.boff + b) * W + col), mb_counter, 0u);
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 110);
         if (!pf_wait<false>(cA, (uint32_t)(ns1 * (t + 1)), done, tp.sync)) return;
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 111);
         const float* arow = tp.a + (rowb + min(b0 + i, B - 1)) * H;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        {
+            float4 av[16];
 #pragma unroll
-        for (int h8 = 0; h8 < 16; h8 += 8) {
-            float4 av[8];
+            for (int u = 0; u < 16; ++u) av[u] = ld_cc4(arow + min(g0 + u, kg - 1) * 16 + q * 4);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = ld_cc4(arow + min(g0 + h8 + u, kg - 1) * 16 + q * 4);
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                if (h8 + u < n) {
-                    acc0 = mfma16(av[u].x, wb[h8 + u].x, acc0); acc0 = mfma16(av[u].y, wb[h8 + u].y, acc0);
-                    acc0 = mfma16(av[u].z, wb[h8 + u].z, acc0); acc0 = mfma16(av[u].w, wb[h8 + u].w, acc0);
+            for (int u = 0; u < 16; u += 2) {
+                if (u < n) {
+                    acc0 = mfma16(av[u].x, wb[u].x, acc0); acc0 = mfma16(av[u].y, wb[u].y, acc0);
+                    acc0 = mfma16(av[u].z, wb[u].z, acc0); acc0 = mfma16(av[u].w, wb[u].w, acc0);
                 }
-                if (h8 + u + 1 < n) {
-                    acc1 = mfma16(av[u + 1].x, wb[h8 + u + 1].x, acc1); acc1 = mfma16(av[u + 1].y, wb[h8 + u + 1].y, acc1);
-                    acc1 = mfma16(av[u + 1].z, wb[h8 + u + 1].z, acc1); acc1 = mfma16(av[u + 1].w, wb[h8 + u + 1].w, acc1);
+                if (u + 1 < n) {
+                    acc1 = mfma16(av[u + 1].x, wb[u + 1].x, acc1); acc1 = mfma16(av[u + 1].y, wb[u + 1].y, acc1);
+                    acc1 = mfma16(av[u + 1].z, wb[u + 1].z, acc1); acc1 = mfma16(av[u + 1].w, wb[u + 1].w, acc1);
                 }
             }
         }
@@ -574,6 +674,7 @@ __device__ __forceinline__ void rc_s2_role(const Dims& dm, const Params& P, cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = acc[r];
         __syncthreads();
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 112);
         {
             const float lz = (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]) + bb;
             float zz = lz;
@@ -584,7 +685,9 @@ __device__ __forceinline__ void rc_s2_role(const Dims& dm, const Params& P, cons
             }
             if (m < nb) st_wt(&tp.z[(rowb + b) * W + col], zz);
         }
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 113);
         pf_signal(cZ);                                                  // (its barrier also frees s_acc for the next step)
+        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 114);
     }
 }
 
@@ -602,16 +705,30 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
     bool whole = true;
     for (int t = 0; t < T; ++t) {
+        const bool stamp = tile == 0 && t == 3 && (k == 0 || k == 5);
+        const int so = (k == 0) ? 120 : 140;
+        MMG_RSTAMP(stamp, so + 0);
         if (!pf_wait<false>(cZ, (uint32_t)(ns2 * (t + 1)), done, tp.sync)) return;
+        MMG_RSTAMP(stamp, so + 1);
         if (k < NJ) rc_gru_body<true>(dm, P, tp, ar, t, tile, k);
+        MMG_RSTAMP(stamp, so + 2);
         pf_signal(cH);
+        MMG_RSTAMP(stamp, so + 3);
+        MMG_RSTAMP(stamp, so + 4);
         if (!pf_wait<false>(cH, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
+        MMG_RSTAMP(stamp, so + 5);
         bool alive = true;
         if (k < NJ) alive = rc_heads_body<true>(dm, P, tp, ar, t, tile, k);
+        MMG_RSTAMP(stamp, so + 6);
         pf_signal(cY);
+        MMG_RSTAMP(stamp, so + 7);
         if (!pf_wait<false>(cY, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
+        MMG_RSTAMP(stamp, so + 8);
         if (k < NJW) rc_query_body<true>(dm, P, tp, ar, t, tile, k);
+        MMG_RSTAMP(stamp, so + 9);
         pf_signal(cW);
+        MMG_RSTAMP(stamp, so + 10);
+        if (k == 0) rc_gru_extras<true>(dm, tp, ar, t, tile);          // (while the sender roles work: rclw is double-buffered by step parity)
         if (k == 0 && may_stop && !alive) {                            // every conversation of the tile has ended: the other roles stop at their next wait
             if (threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             whole = false;
@@ -624,6 +741,16 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
     rc_tail_body<true>(dm, tp, ar, tile, whole);
     if (threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+#ifdef MMG_ROLE_DIAG
+// diagnosis only (scripts/isa_stats.py -D MMG_ROLE_DIAG --kernel k_diag_rc): the roles / bodies of k_rc_persist as kernels of their own,
+// so that register counts and spills can be attributed
+__global__ __launch_bounds__(256) void k_diag_rc_s1(Dims dm, Params P, Tape tp, ConvArgs ar) { rc_s1_role(dm, P, tp, ar, blockIdx.x, 0, 16); }
+__global__ __launch_bounds__(256) void k_diag_rc_s2(Dims dm, Params P, Tape tp, ConvArgs ar) { rc_s2_role(dm, P, tp, ar, blockIdx.x, 0, 16); }
+__global__ __launch_bounds__(256) void k_diag_rc_gru(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_gru_body<true>(dm, P, tp, ar, t, blockIdx.x, 0); }
+__global__ __launch_bounds__(256) void k_diag_rc_heads(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_heads_body<true>(dm, P, tp, ar, t, blockIdx.x, 0); }
+__global__ __launch_bounds__(256) void k_diag_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_query_body<true>(dm, P, tp, ar, t, blockIdx.x, 0); }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_rc_bwd: the reverse-time loop of k_bwd_tile (same math and tape contract) with a tile's hidden units split over R/16
