@@ -32,6 +32,10 @@ template <bool PS> __device__ __forceinline__ float rc_ld(const float* p) { retu
 template <bool PS> __device__ __forceinline__ float4 rc_ld4(const float* p) { return PS ? ld_cc4(p) : *reinterpret_cast<const float4*>(p); }
 template <bool PS> __device__ __forceinline__ void rc_st(float* p, float v) { if (PS) st_wt(p, v); else *p = v; }
 
+// an opaque zero added to the addresses of step-invariant operands that are NOT meant to stay in registers across the persistent
+// launch's step loop: hipcc otherwise hoists every such load out of the loop and spills (k_rc_persist: 256 + 256 registers, 1.6 KB scratch)
+__device__ __forceinline__ int rc_opaque0() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+
 // this wave's k-groups [g0, g0 + RC_MAXG) of one operand row (clamped, branch-free: all loads of a phase go out together)
 __device__ __forceinline__ void rc_load(RcFrag& f, const float* __restrict__ row, int K, int g0, int q) {
     const int kgroups = K >> 4;
@@ -84,41 +88,58 @@ __device__ __forceinline__ void rc_sum_lw(const Dims& dm, const Tape& tp, int tp
 }
 
 // ---------------------------------------------------------------------------------------------
+// step-invariant operands of a role's phases: the persistent launch loads them ONCE, ahead of its step loop (register-resident
+// weight fragments: 24 + 8 + 4 float4 per lane), the per-step kernels at every launch
+struct RcGruW { RcFrag wi0, wi1, wi2, wh0, wh1, wh2; float bir, biu, bin_, bhr, bhu, bhn; };
+__device__ __forceinline__ void rc_gru_w(RcGruW& w, const Dims& dm, const Params& P, const int j) {
+    const int W = dm.W, R = dm.R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    const int unit = 16 * j + i, unit_e = 16 * j + (tid & 15);
+    int gw0, nw_, gr0, nr_;
+    rc_share(W, wave, gw0, nw_); rc_share(R, wave, gr0, nr_);
+    gw0 += rc_opaque0(); gr0 += rc_opaque0();
+    rc_load(w.wi0, P.p[R_WIH] + (size_t)(unit) * W, W, gw0, q);
+    rc_load(w.wi1, P.p[R_WIH] + (size_t)(R + unit) * W, W, gw0, q);
+    rc_load(w.wi2, P.p[R_WIH] + (size_t)(2 * R + unit) * W, W, gw0, q);
+    rc_load(w.wh0, P.p[R_WHH] + (size_t)(unit) * R, R, gr0, q);
+    rc_load(w.wh1, P.p[R_WHH] + (size_t)(R + unit) * R, R, gr0, q);
+    rc_load(w.wh2, P.p[R_WHH] + (size_t)(2 * R + unit) * R, R, gr0, q);
+    const float* bih = P.p[R_BIH]; const float* bhh = P.p[R_BHH];
+    w.bir = bih[unit_e]; w.biu = bih[R + unit_e]; w.bin_ = bih[2 * R + unit_e];
+    w.bhr = bhh[unit_e]; w.bhu = bhh[R + unit_e]; w.bhn = bhh[2 * R + unit_e];
+}
 // PS = false: returns early (false) when the tile's conversations are over; PS = true: always runs through (its signals must go out)
 template <bool PS>
-__device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int j) {
+__device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int j,
+                                            const RcGruW* pw = nullptr) {
     __shared__ float s_acc[6][4][16][17];
     __shared__ float s_live[16];
     const int B = dm.B, W = dm.W, R = dm.R;
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    // (per-thread indices re-derived from an OPAQUE copy of the thread id in every call: inside the persistent launch's step loop hipcc
+    //  otherwise hoists each phase's row / column / tape-address arithmetic out of the loop and keeps hundreds of registers live across it)
+    const int tid = rc_opaque0() + (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, q = lane >> 4;
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
     const float live_in = rc_live<PS>(tp, B, t, min(b0 + (tid & 15), B - 1), (tid & 15) < nb, may_stop) ? 1.f : 0.f;
     const size_t rowb = (size_t)t * B;
     // operands of the epilogue (biases, h_{t-1} of this thread's unit): in flight with the product's operands
     const int m = tid >> 4, c = tid & 15, unit_e = 16 * j + c, b = min(b0 + m, B - 1);
-    const float* bih = P.p[R_BIH]; const float* bhh = P.p[R_BHH];
-    const float bir = bih[unit_e], biu = bih[R + unit_e], bin_ = bih[2 * R + unit_e];
-    const float bhr = bhh[unit_e], bhu = bhh[R + unit_e], bhn = bhh[2 * R + unit_e];
     const float hprev = (t > 0) ? rc_ld<PS>(&tp.h[(rowb + b) * R + unit_e]) : 0.f;
+    RcGruW wl;
+    if (!pw) rc_gru_w(wl, dm, P, j);
+    const RcGruW& w = pw ? *pw : wl;
+    const float bir = w.bir, biu = w.biu, bin_ = w.bin_, bhr = w.bhr, bhu = w.bhu, bhn = w.bhn;
     {
-        const int bx = min(b0 + i, B - 1), unit = 16 * j + i;
+        const int bx = min(b0 + i, B - 1);
         int gw0, nw_, gr0, nr_;
         rc_share(W, wave, gw0, nw_); rc_share(R, wave, gr0, nr_);
-        RcFrag az, ah, wi0, wi1, wi2, wh0, wh1, wh2;
+        RcFrag az, ah;
         rc_load_act<PS>(az, tp.z + (rowb + bx) * W, W, gw0, q);
-        rc_load(wi0, P.p[R_WIH] + (size_t)(unit) * W, W, gw0, q);
-        rc_load(wi1, P.p[R_WIH] + (size_t)(R + unit) * W, W, gw0, q);
-        rc_load(wi2, P.p[R_WIH] + (size_t)(2 * R + unit) * W, W, gw0, q);
         // (t == 0: h_0 = 0 is being written by this very launch -- the hidden-side product is b_hh alone)
         const int nh = (t > 0) ? nr_ : 0;
         rc_load_act<PS>(ah, tp.h + (rowb + bx) * R, R, gr0, q);
-        rc_load(wh0, P.p[R_WHH] + (size_t)(unit) * R, R, gr0, q);
-        rc_load(wh1, P.p[R_WHH] + (size_t)(R + unit) * R, R, gr0, q);
-        rc_load(wh2, P.p[R_WHH] + (size_t)(2 * R + unit) * R, R, gr0, q);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 a0 = rc_mma(az, wi0, nw_, z4), a1 = rc_mma(az, wi1, nw_, z4), a2 = rc_mma(az, wi2, nw_, z4);
-        const f32x4 a3 = rc_mma(ah, wh0, nh, z4), a4 = rc_mma(ah, wh1, nh, z4), a5 = rc_mma(ah, wh2, nh, z4);
+        const f32x4 a0 = rc_mma(az, w.wi0, nw_, z4), a1 = rc_mma(az, w.wi1, nw_, z4), a2 = rc_mma(az, w.wi2, nw_, z4);
+        const f32x4 a3 = rc_mma(ah, w.wh0, nh, z4), a4 = rc_mma(ah, w.wh1, nh, z4), a5 = rc_mma(ah, w.wh2, nh, z4);
         MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 160);
         __syncthreads();                                                // (PS: the LDS of the phase before is free)
         if (tid < MMG_TM) s_live[tid] = live_in;
@@ -186,15 +207,44 @@ __global__ __launch_bounds__(256) void k_rc_gru(Dims dm, Params P, Tape tp, Conv
 }
 
 // ---------------------------------------------------------------------------------------------
+struct RcHeadsW { RcFrag wa, wg; float bh, bs; float4 wq[4], cq[2][4], sq[4]; };
+// frags: the two weight fragments and the scalars (what the persistent launch keeps across steps); the class rows, w_y2 and s.weight
+// slices are loaded in any case (keeping all of it resident next to the GRU's 24 fragments spills)
+__device__ __forceinline__ void rc_heads_w(RcHeadsW& w, const Dims& dm, const Params& P, const Tape& tp, const int j, const bool frags) {
+    const int R = dm.R, V = dm.V, D = dm.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4, c = tid & 15;
+    int g0, n;
+    rc_share(R, wave, g0, n);
+    const int oz = rc_opaque0();
+    if (frags) {
+        rc_load(w.wa, P.p[R_Y1_W] + (size_t)(16 * j + i) * (R + V) + oz, R, g0, q);
+        rc_load(w.wg, P.p[R_WH_W] + (size_t)(16 * j + i) * R + oz, R, g0, q);
+        w.bh = P.p[R_WH_B][16 * j + c + oz]; w.bs = P.p[R_S_B][oz];
+    }
+    const float4* w4 = reinterpret_cast<const float4*>(P.p[R_Y2_W] + 16 * j + oz);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w.wq[e] = w4[e];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                                       // Cd[d][slice] of this thread's first two classes (d = c, c + 16)
+        const float4* c4 = reinterpret_cast<const float4*>(tp.Cd + (size_t)min(c + 16 * e, D - 1) * R + 16 * j + oz);
+        w.cq[e][0] = c4[0]; w.cq[e][1] = c4[1]; w.cq[e][2] = c4[2]; w.cq[e][3] = c4[3];
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w.sq[e] = *reinterpret_cast<const float4*>(P.p[R_S_W] + min(c * 4 + 64 * e, R - 4) + oz);      // (role 0: s.weight)
+    }
+}
 // returns (role 0 only; true elsewhere): a sample of the tile goes on after this step
 template <bool PS>
-__device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int j) {
+__device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int j,
+                                              const RcHeadsW* pw = nullptr) {
     __shared__ float s_acc[2][4][16][17];
     __shared__ __attribute__((aligned(16))) float s_A[16][20];
     __shared__ float s_live[16], s_mn[16];
     const int B = dm.B, R = dm.R, V = dm.V, D = dm.D, T = dm.T;
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    // (per-thread indices re-derived from an OPAQUE copy of the thread id in every call: inside the persistent launch's step loop hipcc
+    //  otherwise hoists each phase's row / column / tape-address arithmetic out of the loop and keeps hundreds of registers live across it)
+    const int tid = rc_opaque0() + (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, q = lane >> 4;
     const int m = tid >> 4, c = tid & 15, b = min(b0 + m, B - 1);
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train, train = ar.train != 0;
     const size_t rowb = (size_t)t * B, rowh = (size_t)(t + 1) * B;
@@ -204,30 +254,20 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
     const int bx = min(b0 + i, B - 1);
     int g0, n;
     rc_share(R, wave, g0, n);
-    RcFrag ah, wa, wg;
+    RcFrag ah;
     rc_load_act<PS>(ah, tp.h + (rowh + bx) * R, R, g0, q);
-    rc_load(wa, P.p[R_Y1_W] + (size_t)(16 * j + i) * (R + V), R, g0, q);
-    rc_load(wg, P.p[R_WH_W] + (size_t)(16 * j + i) * R, R, g0, q);
-    const float bh = P.p[R_WH_B][16 * j + c];
-    const float4* w4 = reinterpret_cast<const float4*>(P.p[R_Y2_W] + 16 * j);
-    const float4 wq0 = w4[0], wq1 = w4[1], wq2 = w4[2], wq3 = w4[3];
-    float4 cq[2][4];                                                    // Cd[d][slice] of this thread's first two classes (d = c, c + 16)
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float4* c4 = reinterpret_cast<const float4*>(tp.Cd + (size_t)min(c + 16 * e, D - 1) * R + 16 * j);
-        cq[e][0] = c4[0]; cq[e][1] = c4[1]; cq[e][2] = c4[2]; cq[e][3] = c4[3];
-    }
-    float4 hq[4], sq[4];                                                // role 0: s.weight and h_{t+1} of sample m, 16 lanes x 4 floats x 4
+    RcHeadsW w;
+    rc_heads_w(w, dm, P, tp, j, pw == nullptr);
+    if (pw) { w.wa = pw->wa; w.wg = pw->wg; w.bh = pw->bh; w.bs = pw->bs; }
+    const float bh = w.bh;
+    const float4 wq0 = w.wq[0], wq1 = w.wq[1], wq2 = w.wq[2], wq3 = w.wq[3];
+    float4 hq[4];                                                       // role 0: h_{t+1} of sample m, 16 lanes x 4 floats x 4
     float m_t = 1.f, sp_before = 1.f, u_s = 0.f;
     int ts_before = -1;
     if (j == 0) {
         const float* hr = tp.h + (rowh + b) * R;
-        const float* ws = P.p[R_S_W];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = min(c * 4 + 64 * e, R - 4);
-            hq[e] = rc_ld4<PS>(hr + r); sq[e] = *reinterpret_cast<const float4*>(ws + r);
-        }
+        for (int e = 0; e < 4; ++e) hq[e] = rc_ld4<PS>(hr + min(c * 4 + 64 * e, R - 4));
         if (t > 0) {
             m_t = rc_ld<PS>(&tp.rcst[(size_t)(t & 1) * B + b]);
             ts_before = PS ? __hip_atomic_load(&tp.tstar[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tp.tstar[b];
@@ -236,7 +276,7 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
         if (train) u_s = ar.u_s ? ar.u_s[rowb + b] : philox_uniform(ar.seed, (uint32_t)(t * dm.Bg + dm.boff + b), tp.counter[0], 1u);
     }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 a0 = rc_mma(ah, wa, n, z4), a1 = rc_mma(ah, wg, n, z4);
+    const f32x4 a0 = rc_mma(ah, w.wa, n, z4), a1 = rc_mma(ah, w.wg, n, z4);
     MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 165);
     __syncthreads();                                                    // (PS: the LDS of the phase before is free)
     if (tid < MMG_TM) s_live[tid] = live_in;
@@ -274,7 +314,7 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int d = c + 16 * e;
-            if (d < D && m < nb) rc_st<PS>(&tp.rcyp[((size_t)j * B + b0 + m) * D + d], part(cq[e][0], cq[e][1], cq[e][2], cq[e][3]));
+            if (d < D && m < nb) rc_st<PS>(&tp.rcyp[((size_t)j * B + b0 + m) * D + d], part(w.cq[e][0], w.cq[e][1], w.cq[e][2], w.cq[e][3]));
         }
         for (int d = c + 32; d < D; d += 16) {                          // (more than 32 classes: rows fetched here)
             const float4* c4 = reinterpret_cast<const float4*>(tp.Cd + (size_t)d * R + 16 * j);
@@ -289,14 +329,14 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (c * 4 + 64 * e < R) {
-                acc = fmaf(sq[e].x, hq[e].x, acc); acc = fmaf(sq[e].y, hq[e].y, acc);
-                acc = fmaf(sq[e].z, hq[e].z, acc); acc = fmaf(sq[e].w, hq[e].w, acc);
+                acc = fmaf(w.sq[e].x, hq[e].x, acc); acc = fmaf(w.sq[e].y, hq[e].y, acc);
+                acc = fmaf(w.sq[e].z, hq[e].z, acc); acc = fmaf(w.sq[e].w, hq[e].w, acc);
             }
         }
         acc = dpp_group_sum<16>(acc);
         if (c == 0) {
             const bool valid = m < nb, live = s_live[m] != 0.f;
-            const float p = fsigmoid(acc + P.p[R_S_B][0]);
+            const float p = fsigmoid(acc + w.bs);
             float sv, prod = 1.f;
             if (train) sv = (u_s < p) ? 1.f : 0.f;                                          // model.py:420
             else {
@@ -337,20 +377,53 @@ __global__ __launch_bounds__(256) void k_rc_heads(Dims dm, Params P, Tape tp, Co
 }
 
 // ---------------------------------------------------------------------------------------------
+// part 0: the step's critical path (logits, softmax, h_w, message).  part 1 (role 0 of the tile, after its message has gone out): the
+// description mixture dbar = softmax(y) . desc (model.py:442-449) for the tape -- only k_wgrad's w_d job reads it; the query head
+// itself uses W_d dbar = softmax(y) . Dd with Dd = desc . W_d^T folded onto the classes by k_prep (tape.Dd, 30 KB in LDS).
+struct RcQueryW { RcFrag ww; float bw, b2; };
+__device__ __forceinline__ void rc_query_w(RcQueryW& w, const Dims& dm, const Params& P, const int jw) {
+    const int R = dm.R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    int g0, n;
+    rc_share(R, wave, g0, n);
+    const int oz = rc_opaque0();
+    rc_load(w.ww, P.p[R_W_W] + (size_t)(16 * jw + i) * R + oz, R, g0, q);
+    w.bw = P.p[R_W_B][16 * jw + (tid & 15) + oz]; w.b2 = P.p[R_Y2_B][oz];
+}
 template <bool PS>
-__device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int jw) {
+__device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int jw, const int part,
+                                              const RcQueryW* pw = nullptr) {
     __shared__ __attribute__((aligned(16))) float s_y[16][68];
-    __shared__ __attribute__((aligned(16))) float s_dbar[16][132];
     __shared__ __attribute__((aligned(16))) float s_g[16][260];
-    __shared__ __attribute__((aligned(16))) float s_desc[64 * 128];       // the description matrix: read once per launch (PS) instead of once per step
+    __shared__ __attribute__((aligned(16))) float s_Dd[32][260];         // read once per launch (PS) instead of once per step
     __shared__ float s_acc[4][16][17];
     __shared__ float s_live[16], s_live2[16], s_take[16];
     const int B = dm.B, W = dm.W, R = dm.R, V = dm.V, D = dm.D, NJ = R >> 4;
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    // (per-thread indices re-derived from an OPAQUE copy of the thread id in every call: inside the persistent launch's step loop hipcc
+    //  otherwise hoists each phase's row / column / tape-address arithmetic out of the loop and keeps hundreds of registers live across it)
+    const int tid = rc_opaque0() + (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, q = lane >> 4;
     const int m = tid >> 4, c = tid & 15, b = min(b0 + m, B - 1), ncol = 16 * jw + c;
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train, train = ar.train != 0, binary = dm.use_binary != 0;
     const size_t rowb = (size_t)t * B;
+    if (part == 1) {
+        // softmax(y) is still in s_y; desc from L2 (16 x D x V on the matrix cores: K = D in steps of 4, lane (i, q): A[i][4 s + q], B[4 s + q][16 vt + i])
+        const int ks = (D + 3) >> 2, nv = (V + 15) >> 4;
+        for (int vt = wave; vt < nv; vt += 4) {
+            const int col = vt * 16 + i;
+            float bv[8];
+#pragma unroll
+            for (int sk = 0; sk < 8; ++sk) { const int kk = 4 * sk + q; bv[sk] = (kk < D && col < V) ? ar.desc[(size_t)kk * V + col] : 0.f; }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sk = 0; sk < 8; ++sk) if (sk < ks) acc = mfma16(s_y[i][4 * sk + q], bv[sk], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = q * 4 + r;
+                if (col < V && s_live2[mm] != 0.f) tp.dbar[(rowb + b0 + mm) * V + col] = acc[r];
+            }
+        }
+        return;
+    }
     // ---- operands that do not wait for anything this phase computes: row flags, the partial logits, this role's rows of W_w,
     //      its bias and Bernoulli uniforms -- one round trip
     float f_live = 0.f, f_next = 0.f, f_take = 0.f;
@@ -369,16 +442,20 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
     }
     int gm0, nm;
     rc_share(R, wave, gm0, nm);
-    RcFrag ww;
-    rc_load(ww, P.p[R_W_W] + (size_t)(16 * jw + i) * R, R, gm0, q);
-    const float bw = P.p[R_W_B][ncol], b2 = P.p[R_Y2_B][0];
+    RcQueryW wl;
+    if (!pw) rc_query_w(wl, dm, P, jw);
+    const RcQueryW& w = pw ? *pw : wl;
+    const float bw = w.bw, b2 = w.b2;
     float u_w = 0.f;
     if (binary && train)
         u_w = ar.u_w ? ar.u_w[(rowb + b) * W + ncol] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + dm.boff + b) * W + ncol), tp.counter[0], 2u);
     __syncthreads();                                                    // (PS: the LDS of the phase before is free)
     if (tid < MMG_TM) { s_live[tid] = f_live; s_live2[tid] = (f_live != 0.f && f_next != 0.f) ? 1.f : 0.f; s_take[tid] = f_take; }
-    if (!PS || t == 0) for (int idx = tid; idx < D * V; idx += 256) s_desc[idx] = ar.desc[idx];
-    for (int idx = tid; idx < 16 * 132; idx += 256) (&s_dbar[0][0])[idx] = 0.f;        // K padding of the w_d product
+    if (!PS || t == 0)
+        for (int idx = tid * 4; idx < 32 * R; idx += 1024) {            // (rows D..31 zero: K padding of softmax(y) . Dd)
+            const int d = idx / R, r = idx - d * R;
+            *reinterpret_cast<float4*>(&s_Dd[d][r]) = (d < D) ? *reinterpret_cast<const float4*>(tp.Dd + (size_t)d * R + r) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     __syncthreads();
     if (!PS && may_stop) {
         bool any = false;
@@ -415,71 +492,25 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
     }
     __syncthreads();
     MMG_RSTAMP(PS && tile == 0 && jw == 0 && t == 3, 172);
-    // ---- description mixture softmax(y) . desc (model.py:442-449) on the matrix cores, both operands in LDS: K = D in steps of
-    //      4 (lane (i, q): A[i][4 s + q], B[4 s + q][16 vt + i]), the 16-column tiles of V round-robin over the waves
-    {
-        const int ks = (D + 3) >> 2, nv = (V + 15) >> 4;
-        for (int vt = wave; vt < nv; vt += 4) {
-            const int col = vt * 16 + i;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int sk = 0; sk < ks; ++sk) {
-                const int kk = 4 * sk + q;
-                const float bv = (kk < D && col < V) ? s_desc[kk * V + col] : 0.f;
-                acc = mfma16(s_y[i][kk], bv, acc);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mm = q * 4 + r;
-                if (col < V) {
-                    s_dbar[mm][col] = acc[r];
-                    if (jw == 0 && s_live2[mm] != 0.f) tp.dbar[(rowb + b0 + mm) * V + col] = acc[r];
-                }
-            }
-        }
-    }
-    __syncthreads();
     MMG_RSTAMP(PS && tile == 0 && jw == 0 && t == 3, 173);
-    // ---- h_w = tanh(w_h h + b_h + w_d dbar)   (model.py:452): all R columns, 16-column tiles round-robin over the waves, two
-    //      tiles' weight fragments and w_h h values in flight together
+    // ---- h_w = tanh(w_h h + b_h + softmax(y) . Dd)   (model.py:452; Dd = desc . W_d^T): all R columns on the matrix cores, both operands
+    //      in LDS (K = D in steps of 4), the 16-column tiles round-robin over the waves
     {
-        const int kg = (V + 15) >> 4;                                   // <= 8
-        for (int tn0 = wave; tn0 < NJ; tn0 += 8) {
-            const int tn1 = min(tn0 + 4, NJ - 1);
-            const bool has1 = tn0 + 4 < NJ;
-            const float* wr0 = P.p[R_WD_W] + (size_t)(tn0 * 16 + i) * V;
-            const float* wr1 = P.p[R_WD_W] + (size_t)(tn1 * 16 + i) * V;
-            float4 bq0[8], bq1[8];
+        const int ks = (D + 3) >> 2;
+        for (int tn = wave; tn < NJ; tn += 4) {
+            const int col = tn * 16 + i;
+            float gwv[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { bq0[u] = ldrow4c<true>(wr0, min(u, kg - 1) * 16 + q * 4, V); bq1[u] = ldrow4c<true>(wr1, min(u, kg - 1) * 16 + q * 4, V); }
-            float gw0[4], gw1[4];
+            for (int r = 0; r < 4; ++r) gwv[r] = rc_ld<PS>(&tp.rcgw[(size_t)min(b0 + q * 4 + r, B - 1) * R + col]);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const size_t ro = (size_t)min(b0 + q * 4 + r, B - 1) * R;
-                gw0[r] = rc_ld<PS>(&tp.rcgw[ro + tn0 * 16 + i]); gw1[r] = rc_ld<PS>(&tp.rcgw[ro + tn1 * 16 + i]);
-            }
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (u < kg) {
-                    const float4 a = *reinterpret_cast<const float4*>(&s_dbar[i][u * 16 + q * 4]);
-                    acc0 = mfma16(a.x, bq0[u].x, acc0); acc0 = mfma16(a.y, bq0[u].y, acc0);
-                    acc0 = mfma16(a.z, bq0[u].z, acc0); acc0 = mfma16(a.w, bq0[u].w, acc0);
-                    acc1 = mfma16(a.x, bq1[u].x, acc1); acc1 = mfma16(a.y, bq1[u].y, acc1);
-                    acc1 = mfma16(a.z, bq1[u].z, acc1); acc1 = mfma16(a.w, bq1[u].w, acc1);
-                }
-            }
+            for (int sk = 0; sk < 8; ++sk) if (sk < ks) acc = mfma16(s_y[i][4 * sk + q], s_Dd[4 * sk + q][col], acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int mm = q * 4 + r;
-                const float gv0 = ftanh(gw0[r] + acc0[r]);
-                s_g[mm][tn0 * 16 + i] = gv0;
-                if (jw == 0 && s_live2[mm] != 0.f) tp.g[(rowb + b0 + mm) * R + tn0 * 16 + i] = gv0;
-                if (has1) {
-                    const float gv1 = ftanh(gw1[r] + acc1[r]);
-                    s_g[mm][tn1 * 16 + i] = gv1;
-                    if (jw == 0 && s_live2[mm] != 0.f) tp.g[(rowb + b0 + mm) * R + tn1 * 16 + i] = gv1;
-                }
+                const float gv = ftanh(gwv[r] + acc[r]);
+                s_g[mm][col] = gv;
+                if (jw == 0 && s_live2[mm] != 0.f) tp.g[(rowb + b0 + mm) * R + col] = gv;
             }
         }
     }
@@ -492,7 +523,7 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
 #pragma unroll
         for (int u = 0; u < RC_MAXG; ++u) ag.v[u] = *reinterpret_cast<const float4*>(&s_g[i][min(gm0 + u, kgr - 1) * 16 + q * 4]);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 a0 = rc_mma(ag, ww, nm, z4);
+        const f32x4 a0 = rc_mma(ag, w.ww, nm, z4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = a0[r];
     }
@@ -519,7 +550,8 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
 __global__ __launch_bounds__(256) void k_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
     if (skip && tp.alive[t] == 0) return;
     const int NJW = dm.W >> 4;
-    rc_query_body<false>(dm, P, tp, ar, t, blockIdx.x / NJW, blockIdx.x % NJW);
+    rc_query_body<false>(dm, P, tp, ar, t, blockIdx.x / NJW, blockIdx.x % NJW, 0);
+    if (blockIdx.x % NJW == 0) { __syncthreads(); rc_query_body<false>(dm, P, tp, ar, t, blockIdx.x / NJW, 0, 1); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -568,6 +600,15 @@ __global__ __launch_bounds__(256) void k_rc_tail(Dims dm, Params P, Tape tp, Con
 // (S2 -> RC), 3 h_{t+1} out, 4 partial logits / w_h h / stop masks out, 5 the tile's conversations are over.
 // ---------------------------------------------------------------------------------------------
 #define RC_MAXTILES 40
+#ifndef RC_RES_HEADS
+#define RC_RES_HEADS 0          // 1: the heads' two weight fragments stay in registers across steps (with the GRU's 24: spills)
+#endif
+#ifndef RC_RES_GRU
+#define RC_RES_GRU 0          // 1: the GRU's 24 weight fragments as explicit registers across steps -- hipcc then spills them to scratch (816 B) instead of AGPRs
+#endif
+#ifndef RC_RES_QUERY
+#define RC_RES_QUERY 0
+#endif
 __device__ __forceinline__ uint32_t* rc_ctr(const Tape& tp, int kind, int tile) { return tp.pflags + ((size_t)kind * RC_MAXTILES + tile) * 64; }
 
 __device__ __forceinline__ void rc_s1_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int sidx, const int nrc) {
@@ -704,13 +745,23 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
     uint32_t* cY = rc_ctr(tp, 4, tile); uint32_t* done = rc_ctr(tp, 5, tile);
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
     bool whole = true;
+    RcGruW wgru; RcHeadsW wheads; RcQueryW wquery;                      // step-invariant operands: in registers for the whole conversation
+    rc_gru_w(wgru, dm, P, min(k, NJ - 1)); rc_query_w(wquery, dm, P, min(k, NJW - 1));
+    {
+        const int jj = min(k, NJ - 1), lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+        int g0, n;
+        rc_share(dm.R, threadIdx.x >> 6, g0, n);
+        rc_load(wheads.wa, P.p[R_Y1_W] + (size_t)(16 * jj + i) * (dm.R + dm.V), dm.R, g0, q);
+        rc_load(wheads.wg, P.p[R_WH_W] + (size_t)(16 * jj + i) * dm.R, dm.R, g0, q);
+        wheads.bh = P.p[R_WH_B][16 * jj + (threadIdx.x & 15)]; wheads.bs = P.p[R_S_B][0];
+    }
     for (int t = 0; t < T; ++t) {
         const bool stamp = tile == 0 && t == 3 && (k == 0 || k == 5);
         const int so = (k == 0) ? 120 : 140;
         MMG_RSTAMP(stamp, so + 0);
         if (!pf_wait<false>(cZ, (uint32_t)(ns2 * (t + 1)), done, tp.sync)) return;
         MMG_RSTAMP(stamp, so + 1);
-        if (k < NJ) rc_gru_body<true>(dm, P, tp, ar, t, tile, k);
+        if (k < NJ) rc_gru_body<true>(dm, P, tp, ar, t, tile, k, RC_RES_GRU ? &wgru : nullptr);
         MMG_RSTAMP(stamp, so + 2);
         pf_signal(cH);
         MMG_RSTAMP(stamp, so + 3);
@@ -718,17 +769,20 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
         if (!pf_wait<false>(cH, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
         MMG_RSTAMP(stamp, so + 5);
         bool alive = true;
-        if (k < NJ) alive = rc_heads_body<true>(dm, P, tp, ar, t, tile, k);
+        if (k < NJ) alive = rc_heads_body<true>(dm, P, tp, ar, t, tile, k, RC_RES_HEADS ? &wheads : nullptr);
         MMG_RSTAMP(stamp, so + 6);
         pf_signal(cY);
         MMG_RSTAMP(stamp, so + 7);
         if (!pf_wait<false>(cY, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
         MMG_RSTAMP(stamp, so + 8);
-        if (k < NJW) rc_query_body<true>(dm, P, tp, ar, t, tile, k);
+        if (k < NJW) rc_query_body<true>(dm, P, tp, ar, t, tile, k, 0, RC_RES_QUERY ? &wquery : nullptr);
         MMG_RSTAMP(stamp, so + 9);
         pf_signal(cW);
         MMG_RSTAMP(stamp, so + 10);
-        if (k == 0) rc_gru_extras<true>(dm, tp, ar, t, tile);          // (while the sender roles work: rclw is double-buffered by step parity)
+        if (k == 0) {                                                   // (while the sender roles work: rclw is double-buffered by step parity)
+            rc_query_body<true>(dm, P, tp, ar, t, tile, 0, 1);
+            rc_gru_extras<true>(dm, tp, ar, t, tile);
+        }
         if (k == 0 && may_stop && !alive) {                            // every conversation of the tile has ended: the other roles stop at their next wait
             if (threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             whole = false;
@@ -749,7 +803,7 @@ __global__ __launch_bounds__(256) void k_diag_rc_s1(Dims dm, Params P, Tape tp, 
 __global__ __launch_bounds__(256) void k_diag_rc_s2(Dims dm, Params P, Tape tp, ConvArgs ar) { rc_s2_role(dm, P, tp, ar, blockIdx.x, 0, 16); }
 __global__ __launch_bounds__(256) void k_diag_rc_gru(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_gru_body<true>(dm, P, tp, ar, t, blockIdx.x, 0); }
 __global__ __launch_bounds__(256) void k_diag_rc_heads(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_heads_body<true>(dm, P, tp, ar, t, blockIdx.x, 0); }
-__global__ __launch_bounds__(256) void k_diag_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_query_body<true>(dm, P, tp, ar, t, blockIdx.x, 0); }
+__global__ __launch_bounds__(256) void k_diag_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_query_body<true>(dm, P, tp, ar, t, blockIdx.x, 0, 0); }
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -238,7 +238,7 @@ __host__ __device__ inline bool mc_shape(int H, int W, int R, int V, int D, int 
 // 256-bit message), beside the large sender / few samples of the per-step sender launches
 __host__ __device__ inline bool rc_shape(int B, int H, int W, int R, int V, int D) {
     return R > 128 && R <= 256 && !(R & 15) && !(W & 15) && W <= 256 && (B + 15) / 16 < 64 && (long long)H * W >= 65536 &&
-           D <= 64 && V <= 128 && !(V & 3) && !(H & 3);
+           D <= 32 && V <= 128 && !(V & 3) && !(H & 3);
 }
 
 __host__ __device__ inline int dc_slices(int B) { return B >= 1024 ? 4 : 1; }
