@@ -110,7 +110,7 @@ __device__ __forceinline__ void rc_gru_w(RcGruW& w, const Dims& dm, const Params
 // PS = false: returns early (false) when the tile's conversations are over; PS = true: always runs through (its signals must go out)
 template <bool PS>
 __device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int j,
-                                            const RcGruW* pw = nullptr) {
+                                            const RcGruW& w) {
     __shared__ float s_acc[6][4][16][17];
     __shared__ float s_live[16];
     const int B = dm.B, W = dm.W, R = dm.R;
@@ -124,9 +124,6 @@ __device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, con
     // operands of the epilogue (biases, h_{t-1} of this thread's unit): in flight with the product's operands
     const int m = tid >> 4, c = tid & 15, unit_e = 16 * j + c, b = min(b0 + m, B - 1);
     const float hprev = (t > 0) ? rc_ld<PS>(&tp.h[(rowb + b) * R + unit_e]) : 0.f;
-    RcGruW wl;
-    if (!pw) rc_gru_w(wl, dm, P, j);
-    const RcGruW& w = pw ? *pw : wl;
     const float bir = w.bir, biu = w.biu, bin_ = w.bin_, bhr = w.bhr, bhu = w.bhu, bhn = w.bhn;
     {
         const int bx = min(b0 + i, B - 1);
@@ -202,7 +199,9 @@ __device__ __forceinline__ void rc_gru_extras(const Dims& dm, const Tape& tp, co
 __global__ __launch_bounds__(256) void k_rc_gru(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
     if (skip && tp.alive[t] == 0) return;
     const int NJ = dm.R >> 4;
-    if (rc_gru_body<false>(dm, P, tp, ar, t, blockIdx.x / NJ, blockIdx.x % NJ) && blockIdx.x % NJ == 0)
+    RcGruW w;
+    rc_gru_w(w, dm, P, blockIdx.x % NJ);
+    if (rc_gru_body<false>(dm, P, tp, ar, t, blockIdx.x / NJ, blockIdx.x % NJ, w) && blockIdx.x % NJ == 0)
         rc_gru_extras<false>(dm, tp, ar, t, blockIdx.x / NJ);
 }
 
@@ -236,7 +235,7 @@ __device__ __forceinline__ void rc_heads_w(RcHeadsW& w, const Dims& dm, const Pa
 // returns (role 0 only; true elsewhere): a sample of the tile goes on after this step
 template <bool PS>
 __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int j,
-                                              const RcHeadsW* pw = nullptr) {
+                                              const RcHeadsW& w) {
     __shared__ float s_acc[2][4][16][17];
     __shared__ __attribute__((aligned(16))) float s_A[16][20];
     __shared__ float s_live[16], s_mn[16];
@@ -256,9 +255,6 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
     rc_share(R, wave, g0, n);
     RcFrag ah;
     rc_load_act<PS>(ah, tp.h + (rowh + bx) * R, R, g0, q);
-    RcHeadsW w;
-    rc_heads_w(w, dm, P, tp, j, pw == nullptr);
-    if (pw) { w.wa = pw->wa; w.wg = pw->wg; w.bh = pw->bh; w.bs = pw->bs; }
     const float bh = w.bh;
     const float4 wq0 = w.wq[0], wq1 = w.wq[1], wq2 = w.wq[2], wq3 = w.wq[3];
     float4 hq[4];                                                       // role 0: h_{t+1} of sample m, 16 lanes x 4 floats x 4
@@ -314,12 +310,12 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int d = c + 16 * e;
-            if (d < D && m < nb) rc_st<PS>(&tp.rcyp[((size_t)j * B + b0 + m) * D + d], part(w.cq[e][0], w.cq[e][1], w.cq[e][2], w.cq[e][3]));
+            if (d < D && m < nb) rc_st<PS>(&tp.rcyp[((size_t)(b0 + m) * D + d) * 16 + j], part(w.cq[e][0], w.cq[e][1], w.cq[e][2], w.cq[e][3]));
         }
         for (int d = c + 32; d < D; d += 16) {                          // (more than 32 classes: rows fetched here)
             const float4* c4 = reinterpret_cast<const float4*>(tp.Cd + (size_t)d * R + 16 * j);
             const float4 c0 = c4[0], c1 = c4[1], c2 = c4[2], c3 = c4[3];
-            if (m < nb) rc_st<PS>(&tp.rcyp[((size_t)j * B + b0 + m) * D + d], part(c0, c1, c2, c3));
+            if (m < nb) rc_st<PS>(&tp.rcyp[((size_t)(b0 + m) * D + d) * 16 + j], part(c0, c1, c2, c3));
         }
     }
     if (j != 0) return true;
@@ -373,7 +369,9 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
 __global__ __launch_bounds__(256) void k_rc_heads(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
     if (skip && tp.alive[t] == 0) return;
     const int NJ = dm.R >> 4;
-    rc_heads_body<false>(dm, P, tp, ar, t, blockIdx.x / NJ, blockIdx.x % NJ);
+    RcHeadsW w;
+    rc_heads_w(w, dm, P, tp, blockIdx.x % NJ, true);
+    rc_heads_body<false>(dm, P, tp, ar, t, blockIdx.x / NJ, blockIdx.x % NJ, w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -391,7 +389,7 @@ __device__ __forceinline__ void rc_query_w(RcQueryW& w, const Dims& dm, const Pa
 }
 template <bool PS>
 __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int t, const int tile, const int jw, const int part,
-                                              const RcQueryW* pw = nullptr) {
+                                              const RcQueryW& w) {
     __shared__ __attribute__((aligned(16))) float s_y[16][68];
     __shared__ __attribute__((aligned(16))) float s_g[16][260];
     __shared__ __attribute__((aligned(16))) float s_Dd[32][260];         // read once per launch (PS) instead of once per step
@@ -433,18 +431,20 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
         f_next = may_stop ? rc_ld<PS>(&tp.rcst[(size_t)((t + 1) & 1) * B + bb]) : 1.f;
         f_take = (tid < nb) ? rc_ld<PS>(&tp.rcst[(size_t)2 * B + bb]) : 0.f;
     }
-    float pv[2][16];                                                    // thread (m, d = c) and (m, d = c + 16): the partials of its first two classes
+    float4 pv[2][4];                                                    // thread (m, d = c) and (m, d = c + 16): the 16 slice partials of its first two classes
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int d = min(c + 16 * e, D - 1);
+        const float* yp = tp.rcyp + ((size_t)b * D + min(c + 16 * e, D - 1)) * 16;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pv[e][u] = rc_ld<PS>(&tp.rcyp[((size_t)min(u, NJ - 1) * B + b) * D + d]);
+        for (int u = 0; u < 4; ++u) pv[e][u] = rc_ld4<PS>(yp + 4 * u);
     }
+    float gwa[4][4];                                                    // w_h h + b_h of this wave's (at most four: R <= 256) 16-column tiles of h_w
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gwa[u][r] = rc_ld<PS>(&tp.rcgw[(size_t)min(b0 + q * 4 + r, B - 1) * R + min(wave + 4 * u, NJ - 1) * 16 + i]);
     int gm0, nm;
     rc_share(R, wave, gm0, nm);
-    RcQueryW wl;
-    if (!pw) rc_query_w(wl, dm, P, jw);
-    const RcQueryW& w = pw ? *pw : wl;
     const float bw = w.bw, b2 = w.b2;
     float u_w = 0.f;
     if (binary && train)
@@ -466,13 +466,14 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
     MMG_RSTAMP(PS && tile == 0 && jw == 0 && t == 3, 170);
     for (int d = c, e = 0; d < D; d += 16, ++e) {
         float acc = 0.f;
-        float pw_[16];
-        if (e >= 2) {
+        float4 pq[4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) pw_[u] = rc_ld<PS>(&tp.rcyp[((size_t)min(u, NJ - 1) * B + b) * D + d]);
+        for (int u = 0; u < 4; ++u) pq[u] = (e == 0) ? pv[0][u] : pv[1][u];         // (D <= 32: two classes per thread)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                                   // slice order
+            acc += (4 * u < NJ) ? pq[u].x : 0.f; acc += (4 * u + 1 < NJ) ? pq[u].y : 0.f;
+            acc += (4 * u + 2 < NJ) ? pq[u].z : 0.f; acc += (4 * u + 3 < NJ) ? pq[u].w : 0.f;
         }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc += (u < NJ) ? (e == 0 ? pv[0][u] : (e == 1 ? pv[1][u] : pw_[u])) : 0.f;
         const float yv = acc + b2;
         s_y[m][d] = yv;
         if (jw == 0 && m < nb) {
@@ -497,11 +498,14 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
     //      in LDS (K = D in steps of 4), the 16-column tiles round-robin over the waves
     {
         const int ks = (D + 3) >> 2;
-        for (int tn = wave; tn < NJ; tn += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tn = wave + 4 * u;
+            if (tn >= NJ) break;
             const int col = tn * 16 + i;
             float gwv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gwv[r] = rc_ld<PS>(&tp.rcgw[(size_t)min(b0 + q * 4 + r, B - 1) * R + col]);
+            for (int r = 0; r < 4; ++r) gwv[r] = gwa[u][r];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int sk = 0; sk < 8; ++sk) if (sk < ks) acc = mfma16(s_y[i][4 * sk + q], s_Dd[4 * sk + q][col], acc);
@@ -550,8 +554,10 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
 __global__ __launch_bounds__(256) void k_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar, int t, int skip) {
     if (skip && tp.alive[t] == 0) return;
     const int NJW = dm.W >> 4;
-    rc_query_body<false>(dm, P, tp, ar, t, blockIdx.x / NJW, blockIdx.x % NJW, 0);
-    if (blockIdx.x % NJW == 0) { __syncthreads(); rc_query_body<false>(dm, P, tp, ar, t, blockIdx.x / NJW, 0, 1); }
+    RcQueryW w;
+    rc_query_w(w, dm, P, blockIdx.x % NJW);
+    rc_query_body<false>(dm, P, tp, ar, t, blockIdx.x / NJW, blockIdx.x % NJW, 0, w);
+    if (blockIdx.x % NJW == 0) { __syncthreads(); rc_query_body<false>(dm, P, tp, ar, t, blockIdx.x / NJW, 0, 1, w); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -745,42 +751,38 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
     uint32_t* cY = rc_ctr(tp, 4, tile); uint32_t* done = rc_ctr(tp, 5, tile);
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
     bool whole = true;
-    RcGruW wgru; RcHeadsW wheads; RcQueryW wquery;                      // step-invariant operands: in registers for the whole conversation
-    rc_gru_w(wgru, dm, P, min(k, NJ - 1)); rc_query_w(wquery, dm, P, min(k, NJW - 1));
-    {
-        const int jj = min(k, NJ - 1), lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-        int g0, n;
-        rc_share(dm.R, threadIdx.x >> 6, g0, n);
-        rc_load(wheads.wa, P.p[R_Y1_W] + (size_t)(16 * jj + i) * (dm.R + dm.V), dm.R, g0, q);
-        rc_load(wheads.wg, P.p[R_WH_W] + (size_t)(16 * jj + i) * dm.R, dm.R, g0, q);
-        wheads.bh = P.p[R_WH_B][16 * jj + (threadIdx.x & 15)]; wheads.bs = P.p[R_S_B][0];
-    }
+    // The weight fragments of a phase are requested right BEFORE the phase's wait: they arrive while the role polls, and the phase
+    // then pays the payload's round trip only.  (Keeping all of them in registers across the whole step loop spills: RC_RES_GRU.)
     for (int t = 0; t < T; ++t) {
+        RcGruW wgru; RcHeadsW wheads; RcQueryW wquery;
+        rc_gru_w(wgru, dm, P, min(k, NJ - 1));
         const bool stamp = tile == 0 && t == 3 && (k == 0 || k == 5);
         const int so = (k == 0) ? 120 : 140;
         MMG_RSTAMP(stamp, so + 0);
         if (!pf_wait<false>(cZ, (uint32_t)(ns2 * (t + 1)), done, tp.sync)) return;
         MMG_RSTAMP(stamp, so + 1);
-        if (k < NJ) rc_gru_body<true>(dm, P, tp, ar, t, tile, k, RC_RES_GRU ? &wgru : nullptr);
+        if (k < NJ) rc_gru_body<true>(dm, P, tp, ar, t, tile, k, wgru);
         MMG_RSTAMP(stamp, so + 2);
         pf_signal(cH);
         MMG_RSTAMP(stamp, so + 3);
+        rc_heads_w(wheads, dm, P, tp, min(k, NJ - 1), true);
         MMG_RSTAMP(stamp, so + 4);
         if (!pf_wait<false>(cH, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
         MMG_RSTAMP(stamp, so + 5);
         bool alive = true;
-        if (k < NJ) alive = rc_heads_body<true>(dm, P, tp, ar, t, tile, k, RC_RES_HEADS ? &wheads : nullptr);
+        if (k < NJ) alive = rc_heads_body<true>(dm, P, tp, ar, t, tile, k, wheads);
         MMG_RSTAMP(stamp, so + 6);
         pf_signal(cY);
+        rc_query_w(wquery, dm, P, min(k, NJW - 1));
         MMG_RSTAMP(stamp, so + 7);
         if (!pf_wait<false>(cY, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
         MMG_RSTAMP(stamp, so + 8);
-        if (k < NJW) rc_query_body<true>(dm, P, tp, ar, t, tile, k, 0, RC_RES_QUERY ? &wquery : nullptr);
+        if (k < NJW) rc_query_body<true>(dm, P, tp, ar, t, tile, k, 0, wquery);
         MMG_RSTAMP(stamp, so + 9);
         pf_signal(cW);
         MMG_RSTAMP(stamp, so + 10);
         if (k == 0) {                                                   // (while the sender roles work: rclw is double-buffered by step parity)
-            rc_query_body<true>(dm, P, tp, ar, t, tile, 0, 1);
+            rc_query_body<true>(dm, P, tp, ar, t, tile, 0, 1, wquery);
             rc_gru_extras<true>(dm, tp, ar, t, tile);
         }
         if (k == 0 && may_stop && !alive) {                            // every conversation of the tile has ended: the other roles stop at their next wait
@@ -801,9 +803,9 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
 // so that register counts and spills can be attributed
 __global__ __launch_bounds__(256) void k_diag_rc_s1(Dims dm, Params P, Tape tp, ConvArgs ar) { rc_s1_role(dm, P, tp, ar, blockIdx.x, 0, 16); }
 __global__ __launch_bounds__(256) void k_diag_rc_s2(Dims dm, Params P, Tape tp, ConvArgs ar) { rc_s2_role(dm, P, tp, ar, blockIdx.x, 0, 16); }
-__global__ __launch_bounds__(256) void k_diag_rc_gru(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_gru_body<true>(dm, P, tp, ar, t, blockIdx.x, 0); }
-__global__ __launch_bounds__(256) void k_diag_rc_heads(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_heads_body<true>(dm, P, tp, ar, t, blockIdx.x, 0); }
-__global__ __launch_bounds__(256) void k_diag_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar) { for (int t = 0; t < dm.T; ++t) rc_query_body<true>(dm, P, tp, ar, t, blockIdx.x, 0, 0); }
+__global__ __launch_bounds__(256) void k_diag_rc_gru(Dims dm, Params P, Tape tp, ConvArgs ar) { RcGruW w; rc_gru_w(w, dm, P, 0); for (int t = 0; t < dm.T; ++t) rc_gru_body<true>(dm, P, tp, ar, t, blockIdx.x, 0, w); }
+__global__ __launch_bounds__(256) void k_diag_rc_heads(Dims dm, Params P, Tape tp, ConvArgs ar) { RcHeadsW w; rc_heads_w(w, dm, P, tp, 0, true); for (int t = 0; t < dm.T; ++t) rc_heads_body<true>(dm, P, tp, ar, t, blockIdx.x, 0, w); }
+__global__ __launch_bounds__(256) void k_diag_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar) { RcQueryW w; rc_query_w(w, dm, P, 0); for (int t = 0; t < dm.T; ++t) rc_query_body<true>(dm, P, tp, ar, t, blockIdx.x, 0, 0, w); }
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -96,7 +96,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(gip, float, 0, 3, NS2P, B, 3 * R)  /* per-sender-role partials of the GRU input product (k_conv_persist)           */ \
     X(zpart, float, 0, 3, NZP, 16, W)    /* per-SA-role partial message logits of a tile (k_conv_persist, fused sender roles) */ \
     X(rcgw, float, 0, 2, NRCB, R, 1)     /* wide receiver (kernels_rc.h): w_h h + b_h of the step, written per 16-unit slice by k_rc_heads */ \
-    X(rcyp, float, 0, 3, NRCJ, NRCB, D)  /* ... per-slice partial class logits [R/16][B][D], added in slice order by k_rc_query              */ \
+    X(rcyp, float, 0, 3, NRCB, D, 16)    /* ... per-slice partial class logits [B][D][16 slices], added in slice order by k_rc_query          */ \
     X(rclw, float, 0, 3, 2 * NRCW, NRCB, 2)  /* ... per-16-bit-slice partial (log-likelihood, neg-entropy) of the receiver's message            */ \
     X(rcdam, float, 0, 2, NRCB, R, 1)    /* ... backward: dA W_y1h of the output step (k_bwd_tile's prelude -> k_rc_bwd)                                */ \
     X(rcx, float, 0, 3, NRCX, 16, 3 * R) /* ... backward: the tile's gate gradients dgh_t, double-buffered by step parity (all-gather between k_rc_bwd's roles) */ \
