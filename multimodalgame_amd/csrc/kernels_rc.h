@@ -498,6 +498,14 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
     //      in LDS (K = D in steps of 4), the 16-column tiles round-robin over the waves
     {
         const int ks = (D + 3) >> 2;
+        // (every LDS operand of the four products is read before the first MFMA: one LDS round trip, not one per MFMA)
+        float av[8], bv[4][8];
+#pragma unroll
+        for (int sk = 0; sk < 8; ++sk) av[sk] = s_y[i][4 * sk + q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int sk = 0; sk < 8; ++sk) bv[u][sk] = s_Dd[4 * sk + q][min(wave + 4 * u, NJ - 1) * 16 + i];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int tn = wave + 4 * u;
@@ -508,7 +516,7 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
             for (int r = 0; r < 4; ++r) gwv[r] = gwa[u][r];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int sk = 0; sk < 8; ++sk) if (sk < ks) acc = mfma16(s_y[i][4 * sk + q], s_Dd[4 * sk + q][col], acc);
+            for (int sk = 0; sk < 8; ++sk) if (sk < ks) acc = mfma16(av[sk], bv[u][sk], acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int mm = q * 4 + r;
