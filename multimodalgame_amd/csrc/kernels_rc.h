@@ -824,7 +824,7 @@ __global__ __launch_bounds__(256) void k_diag_rc_query(Dims dm, Params P, Tape t
 // (model.py:340) and publishes its slice of dgh_t.  The output-step prelude (dy, h*, A*, dA, dA W_y1h) stays k_bwd_tile's
 // (make_map & 2), which also zeroes the tile's counter.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, int zero_dead) {
+__global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, int zero_dead, int pre_bands) {
     __shared__ float s_acc[4][16][17];
     const int B = dm.B, R = dm.R, T = dm.T, NJ = R >> 4, R3 = 3 * R;
     const int tile = blockIdx.x / NJ, j = blockIdx.x - tile * NJ;
@@ -854,7 +854,14 @@ __global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, int 
         const float* gr = tp.gru + (rowb + b) * 4 * R;
         const float rr = gr[unit], uu = gr[R + unit], nn = gr[2 * R + unit], ghn = gr[3 * R + unit];
         const float fh = tp.h[(rowb + b) * R + unit];
-        const float fin = binary ? tp.dhin[(rowb + b) * R + unit] : 0.f;
+        float fin = 0.f;                                                // (k_bwd_pre's column bands: partial products, added in band order)
+        if (binary) {
+            float fp[4];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) fp[pb] = tp.dhin[((size_t)min(pb, pre_bands - 1) * T * B + rowb + b) * R + unit];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) fin += (pb < pre_bands) ? fp[pb] : 0.f;
+        }
         float prod = 0.f;
         if (have) {
             if (!pf_wait<false>(ctr, (uint32_t)(NJ * step), nullptr, tp.sync)) return;

@@ -2371,8 +2371,14 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
 // grid = T x ceil(B/16): a workgroup owns 16 samples of one step.  Rows of steps a sample never took: skipped (live-row
 // contract) or zero-filled (zero_dead).
 // ---------------------------------------------------------------------------------------------
+// staging area of bwd_pre_body's two products: [k-parts][16][ld16(N)] with N = R, or -- column bands (pre_bands = 4 at R = 256:
+// a 64-column band of dgpre per workgroup) -- N = 64 in four k-parts
+__host__ __device__ inline int bwd_pre_raw_floats(int R, int nw) {
+    const int a = tile_raw_floats_nn(R, nw), b = tile_raw_floats_nn(64, nw);
+    return a > b ? a : b;
+}
 __host__ __device__ inline int bwd_pre_lds_floats(const Dims& d) {
-    return MMG_TM * ld16(d.W) + MMG_TM * ld16(d.R) + tile_raw_floats_nn(d.R, MMG_BLOCK / 64) + 7 * 64 + 64 + ld16(d.R);
+    return MMG_TM * ld16(d.W) + MMG_TM * ld16(d.R) + bwd_pre_raw_floats(d.R, MMG_BLOCK / 64) + 7 * 64 + 64 + ld16(d.R);
 }
 // weight fragment of an "NN" product with N <= 64 output columns, loaded ahead of its use: wave w owns k-part w (all four
 // n-tiles), lane (i, q) holds float4 Bm[16 kg + 4 q + c][4 i ..] for its <= MAXKG k-groups (tgemm_nn_body's layout)
@@ -2419,8 +2425,13 @@ __device__ __forceinline__ void nfrag_mma(const NFrag<MAXKG>& f, const float* A,
 }
 
 // UR: g values a thread holds per step: 16 * R <= UR * NT (host: 8 up to R = 128, 16 up to R = 256)
+// pre_bands > 1 (wide receivers, R = 256: each product streams 256 KB per workgroup otherwise): the workgroup of (step, tile) is
+// split over column bands of dgpre -- band c forms dgpre[:, band] = (dlw W_w[:, band])(1 - g^2) and the PARTIAL product
+// dgpre[:, band] W_h[band, :] into tape.dhin[band] (band 0 adds dls w_s); k_rc_bwd adds the partials
 template <int UR>
-__device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, const Tape& tp, const int zero_dead, const int blk) {
+__device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, const Tape& tp, const int zero_dead, const int blk_in, const int pre_bands = 1) {
+    const int band = blk_in % pre_bands, blk = blk_in / pre_bands;
+    const int Rb = dm.R / pre_bands, c0 = band * Rb;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = MMG_BLOCK, nw = NT / 64;
     const int B = dm.B, W = dm.W, R = dm.R, T = dm.T;
@@ -2428,7 +2439,7 @@ __device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, co
     const int tiles = (B + MMG_TM - 1) / MMG_TM;
     const int t = blk / tiles, b0 = (blk - t * tiles) * MMG_TM, nb = min(MMG_TM, B - b0);
     float* s_dlw = smem; float* s_dgp = s_dlw + MMG_TM * ldW; float* raw = s_dgp + MMG_TM * ldR;
-    float* s_coef = raw + tile_raw_floats_nn(R, nw); float* misc = s_coef + 7 * 64; float* s_ws = misc + 64;
+    float* s_coef = raw + bwd_pre_raw_floats(R, nw); float* misc = s_coef + 7 * 64; float* s_ws = misc + 64;
     // misc: [0,16) t*   [16,32) reward L   [32,48) baseline_rec score of the row   [48,64) dls
     LossCoef lc; lc.cw = s_coef; lc.ce = s_coef + 3 * T; lc.cb = s_coef + 6 * T;
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -2478,7 +2489,7 @@ __device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, co
             dbs = lc.cb[t] * (r_bs - Lr); dbr = lc.cb[t] * (r_br - Lr);          // MSE seeds, model.py:971-988
         }
         misc[32 + m] = r_br; misc[48 + m] = dls;
-        if (m < nb && (live || zero_dead)) { tp.dls[rowb + b0 + m] = dls; tp.dbs[rowb + b0 + m] = dbs; tp.dbr[rowb + b0 + m] = dbr; }
+        if (band == 0 && m < nb && (live || zero_dead)) { tp.dls[rowb + b0 + m] = dls; tp.dbs[rowb + b0 + m] = dbs; tp.dbr[rowb + b0 + m] = dbr; }
     }
     __syncthreads();
     // seeds of the receiver-message stream (active while m_{t+1} == 1, i.e. t < t*)
@@ -2490,10 +2501,38 @@ __device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, co
             const bool act = (float)t < misc[m];
             const float sv = act ? bit_seed_fast(rw[u].x, rw[u].y, (misc[16 + m] - misc[32 + m]) * lc.cw[T + t], lc.ce[T + t]) : 0.f;
             s_dlw[m * ldW + j] = sv;
-            if (m < nb && (zero_dead || (float)t <= misc[m])) tp.dlw[(rowb + b0 + m) * W + j] = sv;
+            if (band == 0 && m < nb && (zero_dead || (float)t <= misc[m])) tp.dlw[(rowb + b0 + m) * W + j] = sv;
         }
     }
     __syncthreads();
+    if (pre_bands > 1) {
+        tgemm_nn_raw(s_dlw, ldW, P.p[R_W_W] + c0, R, Rb, W, raw, wave, nw);   // dg[:, band] = dlw W_w[:, band]
+        __syncthreads();
+        const int kpb = tile_kparts((Rb + 63) >> 6, nw), ldb = ld16(Rb);
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int idx = tid + u * NT;
+            if (idx < MMG_TM * R) {
+                const int m = idx / R, r = idx - m * R;
+                if (r >= c0 && r < c0 + Rb) {
+                    const bool act = (float)t < misc[m];
+                    const float v = act ? raw_sum(raw, ldb, kpb, m, r - c0) * (1.f - rg[u] * rg[u]) : 0.f;
+                    s_dgp[m * ldR + r] = v;
+                    if (m < nb && (zero_dead || (float)t <= misc[m])) tp.dgpre[(rowb + b0 + m) * R + r] = v;
+                }
+            }
+        }
+        __syncthreads();
+        tgemm_nn_raw(s_dgp + c0, ldR, P.p[R_WH_W] + (size_t)c0 * R, R, R, Rb, raw, wave, nw);      // dgpre[:, band] W_h[band, :]
+        __syncthreads();
+        const int kp2 = tile_kparts((R + 63) >> 6, nw);
+        float* dhin = tp.dhin + (size_t)band * T * B * R;
+        for (int idx = tid; idx < MMG_TM * R; idx += NT) {
+            const int m = idx / R, i = idx - m * R;
+            if (m < nb && (float)t <= misc[m]) dhin[(rowb + b0 + m) * R + i] = raw_sum(raw, ldR, kp2, m, i) + (band == 0 ? misc[48 + m] * s_ws[i] : 0.f);
+        }
+        return;
+    }
     if (fr1) nfrag_mma<4>(fw, s_dlw, ldW, raw, ldR);                          // dg = dlw W_w
     else tgemm_nn_raw(s_dlw, ldW, P.p[R_W_W], R, R, W, raw, wave, nw);
     __syncthreads();
@@ -2528,9 +2567,9 @@ __device__ __forceinline__ void send_bwd_body(const Dims& dm, const Params& P, c
 // on the other, both are "statistics -> seeds -> one or two products" latency chains of ~20 us -- side by side instead of
 // one after the other.  Blocks [0, npre): bwd_pre_body; then nbands blocks per 16-row block: send_bwd_body.
 template <int UR>
-__global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre_send(Dims dm, Params P, Tape tp, int zero_dead, int npre, int nbands) {
+__global__ __launch_bounds__(MMG_BLOCK) void k_bwd_pre_send(Dims dm, Params P, Tape tp, int zero_dead, int npre, int nbands, int pre_bands) {
     const int blk = blockIdx.x;
-    if (blk < npre) { bwd_pre_body<UR>(dm, P, tp, zero_dead, blk); return; }
+    if (blk < npre) { bwd_pre_body<UR>(dm, P, tp, zero_dead, blk, pre_bands); return; }
     const int sb = blk - npre;
     send_bwd_body(dm, P, tp, nullptr, sb / nbands, sb % nbands);
 }

@@ -173,7 +173,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(dls, float, 0, 2, T, B, 1)         /* dL/d stop logit                        */ \
     X(dlw, float, 0, 3, T, B, W)         /* dL/d receiver message logits           */ \
     X(dgpre, float, 0, 3, T, B, R)       /* dL/d pre-tanh of h_w                   */ \
-    X(dhin, float, 0, 3, T, B, R)        /* dgpre W_h + dls w_s: what a step adds to dh besides the recurrence (k_bwd_pre) */ \
+    X(dhin, float, 0, 3, T * NRCP, B, R)        /* dgpre W_h + dls w_s: what a step adds to dh besides the recurrence (k_bwd_pre) */ \
     X(dgi, float, 0, 3, T, B, 3 * R)     /* dL/d GRU input-side gate pre-acts      */ \
     X(dgh, float, 0, 3, T, B, 3 * R)     /* dL/d GRU hidden-side gate pre-acts     */ \
     X(dA, float, 0, 2, B, R, 1)          /* dL/d (W_y1h h) at t*                   */ \
@@ -259,10 +259,11 @@ inline TapeLayout tape_layout(const mmg_config& c) {
                   NRCB = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? B : 1,
                   NRCJ = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? R / 16 : 1,
                   NRCX = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? 2 * ((B + 15) / 16) : 1,
+                  NRCP = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) && R == 256 ? 4 : 1,   /* column bands of k_bwd_pre's partial dhin */
                   NRCW = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? W / 16 : 1,
                   NMCB = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) && !c.use_binary ? 16 : 0,
                   NWP = wgrad_any_split((int)(T * B), param_layout(c).total) ? (int64_t)16 * (param_layout(c).total + 512 * 64) : 4;   /* (every job splits <= 16 ways) */
-    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX;
+    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX; (void)NRCP;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \

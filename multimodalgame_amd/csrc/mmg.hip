@@ -895,11 +895,13 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         {
             Scope sc(h, st, "k_bwd_tile");
             // the dh-independent part of the receiver's BPTT (seeds, dgpre, dhin) for all (step, sample) rows, then the recurrence
+            // wide receiver whose reverse-time loop runs as roles (k_rc_bwd adds the partials): four column bands per (step, tile)
+            const int pre_bands = (h->rc_fwd && h->rc_bwd && d.R == 256 && !getenv("MMG_NO_PRE_BANDS")) ? 4 : 1;
             if (d.use_binary && merged_send) {
                 const int nbands = (d.H + 63) / 64, nrb = (d.T * d.B + MMG_TM - 1) / MMG_TM;
                 const int smem = bwd_pre_lds_floats(d) * 4 > h->send_bwd_smem ? bwd_pre_lds_floats(d) * 4 : h->send_bwd_smem;
-                if (d.R <= 128) hipLaunchKernelGGL(k_bwd_pre_send<8>, dim3(d.T * tiles + nrb * nbands), dim3(MMG_BLOCK), smem, st, h->dm, h->P, h->tp, zero_dead, d.T * tiles, nbands);
-                else hipLaunchKernelGGL(k_bwd_pre_send<16>, dim3(d.T * tiles + nrb * nbands), dim3(MMG_BLOCK), smem, st, h->dm, h->P, h->tp, zero_dead, d.T * tiles, nbands);
+                if (d.R <= 128) hipLaunchKernelGGL(k_bwd_pre_send<8>, dim3(d.T * tiles + nrb * nbands), dim3(MMG_BLOCK), smem, st, h->dm, h->P, h->tp, zero_dead, d.T * tiles, nbands, 1);
+                else hipLaunchKernelGGL(k_bwd_pre_send<16>, dim3(d.T * tiles * pre_bands + nrb * nbands), dim3(MMG_BLOCK), smem, st, h->dm, h->P, h->tp, zero_dead, d.T * tiles * pre_bands, nbands, pre_bands);
             } else if (d.use_binary) {
                 if (d.R <= 128) hipLaunchKernelGGL(k_bwd_pre<8>, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
                 else hipLaunchKernelGGL(k_bwd_pre<16>, dim3(d.T * tiles), dim3(MMG_BLOCK), bwd_pre_lds_floats(d) * 4, st, h->dm, h->P, h->tp, zero_dead);
@@ -918,7 +920,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             else if (h->rc_fwd && h->rc_bwd) {
                 // wide receiver: k_bwd_tile's output-step prelude, then the reverse-time loop as roles over 16-unit slices (kernels_rc.h)
                 hipLaunchKernelGGL((k_bwd_tile<512, 8>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, (row_map ? 1 : 0) | 2);
-                hipLaunchKernelGGL(k_rc_bwd, dim3(tiles * (d.R / 16)), dim3(256), 0, st, h->dm, h->P, h->tp, zero_dead);
+                hipLaunchKernelGGL(k_rc_bwd, dim3(tiles * (d.R / 16)), dim3(256), 0, st, h->dm, h->P, h->tp, zero_dead, (d.use_binary && merged_send) ? pre_bands : 1);
             } else
                 hipLaunchKernelGGL((k_bwd_tile<512, 8>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             if (launch_check("k_bwd_tile")) return -1;
