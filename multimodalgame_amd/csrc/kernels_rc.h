@@ -601,6 +601,7 @@ __device__ __forceinline__ void rc_tail_body(const Dims& dm, const Tape& tp, con
 }
 __global__ __launch_bounds__(256) void k_rc_tail(Dims dm, Params P, Tape tp, ConvArgs ar) {
     rc_tail_body<false>(dm, tp, ar, blockIdx.x, true);
+    if (threadIdx.x == 0) tp.rcflags[(size_t)blockIdx.x * 64] = 0u;    // the backward roles' hand-off counter of the tile (k_rc_bwd)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -803,7 +804,10 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
     if (whole && !pf_wait<false>(cW, (uint32_t)(nrc * T), nullptr, tp.sync)) return;       // the last message's partial sums
     __syncthreads();
     rc_tail_body<true>(dm, tp, ar, tile, whole);
-    if (threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tp.rcflags[(size_t)tile * 64] = 0u;                             // the backward roles' hand-off counter of the tile (k_rc_bwd)
+    }
 }
 
 #ifdef MMG_ROLE_DIAG
@@ -824,8 +828,14 @@ __global__ __launch_bounds__(256) void k_diag_rc_query(Dims dm, Params P, Tape t
 // (model.py:340) and publishes its slice of dgh_t.  The output-step prelude (dy, h*, A*, dA, dA W_y1h) stays k_bwd_tile's
 // (make_map & 2), which also zeroes the tile's counter.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, int zero_dead, int pre_bands) {
+// prelude != 0: the output-step prelude runs HERE too, per 16-unit slice (k_bwd_tile is not launched): every role forms dy of the
+// tile (role 0 stores it), ITS 16 columns of A* = W_y1[:, :R] h* and of dA[m][r] = w_y2[r] sum_d dy[m][d] 1[A*[m][r] + Cd[d][r] > 0]
+// -- both local to the slice -- then the roles all-gather dA (hand-off 0) and each forms its columns of dA W_y1h (what enters dh at
+// the sample's output step).  The tile's counter is zeroed by the forward launch (k_rc_persist / k_rc_tail).  prelude & 2: role 0 of
+// tile 0 also lists the live (step, sample) rows for k_wgrad / k_send_bwd.
+__global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, const int64_t* __restrict__ target, int zero_dead, int pre_bands, int prelude) {
     __shared__ float s_acc[4][16][17];
+    __shared__ __attribute__((aligned(16))) float s_dy[16][36];
     const int B = dm.B, R = dm.R, T = dm.T, NJ = R >> 4, R3 = 3 * R;
     const int tile = blockIdx.x / NJ, j = blockIdx.x - tile * NJ;
     const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0), u0 = 16 * j;
@@ -836,7 +846,81 @@ __global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, int 
     int tmax = 0;
     for (int mm = 0; mm < nb; ++mm) tmax = max(tmax, tp.tstar[b0 + mm]);
     const int ts = (m < nb) ? tp.tstar[b] : -1;                         // padded rows: never live
-    const float dam = tp.rcdam[(size_t)b * R + unit];
+    float dam;
+    int step = 0;
+    if (prelude) {
+        const int D = dm.D, V = dm.V;
+        if ((prelude & 2) && blockIdx.x == 0 && tid < 64) build_row_map(dm, tp);        // live (step, sample) rows for k_wgrad / k_send_bwd
+        // ---- dNLL/d outp (model.py:1264-1275): thread (m, d = c), (m, c + 16)
+        for (int d = c; d < 32; d += 16) {
+            float dv = 0.f;
+            if (d < D && m < nb) {
+                dv = (tp.sm[(size_t)b * D + d] - (d == (int)target[b] ? 1.f : 0.f)) / (float)dm.Bg;
+                if (j == 0) { tp.dy[(size_t)b * D + d] = dv; tp.dyT[(size_t)d * B + b] = dv; }
+            }
+            s_dy[m][d] = dv;
+        }
+        // ---- A* slice: h* rows (h after the sample's output step) x the role's 16 rows of W_y1[:, :R]
+        {
+            const int bi = min(b0 + i, B - 1), tsi = max(tp.tstar[bi], 0);
+            int g0, n;
+            rc_share(R, wave, g0, n);
+            RcFrag ah, wa;
+            rc_load(ah, tp.h + ((size_t)(tsi + 1) * B + bi) * R, R, g0, q);
+            rc_load(wa, P.p[R_Y1_W] + (size_t)(u0 + i) * (R + V), R, g0, q);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 a0 = rc_mma(ah, wa, n, z4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = a0[r];
+        }
+        __syncthreads();
+        const float astar = (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]);
+        if (j == 0 && c == 0 && m < nb) {
+            float ds = 0.f;
+            for (int d = 0; d < D; ++d) ds += s_dy[m][d];
+            tp.dysum[b] = ds;
+        }
+        // ---- dA slice: class rows of Cd for this unit, all requested together (D <= 32)
+        float cv[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) cv[d] = tp.Cd[(size_t)min(d, D - 1) * R + unit];
+        float da = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) da += (d < D && astar + cv[d] > 0.f) ? s_dy[m][d] : 0.f;
+        da *= P.p[R_Y2_W][unit];
+        if (m < nb) {
+            const int tsm = max(ts, 0);
+            tp.hstar[(size_t)b * R + unit] = tp.h[((size_t)(tsm + 1) * B + b) * R + unit];
+            tp.Astar[(size_t)b * R + unit] = astar;
+            st_wt(&tp.dA[(size_t)b * R + unit], da);                    // (read back by the tile's other roles)
+        }
+        pf_signal(ctr); ++step;
+        // ---- this role's columns of dA W_y1h ("NN": W_y1 [out, in] IS [K, N]); its column fragments go out before the wait
+        int g0, n;
+        rc_share(R, wave, g0, n);
+        float4 wy[RC_MAXG];
+#pragma unroll
+        for (int u = 0; u < RC_MAXG; ++u) {
+            const float* w = P.p[R_Y1_W] + (size_t)(min(g0 + u, (R >> 4) - 1) * 16 + q * 4) * (R + V) + u0 + i;
+            wy[u] = make_float4(w[0], w[R + V], w[2 * (R + V)], w[3 * (R + V)]);
+        }
+        if (!pf_wait<false>(ctr, (uint32_t)(NJ * step), nullptr, tp.sync)) return;
+        RcFrag ad;
+        rc_load_act<true>(ad, tp.dA + (size_t)min(b0 + i, B - 1) * R, R, g0, q);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < RC_MAXG; ++u) {
+            if (u < n) {
+                acc = mfma16(ad.v[u].x, wy[u].x, acc); acc = mfma16(ad.v[u].y, wy[u].y, acc);
+                acc = mfma16(ad.v[u].z, wy[u].z, acc); acc = mfma16(ad.v[u].w, wy[u].w, acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_acc[wave][q * 4 + r][i] = acc[r];
+        __syncthreads();
+        dam = (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]);
+        __syncthreads();                                                // (s_acc is rewritten by the time loop)
+    } else dam = tp.rcdam[(size_t)b * R + unit];
     // this wave's K share of the role's 16 columns of W_hh ("NN" form: the PyTorch [out, in] matrix IS [K, N])
     const int kg = R3 >> 4, per = (kg + 3) >> 2, g0 = wave * per, n = max(0, min(kg, g0 + per) - g0);
     float4 wf[12];
@@ -847,7 +931,6 @@ __global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, int 
     }
     float carry = 0.f;
     bool have = false;
-    int step = 0;
     for (int t = zero_dead ? T - 1 : tmax; t >= 0; --t) {
         const size_t rowb = (size_t)t * B;
         // this step's forward tape (GRU gates, h_{t-1}) and dhin: in flight while the hand-off is awaited

@@ -2432,6 +2432,7 @@ template <int UR>
 __device__ __forceinline__ void bwd_pre_body(const Dims& dm, const Params& P, const Tape& tp, const int zero_dead, const int blk_in, const int pre_bands = 1) {
     const int band = blk_in % pre_bands, blk = blk_in / pre_bands;
     const int Rb = dm.R / pre_bands, c0 = band * Rb;
+    if (blk_in == 0 && threadIdx.x < 64) tp.rcflags[(size_t)threadIdx.x * 64] = 0u;       // hand-off counters of k_rc_bwd's roles (the launch after this one)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = MMG_BLOCK, nw = NT / 64;
     const int B = dm.B, W = dm.W, R = dm.R, T = dm.T;

@@ -919,8 +919,13 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
                 hipLaunchKernelGGL((k_bwd_tile<512, 4>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             else if (h->rc_fwd && h->rc_bwd) {
                 // wide receiver: k_bwd_tile's output-step prelude, then the reverse-time loop as roles over 16-unit slices (kernels_rc.h)
-                hipLaunchKernelGGL((k_bwd_tile<512, 8>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, (row_map ? 1 : 0) | 2);
-                hipLaunchKernelGGL(k_rc_bwd, dim3(tiles * (d.R / 16)), dim3(256), 0, st, h->dm, h->P, h->tp, zero_dead, (d.use_binary && merged_send) ? pre_bands : 1);
+                // (MMG_RC_TILE_PRELUDE=1: the prelude stays a launch of k_bwd_tile's, one workgroup per tile)
+                const bool tile_prelude = getenv("MMG_RC_TILE_PRELUDE") != nullptr;
+                if (!d.use_binary && !tile_prelude) hipMemsetAsync(h->tp.rcflags, 0, 64 * 64 * sizeof(uint32_t), st);   // (binary mode: zeroed by k_bwd_pre)
+                if (tile_prelude)
+                    hipLaunchKernelGGL((k_bwd_tile<512, 8>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, (row_map ? 1 : 0) | 2);
+                hipLaunchKernelGGL(k_rc_bwd, dim3(tiles * (d.R / 16)), dim3(256), 0, st, h->dm, h->P, h->tp, d_target, zero_dead,
+                                   (d.use_binary && merged_send) ? pre_bands : 1, tile_prelude ? 0 : (row_map ? 3 : 1));
             } else
                 hipLaunchKernelGGL((k_bwd_tile<512, 8>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, row_map ? 1 : 0);
             if (launch_check("k_bwd_tile")) return -1;

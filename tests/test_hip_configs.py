@@ -59,13 +59,15 @@ def test_config4_shape_vs_oracle(switch, monkeypatch):
     _compare_cached(_meta(C4, 30, 64, 2), skip=("y2.bias",), label="config4" + ("-" + switch if switch else ""), key="c4")
 
 
-@pytest.mark.parametrize("switch", [None, "MMG_NO_RC_PERSIST", "MMG_NO_RC_BWD"])
+@pytest.mark.parametrize("switch", [None, "MMG_NO_RC_PERSIST", "MMG_NO_RC_BWD", "MMG_RC_TILE_PRELUDE", "MMG_NO_PRE_BANDS"])
 def test_config4_with_rec_hidden_256_vs_oracle(switch, monkeypatch):
     """'rec_w_dim 256 / img_h_dim 1024 ... use R = 64 and additionally report R = 256'.  At R = 256 the
     one-workgroup-per-tile forward does not fit its LDS plan: the receiver of a tile is split over workgroups by 16-unit slices on
     the matrix cores (kernels_rc.h) -- one launch of co-resident roles (k_rc_persist), or with the switch k_rc_gru / k_rc_heads /
     k_rc_query between the per-step sender launches; the backward on the tile kernels, its reverse-time loop as roles over
-    16-unit slices (k_rc_bwd; MMG_NO_RC_BWD: inside k_bwd_tile); B = 64 as the bench times it."""
+    16-unit slices (k_rc_bwd, which also runs the output-step prelude per slice; MMG_RC_TILE_PRELUDE: the prelude as k_bwd_tile's
+    launch; MMG_NO_RC_BWD: all of it inside k_bwd_tile; MMG_NO_PRE_BANDS: k_bwd_pre without its column bands); B = 64 as the bench
+    times it."""
     if switch:
         monkeypatch.setenv(switch, "1")
     meta = _meta(dict(C4, rec_hidden=256, batch_size=64), 30, 64, 2)
@@ -75,6 +77,31 @@ def test_config4_with_rec_hidden_256_vs_oracle(switch, monkeypatch):
     common.assert_parity(got, want, flips, eng, "config4-R256", skip=("y2.bias",))
     names = _kernel_names(eng, meta)
     assert "k_conv_rc" in names and "k_bwd_tile" in names, names
+
+
+@pytest.mark.parametrize("flavour", ["fixed", "continuous", "ragged", "r192"])
+def test_wide_receiver_other_modes_vs_oracle(flavour):
+    """The wide-receiver kernels (kernels_rc.h) outside config 4's own mode: Fixed exchange (every row live, output at T - 1),
+    continuous messages (no sampling, receiver-only backward without k_bwd_pre), a ragged last tile (B = 24) and rec_hidden 192
+    (12 slices, three of the four waves hold a fourth k-group less)."""
+    kw = dict(C4, rec_hidden=256, batch_size=32)
+    B = 32
+    skip = ("y2.bias",)
+    if flavour == "fixed":
+        kw.update(fixed_exchange=True, max_exchange=4)
+    elif flavour == "continuous":
+        kw.update(use_binary=False, fixed_exchange=True, max_exchange=4)
+        skip = ("y2.bias", ".bs", ".br")
+    elif flavour == "ragged":
+        kw.update(batch_size=24); B = 24
+    else:
+        kw.update(rec_hidden=192)
+    meta = _meta(kw, 30, B, 2)
+    got, eng = common.hip_train_case(None, meta)
+    flips = []
+    want = common.oracle_train_case(None, meta, flips=flips)
+    common.assert_parity(got, want, flips, eng, "config4-wide-" + flavour, skip=skip)      # (config 4's 256-bit agents: RELATIVE_ALLOW's ulp gate on the six losses)
+    assert "k_conv_rc" in _kernel_names(eng, meta)
 
 
 def test_config4_with_rec_hidden_256_generic_fallback(monkeypatch):
