@@ -104,6 +104,43 @@ def test_wide_receiver_other_modes_vs_oracle(flavour):
     assert "k_conv_rc" in _kernel_names(eng, meta)
 
 
+def test_wide_receiver_eval_pass_agrees_with_generic_kernels(monkeypatch):
+    """Evaluation pass (train = False: rounded bits, running product of the stop probabilities) of the wide-receiver roles against
+    the generic per-sample kernels on the same weights and inputs.  Rounding sigmoid outputs near 0.5 may differ between two
+    correct fp32 summation orders and then changes everything downstream, so the comparison follows each sample up to its first
+    such near-tie: all probabilities within 1e-4, bits equal away from ties."""
+    meta = _meta(dict(C4, rec_hidden=256, batch_size=32), 30, 32, 1)
+    x, target, desc, _ = common.case_inputs(meta, 0)
+
+    def run():
+        eng = common.make_engine(meta)
+        dev = eng.device
+        eng.forward(torch.from_numpy(x).to(dev), torch.from_numpy(target).to(dev), torch.from_numpy(desc).to(dev), train=False, run_all=True)
+        torch.cuda.synchronize()
+        eng.check_sync()
+        return {k: v.cpu().numpy().copy() for k, v in eng.tape.items() if k in ("s", "ps", "z", "pz", "w", "pw", "y", "tstar", "dist")}
+    got = run()
+    monkeypatch.setenv("MMG_NO_RC", "1")
+    want = run()
+    T, B = got["ps"].shape[0], got["ps"].shape[1]
+    ok = np.ones(B, bool)                                # samples whose conversations are still tie-free
+    checked = 0
+    for t in range(T):
+        for pk, bk in (("pz", "z"), ("ps", "s")):
+            np.testing.assert_allclose(got[pk][t][ok], want[pk][t][ok], atol=1e-4, err_msg="%s[%d]" % (pk, t))
+            tie = (np.abs(want[pk][t].reshape(B, -1) - 0.5) < 2e-5).any(1)
+            ok &= ~tie
+            np.testing.assert_array_equal(got[bk][t][ok], want[bk][t][ok], err_msg="%s[%d]" % (bk, t))
+        np.testing.assert_allclose(got["y"][t][ok] - got["y"][t][ok].mean(-1, keepdims=True),
+                                   want["y"][t][ok] - want["y"][t][ok].mean(-1, keepdims=True), atol=1e-4, err_msg="y[%d]" % t)
+        np.testing.assert_allclose(got["pw"][t][ok], want["pw"][t][ok], atol=1e-4, err_msg="pw[%d]" % t)
+        ok &= ~(np.abs(want["pw"][t].reshape(B, -1) - 0.5) < 2e-5).any(1)
+        np.testing.assert_array_equal(got["w"][t][ok], want["w"][t][ok], err_msg="w[%d]" % t)
+        checked += int(ok.sum())
+    assert checked >= B // 2, "too few tie-free (step, sample) rows were compared: %d" % checked
+    np.testing.assert_array_equal(got["tstar"][ok], want["tstar"][ok])
+
+
 def test_config4_with_rec_hidden_256_generic_fallback(monkeypatch):
     """MMG_NO_RC=1: the same shape on the generic per-sample kernels (what a device without the tile path's alignment runs)."""
     monkeypatch.setenv("MMG_NO_RC", "1")
