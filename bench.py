@@ -40,7 +40,7 @@ WORKLOADS = {
                    "RMSprop; one bench step = one training minibatch"),
     "c3": (dict(C2, fixed_exchange=True), 64, "configs[2]: Fixed-exchange 30-class, global batch 512 = 64 per GPU on 8 GPUs, max_exchange 10"),
     "c4": (dict(C2, w_dim=256, h_dim=1024), 64, "configs[3]: Adaptive 30-class, batch 64, rec_w_dim 256 / img_h_dim 1024 (sample-tile MFMA kernels, co-resident receiver / sender roles in one launch)"),
-    "c4r256": (dict(C2, w_dim=256, h_dim=1024, rec_hidden=256), 64, "configs[3] with rec_hidden 256 (SURVEY.md 8d C4: 'use 64 and additionally report R = 256')"),
+    "c4r256": (dict(C2, w_dim=256, h_dim=1024, rec_hidden=256), 64, "configs[3] with rec_hidden 256 (SURVEY.md 8d C4: 'use 64 and additionally report R = 256'): wide-receiver roles over 16-unit slices on the matrix cores, kernels_rc.h"),
     "c5": (dict(C2, use_binary=False, fixed_exchange=True, n_classes=1000), 256,
            "configs[4]: 1000 classes, continuous messages, global batch 2048 = 256 per GPU on 8 GPUs (256 samples per GPU: one workgroup per sample; the sample-tile MFMA kernels take over from 1024 samples per GPU, --scaling strong at N=1)"),
 }
@@ -143,7 +143,7 @@ def traffic_lookup(workload, kernel, strong, profiles_dir=None):
     import glob
     import re
     pdir = profiles_dir or os.path.join(REPO, "profiles")
-    num = {"c2": "2", "c3": "3", "c4": "4", "c5": "5"}.get(workload, workload)
+    num = {"c2": "2", "c3": "3", "c4": "4", "c5": "5", "c4r256": "4r256"}.get(workload, workload)
     pat = re.compile(r"^r(\d+)_%sconfig%s_pmc_hbm_traffic\.json$" % ("strong_" if strong else "", num))
     files = sorted((int(pat.match(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(pdir, "r*_pmc_hbm_traffic.json"))
                    if pat.match(os.path.basename(f)))
@@ -514,8 +514,8 @@ def main():
             other = {}
             # c3s / c5s: the whole global batch (512 / 2048 samples) on this one GPU = the N = 1 point of --scaling strong;
             # (its ms_per_minibatch) / (the per-GPU shard's) is the ceiling of the strong-scaling speed-up at 8 GPUs
-            for w in ("c3", "c4", "c5", "c3s", "c5s"):
-                o = run_workload(w[:2], 30, 5, args.seed, 0, 1, local_rank, strong=w.endswith("s"))
+            for w in ("c3", "c4", "c4r256", "c5", "c3s", "c5s"):
+                o = run_workload(w[:-1] if w.endswith("s") else w, 30, 5, args.seed, 0, 1, local_rank, strong=w.endswith("s"))
                 rf = o["roofline"] or {}
                 other[w] = dict(workload=o["label"] + (" -- all %d samples on one GPU (--scaling strong, N=1)" % o["Bg"] if w.endswith("s") else ""), batch=o["B"], ms_per_minibatch=1e3 * o["elapsed"] / o["minibatches"],
                                 exchange_steps_per_s=o["ex_steps"] / o["elapsed"],

@@ -12,6 +12,7 @@ CASES = {
     "c3 fixed, one 64-sample shard": dict(bench.C2, fixed_exchange=True),
     "c3 fixed B=512 on one GPU": dict(bench.C2, fixed_exchange=True, batch=512),
     "c4 W=256 H=1024 B=64": dict(bench.C2, w_dim=256, h_dim=1024),
+    "c4 with R=256 (wide receiver)": dict(bench.C2, w_dim=256, h_dim=1024, rec_hidden=256),
     "c5 continuous D=1000 B=2048": dict(bench.C2, use_binary=False, fixed_exchange=True, n_classes=1000, batch=2048),
 }
 only = sys.argv[1] if len(sys.argv) > 1 else None      # e.g. 'c4': run just the cases whose name starts with it
