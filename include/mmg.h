@@ -159,7 +159,9 @@ int mmg_clip_step(mmg_handle* h, void* stream);
  * BASELINE configs 1-2 (k_conversation_fast3 with k_prep's blocks as roles, k_bwd_conv_fast with the baselines / statistics
  * as roles, k_wgrad, k_opt), 5 for config 3's shard (+ k_baselines3; + k_prep with more samples than CUs), 7 for config 5's
  * shard (k_prep, k_conversation_mc, k_bwd_mc1, k_bwd_mc2, k_wgrad, k_wreduce, k_opt), 10-11 for config 4 (k_prep,
- * k_conv_persist, [k_gemm_nt], k_baselines4, k_stats, k_bwd_pre_send, k_bwd_sample, k_dC_tile, k_wgrad, k_opt). */
+ * k_conv_persist, [k_gemm_nt], k_baselines4, k_stats, k_bwd_pre_send, k_bwd_sample, k_dC_tile, k_wgrad, k_opt), 10 for
+ * config 4 with rec_hidden 256 (k_prep, k_rc_persist, k_gemm_nt, k_baselines4, k_stats, k_bwd_pre_send, k_rc_bwd, k_dC_tile,
+ * k_wgrad, k_opt). */
 int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
                    const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed, void* stream);
 
