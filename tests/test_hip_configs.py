@@ -321,6 +321,57 @@ def test_config3_global_batch_512_fixed_sharded_equals_unsharded():
     np.testing.assert_allclose(shards[0].tape["losses"][:6].cpu().numpy(), full.tape["losses"][:6].cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_wide_receiver_sharded_equals_unsharded():
+    """The wide-receiver roles (kernels_rc.h) under the data-parallel protocol: Adaptive, in-kernel Philox keyed on the GLOBAL
+    sample index (dm.boff), NLL normalised by the GLOBAL batch (dm.Bg).  Two shards of 32 (two tiles each) computed one after another with the statistics / gradient sums done by hand must reproduce the single 64-sample engine:
+    sampled bits and rewards exactly, the update within the noise-step allowance of the config-3 test."""
+    meta = _meta(dict(C4, rec_hidden=256, batch_size=64), 30, 64, 1)
+    x, target, desc, _ = common.case_inputs(meta, 0)
+    full = common.make_engine(meta)
+    dev = full.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    full.forward(t(x), t(target), t(desc), seed=11, train=True, run_all=False)
+    full.loss_stats()
+    full.backward(t(x), t(target), t(desc))
+    full.clip_step()
+    torch.cuda.synchronize()
+    shards = [common.make_engine(meta, batch=32, global_batch=64, batch_offset=32 * r) for r in range(2)]
+    args = []
+    for r, e in enumerate(shards):
+        sl = slice(32 * r, 32 * r + 32)
+        a = (t(x[sl]), t(target[sl]), t(desc))
+        args.append(a)
+        e.forward(*a, seed=11, train=True, run_all=False)
+        e.loss_stats()
+    stats = sum(e.stats.clone() for e in shards)                      # the all-reduce of dist.py, by hand
+    for e, a in zip(shards, args):
+        e.stats.copy_(stats)
+        e.backward(*a)
+    grads = sum(e.flat_grads.clone() for e in shards)
+    shards[0].flat_grads.copy_(grads)
+    shards[0].clip_step()
+    torch.cuda.synchronize()
+    for r, e in enumerate(shards):
+        e.check_sync()
+        sl = slice(32 * r, 32 * r + 32)
+        ts_f, ts_s = full.tape["tstar"][sl].cpu().numpy(), e.tape["tstar"].cpu().numpy()
+        np.testing.assert_array_equal(ts_s, ts_f)
+        np.testing.assert_allclose(e.tape["logs"].cpu().numpy(), full.tape["logs"][sl].cpu().numpy(), rtol=1e-5, atol=1e-5)
+        for k in ("s", "z", "w"):                                       # live rows: t <= t* (w: t < t*)
+            a, b = e.tape[k].cpu().numpy(), full.tape[k][:, sl].cpu().numpy()
+            for bi in range(32):
+                n = int(ts_f[bi]) + (0 if k == "w" else 1)
+                np.testing.assert_array_equal(a[:n, bi], b[:n, bi], err_msg="%s sample %d" % (k, bi))
+    for agent, d in full.params.items():
+        for k, v in d.items():
+            if k == "y2.bias":
+                continue
+            a, b = shards[0].params[agent][k].cpu().numpy(), v.cpu().numpy()
+            bad = ~np.isclose(a, b, rtol=2e-4, atol=2e-6)
+            assert bad.mean() <= 1e-4 and np.abs(a - b).max() <= 2 * 10 * 1e-4, "%s.%s: %d bad" % (agent, k, bad.sum())
+    np.testing.assert_allclose(shards[0].tape["losses"][:6].cpu().numpy(), full.tape["losses"][:6].cpu().numpy(), rtol=2e-5, atol=1e-5)
+
+
 def test_config3_global_batch_512_single_engine_vs_oracle():
     """configs[2] as the N = 1 point of strong scaling runs it: all 512 samples on ONE engine (k_baselines2, row-split k_wgrad +
     k_wreduce -- kernels the 64-sample shards never take), two minibatches, against the CPU oracle itself."""
