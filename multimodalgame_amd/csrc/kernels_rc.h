@@ -260,7 +260,7 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
     float4 hq[4];                                                       // role 0: h_{t+1} of sample m, 16 lanes x 4 floats x 4
     float m_t = 1.f, sp_before = 1.f, u_s = 0.f;
     int ts_before = -1;
-    if (j == 0) {
+    if (j == 0 && !PS) {                                                // (PS: the stop head is the tile's stop role, rc_stop_role)
         const float* hr = tp.h + (rowh + b) * R;
 #pragma unroll
         for (int e = 0; e < 4; ++e) hq[e] = rc_ld4<PS>(hr + min(c * 4 + 64 * e, R - 4));
@@ -318,7 +318,7 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
             if (m < nb) rc_st<PS>(&tp.rcyp[((size_t)(b0 + m) * D + d) * 16 + j], part(c0, c1, c2, c3));
         }
     }
-    if (j != 0) return true;
+    if (PS || j != 0) return true;
     MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 167);
     {   // stop bit (model.py:414-427) and the stop-mask bookkeeping (model.py:852) -- per sample
         float acc = 0.f;
@@ -611,8 +611,9 @@ __global__ __launch_bounds__(256) void k_rc_tail(Dims dm, Params P, Tape tp, Con
 //   S1 roles (H / 64)              64 units of a_t = tanh(h_x + w_{t-1} W_c^T + b_c)   (model.py:195-216), weight fragments in registers
 //   S2 roles (W / 16)              16 bits of z_t ~ Bernoulli(sigmoid(a_t W_b^T + b_b)) (model.py:218-236), weight fragments in registers
 //   RC roles (max(R, W) / 16)      GRU slice -> heads slice -> message slice (the three bodies above), two in-cluster hand-offs
+//   stop role (1)                  the stop bit and the stop-mask bookkeeping of the tile's samples (off the receiver roles' path)
 // Counters (tape.pflags, zeroed by k_prep; (kind * 40 + tile) x 256 bytes): 0 w_t out (RC -> S1), 1 a_t out (S1 -> S2), 2 z_t out
-// (S2 -> RC), 3 h_{t+1} out, 4 partial logits / w_h h / stop masks out, 5 the tile's conversations are over.
+// (S2 -> RC), 3 h_{t+1} out, 4 partial logits / w_h h out, 5 the tile's conversations are over, 6 stop masks / row flags out.
 // ---------------------------------------------------------------------------------------------
 #define RC_MAXTILES 40
 #ifndef RC_RES_HEADS
@@ -747,17 +748,127 @@ __device__ __forceinline__ void rc_s2_role(const Dims& dm, const Params& P, cons
     }
 }
 
+// one poll loop over TWO counters (both requests in flight together): the receiver roles need the partial logits (counter 4) and
+// the stop role's flags (counter 6) before the query phase
+__device__ __forceinline__ bool rc_wait2(uint32_t* c1, uint32_t t1, uint32_t* c2, uint32_t t2, uint32_t* done, uint32_t* sync_err) {
+    __shared__ int s_ok2;
+    if (threadIdx.x == 0) {
+        int ok = -1, spins = 0;
+        while (ok < 0) {
+            const uint32_t d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t a = __hip_atomic_load(c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t b = __hip_atomic_load(c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d != 0u) ok = 0;
+            else if (a >= t1 && b >= t2) ok = 1;
+            else {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(sync_err + MMG_SYNC_ERR, 100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; }
+            }
+        }
+        s_ok2 = ok;
+    }
+    __syncthreads();
+    const bool r = s_ok2 != 0;
+    __syncthreads();
+    return r;
+}
+
+// The stop head of a tile as a role of its own (one workgroup per tile): with it inside heads role 0 every role of the tile waited
+// 2.5 us per step for that one (scripts/rc_timeline.py).  Per step: waits h_{t+1}, stop bit (model.py:414-427) + stop-mask
+// bookkeeping (model.py:852) + the step's row flags (rcst) and "a conversation of the tile goes on" (rcst[3][first sample]), signals 6.
+__device__ __forceinline__ void rc_stop_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int nrc) {
+    __shared__ float s_mn[16];
+    const int B = dm.B, R = dm.R, T = dm.T;
+    const int b0 = tile * MMG_TM, nb = min(MMG_TM, B - b0);
+    const int tid = threadIdx.x, m = tid >> 4, c = tid & 15, b = min(b0 + m, B - 1);
+    const bool may_stop = !ar.run_all && !dm.fixed && ar.train, train = ar.train != 0;
+    uint32_t* cH = rc_ctr(tp, 3, tile); uint32_t* cF = rc_ctr(tp, 6, tile); uint32_t* done = rc_ctr(tp, 5, tile);
+    float4 sq[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sq[e] = *reinterpret_cast<const float4*>(P.p[R_S_W] + min(c * 4 + 64 * e, R - 4));
+    const float bs = P.p[R_S_B][0];
+    const uint32_t mb_counter = tp.counter[0];
+    float m_t = 1.f, sprod = 1.f;                                       // carried by this role: nobody else writes them
+    int tstar = -1;
+    for (int t = 0; t < T; ++t) {
+        const size_t rowb = (size_t)t * B, rowh = (size_t)(t + 1) * B;
+        float u_s = 0.f;
+        if (train) u_s = ar.u_s ? ar.u_s[rowb + b] : philox_uniform(ar.seed, (uint32_t)(t * dm.Bg + dm.boff + b), mb_counter, 1u);
+        if (!pf_wait<false>(cH, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
+        const float* hr = tp.h + (rowh + b) * R;
+        float4 hq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hq[e] = ld_cc4(hr + min(c * 4 + 64 * e, R - 4));
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c * 4 + 64 * e < R) {
+                acc = fmaf(sq[e].x, hq[e].x, acc); acc = fmaf(sq[e].y, hq[e].y, acc);
+                acc = fmaf(sq[e].z, hq[e].z, acc); acc = fmaf(sq[e].w, hq[e].w, acc);
+            }
+        }
+        acc = dpp_group_sum<16>(acc);
+        {
+            // (all 16 lanes of a sample carry its state: lane 0 stores)
+            const bool valid = m < nb, live = valid && (!may_stop || m_t != 0.f);
+            const float p = fsigmoid(acc + bs);
+            float sv;
+            if (train) sv = (u_s < p) ? 1.f : 0.f;                                          // model.py:420
+            else {
+                sprod = dm.s_prob_prod ? sprod * p : p;                                     // model.py:423-426
+                sv = rintf(sprod);                                                          // model.py:427
+            }
+            const float m_next = fminf(m_t, sv);
+            const bool take = dm.fixed ? (t == T - 1) : (tstar < 0 && (m_next == 0.f || t == T - 1));
+            if (take) tstar = t;
+            if (c == 0) {
+                s_mn[m] = valid ? m_next : 0.f;
+                if (valid) {
+                    st_wt(&tp.rcst[(size_t)((t + 1) & 1) * B + b], m_next);
+                    st_wt(&tp.rcst[(size_t)2 * B + b], take ? 1.f : 0.f);
+                    tp.tstar[b] = tstar;
+                    tp.mstate[b] = m_next;
+                    if (!train) tp.sprod[b] = sprod;
+                }
+                if (live) {
+                    tp.s[rowb + b] = sv; tp.ps[rowb + b] = p;
+                    const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
+                    tp.lp_s[rowb + b] = sv * l1 + (1.f - sv) * l0;
+                    tp.ne_s[rowb + b] = p * l1 + (1.f - p) * l0;
+                    tp.mask[rowh + b] = (uint8_t)(m_next != 0.f);
+                }
+            }
+            m_t = m_next;
+        }
+        __syncthreads();
+        bool alive = false;
+        for (int mm = 0; mm < nb; ++mm) alive = alive || (s_mn[mm] != 0.f);
+        if (tid == 0) {
+            st_wt(&tp.rcst[(size_t)3 * B + b0], alive ? 1.f : 0.f);
+            if (t + 1 < T && alive) atomicAdd(&tp.alive[t + 1], 1);
+        }
+        pf_signal(cF);
+        if (may_stop && !alive) return;                                 // (receiver role 0 ends the tile's conversation)
+    }
+}
+
 __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles) {
     const int T = dm.T, NJ = dm.R >> 4, NJW = dm.W >> 4, nrc = NJ > NJW ? NJ : NJW, ns1 = (dm.H + 63) >> 6, ns2 = NJW;
-    const int per_tile = nrc + ns1 + ns2;
+    const int per_tile = nrc + ns1 + ns2 + 1;                           // receiver slices, sender slices, the stop role
     // roles of a tile sit side by side in the grid (consecutive workgroups go round the XCDs)
     const int tile = blockIdx.x / per_tile, slot = blockIdx.x - tile * per_tile;
-    if (tile >= tiles) return;
+    if (tile >= tiles) {
+        // trailing workgroups (dispatched after every role, onto CUs the roles leave idle): 16 x 16 tiles of
+        // basehx = h_x . baseline_sen.linear1.weight[:, :H]^T, which k_baselines4 needs next and nothing here produces
+        gemm_nt_tile(blockIdx.x - tiles * per_tile, tp.hx, dm.H, P.p[BS_L1_W], dm.H + dm.W, nullptr, tp.basehx, dm.K, dm.B, dm.K, dm.H);
+        return;
+    }
+    if (slot == nrc + ns2 + ns1) { rc_stop_role(dm, P, tp, ar, tile, nrc); return; }
     if (slot >= nrc + ns2) { rc_s1_role(dm, P, tp, ar, tile, slot - nrc - ns2, nrc); return; }
     if (slot >= nrc) { rc_s2_role(dm, P, tp, ar, tile, slot - nrc, ns1); return; }
     const int k = slot;
     uint32_t* cW = rc_ctr(tp, 0, tile); uint32_t* cZ = rc_ctr(tp, 2, tile); uint32_t* cH = rc_ctr(tp, 3, tile);
-    uint32_t* cY = rc_ctr(tp, 4, tile); uint32_t* done = rc_ctr(tp, 5, tile);
+    uint32_t* cY = rc_ctr(tp, 4, tile); uint32_t* done = rc_ctr(tp, 5, tile); uint32_t* cF = rc_ctr(tp, 6, tile);
     const bool may_stop = !ar.run_all && !dm.fixed && ar.train;
     bool whole = true;
     // The weight fragments of a phase are requested right BEFORE the phase's wait: they arrive while the role polls, and the phase
@@ -784,7 +895,8 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
         pf_signal(cY);
         rc_query_w(wquery, dm, P, min(k, NJW - 1));
         MMG_RSTAMP(stamp, so + 7);
-        if (!pf_wait<false>(cY, (uint32_t)(nrc * (t + 1)), done, tp.sync)) return;
+        if (!rc_wait2(cY, (uint32_t)(nrc * (t + 1)), cF, (uint32_t)(t + 1), done, tp.sync)) return;
+        if (k == 0) alive = ld_cc(&tp.rcst[(size_t)3 * dm.B + tile * MMG_TM]) != 0.f;       // (the stop role's verdict)
         MMG_RSTAMP(stamp, so + 8);
         if (k < NJW) rc_query_body<true>(dm, P, tp, ar, t, tile, k, 0, wquery);
         MMG_RSTAMP(stamp, so + 9);

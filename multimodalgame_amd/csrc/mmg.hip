@@ -480,9 +480,9 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         if (h->rc_fwd && e == hipSuccess)
             h->rc_bwd = tiles <= 64 && tiles * (d.R / 16) <= budget_of((const void*)k_rc_bwd, 256, 0) && !getenv("MMG_NO_RC_BWD");
         if (h->rc_fwd && e == hipSuccess) {
-            const int nj = d.R / 16, njw = d.W / 16, per_tile = (nj > njw ? nj : njw) + njw + (d.H + 63) / 64;
+            const int nj = d.R / 16, njw = d.W / 16, per_tile = (nj > njw ? nj : njw) + njw + (d.H + 63) / 64 + 1;
             h->rc_budget = budget_of((const void*)k_rc_persist, 256, 0);
-            h->rc_persist = !(d.H & 15) && d.H <= 1024 && tiles <= RC_MAXTILES && tiles * per_tile <= h->rc_budget && !getenv("MMG_NO_RC_PERSIST");
+            h->rc_persist = !(d.H & 15) && d.H <= 1024 && tiles <= 15 && tiles * per_tile <= h->rc_budget && !getenv("MMG_NO_RC_PERSIST");
         }
         if (h->tile_ok && h->tile_smem > 48 * 1024 && !h->rc_fwd) {
             e = hipFuncSetAttribute((const void*)k_conv_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
@@ -713,9 +713,13 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
     if (h->rc_fwd && h->rc_persist) {
         // wide receiver, all roles co-resident: one launch for the whole conversation (kernels_rc.h: k_rc_persist)
         Scope sc(h, st, "k_conv_rc");
-        const int nj = d.R / 16, njw = d.W / 16, per_tile = (nj > njw ? nj : njw) + njw + (d.H + 63) / 64;
+        const int nj = d.R / 16, njw = d.W / 16, per_tile = (nj > njw ? nj : njw) + njw + (d.H + 63) / 64 + 1;
         ar.phases = 2;
-        hipLaunchKernelGGL(k_rc_persist, dim3(tiles * per_tile), dim3(256), 0, st, h->dm, h->P, h->tp, ar, tiles);
+        // basehx tiles for k_baselines4 ride along as trailing workgroups (training minibatches of <= 64 samples)
+        const bool want_base = ar.train && d.use_binary && !ar.run_all && d.B <= 64 && !(d.H & 3) && h->merge_roles;
+        const int bt = want_base ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
+        hipLaunchKernelGGL(k_rc_persist, dim3(tiles * per_tile + bt), dim3(256), 0, st, h->dm, h->P, h->tp, ar, tiles);
+        h->basehx_ready = want_base;
         return launch_check("k_rc_persist");
     }
     if (h->rc_fwd) {
