@@ -667,7 +667,10 @@ __device__ __forceinline__ void rc_s1_role(const Dims& dm, const Params& P, cons
         for (int u = 0; u < 4; ++u) {
             const int hn = n0 + u * 16 + c;
             const float hw = (t == 0) ? hw0v[u] : (s_acc[u][0][m][c] + s_acc[u][1][m][c]) + (s_acc[u][2][m][c] + s_acc[u][3][m][c]) + bcv[u];
-            if (m < nb && hn < H) st_wt(&tp.a[(rowb + b) * H + hn], ftanh(hxv[u] + hw));      // model.py:216
+            const float av = ftanh(hxv[u] + hw);                                               // model.py:216
+            if (m < nb && hn < H) tp.a[(rowb + b) * H + hn] = av;                               // the tape (backward, k_wgrad): plain store
+            // the S2 roles' copy in fragment order (k-group (n0 >> 4) + u of the tile: 16 samples x 16 columns = 1 KB contiguous)
+            if (hn < H) st_wt(&tp.rcxa[(((size_t)tile * (H >> 4) + (n0 >> 4) + u) * 16 + m) * 16 + c], (m < nb) ? av : 0.f);
         }
         MMG_RSTAMP(tile == 0 && sidx == 0 && t == 3, 103);
         pf_signal(cA);
@@ -709,12 +712,12 @@ __device__ __forceinline__ void rc_s2_role(const Dims& dm, const Params& P, cons
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 110);
         if (!pf_wait<false>(cA, (uint32_t)(ns1 * (t + 1)), done, tp.sync)) return;
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 111);
-        const float* arow = tp.a + (rowb + min(b0 + i, B - 1)) * H;
+        const float* afrag = tp.rcxa + (size_t)tile * (H >> 4) * 256 + i * 16 + q * 4;     // [k-group][sample i][4 q ..]
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         {
             float4 av[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) av[u] = ld_cc4(arow + min(g0 + u, kg - 1) * 16 + q * 4);
+            for (int u = 0; u < 16; ++u) av[u] = ld_cc4(afrag + (size_t)min(g0 + u, kg - 1) * 256);
 #pragma unroll
             for (int u = 0; u < 16; u += 2) {
                 if (u < n) {

@@ -101,6 +101,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(rcdam, float, 0, 2, NRCB, R, 1)    /* ... backward: dA W_y1h of the output step (k_bwd_tile's prelude -> k_rc_bwd)                                */ \
     X(rcx, float, 0, 3, NRCX, 16, 3 * R) /* ... backward: the tile's gate gradients dgh_t, double-buffered by step parity (all-gather between k_rc_bwd's roles) */ \
     X(rcflags, uint32_t, 2, 1, 64 * 64, 1, 1) /* ... backward: one hand-off counter per sample tile (256-byte blocks), zeroed by k_bwd_tile's prelude */ \
+    X(rcxa, float, 0, 3, NRCA, 16, 16)   /* ... the sender's hidden tile a_t in FRAGMENT order [tile][H/16 k-groups][16 samples][16]: a wave of an S2 role reads a k-group's 1 KB contiguously */ \
     X(rcst, float, 0, 2, 4, B, 1)        /* ... [0..1] running stop mask m_t, double-buffered by step parity; [2] take-output flag of the step */ \
     X(pflags, uint32_t, 2, 1, 4 * 64 * 64, 1, 1) /* k_conv_persist: per (kind, sample tile) counters, one per 256-byte block */ \
     X(mcA, float, 0, 3, NMC, 16, R + 4)  /* k_conversation_mc: A rows (+ take flag) published by the 16 members of a tile       */ \
@@ -260,10 +261,11 @@ inline TapeLayout tape_layout(const mmg_config& c) {
                   NRCJ = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? R / 16 : 1,
                   NRCX = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? 2 * ((B + 15) / 16) : 1,
                   NRCP = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) && R == 256 ? 4 : 1,   /* column bands of k_bwd_pre's partial dhin */
+                  NRCA = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? ((B + 15) / 16) * ((H + 15) / 16) : 1,
                   NRCW = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? W / 16 : 1,
                   NMCB = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) && !c.use_binary ? 16 : 0,
                   NWP = wgrad_any_split((int)(T * B), param_layout(c).total) ? (int64_t)16 * (param_layout(c).total + 512 * 64) : 4;   /* (every job splits <= 16 ways) */
-    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX; (void)NRCP;
+    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX; (void)NRCP; (void)NRCA;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \
