@@ -48,6 +48,13 @@ __device__ __forceinline__ void rc_load_act(RcFrag& f, const float* row, int K, 
 #pragma unroll
     for (int u = 0; u < RC_MAXG; ++u) f.v[u] = rc_ld4<PS>(row + min(g0 + u, kgroups - 1) * 16 + q * 4);
 }
+// the same k-groups from a FRAGMENT-ORDER copy [k-group][16 samples][16] of the tile (hand-off payload of the persistent launch): lane
+// (i, q) reads the 16 bytes at [g][i][4 q], a wave 1 KB contiguous per k-group
+__device__ __forceinline__ void rc_load_frag(RcFrag& f, const float* tilebase, int K, int g0, int i, int q) {
+    const int kgroups = K >> 4;
+#pragma unroll
+    for (int u = 0; u < RC_MAXG; ++u) f.v[u] = ld_cc4(tilebase + (size_t)min(g0 + u, kgroups - 1) * 256 + i * 16 + q * 4);
+}
 __device__ __forceinline__ f32x4 rc_mma(const RcFrag& a, const RcFrag& b, int n, f32x4 acc) {
 #pragma unroll
     for (int u = 0; u < RC_MAXG; ++u) {
@@ -130,10 +137,15 @@ __device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, con
         int gw0, nw_, gr0, nr_;
         rc_share(W, wave, gw0, nw_); rc_share(R, wave, gr0, nr_);
         RcFrag az, ah;
-        rc_load_act<PS>(az, tp.z + (rowb + bx) * W, W, gw0, q);
         // (t == 0: h_0 = 0 is being written by this very launch -- the hidden-side product is b_hh alone)
         const int nh = (t > 0) ? nr_ : 0;
-        rc_load_act<PS>(ah, tp.h + (rowb + bx) * R, R, gr0, q);
+        if (PS) {
+            rc_load_frag(az, tp.rcxz + (size_t)tile * (W >> 4) * 256, W, gw0, i, q);
+            rc_load_frag(ah, tp.rcxh + ((size_t)(t & 1) * ((B + 15) >> 4) * (R >> 4) + (size_t)tile * (R >> 4)) * 256, R, gr0, i, q);
+        } else {
+            rc_load_act<PS>(az, tp.z + (rowb + bx) * W, W, gw0, q);
+            rc_load_act<PS>(ah, tp.h + (rowb + bx) * R, R, gr0, q);
+        }
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         const f32x4 a0 = rc_mma(az, w.wi0, nw_, z4), a1 = rc_mma(az, w.wi1, nw_, z4), a2 = rc_mma(az, w.wi2, nw_, z4);
         const f32x4 a3 = rc_mma(ah, w.wh0, nh, z4), a4 = rc_mma(ah, w.wh1, nh, z4), a5 = rc_mma(ah, w.wh2, nh, z4);
@@ -166,6 +178,8 @@ __device__ __forceinline__ bool rc_gru_body(const Dims& dm, const Params& P, con
             gr[unit_e] = rr; gr[R + unit_e] = uu; gr[2 * R + unit_e] = nn; gr[3 * R + unit_e] = ghn;
             rc_st<PS>(&tp.h[((size_t)(t + 1) * B + b) * R + unit_e], hv);
         }
+        // (PS) h_{t+1} in fragment order for the heads phase and the next GRU step, by step parity (a role writes h_{t+2} while others still read h_{t+1})
+        if (PS) st_wt(&tp.rcxh[((((size_t)((t + 1) & 1) * ((B + 15) >> 4) + tile) * (R >> 4) + j) * 16 + m) * 16 + c], (m < nb) ? hv : 0.f);
     }
     return true;
 }
@@ -254,7 +268,8 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
     int g0, n;
     rc_share(R, wave, g0, n);
     RcFrag ah;
-    rc_load_act<PS>(ah, tp.h + (rowh + bx) * R, R, g0, q);
+    if (PS) rc_load_frag(ah, tp.rcxh + ((size_t)((t + 1) & 1) * ((B + 15) >> 4) + tile) * (R >> 4) * 256, R, g0, i, q);
+    else rc_load_act<PS>(ah, tp.h + (rowh + bx) * R, R, g0, q);
     const float bh = w.bh;
     const float4 wq0 = w.wq[0], wq1 = w.wq[1], wq2 = w.wq[2], wq3 = w.wq[3];
     float4 hq[4];                                                       // role 0: h_{t+1} of sample m, 16 lanes x 4 floats x 4
@@ -553,6 +568,7 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
             lpv = wv * l1 + (1.f - wv) * l0; nev = pp * l1 + (1.f - pp) * l0;
         }
         if (st) rc_st<PS>(&tp.w[(rowb + b) * W + ncol], wv);
+        if (PS) st_wt(&tp.rcxw[(((size_t)tile * (W >> 4) + jw) * 16 + m) * 16 + c], wv);         // the S1 roles' copy, fragment order
         if (binary) {
             lpv = dpp_group_sum<16>(lpv); nev = dpp_group_sum<16>(nev);
             if (c == 0 && m < nb) { float* pl = tp.rclw + (((size_t)(t & 1) * (W >> 4) + jw) * B + b) * 2; rc_st<PS>(pl, lpv); rc_st<PS>(pl + 1, nev); }
@@ -652,7 +668,7 @@ __device__ __forceinline__ void rc_s1_role(const Dims& dm, const Params& P, cons
             if (!pf_wait<false>(cW, (uint32_t)(nrc * t), done, tp.sync)) return;
             MMG_RSTAMP(tile == 0 && sidx == 0 && t == 3, 101);
             RcFrag aw;
-            rc_load_act<true>(aw, tp.w + ((size_t)(t - 1) * B + min(b0 + i, B - 1)) * W, W, g0, q);
+            rc_load_frag(aw, tp.rcxw + (size_t)tile * (W >> 4) * 256, W, g0, i, q);
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -744,6 +760,7 @@ __device__ __forceinline__ void rc_s2_role(const Dims& dm, const Params& P, cons
                 if (m < nb) st_wt(&tp.pz[(rowb + b) * W + col], pp);
             }
             if (m < nb) st_wt(&tp.z[(rowb + b) * W + col], zz);
+            st_wt(&tp.rcxz[(((size_t)tile * (W >> 4) + k) * 16 + m) * 16 + c], (m < nb) ? zz : 0.f);     // the GRU slices' copy, fragment order
         }
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 113);
         pf_signal(cZ);                                                  // (its barrier also frees s_acc for the next step)

@@ -102,6 +102,9 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(rcx, float, 0, 3, NRCX, 16, 3 * R) /* ... backward: the tile's gate gradients dgh_t, double-buffered by step parity (all-gather between k_rc_bwd's roles) */ \
     X(rcflags, uint32_t, 2, 1, 64 * 64, 1, 1) /* ... backward: one hand-off counter per sample tile (256-byte blocks), zeroed by k_bwd_tile's prelude */ \
     X(rcxa, float, 0, 3, NRCA, 16, 16)   /* ... the sender's hidden tile a_t in FRAGMENT order [tile][H/16 k-groups][16 samples][16]: a wave of an S2 role reads a k-group's 1 KB contiguously */ \
+    X(rcxz, float, 0, 3, NRCZ, 16, 16)   /* ... z_t in fragment order [tile][W/16][16][16] (S2 roles -> GRU slices)                              */ \
+    X(rcxw, float, 0, 3, NRCZ, 16, 16)   /* ... w_t in fragment order [tile][W/16][16][16] (message slices -> S1 roles)                        */ \
+    X(rcxh, float, 0, 3, 2 * NRCH, 16, 16) /* ... h_{t+1} in fragment order [parity][tile][R/16][16][16] (GRU slices -> heads, next GRU step)   */ \
     X(rcst, float, 0, 2, 4, B, 1)        /* ... [0..1] running stop mask m_t, double-buffered by step parity; [2] take-output flag of the step */ \
     X(pflags, uint32_t, 2, 1, 4 * 64 * 64, 1, 1) /* k_conv_persist: per (kind, sample tile) counters, one per 256-byte block */ \
     X(mcA, float, 0, 3, NMC, 16, R + 4)  /* k_conversation_mc: A rows (+ take flag) published by the 16 members of a tile       */ \
@@ -262,10 +265,12 @@ inline TapeLayout tape_layout(const mmg_config& c) {
                   NRCX = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? 2 * ((B + 15) / 16) : 1,
                   NRCP = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) && R == 256 ? 4 : 1,   /* column bands of k_bwd_pre's partial dhin */
                   NRCA = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? ((B + 15) / 16) * ((H + 15) / 16) : 1,
+                  NRCZ = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? ((B + 15) / 16) * (W / 16) : 1,
+                  NRCH = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? ((B + 15) / 16) * (R / 16) : 1,
                   NRCW = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? W / 16 : 1,
                   NMCB = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) && !c.use_binary ? 16 : 0,
                   NWP = wgrad_any_split((int)(T * B), param_layout(c).total) ? (int64_t)16 * (param_layout(c).total + 512 * 64) : 4;   /* (every job splits <= 16 ways) */
-    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX; (void)NRCP; (void)NRCA;
+    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX; (void)NRCP; (void)NRCA; (void)NRCZ; (void)NRCH;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \
