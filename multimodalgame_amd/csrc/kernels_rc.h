@@ -303,7 +303,8 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
         const int unit = 16 * j + c;
         auto S = [&](int p) { return (s_acc[p][0][m][c] + s_acc[p][1][m][c]) + (s_acc[p][2][m][c] + s_acc[p][3][m][c]); };
         s_A[m][c] = S(0);                                               // A (App. A.2)
-        if (m < nb) rc_st<PS>(&tp.rcgw[(size_t)(b0 + m) * R + unit], S(1) + bh);     // w_h h + b_h
+        // w_h h + b_h in the MFMA accumulator order of the query phase: [tile][column tile j][r = m & 3][q = m >> 2][c]
+        rc_st<PS>(&tp.rcgw[((((size_t)tile * (R >> 4) + j) * 4 + (m & 3)) * 4 + (m >> 2)) * 16 + c], S(1) + bh);
     }
     __syncthreads();
     {   // this slice's share of y[m][d] = b_y2 + sum_r w_y2[r] relu(A[m][r] + Cd[d][r])     (model.py:432-433)
@@ -325,13 +326,9 @@ __device__ __forceinline__ bool rc_heads_body(const Dims& dm, const Params& P, c
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int d = c + 16 * e;
-            if (d < D && m < nb) rc_st<PS>(&tp.rcyp[((size_t)(b0 + m) * D + d) * 16 + j], part(w.cq[e][0], w.cq[e][1], w.cq[e][2], w.cq[e][3]));
+            if (d < D && m < nb) rc_st<PS>(&tp.rcyp[((((size_t)tile * 4 + (j >> 2)) * 16 + m) * 32 + d) * 4 + (j & 3)], part(w.cq[e][0], w.cq[e][1], w.cq[e][2], w.cq[e][3]));
         }
-        for (int d = c + 32; d < D; d += 16) {                          // (more than 32 classes: rows fetched here)
-            const float4* c4 = reinterpret_cast<const float4*>(tp.Cd + (size_t)d * R + 16 * j);
-            const float4 c0 = c4[0], c1 = c4[1], c2 = c4[2], c3 = c4[3];
-            if (m < nb) rc_st<PS>(&tp.rcyp[((size_t)(b0 + m) * D + d) * 16 + j], part(c0, c1, c2, c3));
-        }
+        // (D <= 32: layout.h rc_shape -- two classes per thread cover them)
     }
     if (PS || j != 0) return true;
     MMG_RSTAMP(PS && tile == 0 && j == 0 && t == 3, 167);
@@ -449,15 +446,16 @@ __device__ __forceinline__ void rc_query_body(const Dims& dm, const Params& P, c
     float4 pv[2][4];                                                    // thread (m, d = c) and (m, d = c + 16): the 16 slice partials of its first two classes
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const float* yp = tp.rcyp + ((size_t)b * D + min(c + 16 * e, D - 1)) * 16;
+        // [tile][slice quad u][sample][class][4]: the 16 lanes of a sample read 256 contiguous bytes per (u, e)
+        const float* yp = tp.rcyp + (((size_t)tile * 4 * 16 + m) * 32 + min(c + 16 * e, D - 1)) * 4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pv[e][u] = rc_ld4<PS>(yp + 4 * u);
+        for (int u = 0; u < 4; ++u) pv[e][u] = rc_ld4<PS>(yp + (size_t)u * 16 * 32 * 4);
     }
     float gwa[4][4];                                                    // w_h h + b_h of this wave's (at most four: R <= 256) 16-column tiles of h_w
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gwa[u][r] = rc_ld<PS>(&tp.rcgw[(size_t)min(b0 + q * 4 + r, B - 1) * R + min(wave + 4 * u, NJ - 1) * 16 + i]);
+        for (int r = 0; r < 4; ++r) gwa[u][r] = rc_ld<PS>(&tp.rcgw[((((size_t)tile * NJ + min(wave + 4 * u, NJ - 1)) * 4 + r) * 4 + q) * 16 + i]);
     int gm0, nm;
     rc_share(R, wave, gm0, nm);
     const float bw = w.bw, b2 = w.b2;

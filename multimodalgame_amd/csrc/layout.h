@@ -95,8 +95,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(cpart, float, 0, 3, NTILE * NHLP, 16, V + 2) /* k_conv_split: per helper: unnormalised mixture partial | slice max | slice sum */ \
     X(gip, float, 0, 3, NS2P, B, 3 * R)  /* per-sender-role partials of the GRU input product (k_conv_persist)           */ \
     X(zpart, float, 0, 3, NZP, 16, W)    /* per-SA-role partial message logits of a tile (k_conv_persist, fused sender roles) */ \
-    X(rcgw, float, 0, 2, NRCB, R, 1)     /* wide receiver (kernels_rc.h): w_h h + b_h of the step, written per 16-unit slice by k_rc_heads */ \
-    X(rcyp, float, 0, 3, NRCB, D, 16)    /* ... per-slice partial class logits [B][D][16 slices], added in slice order by k_rc_query          */ \
+    X(rcgw, float, 0, 2, NRCT16, R, 1)   /* wide receiver (kernels_rc.h): w_h h + b_h of the step, [tile][R/16][r][q][16]: the query phase's MFMA accumulator order */ \
+    X(rcyp, float, 0, 3, NRCT16, 32, 16) /* ... per-slice partial class logits [tile][slice quad][16 samples][32 classes][4], added in slice order by k_rc_query */ \
     X(rclw, float, 0, 3, 2 * NRCW, NRCB, 2)  /* ... per-16-bit-slice partial (log-likelihood, neg-entropy) of the receiver's message            */ \
     X(rcdam, float, 0, 2, NRCB, R, 1)    /* ... backward: dA W_y1h of the output step (k_bwd_tile's prelude -> k_rc_bwd)                                */ \
     X(rcx, float, 0, 3, NRCX, 16, 3 * R) /* ... backward: the tile's gate gradients dgh_t, double-buffered by step parity (all-gather between k_rc_bwd's roles) */ \
@@ -267,10 +267,11 @@ inline TapeLayout tape_layout(const mmg_config& c) {
                   NRCA = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? ((B + 15) / 16) * ((H + 15) / 16) : 1,
                   NRCZ = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? ((B + 15) / 16) * (W / 16) : 1,
                   NRCH = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? ((B + 15) / 16) * (R / 16) : 1,
+                  NRCT16 = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? 16 * ((B + 15) / 16) : 1,
                   NRCW = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? W / 16 : 1,
                   NMCB = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) && !c.use_binary ? 16 : 0,
                   NWP = wgrad_any_split((int)(T * B), param_layout(c).total) ? (int64_t)16 * (param_layout(c).total + 512 * 64) : 4;   /* (every job splits <= 16 ways) */
-    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX; (void)NRCP; (void)NRCA; (void)NRCZ; (void)NRCH;
+    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX; (void)NRCP; (void)NRCA; (void)NRCZ; (void)NRCH; (void)NRCT16;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \
