@@ -1,24 +1,21 @@
 // kernels_rc.h -- the receiver of a 16-sample tile SPLIT OVER WORKGROUPS by hidden-unit slice ("wide receiver": rec_hidden
 // 129..256 beside the large sender of BASELINE config 4, SURVEY.md 8d "additionally report R = 256").  At R = W = 256 the
 // receiver's per-step weights are 2.4 MB (W_ih and W_hh 768 KB each) and the one-workgroup-per-tile forward of kernels_tile.h
-// needs 286 KB of LDS (three 16 x 772 gate tiles), so a step of the tile's receiver runs as three chip-wide launches whose
-// workgroups own 16 hidden units (or 16 message bits) each and read their weight rows straight into MFMA B fragments:
-//   k_rc_gru    (tiles x R/16)  gi = z_t W_ih^T, gh = h_t W_hh^T for the role's 3 x 16 gate columns (six 16x16x4 fp32 MFMA
-//                               products, K split over the four waves, every load of the six in flight together), GRUCell
-//                               (model.py:340) -> tape.gru, tape.h[t+1]; role 0: log-likelihood / neg-entropy of z_t
-//   k_rc_heads  (tiles x R/16)  A = W_y1[:, :R] h, w_h h + b (16 columns each, App. A.2), the role's PARTIAL class logits
-//                               sum_{r in slice} w_y2[r] relu(A[r] + Cd[d][r]) (model.py:432-433); role 0: stop bit
-//                               (model.py:414-427) and the stop-mask bookkeeping (model.py:852)
-//   k_rc_query  (tiles x W/16)  every role adds the R/16 partial logits, softmax (detached, model.py:441), description mixture
-//                               (model.py:442-449), h_w = tanh(w_h h + w_d dbar) (model.py:452: 16 x V x R, recomputed by every
-//                               role -- 13 MFLOP per tile-step, cheaper than one more launch), then ITS 16 message bits
-//                               (model.py:454-475) and their partial log-likelihood sums
-//   k_rc_tail   (tiles)         last step's message log-likelihood, output selection / log-softmax / reward / top-k
-//                               (model.py:1264-1275, 1333-1339)
-// between the per-step sender launches k_send_s1 / k_send_s2.  The launch boundary is the hand-off: no spin waits, no
-// co-residency requirement.  Tape rows follow the live-row contract of k_conv_tile, so the tile backward (k_bwd_pre /
-// k_bwd_tile / k_send_bwd / k_dC_tile) and k_wgrad run unchanged.  State between launches: rcst[0..1] = m_t double-buffered by
-// step parity (a launch never writes the slot its own step reads), rcst[2] = take-output flag of the step, tape.tstar / sprod.
+// needs 286 KB of LDS (three 16 x 772 gate tiles), so a tile's receiver step is cut into three phases whose workgroups own 16
+// hidden units (or 16 message bits) each and read their weight rows straight into MFMA B fragments (v_mfma_f32_16x16x4_f32, K
+// split over the four waves):
+//   GRU     (R/16 slices)  gi = z_t W_ih^T, gh = h_t W_hh^T for the slice's 3 x 16 gate columns, GRUCell (model.py:340)
+//   heads   (R/16 slices)  A = W_y1[:, :R] h, w_h h + b (App. A.2), the slice's PARTIAL class logits (model.py:432-433)
+//   query   (W/16 slices)  adds the partial logits, softmax (model.py:441), h_w = tanh(w_h h + b + softmax(y) . Dd) with Dd = desc . W_d^T
+//                          (model.py:442-452; recomputed by every slice: cheaper than one more hand-off), ITS 16 message bits (model.py:454-475)
+// Default: k_rc_persist -- ONE launch per conversation of co-resident roles (S1 / S2 sender slices, receiver slices running the three
+// phases, one stop role per tile) that hand their results on through memory + counters, every payload in the consumer's fragment
+// order; the backward's output-step prelude and reverse-time loop likewise as k_rc_bwd's roles.  Fallback (roles do not fit the
+// device, MMG_NO_RC_PERSIST=1): the same phase bodies as the launches k_rc_gru / k_rc_heads / k_rc_query / k_rc_tail between the
+// per-step sender launches k_send_s1 / k_send_s2 -- the launch boundary is the hand-off, no spin waits, no co-residency requirement.
+// Tape rows follow the live-row contract of k_conv_tile, so k_bwd_pre / k_send_bwd / k_dC_tile / k_wgrad run unchanged.  State between
+// phases: rcst[0..1] = m_t double-buffered by step parity (a phase never writes the slot its own step reads), rcst[2] = take-output
+// flag of the step, rcst[3] = "a conversation of the tile goes on", tape.tstar / sprod.  DESIGN.md 3e.
 #pragma once
 
 namespace mmg {
