@@ -79,6 +79,27 @@ def test_config4_with_rec_hidden_256_vs_oracle(switch, monkeypatch):
     assert "k_conv_rc" in names and "k_bwd_tile" in names, names
 
 
+@pytest.mark.parametrize("flavour", ["adaptive", "fixed", "continuous"])
+def test_wide_receiver_fused_train_step_vs_oracle(flavour):
+    """EXACTLY what bench.py's c4r256 line runs: the FUSED mmg_train_step (run_all_steps = 2: early stopping, live rows only, in
+    Fixed mode y of the output step only, in continuous mode the lean tape) on the wide-receiver roles -- k_rc_persist, k_bwd_pre_send,
+    k_rc_bwd, k_wgrad, k_opt -- two minibatches at B = 64 against the oracle."""
+    kw = dict(C4, rec_hidden=256, batch_size=64)
+    skip = ("y2.bias",)
+    if flavour == "fixed":
+        kw.update(fixed_exchange=True, max_exchange=4)
+    elif flavour == "continuous":
+        kw.update(use_binary=False, fixed_exchange=True, max_exchange=4)
+        skip = ("y2.bias", ".bs", ".br")
+    meta = _meta(kw, 30, 64, 2)
+    got, eng = common.hip_train_case(None, meta, fused=True)
+    flips = []
+    want = common.oracle_train_case(None, meta, flips=flips)
+    common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-wide-fused-" + flavour, skip=skip)
+    names = _kernel_names(eng, meta)
+    assert "k_conv_rc" in names and "k_bwd_tile" in names and "k_conversation" not in names, names
+
+
 @pytest.mark.parametrize("flavour", ["fixed", "continuous", "ragged", "r192"])
 def test_wide_receiver_other_modes_vs_oracle(flavour):
     """The wide-receiver kernels (kernels_rc.h) outside config 4's own mode: Fixed exchange (every row live, output at T - 1),
