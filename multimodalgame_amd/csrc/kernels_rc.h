@@ -867,12 +867,14 @@ __device__ __forceinline__ void rc_stop_role(const Dims& dm, const Params& P, co
     }
 }
 
-__global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles) {
+// tile0 / tiles: the launch covers the sample tiles [tile0, tile0 + tiles) -- batches whose roles do not all fit the device run as
+// consecutive launches over tile ranges (the conversations of different samples are independent)
+__global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles, int tile0) {
     const int T = dm.T, NJ = dm.R >> 4, NJW = dm.W >> 4, nrc = NJ > NJW ? NJ : NJW, ns1 = (dm.H + 63) >> 6, ns2 = NJW;
     const int per_tile = nrc + ns1 + ns2 + 1;                           // receiver slices, sender slices, the stop role
     // roles of a tile sit side by side in the grid (consecutive workgroups go round the XCDs)
-    const int tile = blockIdx.x / per_tile, slot = blockIdx.x - tile * per_tile;
-    if (tile >= tiles) {
+    const int ltile = blockIdx.x / per_tile, slot = blockIdx.x - ltile * per_tile, tile = tile0 + ltile;
+    if (ltile >= tiles) {
         // trailing workgroups (dispatched after every role, onto CUs the roles leave idle): 16 x 16 tiles of
         // basehx = h_x . baseline_sen.linear1.weight[:, :H]^T, which k_baselines4 needs next and nothing here produces
         gemm_nt_tile(blockIdx.x - tiles * per_tile, tp.hx, dm.H, P.p[BS_L1_W], dm.H + dm.W, nullptr, tp.basehx, dm.K, dm.B, dm.K, dm.H);

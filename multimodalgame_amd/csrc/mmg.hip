@@ -482,7 +482,10 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         if (h->rc_fwd && e == hipSuccess) {
             const int nj = d.R / 16, njw = d.W / 16, per_tile = (nj > njw ? nj : njw) + njw + (d.H + 63) / 64 + 1;
             h->rc_budget = budget_of((const void*)k_rc_persist, 256, 0);
-            h->rc_persist = !(d.H & 15) && d.H <= 1024 && tiles <= 15 && tiles * per_tile <= h->rc_budget && !getenv("MMG_NO_RC_PERSIST");
+            // (up to two consecutive launches over tile ranges; beyond that the per-step launches over the whole batch win:
+            //  profiles/r04_rc_batch_sweep.log)
+            const int ct = h->rc_budget / per_tile;
+            h->rc_persist = !(d.H & 15) && d.H <= 1024 && tiles <= 15 && ct >= 1 && (tiles + ct - 1) / ct <= 2 && !getenv("MMG_NO_RC_PERSIST");
         }
         if (h->tile_ok && h->tile_smem > 48 * 1024 && !h->rc_fwd) {
             e = hipFuncSetAttribute((const void*)k_conv_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->tile_smem);
@@ -716,9 +719,16 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
         const int nj = d.R / 16, njw = d.W / 16, per_tile = (nj > njw ? nj : njw) + njw + (d.H + 63) / 64 + 1;
         ar.phases = 2;
         // basehx tiles for k_baselines4 ride along as trailing workgroups (training minibatches of <= 64 samples)
-        const bool want_base = ar.train && d.use_binary && !ar.run_all && d.B <= 64 && !(d.H & 3) && h->merge_roles;
+        int ct = h->rc_budget / per_tile;
+        const int nchunk = (tiles + ct - 1) / ct;
+        ct = (tiles + nchunk - 1) / nchunk;
+        const bool want_base = nchunk == 1 && ar.train && d.use_binary && !ar.run_all && d.B <= 64 && !(d.H & 3) && h->merge_roles;
         const int bt = want_base ? ((d.B + 15) / 16) * ((d.K + 15) / 16) : 0;
-        hipLaunchKernelGGL(k_rc_persist, dim3(tiles * per_tile + bt), dim3(256), 0, st, h->dm, h->P, h->tp, ar, tiles);
+        for (int c = 0; c < nchunk; ++c) {
+            const int t0 = c * ct, nt = (tiles - t0 < ct) ? tiles - t0 : ct;
+            if (nt <= 0) break;
+            hipLaunchKernelGGL(k_rc_persist, dim3(nt * per_tile + bt), dim3(256), 0, st, h->dm, h->P, h->tp, ar, nt, t0);
+        }
         h->basehx_ready = want_base;
         return launch_check("k_rc_persist");
     }

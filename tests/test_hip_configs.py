@@ -100,11 +100,12 @@ def test_wide_receiver_fused_train_step_vs_oracle(flavour):
     assert "k_conv_rc" in names and "k_bwd_tile" in names and "k_conversation" not in names, names
 
 
-@pytest.mark.parametrize("flavour", ["fixed", "continuous", "ragged", "r192"])
+@pytest.mark.parametrize("flavour", ["fixed", "continuous", "ragged", "r192", "b88"])
 def test_wide_receiver_other_modes_vs_oracle(flavour):
     """The wide-receiver kernels (kernels_rc.h) outside config 4's own mode: Fixed exchange (every row live, output at T - 1),
-    continuous messages (no sampling, receiver-only backward without k_bwd_pre), a ragged last tile (B = 24) and rec_hidden 192
-    (12 slices, three of the four waves hold a fourth k-group less)."""
+    continuous messages (no sampling, receiver-only backward without k_bwd_pre), a ragged last tile (B = 24), rec_hidden 192
+    (12 slices, three of the four waves hold a fourth k-group less) and 88 samples (more roles than fit the device at once: two
+    consecutive launches over tile ranges)."""
     kw = dict(C4, rec_hidden=256, batch_size=32)
     B = 32
     skip = ("y2.bias",)
@@ -115,6 +116,8 @@ def test_wide_receiver_other_modes_vs_oracle(flavour):
         skip = ("y2.bias", ".bs", ".br")
     elif flavour == "ragged":
         kw.update(batch_size=24); B = 24
+    elif flavour == "b88":                       # 6 tiles (the last one ragged): two consecutive role launches over tile ranges (3 + 3)
+        kw.update(batch_size=88); B = 88
     else:
         kw.update(rec_hidden=192)
     meta = _meta(kw, 30, B, 2)
