@@ -1077,11 +1077,12 @@ __global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, cons
         float prod = 0.f;
         if (have) {
             if (!pf_wait<false>(ctr, (uint32_t)(NJ * step), nullptr, tp.sync)) return;
-            const float* xrow = tp.rcx + ((size_t)(tile * 2 + ((t + 1) & 1)) * 16 + i) * R3;
+            // (fragment order [tile][parity][k-group][16 samples][16]: a wave reads a k-group's 1 KB contiguously)
+            const float* xfrag = tp.rcx + (size_t)(tile * 2 + ((t + 1) & 1)) * 16 * R3 + i * 16 + q * 4;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             float4 av[12];
 #pragma unroll
-            for (int u = 0; u < 12; ++u) av[u] = ld_cc4(xrow + min(g0 + u, kg - 1) * 16 + q * 4);
+            for (int u = 0; u < 12; ++u) av[u] = ld_cc4(xfrag + (size_t)min(g0 + u, kg - 1) * 256);
 #pragma unroll
             for (int u = 0; u < 12; u += 2) {
                 if (u < n) {
@@ -1111,8 +1112,9 @@ __global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, cons
         const float g0v = live ? drp : 0.f, g1v = live ? dup : 0.f, g2v = live ? dnp * rr : 0.f;
         carry = live ? dh * uu : 0.f;
         if (t > 0) {                                                    // dh_{t-1} receives dgh_t W_hh: the slice goes out to the tile's roles
-            float* xw = tp.rcx + ((size_t)(tile * 2 + (t & 1)) * 16 + m) * R3;
-            st_wt(xw + unit, g0v); st_wt(xw + R + unit, g1v); st_wt(xw + 2 * R + unit, g2v);
+            // gate g of unit u0 + c sits in k-group g (R / 16) + j, column c
+            float* xw = tp.rcx + (size_t)(tile * 2 + (t & 1)) * 16 * R3 + ((size_t)j * 16 + m) * 16 + c;
+            st_wt(xw, g0v); st_wt(xw + (size_t)NJ * 256, g1v); st_wt(xw + (size_t)2 * NJ * 256, g2v);
         }
         if (m < nb && (live || zero_dead)) {
             float* gi = tp.dgi + (rowb + b) * R3; float* gh = tp.dgh + (rowb + b) * R3;
