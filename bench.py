@@ -79,6 +79,11 @@ def algorithmic_work(kernel, d, B, t_steps, lean=False, prep_inside=False):
     p_sender = H * W + W * H + 2 * H + 2 * W
     p_recv = 3 * R * (W + R) + 6 * R + R * R + R + R * V + W * R + W + R * R + 2 * R + 2 + D * R + D * V
     mac_recv = 3 * R * W + 3 * R * R + 2 * R * R + R + D * V + R * V + W * R      # products of one receiver step of one sample
+    if kernel == "k_game":                    # conversation + backward recurrence in ONE launch: the operands of both, the tape written once
+        a = algorithmic_work("k_conversation", d, B, t_steps, lean=lean, prep_inside=prep_inside)[1]
+        b = algorithmic_work("k_bwd_conv", d, B, t_steps, lean=lean)[1]
+        fwd_tape = rows * 4 * (H + 6 * W + 6 * R + D + min(V, 32) + 12)     # (not re-read: it stays in LDS between the two recurrences)
+        return "hbm", a + b - fwd_tape - 4 * (p_sender + p_recv)
     if kernel in ("k_conversation", "k_conversation_mc"):
         if lean and not d["use_binary"]:
             # lean tape: per (step, sample) the message z [W], the GRU state h [R] and gates [4R], stop bit / prob / mask /
@@ -94,9 +99,10 @@ def algorithmic_work(kernel, d, B, t_steps, lean=False, prep_inside=False):
     if kernel == "k_bwd_mc":                  # continuous many-class backward: softmax in, dy out, class tables once, GRU tape in, gate gradients out
         return "hbm", 4 * (2 * B * D + 3 * D * R + rows * 11 * R + 3 * R * R)
     if kernel == "k_bwd_conv":
-        # read the forward tape + write the delta tape; with the register-resident kernels the launch also carries the
-        # baselines' forward pass over the live rows (their weights once, hidden tiles [2 K] out) and dbar = softmax(y) . desc [V]
-        tape = rows * 4 * (2 * H + 6 * W + 13 * R + 2 * K + D + V + 16)
+        # read the forward tape + write the delta tape (+ dbar = softmax(y) . desc [V]); with the register-resident kernels the
+        # launch also carries the baselines' forward pass over the live rows: their weights count once, their hidden tiles
+        # [2 K per row] do NOT -- they are this implementation's tape (k_wgrad's operand), not SURVEY.md 8(d)'s algorithmic bytes
+        tape = rows * 4 * (2 * H + 6 * W + 13 * R + D + V + 16)
         return "hbm", 4 * (p_sender + p_recv) + tape + 4 * (K * (W + R) + K * (H + W) + 4 * K)
     if kernel == "k_conv_tile":               # sample-tile recurrence on the matrix cores (kernels_tile.h)
         sender = 2 * H * W if H * W < 65536 else 0                      # large sender MLPs run in k_send_s1 / k_send_s2
@@ -161,6 +167,83 @@ def traffic_lookup(workload, kernel, strong, profiles_dir=None):
     return None, None
 
 
+# rocprofv3 kernel function -> the launch group (library hook mmg_set_profiling brackets groups of launches under these names)
+GROUP_OF = {
+    "k_conversation_fast3": "k_conversation", "k_conversation_fast2": "k_conversation", "k_conversation": "k_conversation",
+    "k_game_fast": "k_game",
+    "k_conversation_mc3": "k_conversation_mc", "k_conversation_mc": "k_conversation_mc",
+    "k_conv_persist": "k_conv_persist", "k_conv_tile": "k_conv_tile", "k_conv_split": "k_conv_split",
+    "k_rc_persist": "k_conv_rc", "k_rc_gru": "k_conv_rc", "k_rc_heads": "k_conv_rc", "k_rc_query": "k_conv_rc", "k_rc_tail": "k_conv_rc",
+    "k_send_s1": "k_send_s1", "k_send_s2": "k_send_s2",
+    "k_bwd_conv_fast": "k_bwd_conv", "k_bwd_conv": "k_bwd_conv",
+    "k_bwd_pre_send": "k_bwd_tile", "k_bwd_pre": "k_bwd_tile", "k_bwd_sample": "k_bwd_tile", "k_bwd_tile": "k_bwd_tile", "k_rc_bwd": "k_bwd_tile",
+    "k_send_bwd": "k_send_bwd", "k_dhx": "k_send_bwd", "k_bwd_mc1": "k_bwd_mc", "k_bwd_mc2": "k_bwd_mc",
+    "k_dC_tile": "k_dC", "k_dC": "k_dC", "k_wgrad": "k_wgrad", "k_wreduce": "k_wgrad",
+    "k_baselines": "k_baselines", "k_baselines2": "k_baselines", "k_baselines3": "k_baselines", "k_baselines4": "k_baselines", "k_gemm_nt": "k_baselines",
+    "k_prep": "k_prep+h_x", "k_stats": "k_stats", "k_bas_stats": "k_bas_stats", "k_gradnorm": "k_gradnorm", "k_opt": "k_opt",
+}
+
+
+def rocprof_lookup(workload, strong, profiles_dir=None):
+    """Per-minibatch kernel times of THIS workload from the newest committed rocprofv3 --kernel-trace --stats summary
+    (profiles/rNN_[strong_]config<N>_kernel_stats.csv, written by scripts/profile_workload.sh from the same bench command).
+    Returns None or dict(source=..., per_kernel={function: us per minibatch}, per_group={launch group: us per minibatch},
+    dominant=function with the largest share).  One minibatch = one k_opt dispatch."""
+    import csv
+    import glob
+    import re
+    pdir = profiles_dir or os.path.join(REPO, "profiles")
+    num = {"c2": "2", "c3": "3", "c4": "4", "c5": "5", "c4r256": "4r256"}.get(workload, workload)
+    pat = re.compile(r"^r(\d+)_%sconfig%s_kernel_stats\.csv$" % ("strong_" if strong else "", num))
+    files = sorted((int(pat.match(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(pdir, "r*_kernel_stats.csv"))
+                   if pat.match(os.path.basename(f)))
+    for _, f in reversed(files):
+        try:
+            rows = list(csv.DictReader(open(f)))
+        except Exception:
+            continue
+        per, calls = {}, {}
+        for r in rows:
+            m = re.search(r"mmg::(k_[A-Za-z0-9_]+)", r.get("Name", ""))
+            if not m:
+                continue
+            per[m.group(1)] = per.get(m.group(1), 0.0) + float(r["TotalDurationNs"])
+            calls[m.group(1)] = calls.get(m.group(1), 0) + int(r["Calls"])
+        n_mb = calls.get("k_opt", 0)
+        if not n_mb:
+            continue
+        per_kernel = {k: v / n_mb * 1e-3 for k, v in per.items()}
+        per_group = {}
+        for k, v in per_kernel.items():
+            g = GROUP_OF.get(k, k)
+            per_group[g] = per_group.get(g, 0.0) + v
+        return dict(source=os.path.relpath(f, REPO), per_kernel=per_kernel, per_group=per_group,
+                    dominant=max(per_kernel, key=per_kernel.get), minibatches=n_mb)
+    return None
+
+
+def sec8d_bytes_per_minibatch(d, B, n_params):
+    """SURVEY.md 8(d) "bytes per optimizer step": data 4 (B F + D V + B) + parameter / optimizer traffic 4 P * 6
+    (read w, write + read g, read + write the RMSprop state, write w)."""
+    return 4 * (B * d["feat_dim"] + d["n_classes"] * d["wv_dim"] + B) + 24 * n_params
+
+
+def event_floor_us(dev, n=200):
+    """What a HIP-event pair measures with NOTHING in between, recorded in a stream of small kernels on the engine's stream
+    (= torch's current stream): the bracket overhead every HIP-event kernel time of this file contains and rocprofv3's
+    kernel-trace durations do not (profiles/README.md)."""
+    x = torch.zeros(64, device=dev)
+    evs = []
+    for _ in range(n):
+        x.add_(1.0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b.record()
+        evs.append((a, b))
+    x.add_(1.0)
+    torch.cuda.synchronize(dev)
+    return float(np.median([a.elapsed_time(b) for a, b in evs]) * 1e3)
+
+
 def build_batches(CFG, Bg, B, rank, n, dev):
     """Minibatches of the epoch loop resident in HBM (misc.py:257-302 order: seeded shuffle, sorted indices inside a batch)."""
     import random
@@ -174,6 +257,27 @@ def build_batches(CFG, Bg, B, rank, n, dev):
         idx = sorted(order[(i % nb) * Bg:(i % nb + 1) * Bg])[rank * B:(rank + 1) * B]
         xs.append(feats[idx]); ts.append(target[idx])
     return torch.from_numpy(np.stack(xs)).to(dev), torch.from_numpy(np.stack(ts)).to(dev), torch.from_numpy(desc).to(dev)
+
+
+def collective_us(dp, eng, dev, n=100):
+    """us per all-reduce of the two collectives of a data-parallel step (multimodalgame_amd/dist.py), enqueued back to back on
+    the engine's stream exactly as the step enqueues them; every rank calls it."""
+    out = {}
+    for name, t in (("stats_f64_allreduce_us", eng.stats), ("grads_f32_allreduce_us", eng.flat_grads)):
+        if name.startswith("stats") and not eng.use_binary:
+            out[name] = None                      # continuous messages: no statistics collective (SURVEY.md 8e)
+            continue
+        buf = torch.zeros_like(t)
+        for _ in range(5):
+            dp._all_reduce(buf)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            dp._all_reduce(buf)
+        torch.cuda.synchronize(dev)
+        out[name] = (time.perf_counter() - t0) / n * 1e6
+        out[name.replace("_us", "_bytes")] = buf.numel() * buf.element_size()
+    return out
 
 
 def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=False, want_roofline=True):
@@ -215,103 +319,142 @@ def run_workload(workload, steps, warmup, seed, rank, world, local_rank, strong=
         one(i)
     sync()
     totals_before = eng.tape["totals"].cpu().numpy().copy()   # device-side running sums (semantic exchange steps, ..., sample-steps)
-    # EXACTLY `steps` minibatches per pass; passes are repeated (all inside one timed region, same count on every rank)
-    # until the region lasts MIN_TIMED_SECONDS (2 s): a 20-step run of a 75 us minibatch is 1.5 ms, too short for any sampler
-    # pass 1 is measured (one sync), then as many further passes as the window needs are enqueued back to back and
-    # synchronised ONCE: a sync per 20-step pass would leave the GPU idle while the host refills the launch queue
-    done, elapsed = 0, 0.0
+    # ---- first pass: EXACTLY `steps` minibatches from the SAME start (warmup minibatches after the seed-0 initialisation) in every
+    # round and on every box -- ms per minibatch and conversation length here are comparable, whatever the window below trains
+    # the agents into afterwards.  value_first_pass is derived from it.
     t0 = time.perf_counter()
     for i in range(steps):
         one(warmup + i)
-    done += steps
     sync()
-    elapsed = time.perf_counter() - t0
-    # the first pass on its own: `steps` minibatches from the SAME start (warmup minibatches after the seed-0 initialisation) in
-    # every round -- ms per minibatch and conversation length here are comparable across rounds, whatever the 2 s window
-    # trains the agents into afterwards (one 32-byte copy; the stream is idle after the sync above)
-    first_elapsed = elapsed
-    first_steps = float(eng.tape["totals"][0].item()) - float(totals_before[0])
-    more = torch.tensor([max(0.0, (MIN_TIMED_SECONDS - elapsed) / max(elapsed, 1e-6))], device=dev)
+    first_elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([first_elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        first_elapsed = float(tt.item())
+    totals_first = eng.tape["totals"].cpu().numpy().copy()
+    first_steps = float(totals_first[0] - totals_before[0])
+    done = steps
+    # ---- per-kernel durations at THIS point of the trajectory (right after the first pass, before the window trains the agents
+    # further): HIP events on the launch stream (library hook mmg_set_profiling; rank 0 records, every rank runs the steps:
+    # collectives!); per-step launches of one kernel are summed per minibatch.  Untimed.
+    kern_ms, tstar_live, floor_us = {}, None, 0.0
+    if want_roofline:
+        reps = min(20, steps)
+        for i in range(reps):
+            if rank == 0:
+                eng.set_profiling(True)
+            one(warmup + done + i)
+            torch.cuda.synchronize(dev)
+            if rank == 0:
+                per = {}
+                for name, ms in eng.kernel_times(max_kernels=512):
+                    per[name] = per.get(name, 0.0) + ms
+                for name, ms in per.items():
+                    kern_ms.setdefault(name, []).append(ms)
+        if rank == 0:
+            eng.set_profiling(False)
+            tstar_live = eng.tape["tstar"].float().mean().item() + 1.0      # live steps per sample (B * tstar live rows)
+            floor_us = event_floor_us(dev)
+        done += reps
+        sync()
+    # ---- the timed window: passes of EXACTLY `steps` minibatches, enqueued back to back and synchronised ONCE, as many as
+    # MIN_TIMED_SECONDS (2 s) needs (same count on every rank): a 20-step run of a 60 us minibatch is 1.2 ms, too short for any
+    # outside sampler, and a sync per pass would leave the GPU idle while the host refills the launch queue
+    totals_w0 = eng.tape["totals"].cpu().numpy().copy()
+    more = torch.tensor([max(1.0, MIN_TIMED_SECONDS / max(first_elapsed, 1e-6))], device=dev)
     if world > 1:
         dist.all_reduce(more, op=dist.ReduceOp.MAX)
-    n_more = min(int(np.ceil(more.item())), 1 << 20)
-    if n_more > 0:
-        for _ in range(n_more):
-            for i in range(steps):
-                one(warmup + done + i)
-            done += steps
-        sync()
-        elapsed = time.perf_counter() - t0
+    n_pass = min(int(np.ceil(more.item())), 1 << 20)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n_pass):
+        for i in range(steps):
+            one(warmup + done + i)
+        done += steps
+    sync()
+    elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     totals_after = eng.tape["totals"].cpu().numpy()
-    ex_steps = float(totals_after[0] - totals_before[0])
-    sample_steps = float(totals_after[3] - totals_before[3])        # sum_t n_active,t over the GLOBAL minibatches
+    timed_mb = n_pass * steps
+    ex_steps = float(totals_after[0] - totals_w0[0])
+    sample_steps = float(totals_after[3] - totals_w0[3])            # sum_t n_active,t over the GLOBAL minibatches
     eng.check_sync()                                                # no in-launch dependency wait may have timed out
-    collective = "none (single rank)"
+    collective, coll_us = "none (single rank)", None
     if world > 1:
         collective = ("direct RCCL communicator on the engine's stream (multimodalgame_amd/rccl.py), world %d" % dp.comm.world
                       if dp.comm is not None else "torch.distributed.all_reduce, backend %s" % dist.get_backend())
-    res = dict(workload=workload, label=label, B=B, Bg=Bg, elapsed=elapsed, minibatches=done, ex_steps=ex_steps,
-               sample_steps=sample_steps, cfg=CFG, roofline=None, collective=collective,
+        coll_us = collective_us(dp, eng, dev)
+    res = dict(workload=workload, label=label, B=B, Bg=Bg, elapsed=elapsed, minibatches=timed_mb, ex_steps=ex_steps,
+               sample_steps=sample_steps, cfg=CFG, roofline=None, collective=collective, collective_us=coll_us,
                first_pass_ms_per_minibatch=1e3 * first_elapsed / steps, first_pass_steps_per_minibatch=first_steps / steps,
+               first_pass_ex_steps=first_steps, first_pass_seconds=first_elapsed,
                dist_world=(dist.get_world_size() if world > 1 else 1))
-    if not want_roofline:
-        return res
-    # per-kernel durations of the same workload, HIP events on the launch stream (rank 0); per-step launches of one kernel
-    # are summed per minibatch
-    kern_ms = {}
-    reps = min(20, steps)
-    for i in range(reps):                    # every rank runs these steps (collectives!); only rank 0 records timings
-        if rank == 0:
-            eng.set_profiling(True)
-        one(warmup + i)
-        torch.cuda.synchronize(dev)
-        if rank == 0:
-            per = {}
-            for name, ms in eng.kernel_times(max_kernels=512):
-                per[name] = per.get(name, 0.0) + ms
-            for name, ms in per.items():
-                kern_ms.setdefault(name, []).append(ms)
-    if rank == 0:
-        eng.set_profiling(False)
-        avg = {k: float(np.mean(v)) for k, v in kern_ms.items()}
-        dom = max(avg, key=avg.get)
-        tstar = eng.tape["tstar"].float().mean().item() + 1.0      # live steps per sample (B * tstar live rows)
+    if want_roofline and rank == 0:
+        avg = {k: float(np.mean(v)) for k, v in kern_ms.items()}           # ms per minibatch, HIP events (raw brackets)
+        n_params = sum(e["rows"] * max(e["cols"], 1) for e in eng.param_entries)
         lean = not CFG["use_binary"]                                # (mmg_train_step and the phased DP step both run the lean tape)
         prep_inside = not any(k.startswith("k_prep") for k in avg)         # (the register-resident path with a CU per role)
-        bound, amount = algorithmic_work(dom, CFG, B, tstar, lean=lean, prep_inside=prep_inside)
-        secs = avg[dom] * 1e-3
+        # The dominant kernel is NAMED by the newest committed rocprofv3 summary of this workload (profiles/, stable across
+        # runs and boxes); the live HIP-event brackets -- which contain event_floor_us of bracket overhead each -- only decide
+        # when no summary is committed.  `achieved` = this kernel's operand bytes (or flops) / its live duration minus the
+        # bracket floor; `frac_rocprof` = the same amount / the committed rocprofv3 average (tests/test_bench_cpu.py recomputes it).
+        rp = rocprof_lookup(workload, strong)
+        dom = None
+        if rp is not None:
+            g = GROUP_OF.get(rp["dominant"], rp["dominant"])
+            dom = g if g in avg else None
+        if dom is None:
+            dom = max(avg, key=avg.get)
+        bound, amount = algorithmic_work(dom, CFG, B, tstar_live, lean=lean, prep_inside=prep_inside)
+        n_launch = {"k_wgrad": 1}.get(dom, 1)
+        live_us = max(avg[dom] * 1e3 - floor_us * n_launch, 1e-3)
+        secs = live_us * 1e-6
         if bound == "hbm":
-            achieved, peak, unit = amount / secs / 1e9, HBM_PEAK_GBS, "GB/s"
+            achieved, peak, unit, scale = amount / secs / 1e9, HBM_PEAK_GBS, "GB/s", 1e9
         else:
-            achieved, peak, unit = amount / secs / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+            achieved, peak, unit, scale = amount / secs / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", 1e12
         # HBM traffic of that kernel from the committed PMC summary of THIS workload (counters need their own rocprofv3
         # passes and cannot be collected inside this run): per-dispatch FETCH_SIZE / WRITE_SIZE
         traffic, traffic_source = traffic_lookup(workload, dom, strong)
         per_kernel = {}
         for k, ms in avg.items():
-            bk, amt = algorithmic_work(k, CFG, B, tstar, lean=lean, prep_inside=prep_inside)
+            bk, amt = algorithmic_work(k, CFG, B, tstar_live, lean=lean, prep_inside=prep_inside)
             if amt:
-                a_k = amt / (ms * 1e-3) / (1e9 if bk == "hbm" else 1e12)
+                a_k = amt / (max(ms * 1e3 - floor_us, 1e-3) * 1e-6) / (1e9 if bk == "hbm" else 1e12)
                 per_kernel[k] = dict(bound=bk, achieved=round(a_k, 3), unit="GB/s" if bk == "hbm" else "TFLOP/s",
                                      frac=round(a_k / (HBM_PEAK_GBS if bk == "hbm" else MFMA_F32_PEAK_TFLOPS), 5))
-        res["roofline"] = dict(bound=bound, kernel=dom, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                               traffic=traffic, traffic_source=traffic_source, launch_us=avg[dom] * 1e3,
-                               algorithmic_amount=amount,
-                               note="launch_us / kernels_us: HIP-event time of ALL launches of the kernel in one minibatch",
-                               kernels_us={k: round(v * 1e3, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
-                               per_kernel=per_kernel)
+        s8 = sec8d_bytes_per_minibatch(CFG, B, n_params)
+        per_mb_s = elapsed / timed_mb
+        roof = dict(bound=bound, kernel=dom, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                    traffic=traffic, traffic_source=traffic_source,
+                    traffic_ratio=(traffic / amount if (traffic and bound == "hbm" and amount) else None),
+                    launch_us=live_us, launch_us_raw=avg[dom] * 1e3, event_floor_us=floor_us,
+                    algorithmic_amount=amount, live_rows_per_sample=tstar_live,
+                    rocprof_kernel=(rp["dominant"] if rp else None), rocprof_source=(rp["source"] if rp else None),
+                    rocprof_avg_us=(rp["per_group"].get(dom) if rp else None),
+                    frac_rocprof=((amount / (rp["per_group"][dom] * 1e-6) / scale / peak) if rp and rp["per_group"].get(dom) else None),
+                    sec8d_bytes_per_minibatch=s8,
+                    step_frac=s8 / per_mb_s / 1e9 / HBM_PEAK_GBS,
+                    first_pass_step_frac=s8 / (first_elapsed / steps) / 1e9 / HBM_PEAK_GBS,
+                    note="launch_us = HIP-event time of ALL launches of `kernel` in one minibatch, taken right after the first pass, minus "
+                         "event_floor_us (an empty event bracket); kernels_us are the raw brackets; `kernel` is the launch group of "
+                         "rocprof_kernel, the largest entry of rocprof_source; step_frac = SURVEY.md 8(d) bytes per optimizer step / "
+                         "ms_per_step / HBM peak: the path is latency-bound (DESIGN.md section 0)",
+                    kernels_us={k: round(v * 1e3, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
+                    launches_per_minibatch=len(avg),
+                    per_kernel=per_kernel)
         # the conversation launch against the OTHER roof as well: SURVEY.md 8(d)'s minimal forward flops of the shard over the
         # fp32 matrix peak (most of them -- the 3 B D R relu-dot of the y head -- are VALU work by nature)
-        conv = next((k for k in avg if k.startswith(("k_conversation", "k_conv_"))), None)
+        conv = next((k for k in avg if k.startswith(("k_conversation", "k_conv_", "k_game"))), None)
         if conv is not None:
-            fl = conversation_flops(CFG, B, tstar)
-            res["roofline"]["conversation_flop"] = dict(kernel=conv, flops=fl, tflops=fl / (avg[conv] * 1e-3) / 1e12,
-                                                        flop_frac=fl / (avg[conv] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                                        peak="fp32 MFMA %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS)
+            fl = conversation_flops(CFG, B, tstar_live)
+            cs = max(avg[conv] * 1e3 - floor_us, 1e-3) * 1e-6
+            roof["conversation_flop"] = dict(kernel=conv, flops=fl, tflops=fl / cs / 1e12, flop_frac=fl / cs / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                             peak="fp32 MFMA %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS)
+        res["roofline"] = roof
     del eng
     return res
 
@@ -489,14 +632,18 @@ def main():
         # weak: one unit = an exchange step of one per-GPU-sized batch, a global minibatch of B*N samples advances N of them;
         # strong: one unit = an exchange step of the fixed global batch
         value = (1.0 if strong else world) * r["ex_steps"] / r["elapsed"]
+        value_first = (1.0 if strong else world) * r["first_pass_ex_steps"] / r["first_pass_seconds"]
         line = {
             "metric": ("exchange-steps/sec (whole node), 30-class Adaptive max_exchange=10 bs=64" if args.workload == "c2" else
                        "exchange-steps/sec (whole node) of reference workload %s -- NOT BASELINE.json's metric" % args.workload),
-            "value": value, "unit": "exchange-steps/s", "n_gpus": world, "steps": args.steps,
+            "value": value, "value_first_pass": value_first, "unit": "exchange-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * per_mb, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": r["label"], "global_batch": r["Bg"], "per_gpu_batch": r["B"], "parallelism": "dp%d" % world,
-                       "rccl_world": r["dist_world"], "collective": r["collective"],
+                       "rccl_world": r["dist_world"], "collective": r["collective"], "collective_us": r["collective_us"],
+                       "value_first_pass_definition": "the first --steps minibatches after the warm-up (seed-0 initialisation): the same point of the "
+                                                      "same training trajectory in every round and on every box; `value` is the %g s window that follows, in which "
+                                                      "training lengthens the conversations" % MIN_TIMED_SECONDS,
                        "exchange_steps_per_minibatch": r["ex_steps"] / r["minibatches"], "sampling": "in-kernel Philox4x32-10",
                        # the first --steps minibatches after the warmup, from the seed-0 initialisation: comparable across rounds
                        "first_pass_ms_per_minibatch": r["first_pass_ms_per_minibatch"],
@@ -520,7 +667,8 @@ def main():
                 other[w] = dict(workload=o["label"] + (" -- all %d samples on one GPU (--scaling strong, N=1)" % o["Bg"] if w.endswith("s") else ""), batch=o["B"], ms_per_minibatch=1e3 * o["elapsed"] / o["minibatches"],
                                 exchange_steps_per_s=o["ex_steps"] / o["elapsed"],
                                 first_pass_ms_per_minibatch=o["first_pass_ms_per_minibatch"],
-                                roofline={k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_us", "algorithmic_amount", "traffic", "traffic_source", "conversation_flop")},
+                                roofline={k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_us", "launch_us_raw", "event_floor_us", "algorithmic_amount", "traffic", "traffic_source", "traffic_ratio",
+                                                                  "rocprof_kernel", "rocprof_avg_us", "rocprof_source", "frac_rocprof", "sec8d_bytes_per_minibatch", "step_frac", "launches_per_minibatch", "conversation_flop")},
                                 kernels_us=rf.get("kernels_us"))
             line["other_configs"] = other
         if world == 1 and args.workload == "c2" and not args.no_cli and not strong:
@@ -529,6 +677,26 @@ def main():
             line["config"]["cli_over_resident"] = line["config"]["cli_steps_per_s"] / value
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             line["cpu_baseline"] = cpu_baseline()
+            cb = line["cpu_baseline"]
+            # both legs from the same initial weights: the GPU's FIRST PASS is the leg at the CPU sample's conversation length
+            cb["gpu_first_pass_over_cpu"] = value_first / cb["value"]
+            cb["gpu_first_pass_exchange_steps_per_minibatch"] = r["first_pass_steps_per_minibatch"]
+    # N > 1, default workload: the SURVEY.md 8(d) whole-node figures -- the GLOBAL batch of configs[2] (512) and configs[4] (2048)
+    # sharded over the ranks (strong scaling) -- in the SAME line, so that one driver invocation per N yields them
+    if world > 1 and args.workload == "c2" and not strong and not args.no_other_configs:
+        sc = {}
+        for w in ("c3", "c5"):
+            if STRONG_GLOBAL_BATCH[w] % world:
+                continue
+            o = run_workload(w, 30, 5, args.seed, rank, world, local_rank, strong=True, want_roofline=False)
+            sc[w + "s"] = dict(workload=o["label"], scaling="strong", global_batch=o["Bg"], per_gpu_batch=o["B"], rccl_world=o["dist_world"],
+                               value=o["ex_steps"] / o["elapsed"], unit="exchange-steps/s of the %d-sample global batch" % o["Bg"],
+                               ms_per_minibatch=1e3 * o["elapsed"] / o["minibatches"],
+                               first_pass_ms_per_minibatch=o["first_pass_ms_per_minibatch"],
+                               collective=o["collective"], collective_us=o["collective_us"])
+        if rank == 0:
+            line["strong_configs"] = sc
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
