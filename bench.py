@@ -186,7 +186,7 @@ GROUP_OF = {
 
 def rocprof_lookup(workload, strong, profiles_dir=None):
     """Per-minibatch kernel times of THIS workload from the newest committed rocprofv3 --kernel-trace --stats summary
-    (profiles/rNN_[strong_]config<N>_kernel_stats.csv, written by scripts/profile_workload.sh from the same bench command).
+    (profiles/rNN_[strong_]config<N>_kernel_stats.csv, written by scripts/round_evidence.sh from the same bench command).
     Returns None or dict(source=..., per_kernel={function: us per minibatch}, per_group={launch group: us per minibatch},
     dominant=function with the largest share).  One minibatch = one k_opt dispatch."""
     import csv
@@ -520,7 +520,7 @@ def cpu_baseline(seconds_budget=24.0):
                     ", ".join("%d thr: %.1f" % (k, v["steps_per_s"]) for k, v in sorted(out.items())), ncpu))
 
 
-def run_cli(seconds=2.0, epochs=None, dist_backend=None):
+def run_cli(seconds=2.0, epochs=None, dist_backend=None, log_dev=10 ** 9):
     """The SHIPPED training loop -- `python -m multimodalgame_amd.model`, i.e. model.run(): flag parsing, description
     pipeline, device-resident HDF5 epoch loop (misc.load_hdf5), Game.train_step per minibatch, a log line every 50 steps --
     on synthetic HDF5 / CSV / GloVe files of configs[1]'s shape (3000 train samples, 30 classes).  Returns
@@ -539,7 +539,7 @@ def run_cli(seconds=2.0, epochs=None, dist_backend=None):
         argv = ["model.py", "-experiment_name", "bench_cli", "-log_path", os.path.join(tmp, "logs"), "-model_type", "Adaptive",
                 "-batch_size", "64", "-max_exchange", "10", "-rec_w_dim", "32", "-sender_out_dim", "32", "-img_h_dim", "256",
                 "-rec_hidden", "64", "-learning_rate", "1e-4", "-entropy_rec", "0.01", "-entropy_sen", "0.01", "-entropy_s", "0.08",
-                "-use_binary", "-max_epoch", str(epochs), "-log_dev", str(10 ** 9), "-save_after", str(10 ** 9), "-exchange_samples", "0",
+                "-use_binary", "-max_epoch", str(epochs), "-log_dev", str(log_dev), "-save_after", str(10 ** 9), "-exchange_samples", "0",
                 "-top_k_train", "6"] + [a for k, v in paths.items() for a in ("-" + k, v)]
         if dist_backend:
             argv += ["-dist_backend", dist_backend]
@@ -551,6 +551,15 @@ def run_cli(seconds=2.0, epochs=None, dist_backend=None):
         with open(os.devnull, "w") as devnull, contextlib.redirect_stderr(devnull):      # (FileLogger echoes every line to stderr)
             _model.run(stats=stats)
         _flags.FLAGS.Reset()
+        if log_dev < 10 ** 9:
+            # the reference's DEFAULT cadence (-log_dev 1000, -batch_size_dev 50: eval_dev over the 3000 dev samples every 1000
+            # steps, model.py:1545-1576): the loop INCLUDING its dev evaluations
+            wall = stats["train_seconds"] + stats["eval_seconds"]
+            return dict(cli_default_flags_steps_per_s=stats["exchange_steps"] / wall,
+                        eval_dev_ms=1e3 * stats["eval_seconds"] / max(stats["evals"], 1), eval_dev_calls=stats["evals"],
+                        eval_dev_what="model.eval_dev over 3000 dev samples, -batch_size_dev 50 (60 batches: one eval-mode launch + device-side "
+                                      "reductions each, one copy to the host at the end), every 1000 training steps (-log_dev 1000, the reference's default)",
+                        cli_default_flags_eval_share=stats["eval_seconds"] / wall)
         return dict(cli_steps_per_s=stats["exchange_steps"] / stats["train_seconds"],
                     cli_ms_per_minibatch=1e3 * stats["train_seconds"] / stats["minibatches"],
                     cli_minibatches=stats["minibatches"], cli_seconds=stats["train_seconds"],
@@ -675,6 +684,7 @@ def main():
             # what `python -m multimodalgame_amd.model` sustains end to end (same GPU, right after the HBM-resident measurement)
             line["config"].update(run_cli())
             line["config"]["cli_over_resident"] = line["config"]["cli_steps_per_s"] / value
+            line["config"].update(run_cli(log_dev=1000))
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             line["cpu_baseline"] = cpu_baseline()
             cb = line["cpu_baseline"]

@@ -390,13 +390,18 @@ __device__ __forceinline__ unsigned long long ld_ll(const float* ll, size_t i) {
 __device__ __forceinline__ float ll_value(unsigned long long u) { return __builtin_bit_cast(float, (unsigned)u); }
 __device__ __forceinline__ bool ll_fresh(unsigned long long u, uint32_t epoch) { return (uint32_t)(u >> 32) == epoch; }
 
-// four consecutive pairs as one float4, spinning (bounded) until all four carry this launch's epoch
-__device__ __forceinline__ float4 ll_wait4(const float* ll, size_t i, uint32_t epoch) {
+// four consecutive pairs as one float4, spinning (bounded) until all four carry this launch's epoch.  On expiry the error word
+// sync[MMG_SYNC_ERR] is set like every other hand-off of the library does (k_opt then skips the update on every rank and every
+// later training call fails); the budget matches the sample roles' (1 << 16 rounds of 18 loads there, 4 loads a round here).
+#define MMG_LL_ERR_BASEHX 6u
+__device__ __forceinline__ float4 ll_wait4(const float* ll, size_t i, uint32_t epoch, uint32_t* sync) {
     unsigned long long u0, u1, u2, u3;
     int spins = 0;
-    do {
+    for (;;) {
         u0 = ld_ll(ll, i); u1 = ld_ll(ll, i + 1); u2 = ld_ll(ll, i + 2); u3 = ld_ll(ll, i + 3);
-    } while (!(ll_fresh(u0, epoch) && ll_fresh(u1, epoch) && ll_fresh(u2, epoch) && ll_fresh(u3, epoch)) && ++spins < (1 << 16));
+        if (ll_fresh(u0, epoch) && ll_fresh(u1, epoch) && ll_fresh(u2, epoch) && ll_fresh(u3, epoch)) break;
+        if (++spins > (1 << 18)) { if (sync) __hip_atomic_store(sync + MMG_SYNC_ERR, MMG_LL_ERR_BASEHX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
     return make_float4(ll_value(u0), ll_value(u1), ll_value(u2), ll_value(u3));
 }
 

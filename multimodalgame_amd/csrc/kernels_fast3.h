@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
     constexpr bool merged = MERGED;
     const uint32_t n_consumers = (uint32_t)(dm.B + ar.nbase);
     if (merged && (int)blockIdx.x >= dm.B && (int)blockIdx.x < dm.B + ar.nprep) {
-        prep_body<true>(dm, P, tp, ar.desc, ar.x, ar.prep_cpb, (int)blockIdx.x - dm.B, lds);
+        prep_body<true>(dm, P, tp, ar.desc, ar.x, ar.prep_cpb, (int)blockIdx.x - dm.B, lds, ar.train);
 #ifdef MMG_TIMING
         {   // when the first class block, the first hw0 block and the first / last h_x tile are through (scripts/timeline.py)
             const int nC = (dm.D + ar.prep_cpb - 1) / ar.prep_cpb, HB = (dm.H + 63) / 64, blk = (int)blockIdx.x - dm.B;
@@ -124,12 +124,12 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
 #endif
         return;
     }
-    if (merged && (int)blockIdx.x == ar.nprep + dm.B + ar.nbase) { prep_closing_role(tp, n_consumers); return; }
+    if (merged && (int)blockIdx.x == ar.nprep + dm.B + ar.nbase) { prep_closing_role(tp, n_consumers, ar.train); return; }
     if ((int)blockIdx.x >= ar.nprep + dm.B) {
         const int tile = (int)blockIdx.x - ar.nprep - dm.B;
         if (!merged) { gemm_nt_tile(tile, tp.hx, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H); return; }
         // (A operand = the h_x pairs of this launch's prep roles: the loads spin until they carry this launch's epoch)
-        gemm_nt_tile<false, true>(tile, tp.prepll, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H, nullptr, tp.counter[3] + 1u);
+        gemm_nt_tile<false, true>(tile, tp.prepll, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H, nullptr, tp.counter[3] + 1u, tp.sync);
         if (threadIdx.x == 0) prep_consumer_arrive(tp);
         return;
     }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
 #ifdef MMG_TIMING
     if (b == 0 && tid == 0) tp.dbg[4] = (long long)__builtin_readcyclecounter();
 #endif
-    const uint32_t mb_counter = tp.counter[0] + (merged ? 1u : 0u);      // (merged: bumped by the launch's closing role)
+    const uint32_t mb_counter = tp.counter[0] + ((merged && train) ? 1u : 0u);      // (merged: bumped by the launch's closing role -- training launches only)
     const uint32_t ll_epoch = tp.counter[3] + 1u;                         // epoch of this launch's (value, epoch) pairs
     const uint32_t gb = (uint32_t)(dm.boff + b);
     const int tgt = ar.target ? (int)ar.target[b] : -1;     // (read here: no dependent memory round trip after the conversation)

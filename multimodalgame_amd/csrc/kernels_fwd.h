@@ -21,7 +21,7 @@ namespace mmg {
 template <bool LLO = false, bool LLA = false>
 __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__ X, int ldx, const float* __restrict__ Wm, int ldw,
                                              const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K,
-                                             float* ll = nullptr, uint32_t epoch = 0u);
+                                             float* ll = nullptr, uint32_t epoch = 0u, uint32_t* sync = nullptr);
 
 // blocks [0, D]: parameter-only constants; blocks (D, D + hx_tiles]: tiles of h_x = image_layer(x)
 // (model.py:195) -- independent work sharing one launch.
@@ -71,7 +71,7 @@ __device__ __forceinline__ void prep_repack(const Dims& dm, const Params& P, con
 }
 template <bool ROLE>
 __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const Tape& tp, const float* __restrict__ desc,
-                                          const float* __restrict__ x, const int cpb, const int blk, float* smem) {
+                                          const float* __restrict__ x, const int cpb, const int blk, float* smem, const int bump_mb) {
     const int tid = threadIdx.x;
     const uint32_t epoch = ROLE ? tp.counter[3] + 1u : 0u;
     const int HB = (dm.H + 63) / 64;                 // blocks [nC, nC + HB): 64 rows of hw0 each
@@ -192,7 +192,10 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
         if (first && mc_shape(dm.H, dm.W, dm.R, dm.V, dm.D, dm.T))                                    // ... and of k_conversation_mc
             for (int i = tid; i < 2 * ((dm.B + 15) / 16); i += blockDim.x) tp.mcflags[(size_t)i * 64] = 0u;
         if (first && tid == 0) {
-            if (!ROLE) { tp.counter[0] += 1u; tp.counter[3] += 1u; }   // minibatch counter: the Philox stream of this conversation; launch epoch
+            // minibatch counter = the Philox stream of a TRAINING conversation: evaluation passes draw nothing and leave it alone (an
+            // eval_dev on the training engine must not move the sampling stream -- data-parallel ranks evaluate on rank 0 only);
+            // the launch epoch of the (value, epoch) pair hand-offs moves with every launch
+            if (!ROLE) { if (bump_mb) tp.counter[0] += 1u; tp.counter[3] += 1u; }
             if (tp.counter[2] > tp.counter[1]) tp.counter[1] = tp.counter[2];   // optimizer step bumped by k_opt
         }
         __syncthreads();
@@ -231,7 +234,7 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
 __device__ __forceinline__ void prep_consumer_arrive(const Tape& tp) {
     __hip_atomic_fetch_add(PREP_CTR(tp, PREP_CTR_ARRIVE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void prep_closing_role(const Tape& tp, const uint32_t consumers) {
+__device__ __forceinline__ void prep_closing_role(const Tape& tp, const uint32_t consumers, const int bump_mb) {
     if (threadIdx.x != 0) return;
     int spins = 0;
     while (__hip_atomic_load(PREP_CTR(tp, PREP_CTR_ARRIVE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < consumers) {
@@ -239,16 +242,17 @@ __device__ __forceinline__ void prep_closing_role(const Tape& tp, const uint32_t
         if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
     __hip_atomic_store(PREP_CTR(tp, PREP_CTR_ARRIVE), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tp.counter[0] += 1u; tp.counter[3] += 1u;
+    if (bump_mb) tp.counter[0] += 1u;
+    tp.counter[3] += 1u;
 }
 __host__ __device__ inline int prep_blocks(const Dims& d, int cpb, bool with_hx) {
     return (d.D + cpb - 1) / cpb + (d.H + 63) / 64 + (with_hx ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0) + (prep_has_repack(d) ? MMG_REPACK_BLOCKS : 0);
 }
 
 __global__ __launch_bounds__(MMG_BLOCK) void k_prep(Dims dm, Params P, Tape tp, const float* __restrict__ desc,
-                                                    const float* __restrict__ x, int cpb) {
+                                                    const float* __restrict__ x, int cpb, int bump_mb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    prep_body<false>(dm, P, tp, desc, x, cpb, (int)blockIdx.x, smem);
+    prep_body<false>(dm, P, tp, desc, x, cpb, (int)blockIdx.x, smem, bump_mb);
 }
 
 
@@ -264,7 +268,7 @@ template <bool LLO, bool LLA>
 __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__ X, int ldx,
                                                        const float* __restrict__ Wm, int ldw,
                                                        const float* __restrict__ bias,
-                                                       float* __restrict__ out, int ldo, int M, int N, int K, float* ll, uint32_t epoch) {
+                                                       float* __restrict__ out, int ldo, int M, int N, int K, float* ll, uint32_t epoch, uint32_t* sync) {
     __shared__ float s_acc[4][16][17];
     const int tiles_n = (N + 15) >> 4;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -287,7 +291,7 @@ __device__ __forceinline__ void gemm_nt_tile(int tile, const float* __restrict__
             for (int u = 0; u < 8; ++u) {
                 const int k = (cb0 + u) * 16 + q * 4;
                 const bool kv = (cb0 + u) < c1;
-                a[u] = (mv && kv) ? (LLA ? ll_wait4(X, (size_t)(mv ? m : 0) * ldx + k, epoch) : *reinterpret_cast<const float4*>(xr + k)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[u] = (mv && kv) ? (LLA ? ll_wait4(X, (size_t)(mv ? m : 0) * ldx + k, epoch, sync) : *reinterpret_cast<const float4*>(xr + k)) : make_float4(0.f, 0.f, 0.f, 0.f);
                 b[u] = (nv && kv) ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll

@@ -78,6 +78,7 @@ struct mmg_handle {
     uint32_t* d_err;           // its device-side address
     // debugging switches of the launch paths (environment, read ONCE at mmg_create -- never on the per-minibatch path)
     bool sw_rsample, sw_rmsg, sw_fused_s, sw_xcd_map, rs_capable;
+    bool sw_pre_bands, sw_rc_tile_prelude;   // MMG_NO_PRE_BANDS=1 / MMG_RC_TILE_PRELUDE=1 (wide-receiver backward, kernels_rc.h)
     bool mc_ok;                // many-class register-resident conversation (kernels_mc.h); MMG_NO_MC=1: off
     bool mc_never_big, mc_bwd_ok;
     bool mc3_ok;               // continuous messages: the one-wave-per-SIMD many-class kernel (kernels_mc3.h); MMG_MC_OLD=1: k_conversation_mc
@@ -354,6 +355,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->sw_merge_bas = !getenv("MMG_NO_MERGE_BAS"); h->defer_bas = false; h->bas_deferred = false;
     h->sw_rsample = !getenv("MMG_NO_RSAMPLE"); h->sw_rmsg = !getenv("MMG_NO_RMSG"); h->sw_fused_s = !getenv("MMG_NO_FUSED_S");
     h->sw_xcd_map = getenv("MMG_XCD_MAP") != nullptr;
+    h->sw_pre_bands = !getenv("MMG_NO_PRE_BANDS"); h->sw_rc_tile_prelude = getenv("MMG_RC_TILE_PRELUDE") != nullptr;
     h->mc_ok = h->use_fast && mc_shape(h->dm.H, h->dm.W, h->dm.R, h->dm.V, h->dm.D, h->dm.T) && !getenv("MMG_NO_MC");
     h->mc_per = (((h->dm.D + 15) / 16) + 3) & ~3;
     h->mc_xcd = (getenv("MMG_MC_XCD") && atoi(getenv("MMG_MC_XCD")) == 0) ? 0 : 1;     // (measured at config 5, 256 samples: 192 us per minibatch against 201)
@@ -600,13 +602,13 @@ static int launch_gemm_nt(mmg_handle* h, hipStream_t st, const char* name, const
 }
 
 // x != NULL: also computes h_x = image_layer(x) in the same launch
-static int launch_prep(mmg_handle* h, hipStream_t st, const float* desc, const float* x) {
+static int launch_prep(mmg_handle* h, hipStream_t st, const float* desc, const float* x, int bump_mb) {
     Scope sc(h, st, x ? "k_prep+h_x" : "k_prep");
     const Dims& d = h->dm;
     const int hx_tiles = x ? ((d.B + 15) / 16) * ((d.H + 15) / 16) : 0;
     const int cpb = h->prep_cpb, nC = (d.D + cpb - 1) / cpb;
     (void)nC; (void)hx_tiles;
-    hipLaunchKernelGGL(k_prep, dim3(prep_blocks(d, cpb, x != nullptr)), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc, x, cpb);
+    hipLaunchKernelGGL(k_prep, dim3(prep_blocks(d, cpb, x != nullptr)), dim3(MMG_BLOCK), h->prep_smem, st, h->dm, h->P, h->tp, desc, x, cpb, bump_mb);
     return launch_check("k_prep");
 }
 
@@ -780,7 +782,7 @@ extern "C" int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64
     const bool merge_prep = h->sw_merge_prep && !tile_path(h) && !mc_path(h) && fast_shape(h) && h->use_fast3 &&
                             h->prep_smem <= fast3_lds_bytes() &&
                             prep_blocks(d, h->prep_cpb, true) + d.B <= h->n_cu;
-    if (!merge_prep && launch_prep(h, st, d_desc, d_x)) return -1;
+    if (!merge_prep && launch_prep(h, st, d_desc, d_x, train ? 1 : 0)) return -1;
     const bool bas = train && d.use_binary;
     ConvArgs ar;
     memset(&ar, 0, sizeof(ar));
@@ -910,7 +912,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             Scope sc(h, st, "k_bwd_tile");
             // the dh-independent part of the receiver's BPTT (seeds, dgpre, dhin) for all (step, sample) rows, then the recurrence
             // wide receiver whose reverse-time loop runs as roles (k_rc_bwd adds the partials): four column bands per (step, tile)
-            const int pre_bands = (h->rc_fwd && h->rc_bwd && d.R == 256 && !getenv("MMG_NO_PRE_BANDS")) ? 4 : 1;
+            const int pre_bands = (h->rc_fwd && h->rc_bwd && d.R == 256 && h->sw_pre_bands) ? 4 : 1;
             if (d.use_binary && merged_send) {
                 const int nbands = (d.H + 63) / 64, nrb = (d.T * d.B + MMG_TM - 1) / MMG_TM;
                 const int smem = bwd_pre_lds_floats(d) * 4 > h->send_bwd_smem ? bwd_pre_lds_floats(d) * 4 : h->send_bwd_smem;
@@ -934,7 +936,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             else if (h->rc_fwd && h->rc_bwd) {
                 // wide receiver: k_bwd_tile's output-step prelude, then the reverse-time loop as roles over 16-unit slices (kernels_rc.h)
                 // (MMG_RC_TILE_PRELUDE=1: the prelude stays a launch of k_bwd_tile's, one workgroup per tile)
-                const bool tile_prelude = getenv("MMG_RC_TILE_PRELUDE") != nullptr;
+                const bool tile_prelude = h->sw_rc_tile_prelude;
                 if (!d.use_binary && !tile_prelude) hipMemsetAsync(h->tp.rcflags, 0, 64 * 64 * sizeof(uint32_t), st);   // (binary mode: zeroed by k_bwd_pre)
                 if (tile_prelude)
                     hipLaunchKernelGGL((k_bwd_tile<512, 8>), dim3(tiles), dim3(512), h->tile_bwd_smem, st, h->dm, h->P, h->tp, d_target, zero_dead, (row_map ? 1 : 0) | 2);
@@ -1139,7 +1141,7 @@ extern "C" int mmg_sender_forward(mmg_handle* h, const float* d_x, const float* 
         Scope sc(h, st, "k_prep(sender)");
         Dims d1 = h->dm; d1.D = 0;
         hipLaunchKernelGGL(k_prep, dim3((d1.H + 63) / 64), dim3(MMG_BLOCK), h->prep_smem, st, d1, h->P, h->tp, (const float*)nullptr,
-                           (const float*)nullptr, 1);
+                           (const float*)nullptr, 1, train ? 1 : 0);
         if (launch_check("k_prep")) return -1;
     }
     if (launch_gemm_nt(h, st, "k_gemm_nt(h_x)", d_x, d.F, h->P.p[S_IMG_W], d.F, h->P.p[S_IMG_B], h->tp.hx, d.H, d.B, d.H, d.F)) return -1;
@@ -1168,7 +1170,7 @@ extern "C" int mmg_receiver_forward(mmg_handle* h, const float* d_z, const float
     const Dims& d = h->dm;
     const size_t offW = (size_t)t * d.B * d.W, offB = (size_t)t * d.B;
     HIP_OK(hipMemcpyAsync(h->tp.z + offW, d_z, sizeof(float) * d.B * d.W, hipMemcpyDeviceToDevice, st));
-    if (launch_prep(h, st, d_desc, nullptr)) return -1;
+    if (launch_prep(h, st, d_desc, nullptr, train ? 1 : 0)) return -1;
     ConvArgs ar;
     memset(&ar, 0, sizeof(ar));
     ar.desc = d_desc; ar.seed = seed; ar.train = train; ar.run_all = 1;

@@ -40,9 +40,11 @@ class DataParallel(object):
         else:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
 
-    def train_step(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0):
+    def train_step(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0, full_tape=False):
+        """full_tape: every sample runs all steps and the whole tape is stored (the minibatches whose log block reads it,
+        model.py:1342-1542); same update."""
         e = self.engine
-        e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=False, minimal=True)
+        e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=bool(full_tape), minimal=not full_tape)
         if e.use_binary:
             e.loss_stats()
             if self.world > 1:

@@ -186,15 +186,39 @@ class Game(object):
         self.modules["receiver"].h_w = tp["g"][n - 1]
         return s, sen_w, rec_w, y, bs, br
 
+    def eval_forward(self, data, target, desc):
+        """The eval-mode conversation of exchange() (rounded messages, cumulative-product stop bit, every sample runs all
+        max_exchange steps) WITHOUT slicing / cloning the tape into the reference's per-step lists and without any host
+        synchronisation: returns the engine, whose tape views (mask, s, ps, z, pz, w, pw, y, ...) stay valid until its next
+        forward pass.  eval_dev() reduces them on the device (model.py:640-691)."""
+        for k in ("sender", "receiver"):
+            if self.modules.get(k) is not None:
+                self.modules[k].train(False)
+        B = data.size(0)
+        eng = self.engine_for(B, desc.size(0))
+        dev = eng.device
+        data = data.to(dev, torch.float32).contiguous().view(B, -1)
+        desc = desc.to(dev, torch.float32).contiguous()
+        target = None if target is None else target.to(dev, torch.int64).contiguous()
+        self._call += 1
+        eng.forward(data, target, desc, seed=self.seed, train=False, run_all=True)
+        return eng
+
     # ------------------------------------------------------------------ model.py:1240-1339
-    def train_step(self, data, target, desc, uniforms=None):
+    def train_step(self, data, target, desc, uniforms=None, full_tape=False):
         """exchange + masks + losses + four backward/clip/optimizer blocks, fused on the device.
         Nothing is copied to the host; read ``losses()`` when a log line needs them.
         The step keeps only what training reads (include/mmg.h: run_all_steps == 2): per-(step, sample) tape arrays are valid on
         the LIVE rows (t <= tstar[b]) only, in Fixed mode tape["y"] holds the output step only, and in continuous mode
         (-nouse_binary) the arrays a / c / zr / dbar / g / w are NOT written -- code that wants them after a training step
         calls exchange() (run-all) instead.  model.run's sample dump reads live rows of binary runs only
-        (flags.default_flags sets -exchange_samples 0 without -use_binary, model.py:1758-1759)."""
+        (flags.default_flags sets -exchange_samples 0 without -use_binary, model.py:1758-1759).
+
+        full_tape=True (the minibatches that write a log block, model.py:1342-1542): the SAME update through the phased calls
+        with every sample running all steps of the conversation (run-all), so that the tape holds what the reference's log
+        block prints -- the class logits of stopped samples too ("Entropy Receiver Predictions" is a mean over the whole
+        batch at every executed step, model.py:880-886) and every row of the sample dump.  Early exit == run-all and
+        fused == phased are parity-tested (tests/test_hip_parity.py); the extra launches cost ~30 us once per log_interval."""
         B = data.size(0)
         eng = self.train_engine_for(B, desc.size(0))
         u = uniforms or (None, None, None)
@@ -209,7 +233,12 @@ class Game(object):
             if dp is None:
                 from .dist import DataParallel
                 dp = self._dp[id(eng)] = DataParallel(eng, group=self.group)
-            dp.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed)
+            dp.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed, full_tape=full_tape)
+        elif full_tape:
+            eng.forward(data, target, desc, u[0], u[1], u[2], seed=self.seed, train=True, run_all=True)
+            eng.loss_stats()
+            eng.backward(data, target, desc)
+            eng.clip_step()
         else:
             eng.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed)
         return eng

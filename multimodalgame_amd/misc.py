@@ -295,16 +295,37 @@ def _resident(hdf5_file, feats, device):
 RESIDENT_FRACTION = 0.5       # of the device's free memory: resident copy + the epoch's gathered copy must fit below it
 
 
-def _fits_on_device(data, feats, device):
+_RESIDENT_DECISION = {}       # (file key, feats, device) -> bool, decided ONCE per file and device
+
+
+def _fits_on_device(data, feats, device, hdf5_file=None):
     """The device-resident epoch holds every requested feature array twice (the preloaded file and the epoch's batch-ordered
     gather).  A dataset beyond RESIDENT_FRACTION of the free device memory streams from the host instead, batch by batch, as
-    the reference does (misc.py:284-302)."""
+    the reference does (misc.py:284-302).  The decision is taken ONCE per (file, device): from epoch 1 on the resident copy is
+    pinned in _RESIDENT_CACHE and the previous epoch's gather sits in torch's caching allocator, so the memory that is "free"
+    then is two dataset sizes smaller than in epoch 0 -- re-deciding per epoch silently dropped mid-sized datasets to host
+    streaming with the unused resident copy still allocated.  A file that is already resident only needs room for its gather."""
     device = torch.device(device)
     if device.type != "cuda":
         return True
-    need = 2 * sum(int(np.prod(data[name].shape)) * 4 for name in feats)
+    key = None
+    if hdf5_file is not None:
+        key = (_file_key(hdf5_file), tuple(feats), str(device))
+        if key in _RESIDENT_DECISION:
+            return _RESIDENT_DECISION[key]
+    one = sum(int(np.prod(data[name].shape)) * 4 for name in feats)
+    resident = key is not None and key in _RESIDENT_CACHE
     free, _ = torch.cuda.mem_get_info(device)
-    return need <= RESIDENT_FRACTION * free
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)     # blocks torch's allocator holds but nobody uses
+    fits = (one if resident else 2 * one) <= RESIDENT_FRACTION * free
+    if key is not None:
+        _RESIDENT_DECISION[key] = fits
+    if not fits:
+        import sys
+        sys.stderr.write("load_hdf5: %s (%d MB per copy) does not fit twice into %.0f%% of the free memory of %s: streaming "
+                         "batches from the host instead of the device-resident epoch loop\n"
+                         % (hdf5_file, one >> 20, 100 * RESIDENT_FRACTION, device))
+    return fits
 
 
 def load_hdf5(hdf5_file, batch_size, random_seed, shuffle, truncate_final_batch=False, map_labels=int,
@@ -328,7 +349,7 @@ def load_hdf5(hdf5_file, batch_size, random_seed, shuffle, truncate_final_batch=
         assert not truncate_final_batch, "a ragged final batch cannot be sharded evenly (training drops it, misc.py:279)"
         lo, per = shard_range(batch_size, shard[0], shard[1])
         batches = [idx[lo:lo + per] for idx in batches]
-    if device is not None and not _fits_on_device(data, feats, device):
+    if device is not None and not _fits_on_device(data, feats, device, hdf5_file):
         for idx in batches:                              # streaming fallback: host batches, one copy per batch
             batch = {"target": torch.tensor([map_labels(int(t)) for t in data["Target"][idx]], dtype=torch.int64).to(device)}
             if with_ids:

@@ -29,44 +29,78 @@ def _desc_matrix(csv_path, glove_path, wv_dim):
     return desc, (lambda x: label_id_to_idx.get(x))
 
 
-def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels, conf_mat_path, device):
-    """model.py:580-722: deterministic conversations on the dev set, top-k accuracy (nominal batch size in
-    the denominator, line 667), confusion matrix, conversation length and Hamming statistics."""
-    m = game.modules
-    conversation_lengths, hamming_sen, hamming_rec, true_labels, pred_labels = [], [], [], [], []
-    total, correct = 0.0, 0
+def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels, conf_mat_path, device, dump=None):
+    """model.py:580-722 ON THE DEVICE: deterministic conversations on the dev set, top-k accuracy (nominal batch size in the
+    denominator, line 667), confusion matrix, conversation length and Hamming statistics.
+
+    One pass per dev batch with NO host synchronisation: the eval-mode conversation (Game.eval_forward: one launch, all T
+    steps of every sample) leaves masks / stop bits / messages / class logits on the engine's tape, and everything the
+    reference then does on the host per batch -- the early-break step count n (model.py:866), output selection
+    (get_rec_outp, 879-904), log-softmax, top-k membership (657-668), argmax, conversation lengths (671-672), the per-step
+    mean Hamming distance of both agents' messages averaged over the n executed steps (675-691) -- is a handful of torch ops
+    enqueued behind it; per-batch results are accumulated in device tensors (hit count, a [D, D] confusion matrix by
+    index_add_, the conversation lengths, the two Hamming means) and copied to the host ONCE after the last batch.
+    (Round 4 transcribed the host loop literally: numpy argsort per batch and ~20 float() syncs per batch.)
+
+    dump: optional dict that receives the last batch's engine (the dev sample dump of model.py:1463-1518 reads its tape)."""
+    W = FLAGS.rec_w_dim
+    n_cls = desc.size(0)
+    dev = torch.device(device)
+    correct = torch.zeros((), dtype=torch.int64, device=dev)
+    conf_flat = torch.zeros(n_cls * n_cls, dtype=torch.int64, device=dev)
+    seen = torch.zeros(n_cls, dtype=torch.int64, device=dev)
+    conv_lens, ham_sen, ham_rec = [], [], []
+    total = 0.0
+    eng = None
     for batch in load_hdf5(dev_file, batch_size, epoch, shuffle, truncate_final_batch=True, map_labels=map_labels,
                            feats=(FLAGS.img_feat,), device=device):
         target, data = batch["target"], batch[FLAGS.img_feat]
         _bs = target.size(0)
-        args = dict(data=data, target=target, desc=desc, train=False, break_early=not FLAGS.fixed_exchange)
-        s, sen_w, rec_w, y, _, _ = exchange(m["sender"], m["receiver"], None, None, args)
-        s_masks, s_feats, _ = s
-        y_masks = None if FLAGS.fixed_exchange else [torch.min(1 - m1, m2) for m1, m2 in zip(s_masks[1:], s_masks[:-1])]
-        outp, _ = get_rec_outp(y, y_masks)
+        eng = game.eval_forward(data, target, desc)
+        tp = eng.tape
+        T = game.max_exchange
+        mask = tp["mask"].view(T + 1, _bs).to(torch.float32)                 # m_0 .. m_T, running minimum of the stop bits
+        steps = torch.arange(T, device=mask.device)
+        if FLAGS.fixed_exchange:
+            n = torch.full((), T, dtype=torch.int64, device=mask.device)
+            tsel = torch.full((_bs,), T - 1, dtype=torch.int64, device=mask.device)
+        else:
+            dead = mask[1:].sum(1) == 0                                      # step t after which nobody is alive (model.py:866)
+            n = torch.where(dead.any(), torch.argmax(dead.to(torch.int8)) + 1, torch.full((), T, dtype=torch.int64, device=mask.device))
+            # y_masks[t] = min(1 - m'_{t+1}, m'_t) with m'_n forced to 0 (model.py:870, 1261): the masks are a running minimum
+            # that starts at 1, so the selected step of a sample is the number of t in 1..n-1 with m_t = 1
+            tsel = (mask[1:] * (steps + 1 < n).to(mask.dtype).view(T, 1)).sum(0).to(torch.int64)
+        live = (steps < n).to(torch.float32)                                 # the steps the reference executed: t < n
+        y = tp["y"].view(T, _bs, -1)
+        outp = y.gather(0, tsel.view(1, _bs, 1).expand(1, _bs, y.size(2)))[0]
         dist = F.log_softmax(outp, dim=1)
-        top_k_ind = torch.from_numpy(dist.cpu().numpy().argsort()[:, -top_k:]).long()          # model.py:658
-        pred_labels.append(dist.argmax(1).cpu().numpy())
-        true_labels.append(target.cpu().numpy().reshape(-1))
-        total += float(batch_size)                                                             # model.py:667
-        correct += int((top_k_ind == target.cpu().view(-1, 1).expand(_bs, top_k)).sum())
-        conversation_lengths += torch.cat(s_feats, 1).float().sum(1).view(-1).tolist()
-        for feats, acc in ((sen_w[0], hamming_sen), (rec_w[0], hamming_rec)):
-            prev, h = torch.zeros(_bs, FLAGS.rec_w_dim, device=device), 0.0
-            for msg in feats:
-                h += float((msg - prev).abs().sum(1).mean())
-                prev = msg
-            acc.append(h / float(len(feats)))
-    true_labels, pred_labels = np.concatenate(true_labels), np.concatenate(pred_labels)
+        tgt = target.to(dist.device).view(-1)
+        top_k_ind = dist.topk(min(top_k, dist.size(1)), dim=1).indices      # (= argsort()[:, -top_k:] as a set, model.py:658)
+        correct += (top_k_ind == tgt.view(-1, 1)).sum().to(correct.device)
+        pred = dist.argmax(1)
+        conf_flat.index_add_(0, (tgt * n_cls + pred).to(conf_flat.device), torch.ones(_bs, dtype=torch.int64, device=conf_flat.device))
+        seen.index_add_(0, torch.cat([tgt, pred]).to(seen.device), torch.ones(2 * _bs, dtype=torch.int64, device=seen.device))
+        total += float(batch_size)                                           # model.py:667: the NOMINAL batch size
+        conv_lens.append((tp["s"].view(T, _bs).to(torch.float32) * live.view(T, 1)).sum(0))
+        for name, acc in (("z", ham_sen), ("w", ham_rec)):
+            msg = tp[name].view(T, _bs, W).to(torch.float32)
+            prev = torch.cat([torch.zeros(1, _bs, W, device=msg.device), msg[:-1]], 0)
+            per_step = (msg - prev).abs().sum(2).mean(1)                     # [T]: mean over the batch of the Hamming distance
+            acc.append((per_step * live).sum() / n.to(torch.float32))
+    # ---- ONE copy to the host
+    correct_h = int(correct.item())
+    conf_full = conf_flat.view(n_cls, n_cls).cpu().numpy()
+    occ = np.nonzero(seen.cpu().numpy() > 0)[0]
     # sklearn.metrics.confusion_matrix (model.py:709): rows / columns = the SORTED CLASSES THAT OCCUR in truth or prediction
-    labels = np.unique(np.concatenate([true_labels, pred_labels]))
-    conf = np.zeros((labels.size, labels.size), np.int64)
-    np.add.at(conf, (np.searchsorted(labels, true_labels), np.searchsorted(labels, pred_labels)), 1)
-    np.savetxt(conf_mat_path, conf, delimiter=",", fmt="%d")
-    cl = np.array(conversation_lengths)
+    np.savetxt(conf_mat_path, conf_full[np.ix_(occ, occ)], delimiter=",", fmt="%d")
+    cl = torch.cat(conv_lens).cpu().numpy().astype(np.float64) if conv_lens else np.zeros(0)
+    hs = torch.stack(ham_sen).cpu().numpy().astype(np.float64) if ham_sen else np.zeros(0)
+    hr = torch.stack(ham_rec).cpu().numpy().astype(np.float64) if ham_rec else np.zeros(0)
     extra = dict(conversation_lengths_mean=cl.mean(), conversation_lengths_std=cl.std(),
-                 hamming_sen_mean=np.array(hamming_sen).mean(), hamming_rec_mean=np.array(hamming_rec).mean())
-    return correct / total, extra
+                 hamming_sen_mean=hs.mean(), hamming_rec_mean=hr.mean())
+    if dump is not None:
+        dump["engine"] = eng
+    return correct_h / total, extra
 
 
 def _device(local_rank):
@@ -209,7 +243,7 @@ def _run(stats, flogger, device, rank, world):
     # subtracts what the previous log line read -- nothing is copied or enqueued per minibatch.
     steps_run, steps_at_log, hits_at_log = 0, 0, 0.0
     totals0 = None
-    eval_seconds = 0.0
+    eval_seconds, n_evals = 0.0, 0
     import time as _time
 
     def finish():
@@ -217,7 +251,8 @@ def _run(stats, flogger, device, rank, world):
             _sync(device)
             tot = game._train_engine.tape["totals"].cpu().tolist()
             stats.update(train_seconds=_time.perf_counter() - t_loop - eval_seconds, minibatches=steps_run,
-                         exchange_steps=tot[0] - totals0[0], sample_steps=tot[3] - totals0[3])
+                         exchange_steps=tot[0] - totals0[0], sample_steps=tot[3] - totals0[3],
+                         eval_seconds=eval_seconds, evals=n_evals)
     _sync(device)
     t_loop = _time.perf_counter()
     while epoch < FLAGS.max_epoch:
@@ -230,7 +265,9 @@ def _run(stats, flogger, device, rank, world):
             if totals0 is None:                      # (the first minibatch creates the engine)
                 totals0 = game.train_engine_for(batch["target"].size(0), desc_train.size(0)).tape["totals"].cpu().tolist()
                 hits_at_log = totals0[1]
-            eng = game.train_step(batch[FLAGS.img_feat], batch["target"], desc_train)     # model.py:1240-1339
+            # (a minibatch that writes a log block keeps the whole tape: every sample runs all steps -- same update, see Game.train_step)
+            eng = game.train_step(batch[FLAGS.img_feat], batch["target"], desc_train,
+                                  full_tape=(step % FLAGS.log_interval == 0))                # model.py:1240-1339
             steps_run += 1
             if step % FLAGS.log_interval == 0 and rank == 0:               # model.py:1342-1377 (global-minibatch figures)
                 L = eng.losses()
@@ -248,14 +285,20 @@ def _run(stats, flogger, device, rank, world):
                         flogger.Log(pre + "Loss Receiver (S): {}".format(L["loss_binary_s"]))
                     flogger.Log(pre + "Loss Baseline (S): {}".format(L["loss_bas_sen"]))
                     flogger.Log(pre + "Loss Baseline (R): {}".format(L["loss_bas_rec"]))
+                for line in _entropy_lines(eng, batch["target"], L):       # model.py:1379-1407
+                    flogger.Log(line)
                 if FLAGS.exchange_samples > 0:                             # model.py:1411-1461 (train sample dump)
-                    flogger.Log(_sample_dump(eng, "Train:"))
+                    flogger.Log(_sample_dump(eng, "Train:", int(L["n_steps"])))
+                    # model.py:1463-1518: the same minibatch once more in evaluation mode (rounded messages), same layout
+                    ev = game.eval_forward(batch[FLAGS.img_feat], batch["target"], desc_train)
+                    flogger.Log(_sample_dump(ev, "Eval:", _executed_steps(ev, FLAGS.fixed_exchange)))
             if step % FLAGS.log_dev == 0 and rank == 0:                    # model.py:1545-1576
                 _sync(device)
                 t_ev = _time.perf_counter()
                 dev_acc, extra = do_eval()
                 _sync(device)
                 eval_seconds += _time.perf_counter() - t_ev
+                n_evals += 1
                 pre = "Epoch: {} Step: {} Batch: {} ".format(epoch, step, i_batch)
                 flogger.Log(pre + "Development Accuracy: {}".format(dev_acc))
                 flogger.Log(pre + "Conversation Length (avg/std): {}/{}".format(
@@ -278,16 +321,62 @@ def _run(stats, flogger, device, rank, world):
     flogger.Log("Finished training.")
 
 
-def _sample_dump(eng, title):
-    """model.py:1415-1461: sparkline of the probabilities and the sampled bits of the first samples."""
+def _executed_steps(eng, fixed):
+    """Steps the reference's exchange() executes on this batch (model.py:866: break once every sample has stopped)."""
+    T = eng.tape["mask"].size(0) - 1
+    if fixed:
+        return T
+    alive = eng.tape["mask"][1:, :, 0].sum(1).tolist()
+    for t, a in enumerate(alive):
+        if a == 0:
+            return t + 1
+    return T
+
+
+def _entropy_lines(eng, target, L):
+    """model.py:1379-1407: "Predictions" (targets over argmax predictions of the minibatch) and the per-step entropies the
+    losses report -- "Entropy Sender Binary" / "Entropy Receiver Binary": minus the mean over the step's ACTIVE samples of
+    sum_j p log(p + 1e-8) + (1 - p) log(1 - p + 1e-8) (calculate_loss_binary, 919-923), read from the batch statistics the
+    loss kernels reduced anyway (sum of neg-entropies and count per (stream, step): csrc/layout.h, all-reduced in a
+    data-parallel job, i.e. of the GLOBAL minibatch); "Entropy Receiver Predictions": minus the mean over the WHOLE batch
+    (stopped samples too, model.py:880-886) of sum_d softmax(y_t) log(softmax(y_t) + 1e-8) at every executed step, from the
+    run-all tape of this log minibatch (a data-parallel job prints rank 0's rows here and in "Predictions")."""
     tp = eng.tape
-    n = int(tp["losses"][6].item())
+    n = int(L["n_steps"])
+    T = tp["y"].size(0)
+    B = tp["dist"].size(0)
+    argmax = tp["dist"].argmax(1).view(-1).cpu()
+    out = ["Predictions: {}".format(torch.cat([target.view(-1).cpu(), argmax], 0).view(-1, B))]
+    if FLAGS.use_binary:
+        st = eng.stats.cpu().tolist()
+        per = 5                                                             # layout.h: MMG_ST_PER (n, sum w, sum w^2, sum w logp, sum negent)
+        for title, stream, count in (("Entropy Sender Binary", 2, n), ("Entropy Receiver Binary", 1, n - 1)):
+            if count <= 0:
+                continue
+            msg = title
+            for i in range(count):
+                base = (stream * T + i) * per
+                msg += "\n{}. {}".format(i, -(st[base + 4] / st[base]) if st[base] > 0 else 0.0)
+            out.append(msg + "\n")
+    if n > 0:
+        p = F.softmax(tp["y"][:n].to(torch.float32), dim=2)
+        ent = (torch.log(p + 1e-8) * p).sum(2).mean(1).cpu().tolist()
+        msg = "Entropy Receiver Predictions"
+        for i, e in enumerate(ent):
+            msg += "\n{}. {}".format(i, -e)
+        out.append(msg + "\n")
+    return out
+
+
+def _sample_dump(eng, title, n):
+    """model.py:1415-1461 / 1463-1518: sparkline of the probabilities and the bits of the first samples at every one of the `n`
+    executed steps (the tape of a log minibatch / of an evaluation pass holds all of them)."""
+    tp = eng.tape
     W = FLAGS.rec_w_dim
     out = title
     for i in range(min(FLAGS.exchange_samples, eng.cfg.batch)):
         prev_sen, prev_rec = torch.zeros(W), torch.zeros(W)
-        ts = int(tp["tstar"][i].item())
-        for t in range(min(n, ts + 1)):
+        for t in range(n):
             sp, rp, stp = tp["pz"][t, i].tolist(), tp["pw"][t, i].tolist(), tp["ps"][t, i].tolist()
             sb, rb = tp["z"][t, i].cpu(), tp["w"][t, i].cpu()
             sh, rh = float((prev_sen - sb).abs().sum()), float((prev_rec - rb).abs().sum())
@@ -295,7 +384,8 @@ def _sample_dump(eng, title):
             out += ("\n{:>3}".format(i) if t == 0 else "\n   ")
             out += "        {}".format(sparks([1] + sp)[1:]) + "           {}    {}".format(sparks([1] + stp)[1:], sparks([1] + rp)[1:])
             out += "\n    {:>3} S: {} {:4}".format(t, "".join(str(int(v)) for v in sb.tolist()), sh)
-            out += "    s={} R: {} {:4}".format(int(tp["mask"][t + 1, i, 0].item()), "".join(str(int(v)) for v in rb.tolist()), rh)
+            # (the forced zero of the LAST mask, model.py:870)
+            out += "    s={} R: {} {:4}".format(0 if t == n - 1 else int(tp["mask"][t + 1, i, 0].item()), "".join(str(int(v)) for v in rb.tolist()), rh)
     return out + "\n"
 
 

@@ -89,7 +89,7 @@ class ShardEngine(object):
         outp = torch.stack([y[int(tstar[b])][b] for b in range(B)])
         dist = F.log_softmax(outp, dim=1)
         logs = dist.detach().gather(1, target.view(-1, 1)).view(-1)
-        self.saved = dict(s=s, sen_w=sen_w, rec_w=rec_w, bs=bs, br=br, tstar=tstar, dist=dist, logs=logs, target=target)
+        self.saved = dict(s=s, sen_w=sen_w, rec_w=rec_w, bs=bs, br=br, tstar=tstar, dist=dist, logs=logs, target=target, y=y)
 
     @staticmethod
     def _lp_ne(q, p):

@@ -1,6 +1,6 @@
 """One-off investigation (not collected by pytest): which gradient entries of g3_continuous differ between the golden
 vectors (generated on the build host) and the oracle run on the GPU box -- a ReLU-mask flip of one |pre| ~ 1e-6 unit.
-Run by hand on a GPU box: python tests/debug_continuous.py"""
+Run by hand on a GPU box: python scripts/debug_continuous.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

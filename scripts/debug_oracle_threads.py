@@ -1,5 +1,5 @@
 """One-off investigation (not collected by pytest): sensitivity of the CPU oracle to the torch thread count on
-g3_continuous (same ReLU-mask flip).  python tests/debug_oracle_threads.py"""
+g3_continuous (same ReLU-mask flip).  python scripts/debug_oracle_threads.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

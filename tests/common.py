@@ -266,7 +266,8 @@ def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None, s
     min(atol, 1e-4) ABSOLUTE (FORWARD_ATOL; max(1e-4, 16 ulp of |want|) only for the (label, key) pairs of RELATIVE_ALLOW);
     gradient / parameter entries within atol + rtol*|want|.
 
-    shift_invariant: compare the class logits (``y``, ``outp``) after removing each row's mean.
+    shift_invariant: compare the class logits (``y``, ``outp``) of every minibatch AFTER the first one with each row's mean removed
+    (``mb0.*``: raw -- no update has happened yet).
     dL/d(y2.bias) is identically zero (softmax is shift invariant), so what reaches the optimizer
     is rounding noise which RMSprop/Adam normalise into +-O(lr) steps: y2.bias (a common shift of
     all logits of a sample, invisible to every loss and to top-k) performs an implementation-
@@ -289,7 +290,8 @@ def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None, s
             problems.append("%s shape %s vs %s" % (k, a.shape, b.shape))
             continue
         tail = k.split(".")[-1]
-        if shift_invariant and tail in SHIFT_INVARIANT and a.size:
+        # (minibatch 0 has seen no update: y2.bias is the initial one on both sides and the RAW logits must agree)
+        if shift_invariant and tail in SHIFT_INVARIANT and a.size and not k.startswith("mb0."):
             a = a - a.mean(-1, keepdims=True)
             b = b - b.mean(-1, keepdims=True)
         is_bits = b.size == 0 or bool(np.all((b == 0) | (b == 1))) or tail in ("n_steps", "hits")

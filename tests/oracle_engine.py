@@ -84,6 +84,13 @@ class OracleEngine(dp_ref.ShardEngine):
             u_z, u_s, u_w = self._uniforms(seed)
         dp_ref.ShardEngine.forward(self, x, target, desc, u_z, u_s, u_w)
         self.tape["tstar"] = self.saved["tstar"].to(torch.int32)
+        # what the log block of model.run() reads after a run-all training step (the real engine's tape entries of the same names)
+        sv, B = self.saved, x.size(0)
+        st = lambda lst: torch.stack([t.detach().float().view(B, -1) for t in lst])
+        self.tape.update(mask=torch.stack([mm.view(B, 1) for mm in sv["s"][0]]).to(torch.uint8), s=st(sv["s"][1]), ps=st(sv["s"][2]),
+                         z=st(sv["sen_w"][0]), w=st(sv["rec_w"][0]), y=st(sv["y"]), dist=sv["dist"].detach())
+        if self.fl.use_binary:
+            self.tape.update(pz=st(sv["sen_w"][1]), pw=st(sv["rec_w"][1]))
 
     def _eval_forward(self, x, target, desc):
         fl, m = self.fl, self.models

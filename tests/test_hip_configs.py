@@ -278,6 +278,22 @@ def test_config5_sharded_equals_unsharded(sampling):
     assert "k_conversation_mc" in names and "k_bwd_mc" in names, names
 
 
+def test_config5_full_size_fused_vs_oracle():
+    """configs[4] at its FULL size on one GPU -- B = 2048, D = 1000, continuous, Fixed: what bench.py's `c5s` line (and the N = 1 point
+    of --scaling strong) times.  The path differs from the 256-sample shard's in a way that matters: 2 048 role workgroups run as 8
+    rounds of 256 with in-launch hand-offs inside each 16-member tile.  Reference semantics: build_inp over B * D = 2.05 M rows
+    (model.py:519-551) and the y head / softmax . desc (model.py:432-449); the oracle materialises them (1.34 GB per exchange step plus
+    autograd copies), so the conversation is cut to max_exchange = 3 -- every per-step code path of the kernels (t = 0, a middle step,
+    the output step) still runs, in the same 8 rounds.  Same gate as test_config5_shard_fused_vs_oracle."""
+    meta = _meta(dict(C5, batch_size=2048, max_exchange=3), 1000, 2048, 1)
+    got, eng = common.hip_train_case(None, meta, fused=True)
+    flips = []
+    want = common.oracle_train_case(None, meta, flips=flips)
+    common.assert_parity(_pick(got), _pick(want), flips, eng, "config5-full-fused", skip=("y2.bias", ".bs", ".br"))
+    names = _kernel_names(eng, meta)
+    assert "k_conversation_mc" in names and "k_bwd_mc" in names and "k_stats" not in names, names
+
+
 def test_config5_full_size_properties():
     """B=2048 per call, D=1000, continuous: (1) bitwise-reproducible, (2) the loss goes down over a few
     updates on a fixed batch, (3) NLL equals -mean of the stored per-sample rewards, (4) selected logits are

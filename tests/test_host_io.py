@@ -142,3 +142,30 @@ def test_host_shuffle_reproduces_random_shuffle():
         random.shuffle(want)
         assert perm.tolist() == want
     assert misc._shuffled_order(10) is not None and misc._FAST_SHUFFLE is True
+
+
+def test_device_residency_is_decided_once_per_file(tmp_path, monkeypatch, capsys):
+    """the resident-or-streaming decision of load_hdf5(device=...) was re-taken every epoch against the memory free
+    at that moment -- after epoch 0 the resident copy and the gather blocks are allocated, so a mid-sized dataset flipped to host
+    streaming from epoch 1 on.  Decided once per (file, device); memory torch's allocator merely caches counts as free; the
+    streaming fallback says so on stderr."""
+    p = tmp_path / "f.hdf5"
+    p.write_bytes(b"x")
+    data = {"avgpool_512": np.zeros((1000, 1, 512), np.float32)}          # 2 MB per copy
+    state = {"free": 10 << 20}
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (state["free"], 64 << 20))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda device=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda device=None: 0)
+    misc._RESIDENT_DECISION.clear()
+    assert misc._fits_on_device(data, ("avgpool_512",), "cuda:0", str(p))            # 4 MB needed, 5 MB allowed
+    state["free"] = 3 << 20                                                          # epoch 1: two copies are allocated now
+    assert misc._fits_on_device(data, ("avgpool_512",), "cuda:0", str(p))            # ... the decision stands
+    q = tmp_path / "g.hdf5"
+    q.write_bytes(b"y")
+    assert not misc._fits_on_device(data, ("avgpool_512",), "cuda:0", str(q))        # a NEW file is judged against today's memory
+    assert "streaming" in capsys.readouterr().err
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda device=None: 8 << 20)  # cached-but-unused allocator blocks are free
+    r = tmp_path / "h.hdf5"
+    r.write_bytes(b"z")
+    assert misc._fits_on_device(data, ("avgpool_512",), "cuda:0", str(r))
+    misc._RESIDENT_DECISION.clear()
