@@ -366,7 +366,17 @@ __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p,
 // ... 16 bytes at once (p 16-byte aligned): the agent-scope store of gfx942 / gfx950 is a global store with sc1 set
 __device__ __forceinline__ void st_wt4(float* p, float4 v) {
     const f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+    // (the trailing s_nop: on gfx9-family chips a VMEM store of more than 64 bits must not be followed directly by a VALU write of
+    //  its data VGPRs -- the compiler's hazard recogniser inserts the wait state for its own stores, not behind inline assembly.
+    //  Found in round 5: kernels_game.h read back address bits in the first two floats of such a store.)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
+}
+// ... the same 16 bytes as two 8-byte agent-scope stores through the compiler's own atomics (no inline assembly)
+__device__ __forceinline__ void st_wt4c(float* p, float4 v) {
+    const unsigned long long lo = ((unsigned long long)__builtin_bit_cast(unsigned, v.y) << 32) | __builtin_bit_cast(unsigned, v.x);
+    const unsigned long long hi = ((unsigned long long)__builtin_bit_cast(unsigned, v.w) << 32) | __builtin_bit_cast(unsigned, v.z);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // agent-scope (sc1) loads of such a payload: coherent across the XCDs' L2s by themselves, so the consumer needs NO acquire fence
 // (an agent-scope acquire is a buffer_inv of the whole L2: everything the role reads afterwards comes from memory again)

@@ -70,7 +70,20 @@ __device__ __forceinline__ void st_ll_d(float* ll, size_t i, double v, uint32_t 
     st_ll(ll, i, __builtin_bit_cast(float, (unsigned)u), epoch); st_ll(ll, i + 1, __builtin_bit_cast(float, (unsigned)(u >> 32)), epoch);
 }
 // PLL: the partial baseline scores are pairs of this launch's baseline roles (combine_score_ll; npb <= 8)
-template <bool WT = false, bool CC = false, bool PLL = false>
+// LLIN (kernels_game.h: the conversation runs in THIS launch too, B <= 64): the wave first spins on the samples' "forward pass
+// written through" pairs (tape.gamell, value = t*), then reads rewards, hits and log-likelihood sums with agent-scope loads
+__device__ __forceinline__ int game_wait_done(const Tape& tp, int B, uint32_t epoch, int first = 0) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long u = 0;
+    for (int spins = 0;; ) {
+        u = ld_ll(tp.gamell, (size_t)first + min(lane, B - 1));
+        if (!__any(!ll_fresh(u, epoch))) break;
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 20)) { if (lane == 0) __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    return (int)ll_value(u);
+}
+template <bool WT = false, bool CC = false, bool PLL = false, bool LLIN = false>
 __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, const Tape& tp, int from_parts, int first, int stride, uint32_t epoch = 0u) {
     auto put_d = [](double* p, double v) { if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
     auto put_f = [](float* p, float v) { if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
@@ -80,11 +93,16 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
     // grid = 5T + 2 blocks of one wave: every (stream, step) pair reduces concurrently
     const int lane = threadIdx.x & 63;
     const int npairs = 5 * T + 2;
+    auto ldf = [](const float* p) { return LLIN ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+    const int ts_ll = LLIN ? game_wait_done(tp, B, epoch, B + 16) : 0;        // pair B of every sample (kernels_game.h)
+#ifdef MMG_TIMING
+    if (LLIN && lane == 0) tp.dbg2[3072 + 4 * first + 1] = (long long)wall_clock64();
+#endif
     for (int p = first; p < npairs; p += stride) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         if (p >= 5 * T) {                       // sum of rewards (-> NLL) and top-k hits
             const int which = p - 5 * T;
-            for (int b = lane; b < B; b += 64) a0 += which == 0 ? (double)tp.logs[b] : (double)tp.hit[b];
+            for (int b = lane; b < B; b += 64) a0 += which == 0 ? (double)ldf(&tp.logs[b]) : (double)(LLIN ? __hip_atomic_load(&tp.hit[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tp.hit[b]);
             a0 = dpp_wave_sum_d(a0);
             if (lane == 0) put_d(&tp.stats[stat_glob(T, which)], a0);
             continue;
@@ -95,14 +113,14 @@ __device__ __forceinline__ void stats_pairs(const Dims& dm, const Params& P, con
             for (int b = lane; b < B; b += 64) {
                 // every load is issued unconditionally (one memory round trip); the activity test masks afterwards
                 const size_t row = (size_t)t * B + b;
-                const int ts = tp.tstar[b];
-                const float L = tp.logs[b];
+                const int ts = LLIN ? ts_ll : tp.tstar[b];
+                const float L = ldf(&tp.logs[b]);
                 const bool sen_side = (kind == 2) || (kind == 4);
                 // the array is chosen FIRST (wave-uniform pointer selects), then ONE load each: a ternary over loads is a chain
                 // of branches, and every join drains vmcnt -- three or four dependent memory round trips instead of one
                 const float* lp_ptr = (kind == 0) ? tp.lp_s : (kind == 1) ? tp.lp_w : tp.lp_z;
                 const float* ne_ptr = (kind == 0) ? tp.ne_s : (kind == 1) ? tp.ne_w : tp.ne_z;
-                const float lp_raw = lp_ptr[row], ne_raw = ne_ptr[row];
+                const float lp_raw = ldf(&lp_ptr[row]), ne_raw = ldf(&ne_ptr[row]);
                 const float beta_all = PLL ? combine_score_ll(dm, tp, sen_side, row, npb, sen_side ? b2s : b2r, epoch, t <= ts)
                                      : from_parts ? combine_score<CC>(sen_side ? tp.bs_part : tp.br_part, row, npb, sen_side ? b2s : b2r)
                                                   : (sen_side ? tp.bs : tp.br)[row];
@@ -499,13 +517,16 @@ __global__ __launch_bounds__(MMG_BLOCK, MANY ? 4 : 1) void k_bwd_conv(Dims dm, P
 // Active rows.  Every gradient tape row (t, b) with t > t*(b) is zero, and with early stopping that is most of them
 // (config 2: ~140 of 640 rows are live).  One wave lists the live rows in (t, b) order; k_wgrad then reduces over
 // that list instead of over all T*B rows.  t*(b) comes from the conversation launch, so this runs anywhere after it.
+// CC: t* was written by other workgroups of THIS launch (write-through stores): agent-scope loads
+template <bool CC = false>
 __device__ __forceinline__ void build_row_map(const Dims& dm, const Tape& tp) {
     const int lane = threadIdx.x & 63, B = dm.B, T = dm.T;
     int base = 0;
     for (int t = 0; t < T; ++t) {
         for (int b0 = 0; b0 < B; b0 += 64) {
             const int b = b0 + lane;
-            const bool act = (b < B) && (t <= tp.tstar[min(b, B - 1)]);
+            const int tsb = CC ? __hip_atomic_load(&tp.tstar[min(b, B - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tp.tstar[min(b, B - 1)];
+            const bool act = (b < B) && (t <= tsb);
             const unsigned long long m = __ballot(act);
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
             if (act) tp.rmap[pos] = t * B + b;
@@ -533,7 +554,7 @@ __device__ __forceinline__ void dC_class(const Dims& dm, const Params& P, const 
         const int r = r0 + rr;
         float dc0 = 0.f, dc1 = 0.f, py0 = 0.f, py1 = 0.f;
         if (g < groups && r < R) {
-            const float cv = tp.Cd[(size_t)d * R + r];
+            const float cv = ld(&tp.Cd[(size_t)d * R + r]);         // (CC: possibly written by a prep role of this launch, kernels_game.h)
             for (int b = g; b < B; b += 16 * groups) {              // 16 samples (32 loads) in flight per thread
                 float yv[16], pv[16];
 #pragma unroll
@@ -1001,7 +1022,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_gradnorm(const JobTable* __restri
 }
 
 struct OptArgs {
-    int optim_type, only_receiver, from_wgrad, bump_step;
+    int optim_type, only_receiver, from_wgrad, bump_step, bump_mb;
     float lr;
     int64_t agent_begin[5];
     int64_t total;
@@ -1017,6 +1038,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
     // the gradients may be built from stale data -- leave parameters and optimizer state untouched, on every rank alike.
     uint32_t err = __hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (err == 0u && grad_tail && grad_tail[0] != 0.f) err = MMG_SYNC_ERR_REMOTE;
+    // fused step of kernels_game.h: no role of its launch may see the minibatch counter (the Philox stream) or the launch epoch of
+    // the (value, epoch) pairs move, so the LAST launch of the step commits them (nothing in this kernel reads either)
+    if (oa.bump_mb && blockIdx.x == 0 && threadIdx.x == 0) { const_cast<uint32_t*>(counter)[0] += 1u; const_cast<uint32_t*>(counter)[3] += 1u; }
     // the word goes to a pinned HOST word (device-mapped) with a posted store: the host reads it before the next minibatch
     // without any stream operation or synchronisation; it is sticky, every later training call fails (mmg.hip: sticky_error)
     if (err_host && blockIdx.x == 0 && threadIdx.x == 0 && (err != 0u || *err_host == 0u)) *err_host = err;

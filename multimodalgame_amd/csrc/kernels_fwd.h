@@ -50,7 +50,10 @@ __host__ __device__ inline size_t prepll_dd(const Dims& d) { return (size_t)d.B 
 #define MMG_REPACK_BLOCKS 8
 #define MMG_REPACK_F4 30
 __host__ __device__ inline bool prep_has_repack(const Dims& d) { return d.H == 256 && d.W == 32 && d.R == 64; }
-__device__ __forceinline__ void prep_repack(const Dims& dm, const Params& P, const Tape& tp, const int rb) {
+// GAME (kernels_game.h: the fragments are read by sample roles of the SAME launch, ~20 us later): write-through stores, and once
+// they have completed the block publishes the pair gamell[B + rb] -- the consumers check it beside their loads
+template <bool GAME = false>
+__device__ __forceinline__ void prep_repack(const Dims& dm, const Params& P, const Tape& tp, const int rb, const uint32_t epoch = 0u) {
     constexpr int H = 256, W = 32, R = 64, NTH = 256;
     const int ldy = R + dm.V;
     for (int idx = rb * NTH + (int)threadIdx.x; idx < MMG_REPACK_F4 * NTH; idx += MMG_REPACK_BLOCKS * NTH) {
@@ -65,11 +68,17 @@ __device__ __forceinline__ void prep_repack(const Dims& dm, const Params& P, con
             else if (j < 22) v[c] = P.p[R_WH_W][(size_t)(4 * (4 * (j - 18) + c) + fq) * R + 16 * wv + fi];
             else { const int f = 4 * (j - 22) + c, nt = f >> 3, ks = f & 7; v[c] = P.p[S_BIN_W][(size_t)(4 * ks + fq) * H + 64 * wv + 16 * nt + fi]; }
         }
-        *reinterpret_cast<float4*>(tp.wrep + (size_t)idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        if (GAME) st_wt4(tp.wrep + (size_t)idx * 4, make_float4(v[0], v[1], v[2], v[3]));
+        else *reinterpret_cast<float4*>(tp.wrep + (size_t)idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (GAME) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) st_ll(tp.gamell, (size_t)dm.B + rb, 1.f, epoch);
     }
     (void)W;
 }
-template <bool ROLE>
+template <bool ROLE, bool GAME = false>
 __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const Tape& tp, const float* __restrict__ desc,
                                           const float* __restrict__ x, const int cpb, const int blk, float* smem, const int bump_mb) {
     const int tid = threadIdx.x;
@@ -78,7 +87,7 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
     const int nC = (dm.D + cpb - 1) / cpb;           // class blocks
     if (blk >= nC + HB) {
         const int nhx = x ? ((dm.B + 15) / 16) * ((dm.H + 15) / 16) : 0;
-        if (blk >= nC + HB + nhx) { prep_repack(dm, P, tp, blk - nC - HB - nhx); return; }
+        if (blk >= nC + HB + nhx) { prep_repack<GAME>(dm, P, tp, blk - nC - HB - nhx, epoch); return; }
         gemm_nt_tile<ROLE, false>(blk - nC - HB, x, dm.F, P.p[S_IMG_W], dm.F, P.p[S_IMG_B], tp.hx, dm.H, dm.B, dm.H, dm.F, tp.prepll, epoch);
         return;
     }
@@ -169,7 +178,7 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
                 for (int v = 0; v < V; ++v) a0 = fmaf(wrow[v], s_desc[v], a0);
             }
             const float cdv = (a0 + a1) + (a2 + a3) + by1[r];
-            tp.Cd[(size_t)d * R + r] = cdv;
+            if (GAME) st_wt(&tp.Cd[(size_t)d * R + r], cdv); else tp.Cd[(size_t)d * R + r] = cdv;      // (GAME: class roles of the same launch read it)
             if (ROLE) st_ll(tp.prepll, prepll_cd(dm) + (size_t)d * R + r, cdv, epoch);
             if (d < 32) tp.cd32[((size_t)(d >> 2) * R + r) * 4 + (d & 3)] = cdv;
             tp.CdT[(size_t)r * dm.D + d] = -cdv;      // NEGATED: relu(A + c) = max(A, -c) + c (kernels_tile.h, many-class y head)

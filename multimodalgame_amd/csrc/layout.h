@@ -118,6 +118,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(prepll, float, 0, 1, 2 * (B * H + H + 2 * D * R), 1, 1) /* (value, launch epoch) pairs of h_x | hw0 | Cd | Dd: hand-off from the prep roles to the sample roles of ONE launch (kernels_fast3.h) */ \
     X(wrep, float, 0, 1, 30 * 256 * 4, 1, 1) /* the register-resident backward's transposed weight fragments, repacked per lane by k_prep's blocks: [30 float4][256 threads] (kernels_fwd.h: prep_repack) */ \
     X(cd32, float, 0, 1, 8 * R * 4, 1, 1) /* Cd of the first 32 classes as [8 float4][R] (class 4 j + c of unit r at ((j R + r) 4 + c)): the register-resident backward's column of Cd in 8 lane-consecutive loads */ \
+    X(basell, float, 0, 1, 2 * B * K, 1, 1) /* k_game_fast: (value, epoch) pairs of basehx [B][K]: hand-off from the basehx tiles to the baseline roles of ONE launch (kernels_game.h) */ \
+    X(gamell, float, 0, 1, 2 * (2 * B + 16), 1, 1) /* k_game_fast: (value, epoch) pairs [0, B): pair A = t*(b), published by sample role b once the rows the baseline roles multiply (z, z_r, h) have been written through; [B, B + 8): "repack block k is through"; [B + 16, 2 B + 16): pair B = t*(b) again, once what the statistics roles read (reward, hit, log-likelihood sums) is through */ \
     X(alive, int32_t, 2, 1, T + 2, 1, 1) /* [t]: sample tiles with a live sample when step t starts (kernels_tile.h)  */ \
     X(hw0, float, 0, 1, H, 1, 1)         /* code_layer(sigmoid(code_bias)) :199-200*/ \
     X(dsig, float, 0, 1, W, 1, 1)        /* sigmoid'(code_bias)                    */ \

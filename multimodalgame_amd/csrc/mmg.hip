@@ -16,6 +16,7 @@
 #include "kernels_bwd.h"
 #include "kernels_fast.h"
 #include "kernels_fast3.h"
+#include "kernels_game.h"
 #include "kernels_tile.h"
 #include "kernels_mc.h"
 #include "kernels_mc3.h"
@@ -54,6 +55,9 @@ struct mmg_handle {
     bool bas_pending;          // phased step: the forward pass left the baselines to mmg_loss_stats (k_bas_stats: one launch for both)
     bool sw_merge_prep;        // k_prep's blocks as roles of k_conversation_fast3's launch (MMG_NO_MERGE_PREP=1: a launch of their own)
     bool use_fast3;            // one-wave-per-SIMD forward kernel of the small agents (kernels_fast3.h); MMG_FAST2=1: the 512-thread one
+    bool game_ok;              // fused step of the small Adaptive agents: conversation + statistics + baselines + backward in ONE launch (kernels_game.h); MMG_NO_GAME=1: off
+    int game_nbas;             // ... its baseline roles (a multiple of 2 * ceil(K / 64), sized by the co-residency budget)
+    bool game_step;            // set by mmg_train_step around clip_step_impl: k_opt commits the minibatch counter / launch epoch
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
     bool basehx_ready;         // this forward pass formed tape.basehx inside the conversation launch
     bool merge_roles;          // MMG_NO_MERGE=1 keeps k_stats / k_dC / basehx as separate launches / in-kernel work
@@ -513,6 +517,30 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
+    h->game_ok = false; h->game_nbas = 0; h->game_step = false;
+    {
+        const Dims& d = h->dm;
+        const bool shape = h->use_fast && h->use_fast3 && h->merge_roles && h->sw_merge_prep && h->sw_merge_bas && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 &&
+                           d.D <= 32 && d.T <= 15 && d.B <= 64 && d.use_binary && !d.fixed && (d.K + 63) / 64 <= 8 && d.K <= 512 &&
+                           !(h->tile_ok && h->tile_force) && h->prep_cpb == 1 && h->prep_smem <= game_lds_bytes() && !getenv("MMG_NO_GAME");
+        if (shape && e == hipSuccess) {
+            const void* fn = d.D == 30 ? (const void*)k_game_fast<30> : (const void*)k_game_fast<32>;
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, game_lds_bytes());
+            if (e == hipSuccess) {
+                // every spinning role must be resident together with the sample roles (the sample roles wait for the statistics roles,
+                // those for the baseline roles): B + n_stats + n_bas + D workgroups inside the co-residency budget of this device
+                const int budget = budget_of(fn, 256, game_lds_bytes());
+                const int n_stats = (5 * d.T + 2 + 3) / 4, per = 2 * ((d.K + 63) / 64);
+                int nb = ((budget - d.B - n_stats - d.D) / per) * per;
+                const int want = ((d.T * d.B + 15) / 16) * per;
+                if (nb > want) nb = want;
+                if (getenv("MMG_GAME_NBAS")) { const int v = atoi(getenv("MMG_GAME_NBAS")); if (v >= per && v <= nb) nb = (v / per) * per; }
+                if (nb >= per && prep_blocks(d, h->prep_cpb, true) + d.B <= n_cu) { h->game_ok = true; h->game_nbas = nb; }
+            }
+        }
+    }
+    if (getenv("MMG_DEBUG"))
+        fprintf(stderr, "mmg_create: game_ok %d game_nbas %d\n", (int)h->game_ok, h->game_nbas);
     if (getenv("MMG_DEBUG"))
         fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d rc %d rc_persist %d rc_budget %d rc_bwd %d\n",
                 (int)h->tile_ok, h->tile_nt, h->tile_smem, (int)h->tile_ext, (int)h->tile_persist, h->persist_smem, h->resident_budget, h->tile_bwd_smem,
@@ -897,10 +925,12 @@ static bool merge_stats(const mmg_handle* h) {
     return fast_shape(h) && h->dm.use_binary && h->scores_in_parts && h->merge_roles;
 }
 
-static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, hipStream_t st, bool with_stats) {
+static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, hipStream_t st, bool with_stats, bool conv_done = false) {
     const Dims& d = h->dm;
     bool row_map = false;
-    if (tile_path(h)) {
+    if (conv_done) {
+        row_map = true;                                  // k_game_fast ran the reverse pass and its first class role listed the live rows
+    } else if (tile_path(h)) {
         row_map = d.T * d.B <= 2048;                     // k_wgrad keeps the live-row list in LDS (2048 entries)
         const int zero_dead = (!row_map && !d.fixed) ? 1 : 0;
         const int tiles = (d.B + MMG_TM - 1) / MMG_TM;
@@ -989,7 +1019,8 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
                 hipLaunchKernelGGL(k_bwd_conv<false>, dim3(d.B), dim3(MMG_BLOCK), h->bwd_smem, st, h->dm, h->P, h->tp, d_target);
         if (launch_check("k_bwd_conv")) return -1;
     }
-    if (tile_path(h)) {
+    if (conv_done) {
+    } else if (tile_path(h)) {
         Scope sc(h, st, "k_dC");
         const int RL = d.R < MMG_BLOCK ? d.R : MMG_BLOCK, CPB = MMG_BLOCK / RL, nsb = dc_slices(d.B);
         hipLaunchKernelGGL(k_dC_tile, dim3((d.D + CPB - 1) / CPB, nsb), dim3(MMG_BLOCK), 0, st, h->dm, h->P, h->tp, nsb, 0);
@@ -1048,7 +1079,7 @@ static int clip_step_impl(mmg_handle* h, hipStream_t st, bool from_wgrad) {
     }
     OptArgs oa;
     oa.optim_type = h->cfg.optim_type; oa.only_receiver = h->cfg.use_binary ? 0 : 1; oa.lr = h->cfg.learning_rate;
-    oa.from_wgrad = from_wgrad ? 1 : 0; oa.bump_step = from_wgrad ? 1 : 0;
+    oa.from_wgrad = from_wgrad ? 1 : 0; oa.bump_step = from_wgrad ? 1 : 0; oa.bump_mb = h->game_step ? 1 : 0;
     for (int a = 0; a < 5; ++a) oa.agent_begin[a] = h->pl.agent_begin[a];
     oa.total = h->pl.total;
     int blocks = (int)((oa.total / 4 + MMG_BLOCK - 1) / MMG_BLOCK);
@@ -1075,6 +1106,33 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
     if (h->cfg.global_batch != h->cfg.batch) return fail("mmg_train_step is single-GPU; with several ranks all-reduce between the phases");
     if (!d_target) return fail("target must not be NULL");
     if (sticky_error(h)) return -1;
+    if (h->game_ok) {
+        // the small Adaptive agents: conversation, baselines, statistics and the reverse pass in ONE launch (kernels_game.h), then
+        // k_wgrad and k_opt -- three launches per minibatch
+        hipStream_t st = (hipStream_t)stream;
+        const Dims& d = h->dm;
+        if (!d_x || !d_desc) return fail("x / desc must not be NULL");
+        if ((d_u_z || d_u_s || d_u_w) && !(d_u_z && d_u_s && d_u_w)) return fail("injected uniforms: all three streams or none");
+        ConvArgs ar;
+        memset(&ar, 0, sizeof(ar));
+        ar.x = d_x; ar.target = d_target; ar.desc = d_desc; ar.u_z = d_u_z; ar.u_s = d_u_s; ar.u_w = d_u_w; ar.seed = seed;
+        ar.train = 1; ar.run_all = 0; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
+        ar.nprep = prep_blocks(d, h->prep_cpb, true); ar.prep_cpb = h->prep_cpb; ar.nbase = ((d.B + 15) / 16) * ((d.K + 15) / 16);
+        GameArgs ga; ga.n_stats = (5 * d.T + 2 + 3) / 4; ga.n_bas = h->game_nbas;
+        h->basehx_ready = true; h->bas_deferred = false; h->bas_pending = false; h->scores_in_parts = true;
+        {
+            Scope sc(h, st, "k_game");
+            const int grid = d.B + ar.nprep + ar.nbase + ga.n_stats + ga.n_bas + d.D;
+            if (d.D == 30) hipLaunchKernelGGL(k_game_fast<30>, dim3(grid), dim3(256), game_lds_bytes(), st, h->dm, h->P, h->tp, ar, ga);
+            else hipLaunchKernelGGL(k_game_fast<32>, dim3(grid), dim3(256), game_lds_bytes(), st, h->dm, h->P, h->tp, ar, ga);
+            if (launch_check("k_game_fast")) return -1;
+        }
+        if (backward_impl(h, d_x, d_target, d_desc, st, true, true)) return -1;
+        h->game_step = true;
+        const int rc = clip_step_impl(h, st, true);
+        h->game_step = false;
+        return rc;
+    }
     h->defer_bas = true;
     const int frc = mmg_exchange_forward(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, 2, stream);
     h->defer_bas = false;

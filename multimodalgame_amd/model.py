@@ -38,18 +38,18 @@ def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels
     reference then does on the host per batch -- the early-break step count n (model.py:866), output selection
     (get_rec_outp, 879-904), log-softmax, top-k membership (657-668), argmax, conversation lengths (671-672), the per-step
     mean Hamming distance of both agents' messages averaged over the n executed steps (675-691) -- is a handful of torch ops
-    enqueued behind it; per-batch results are accumulated in device tensors (hit count, a [D, D] confusion matrix by
-    index_add_, the conversation lengths, the two Hamming means) and copied to the host ONCE after the last batch.
+    enqueued on the device: the tape slices of every batch are stacked (five device copies per batch) and the arithmetic runs
+    ONCE per batch size over all batches together (hit count, a [D, D] confusion matrix by index_add_, the conversation
+    lengths, the two Hamming means); the results are copied to the host ONCE.
     (Round 4 transcribed the host loop literally: numpy argsort per batch and ~20 float() syncs per batch.)
 
     dump: optional dict that receives the last batch's engine (the dev sample dump of model.py:1463-1518 reads its tape)."""
     W = FLAGS.rec_w_dim
     n_cls = desc.size(0)
-    dev = torch.device(device)
-    correct = torch.zeros((), dtype=torch.int64, device=dev)
-    conf_flat = torch.zeros(n_cls * n_cls, dtype=torch.int64, device=dev)
-    seen = torch.zeros(n_cls, dtype=torch.int64, device=dev)
-    conv_lens, ham_sen, ham_rec = [], [], []
+    T = game.max_exchange
+    # ---- pass 1: one eval-mode launch per batch; what the statistics need of its tape is copied into per-batch-size stacks
+    # (five device copies per batch, no host synchronisation, no per-batch reduction kernels)
+    groups = {}                                        # batch size -> dict of lists
     total = 0.0
     eng = None
     for batch in load_hdf5(dev_file, batch_size, epoch, shuffle, truncate_final_batch=True, map_labels=map_labels,
@@ -58,44 +58,58 @@ def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels
         _bs = target.size(0)
         eng = game.eval_forward(data, target, desc)
         tp = eng.tape
-        T = game.max_exchange
-        mask = tp["mask"].view(T + 1, _bs).to(torch.float32)                 # m_0 .. m_T, running minimum of the stop bits
-        steps = torch.arange(T, device=mask.device)
+        g = groups.setdefault(_bs, dict(mask=[], s=[], z=[], w=[], y=[], target=[]))
+        g["mask"].append(tp["mask"].view(T + 1, _bs).clone()); g["s"].append(tp["s"].view(T, _bs).clone())
+        g["z"].append(tp["z"].view(T, _bs, W).clone()); g["w"].append(tp["w"].view(T, _bs, W).clone())
+        g["y"].append(tp["y"].view(T, _bs, -1).clone()); g["target"].append(target.view(-1))
+        total += float(batch_size)                                           # model.py:667: the NOMINAL batch size
+    # ---- pass 2: the reference's per-batch host arithmetic (model.py:648-691), batched over all batches of one size
+    correct = None
+    conf_flat, seen = None, None
+    conv_lens, ham_sen, ham_rec = [], [], []
+    for _bs, g in groups.items():
+        mask = torch.stack(g["mask"]).to(torch.float32)                      # [NB, T + 1, B]: m_0 .. m_T, running minimum of the stop bits
+        NB = mask.size(0)
+        dv = mask.device
+        steps = torch.arange(T, device=dv)
         if FLAGS.fixed_exchange:
-            n = torch.full((), T, dtype=torch.int64, device=mask.device)
-            tsel = torch.full((_bs,), T - 1, dtype=torch.int64, device=mask.device)
+            n = torch.full((NB,), T, dtype=torch.int64, device=dv)
+            tsel = torch.full((NB, _bs), T - 1, dtype=torch.int64, device=dv)
         else:
-            dead = mask[1:].sum(1) == 0                                      # step t after which nobody is alive (model.py:866)
-            n = torch.where(dead.any(), torch.argmax(dead.to(torch.int8)) + 1, torch.full((), T, dtype=torch.int64, device=mask.device))
+            dead = mask[:, 1:].sum(2) == 0                                   # [NB, T]: step after which nobody is alive (model.py:866)
+            n = torch.where(dead.any(1), torch.argmax(dead.to(torch.int8), 1) + 1, torch.full((NB,), T, dtype=torch.int64, device=dv))
             # y_masks[t] = min(1 - m'_{t+1}, m'_t) with m'_n forced to 0 (model.py:870, 1261): the masks are a running minimum
             # that starts at 1, so the selected step of a sample is the number of t in 1..n-1 with m_t = 1
-            tsel = (mask[1:] * (steps + 1 < n).to(mask.dtype).view(T, 1)).sum(0).to(torch.int64)
-        live = (steps < n).to(torch.float32)                                 # the steps the reference executed: t < n
-        y = tp["y"].view(T, _bs, -1)
-        outp = y.gather(0, tsel.view(1, _bs, 1).expand(1, _bs, y.size(2)))[0]
-        dist = F.log_softmax(outp, dim=1)
-        tgt = target.to(dist.device).view(-1)
-        top_k_ind = dist.topk(min(top_k, dist.size(1)), dim=1).indices      # (= argsort()[:, -top_k:] as a set, model.py:658)
-        correct += (top_k_ind == tgt.view(-1, 1)).sum().to(correct.device)
-        pred = dist.argmax(1)
-        conf_flat.index_add_(0, (tgt * n_cls + pred).to(conf_flat.device), torch.ones(_bs, dtype=torch.int64, device=conf_flat.device))
-        seen.index_add_(0, torch.cat([tgt, pred]).to(seen.device), torch.ones(2 * _bs, dtype=torch.int64, device=seen.device))
-        total += float(batch_size)                                           # model.py:667: the NOMINAL batch size
-        conv_lens.append((tp["s"].view(T, _bs).to(torch.float32) * live.view(T, 1)).sum(0))
+            tsel = (mask[:, 1:] * (steps.view(1, T) + 1 < n.view(NB, 1)).to(mask.dtype).view(NB, T, 1)).sum(1).to(torch.int64)
+        live = (steps.view(1, T) < n.view(NB, 1)).to(torch.float32)          # [NB, T]: the steps the reference executed
+        y = torch.stack(g["y"]).to(torch.float32)                            # [NB, T, B, D]
+        outp = y.gather(1, tsel.view(NB, 1, _bs, 1).expand(NB, 1, _bs, y.size(3)))[:, 0]
+        dist = F.log_softmax(outp, dim=2)                                    # [NB, B, D]
+        tgt = torch.stack(g["target"]).to(dv)                                # [NB, B]
+        top_k_ind = dist.topk(min(top_k, dist.size(2)), dim=2).indices       # (= argsort()[:, -top_k:] as a set, model.py:658)
+        c = (top_k_ind == tgt.unsqueeze(2)).sum()
+        correct = c if correct is None else correct + c.to(correct.device)
+        pred = dist.argmax(2)
+        if conf_flat is None:
+            conf_flat = torch.zeros(n_cls * n_cls, dtype=torch.int64, device=dv)
+            seen = torch.zeros(n_cls, dtype=torch.int64, device=dv)
+        conf_flat.index_add_(0, (tgt * n_cls + pred).view(-1), torch.ones(NB * _bs, dtype=torch.int64, device=dv))
+        seen.index_add_(0, torch.cat([tgt.view(-1), pred.view(-1)]), torch.ones(2 * NB * _bs, dtype=torch.int64, device=dv))
+        conv_lens.append((torch.stack(g["s"]).to(torch.float32) * live.view(NB, T, 1)).sum(1).view(-1))
         for name, acc in (("z", ham_sen), ("w", ham_rec)):
-            msg = tp[name].view(T, _bs, W).to(torch.float32)
-            prev = torch.cat([torch.zeros(1, _bs, W, device=msg.device), msg[:-1]], 0)
-            per_step = (msg - prev).abs().sum(2).mean(1)                     # [T]: mean over the batch of the Hamming distance
-            acc.append((per_step * live).sum() / n.to(torch.float32))
+            msg = torch.stack(g[name]).to(torch.float32)                     # [NB, T, B, W]
+            prev = torch.cat([torch.zeros(NB, 1, _bs, W, device=dv), msg[:, :-1]], 1)
+            per_step = (msg - prev).abs().sum(3).mean(2)                     # [NB, T]: mean over the batch of the Hamming distance
+            acc.append((per_step * live).sum(1) / n.to(torch.float32))       # [NB]: mean over the executed steps (model.py:679, 684)
     # ---- ONE copy to the host
-    correct_h = int(correct.item())
-    conf_full = conf_flat.view(n_cls, n_cls).cpu().numpy()
-    occ = np.nonzero(seen.cpu().numpy() > 0)[0]
+    correct_h = int(correct.item()) if correct is not None else 0
+    conf_full = conf_flat.view(n_cls, n_cls).cpu().numpy() if conf_flat is not None else np.zeros((n_cls, n_cls), np.int64)
+    occ = np.nonzero(seen.cpu().numpy() > 0)[0] if seen is not None else np.zeros(0, np.int64)
     # sklearn.metrics.confusion_matrix (model.py:709): rows / columns = the SORTED CLASSES THAT OCCUR in truth or prediction
     np.savetxt(conf_mat_path, conf_full[np.ix_(occ, occ)], delimiter=",", fmt="%d")
     cl = torch.cat(conv_lens).cpu().numpy().astype(np.float64) if conv_lens else np.zeros(0)
-    hs = torch.stack(ham_sen).cpu().numpy().astype(np.float64) if ham_sen else np.zeros(0)
-    hr = torch.stack(ham_rec).cpu().numpy().astype(np.float64) if ham_rec else np.zeros(0)
+    hs = torch.cat(ham_sen).cpu().numpy().astype(np.float64) if ham_sen else np.zeros(0)
+    hr = torch.cat(ham_rec).cpu().numpy().astype(np.float64) if ham_rec else np.zeros(0)
     extra = dict(conversation_lengths_mean=cl.mean(), conversation_lengths_std=cl.std(),
                  hamming_sen_mean=hs.mean(), hamming_rec_mean=hr.mean())
     if dump is not None:
@@ -270,8 +284,8 @@ def _run(stats, flogger, device, rank, world):
                                   full_tape=(step % FLAGS.log_interval == 0))                # model.py:1240-1339
             steps_run += 1
             if step % FLAGS.log_interval == 0 and rank == 0:               # model.py:1342-1377 (global-minibatch figures)
-                L = eng.losses()
-                hits_now = float(eng.tape["totals"][1])
+                snap = _log_snapshot(eng, batch["target"])              # ONE device -> host copy for the whole block
+                L, hits_now = snap["losses"], snap["hits_total"]
                 n_seen = steps_run - steps_at_log                       # = min(minibatches of this process, log_interval)
                 avg_batch_acc = (hits_now - hits_at_log) / float(FLAGS.batch_size) / n_seen
                 steps_at_log, hits_at_log = steps_run, hits_now
@@ -285,7 +299,7 @@ def _run(stats, flogger, device, rank, world):
                         flogger.Log(pre + "Loss Receiver (S): {}".format(L["loss_binary_s"]))
                     flogger.Log(pre + "Loss Baseline (S): {}".format(L["loss_bas_sen"]))
                     flogger.Log(pre + "Loss Baseline (R): {}".format(L["loss_bas_rec"]))
-                for line in _entropy_lines(eng, batch["target"], L):       # model.py:1379-1407
+                for line in _entropy_lines(eng, batch["target"], L, snap):  # model.py:1379-1407
                     flogger.Log(line)
                 if FLAGS.exchange_samples > 0:                             # model.py:1411-1461 (train sample dump)
                     flogger.Log(_sample_dump(eng, "Train:", int(L["n_steps"])))
@@ -333,7 +347,34 @@ def _executed_steps(eng, fixed):
     return T
 
 
-def _entropy_lines(eng, target, L):
+_LOSS_KEYS = ("nll_loss", "loss_binary_s", "loss_binary_rec", "loss_binary_sen", "loss_bas_rec", "loss_bas_sen", "n_steps", "hits")
+
+
+def _log_snapshot(eng, target):
+    """Everything the log block of a minibatch prints, gathered on the device and copied to the host ONCE (a sync per printed
+    quantity left the GPU idle for the whole block): the eight loss scalars, the running hit count, the batch statistics, the
+    per-step prediction entropies of the run-all tape and targets | argmax predictions."""
+    tp = eng.tape
+    f64 = torch.float64
+    y = tp["y"].to(torch.float32)
+    p = F.softmax(y, dim=2)
+    ent = (torch.log(p + 1e-8) * p).sum(2).mean(1)                         # [T] (model.py:880-886; the executed steps are picked below)
+    B = tp["dist"].size(0)
+    parts = [tp["losses"].to(f64).view(-1), tp["totals"].to(f64).view(-1)[1:2], eng.stats.to(f64).view(-1), ent.to(f64).view(-1),
+             tp["dist"].argmax(1).to(f64).view(-1), target.to(tp["dist"].device).to(f64).view(-1)]
+    flat = torch.cat(parts).cpu().tolist()
+    n_stats, T = eng.stats.numel(), y.size(0)
+    o = 0
+    losses = dict(zip(_LOSS_KEYS, flat[o:o + 8])); o += 8
+    hits_total = flat[o]; o += 1
+    stats = flat[o:o + n_stats]; o += n_stats
+    ent_y = flat[o:o + T]; o += T
+    argmax = [int(v) for v in flat[o:o + B]]; o += B
+    tgt = [int(v) for v in flat[o:o + B]]
+    return dict(losses=losses, hits_total=hits_total, stats=stats, ent_y=ent_y, argmax=argmax, target=tgt, T=T, B=B)
+
+
+def _entropy_lines(eng, target, L, snap=None):
     """model.py:1379-1407: "Predictions" (targets over argmax predictions of the minibatch) and the per-step entropies the
     losses report -- "Entropy Sender Binary" / "Entropy Receiver Binary": minus the mean over the step's ACTIVE samples of
     sum_j p log(p + 1e-8) + (1 - p) log(1 - p + 1e-8) (calculate_loss_binary, 919-923), read from the batch statistics the
@@ -341,14 +382,13 @@ def _entropy_lines(eng, target, L):
     data-parallel job, i.e. of the GLOBAL minibatch); "Entropy Receiver Predictions": minus the mean over the WHOLE batch
     (stopped samples too, model.py:880-886) of sum_d softmax(y_t) log(softmax(y_t) + 1e-8) at every executed step, from the
     run-all tape of this log minibatch (a data-parallel job prints rank 0's rows here and in "Predictions")."""
-    tp = eng.tape
+    if snap is None:
+        snap = _log_snapshot(eng, target)
     n = int(L["n_steps"])
-    T = tp["y"].size(0)
-    B = tp["dist"].size(0)
-    argmax = tp["dist"].argmax(1).view(-1).cpu()
-    out = ["Predictions: {}".format(torch.cat([target.view(-1).cpu(), argmax], 0).view(-1, B))]
+    T, B = snap["T"], snap["B"]
+    out = ["Predictions: {}".format(torch.tensor([snap["target"], snap["argmax"]], dtype=torch.int64).view(-1, B))]
     if FLAGS.use_binary:
-        st = eng.stats.cpu().tolist()
+        st = snap["stats"]
         per = 5                                                             # layout.h: MMG_ST_PER (n, sum w, sum w^2, sum w logp, sum negent)
         for title, stream, count in (("Entropy Sender Binary", 2, n), ("Entropy Receiver Binary", 1, n - 1)):
             if count <= 0:
@@ -359,10 +399,8 @@ def _entropy_lines(eng, target, L):
                 msg += "\n{}. {}".format(i, -(st[base + 4] / st[base]) if st[base] > 0 else 0.0)
             out.append(msg + "\n")
     if n > 0:
-        p = F.softmax(tp["y"][:n].to(torch.float32), dim=2)
-        ent = (torch.log(p + 1e-8) * p).sum(2).mean(1).cpu().tolist()
         msg = "Entropy Receiver Predictions"
-        for i, e in enumerate(ent):
+        for i, e in enumerate(snap["ent_y"][:n]):
             msg += "\n{}. {}".format(i, -e)
         out.append(msg + "\n")
     return out

@@ -116,3 +116,32 @@ def test_prep_roles_inside_the_conversation_launch_equal_k_prep_as_a_launch(monk
     # the trajectories are compared in bulk -- all but a handful of the 384 k parameters within 2e-5, none further than 1e-2
     diff = (eng_a.flat_params - eng_b.flat_params).abs()
     assert float((diff > 2e-5).float().mean()) < 1e-4 and float(diff.max()) < 1e-2, (float((diff > 2e-5).float().mean()), float(diff.max()))
+
+
+@pytest.mark.parametrize("merge_prep", [True, False])
+def test_eval_forward_leaves_the_training_sampling_stream_alone(merge_prep, monkeypatch):
+    """k_prep bumped the Philox minibatch counter on EVERY forward pass.  In a single-process run eval_dev shares the
+    training engine whenever -batch_size_dev == -batch_size, so each evaluation moved the training sampling stream -- while a
+    data-parallel job evaluates on rank 0 only, on a separate engine: the two runs then diverged.  An evaluation pass draws
+    nothing and must leave counter[0] alone (the launch epoch counter[3] of the pair hand-offs still moves); training with an
+    evaluation pass in between must take exactly the updates of training without it."""
+    if not merge_prep:
+        monkeypatch.setenv("MMG_NO_MERGE_PREP", "1")
+    z, meta = common.load_golden("g2_adaptive_c1")
+    x, target, desc, _ = common.case_inputs(meta, 0)
+    eng_a, eng_b = common.make_engine(meta), common.make_engine(meta)
+    eng_b.flat_params.copy_(eng_a.flat_params); eng_b.opt_state.copy_(eng_a.opt_state)
+    xd, td, dd = [torch.from_numpy(a).to(eng_a.device) for a in (x, target, desc)]
+    for step in range(4):
+        eng_a.train_step(xd, td, dd, seed=5)
+        eng_b.train_step(xd, td, dd, seed=5)
+        if step in (0, 2):
+            c0 = eng_b.tape["counter"].clone()
+            eng_b.forward(xd, td, dd, seed=5, train=False, run_all=True)          # an eval_dev batch on the training engine
+            torch.cuda.synchronize()
+            c1 = eng_b.tape["counter"]
+            assert int(c1[0]) == int(c0[0]) and int(c1[3]) == int(c0[3]) + 1, (c0.tolist(), c1.tolist())
+    torch.cuda.synchronize()
+    eng_a.check_sync(); eng_b.check_sync()
+    assert int(eng_a.tape["counter"][0]) == int(eng_b.tape["counter"][0]) == 4
+    assert torch.equal(eng_a.flat_params, eng_b.flat_params)

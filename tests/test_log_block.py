@@ -31,8 +31,8 @@ def test_log_block_lines_and_order(tmp_path, monkeypatch):
     captured = []
     real = _model._entropy_lines
 
-    def spy(eng, target, L):
-        out = real(eng, target, L)
+    def spy(eng, target, L, snap=None):
+        out = real(eng, target, L, snap)
         # independent recomputation of step 0 of the sender's entropy: every sample is active at step 0 (model.py:919-923)
         p = eng.tape["pz"][0].double()
         want0 = -float((p * torch.log(p + 1e-8) + (1 - p) * torch.log(1 - p + 1e-8)).sum(1).mean())
