@@ -632,16 +632,117 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, si
     return v;
 }
 
+struct OptArgs {
+    int optim_type, only_receiver, from_wgrad, bump_step, bump_mb;
+    float lr;
+    int64_t agent_begin[5];
+    int64_t total;
+};
+
+// OPT (k_wgrad<true>): the clip + optimizer step of model.py:1310-1330 INSIDE the weight-gradient launch.  Every workgroup still
+// holds the gradient elements it just stored in registers; what it lacks is the four per-agent clip coefficients, which need the
+// squared norm of ALL blocks.  So: each block publishes its sum of squares as a (value, epoch) pair (tape.gnll) and requests its
+// parameter / optimizer-state elements; ONE extra workgroup (the norm role) spins on all n_wblocks pairs, adds them in k_opt's
+// fixed order, and publishes the four coefficients (64 replicas each: no word has more than ~16 pollers); the blocks spin on
+// their replica, update their elements and store parameters + state.  No k_opt launch (6 us), and the gradients are never re-read.
+// A block's phase 2 starts only after EVERY block has published, i.e. finished reading -- some jobs read parameters
+// (linear2.weight, code_layer.weight).  All blocks of the launch must be co-resident (the host checks the occupancy budget).
+struct WgOpt {
+    OptArgs oa;
+    float* params; float* state; const float* grads; float* gnll; float* coefll;
+    uint32_t* counter; uint32_t* err_host;
+};
+#define MMG_COEF_REPL 64
+// one gradient element's update (k_opt's arithmetic); w, s1, s2 were requested before the wait for the coefficient
+__device__ __forceinline__ void opt_update_one(const OptArgs& oa, float* params, float* state, int64_t idx, float g, float coef,
+                                               float w, float s1, float s2, uint32_t step) {
+    const float gv = g * coef;
+    if (oa.optim_type == MMG_OPT_RMSPROP) {
+        const float sv = 0.99f * s1 + (1.f - 0.99f) * gv * gv;
+        w -= oa.lr * gv / (sqrtf(sv) + 1e-8f);
+        state[idx] = sv;
+    } else if (oa.optim_type == MMG_OPT_ADAM) {
+        const float b1 = 0.9f, b2 = 0.999f;
+        const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
+        const float mv = s1 + (gv - s1) * (1.f - b1), vv = b2 * s2 + (1.f - b2) * gv * gv;
+        w -= (oa.lr / bc1) * mv / (sqrtf(vv) / bc2s + 1e-8f);
+        state[idx] = mv; state[oa.total + idx] = vv;
+    } else {
+        w -= oa.lr * gv;
+    }
+    params[idx] = w;
+}
+// the wave's clip coefficient of `agent`: spins on this block's replica of the norm role's pairs; < 0: the update is skipped
+__device__ __forceinline__ float opt_wait_coef(const WgOpt& wo, int agent, uint32_t epoch, const uint32_t* sync) {
+    unsigned long long u;
+    for (int spins = 0;; ) {
+        u = ld_ll(wo.coefll, (size_t)agent * MMG_COEF_REPL + (blockIdx.x & (MMG_COEF_REPL - 1)));
+        if (ll_fresh(u, epoch)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 20)) { __hip_atomic_store(const_cast<uint32_t*>(sync) + MMG_SYNC_ERR, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1.f; }
+    }
+    return ll_value(u);
+}
+
+template <bool OPT>
 __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict__ jt, const float* __restrict__ x,
                                                      const float* __restrict__ desc, float* __restrict__ part,
                                                      Dims dm, const double* __restrict__ stats, float* __restrict__ losses,
                                                      double* __restrict__ totals, const int* __restrict__ rmap,
                                                      const int* __restrict__ rcount, float* __restrict__ wpart,
-                                                     const uint32_t* __restrict__ sync, float* __restrict__ grad_tail
+                                                     const uint32_t* __restrict__ sync, float* __restrict__ grad_tail, WgOpt wo
 #ifdef MMG_TIMING
                                                      , long long* __restrict__ dbg2
 #endif
                                                      ) {
+    const uint32_t oepoch = OPT ? wo.counter[3] + 1u : 0u;          // (the norm role bumps the counters when every block has read them)
+    const uint32_t ostep = OPT ? wo.counter[1] + 1u : 0u;
+    if (OPT && (int)blockIdx.x == jt->n_wblocks + 1) {
+        // ---- the norm role: all n_wblocks sums of squares -> four clip coefficients (k_opt's summation order, bit for bit)
+        __shared__ float s_ss[4][4];
+        const int n = jt->n_wblocks;
+        float ss[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = threadIdx.x; k0 < n; k0 += 8 * MMG_BLOCK) {
+            unsigned long long u[8]; int a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int k = k0 + q * MMG_BLOCK; a[q] = (k < n) ? (int)jt->wblock_agent[k] : -1; }
+            for (int spins = 0;; ) {
+                bool fresh = true;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int k = k0 + q * MMG_BLOCK; u[q] = ld_ll(wo.gnll, (size_t)min(k, n - 1)); fresh = fresh && (k >= n || ll_fresh(u[q], oepoch)); }
+                if (fresh) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 20)) { __hip_atomic_store(const_cast<uint32_t*>(sync) + MMG_SYNC_ERR, 11u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = (a[q] >= 0) ? ll_value(u[q]) : 0.f;
+                ss[0] += (a[q] == 0) ? v : 0.f; ss[1] += (a[q] == 1) ? v : 0.f;
+                ss[2] += (a[q] == 2) ? v : 0.f; ss[3] += (a[q] == 3) ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float wsum = dpp_wave_sum(ss[a]);
+            if ((threadIdx.x & 63) == 0) s_ss[a][threadIdx.x >> 6] = wsum;
+        }
+        __syncthreads();
+        // an in-launch dependency wait of this minibatch timed out (sync[MMG_SYNC_ERR]): parameters and optimizer state stay
+        // untouched (coefficient -1), the word goes to the pinned host word -- exactly k_opt's contract
+        const uint32_t err = __hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            const int a = threadIdx.x >> 6, r = threadIdx.x & 63;          // 4 agents x 64 replicas
+            const float tot = (s_ss[a][0] + s_ss[a][1]) + (s_ss[a][2] + s_ss[a][3]);
+            const float coef = 1.0f / (sqrtf(tot) + 1e-6f);               // max_norm = 1 (model.py:1310)
+            st_ll(wo.coefll, (size_t)a * MMG_COEF_REPL + r, err != 0u ? -1.f : (coef < 1.f ? coef : 1.f), oepoch);
+        }
+        if (threadIdx.x == 0) {
+            if (wo.err_host && (err != 0u || *wo.err_host == 0u)) *wo.err_host = err;
+            if (err == 0u) wo.counter[2] = ostep;                           // committed to counter[1] by the next k_prep
+            if (wo.oa.bump_mb) { wo.counter[0] += 1u; wo.counter[3] += 1u; }
+        }
+        return;
+    }
 #ifdef MMG_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 4096) dbg2[2 * blockIdx.x] = (long long)wall_clock64();
 #define MMG_WG_END() do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) dbg2[2 * blockIdx.x + 1] = (long long)wall_clock64(); } while (0)
@@ -711,6 +812,19 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         }
         sq = block_sum(sq, s_red);
         if (threadIdx.x == 0) part[blockIdx.x] = sq;
+        if (OPT) {
+            if (threadIdx.x == 0) st_ll(wo.gnll, blockIdx.x, sq, oepoch);
+            const float coef = opt_wait_coef(wo, jt->wblock_agent[blockIdx.x], oepoch, sync);
+            // (one workgroup, <= 32 elements: read back what it stored -- same thread, same address)
+            for (int j0 = 0; j0 < Wc && coef >= 0.f; j0 += MMG_BLOCK / 8) {
+                const int j = j0 + jj;
+                if (j < Wc && p8 == 0) {
+                    const int64_t idx = (C.dst - wo.grads) + j;
+                    opt_update_one(wo.oa, wo.params, wo.state, idx, C.dst[j], coef, wo.params[idx], wo.state[idx],
+                                   wo.oa.optim_type == MMG_OPT_ADAM ? wo.state[wo.oa.total + idx] : 0.f, ostep);
+                }
+            }
+        }
         MMG_WG_END();
         return;
     }
@@ -729,7 +843,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     if ((int)blockIdx.x == jt->n_wblocks) {
         // spare block: the six logged loss scalars, the semantic step count and the running totals (off every
         // critical path: this launch lasts ~17 us, the bookkeeping ~3)
-        __shared__ float s_lc[7 * 64];
+        float* s_lc = &s_b[0][0][0];                       // (7 * 64 floats of the staging area: this block stages nothing -- keeps the
+                                                           //  kernel at four workgroups per CU, which k_wgrad<true> needs for co-residency)
         LossCoef lc; lc.cw = s_lc; lc.ce = s_lc + 3 * dm.T; lc.cb = s_lc + 6 * dm.T;
         loss_coefficients(dm, stats, lc, losses, totals);
         // the quad behind the gradients (include/mmg.h: mmg_grad_floats): [0] = 1.0 when a dependency wait of this minibatch
@@ -884,19 +999,39 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         for (int r = 0; r < 4; ++r) { s_acc[wave][q * 4 + r][i] = acc0[r]; s_acc[wave][q * 4 + r][16 + i] = acc1[r]; }
         __syncthreads();
         float sq = 0.f;
+        float gv2[2]; int64_t gi2[2];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             const int rr = threadIdx.x >> 4, cc = (threadIdx.x & 15) + 16 * h2;
             const int n = n0 + rr, k = k0 + cc;
             const float v = (s_acc[0][rr][cc] + s_acc[1][rr][cc]) + (s_acc[2][rr][cc] + s_acc[3][rr][cc]);
+            gv2[h2] = v; gi2[h2] = -1;
             if (ns > 1) wpart[(size_t)tile * 512 + rr * 32 + cc] = v;       // raw partial tile (k_wreduce)
             else if (n < N && k < K) {
                 G.C[(size_t)n * G.ldc + k] = v;
                 sq = fmaf(v, v, sq);
+                gi2[h2] = (G.C - wo.grads) + (int64_t)n * G.ldc + k;
             }
         }
         sq = block_sum(sq, s_red);
         if (threadIdx.x == 0) part[tile] = sq;
+        if (OPT) {
+            if (threadIdx.x == 0) st_ll(wo.gnll, tile, sq, oepoch);
+            // parameter / state elements of this thread: requested now, they arrive while the norm role adds up
+            float w[2], s1[2], s2[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int64_t ic = gi2[h2] >= 0 ? gi2[h2] : 0;
+                w[h2] = wo.params[ic]; s1[h2] = wo.state[ic];
+                s2[h2] = (wo.oa.optim_type == MMG_OPT_ADAM) ? wo.state[wo.oa.total + ic] : 0.f;
+            }
+            const float coef = opt_wait_coef(wo, jt->wblock_agent[tile], oepoch, sync);
+            if (coef >= 0.f) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+                    if (gi2[h2] >= 0) opt_update_one(wo.oa, wo.params, wo.state, gi2[h2], gv2[h2], coef, w[h2], s1[h2], s2[h2], ostep);
+            }
+        }
         MMG_WG_END();
         return;
     }
@@ -952,6 +1087,14 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     }
     const float sq = block_sum(v * v, s_red);
     if (threadIdx.x == 0) part[blockIdx.x] = sq;
+    if (OPT) {
+        if (threadIdx.x == 0) st_ll(wo.gnll, blockIdx.x, sq, oepoch);
+        const bool mine = threadIdx.x < 16 && (c0 + (int)threadIdx.x) < C.cols;
+        const int64_t idx = mine ? (C.dst - wo.grads) + c0 + threadIdx.x : 0;
+        const float w = wo.params[idx], s1 = wo.state[idx], s2 = (wo.oa.optim_type == MMG_OPT_ADAM) ? wo.state[wo.oa.total + idx] : 0.f;
+        const float coef = opt_wait_coef(wo, jt->wblock_agent[blockIdx.x], oepoch, sync);
+        if (coef >= 0.f && mine) opt_update_one(wo.oa, wo.params, wo.state, idx, v, coef, w, s1, s2, ostep);
+    }
     MMG_WG_END();
 }
 
@@ -1021,12 +1164,6 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_gradnorm(const JobTable* __restri
     }
 }
 
-struct OptArgs {
-    int optim_type, only_receiver, from_wgrad, bump_step, bump_mb;
-    float lr;
-    int64_t agent_begin[5];
-    int64_t total;
-};
 
 __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ jt, OptArgs oa, float* __restrict__ params,
                                                    const float* __restrict__ grads, float* __restrict__ state,

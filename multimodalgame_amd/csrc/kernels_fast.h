@@ -137,6 +137,12 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     static_assert(2 * TMAX * W == TMAX * R, "a pair of message arrays holds one [16][R] tile");
     __shared__ float t_gru[TMAX * 4 * R], t_h[(TMAX + 1) * R], t_a[TMAX * H];
     __shared__ float s_statv[27 * TMAX];                 // the statistics roles' pair table, values only (MERGED)
+    // MFMA A operands of the sweeps, rows PADDED (strides 34 / 66 floats): a lane (fi, fq) reads [fi * stride + 4 ks + fq], so with
+    // the natural strides 32 / 64 all sixteen rows fi hit ONE LDS bank (16-way conflicts: 2.4 + 1.9 us of sweeps in rounds 2-4; round 5,
+    // found in kernels_game.h: 2.2 + 0.64)
+    constexpr int SW = 34, SR = 66;
+    __shared__ float s_sbas[4 * TMAX * SW];              // seed bases: w1 | w2 | z1 | z2
+    __shared__ float s_G1[TMAX * SR], s_G2p[TMAX * SR];  // dgpre bases
     // Workgroup roles.  n_bas == 0: [statistics n_stats][samples B][classes D][dbar n_dbar].
     // n_bas > 0 (the baselines' forward pass rides in this launch, kernels_fwd.h: baselines3_body): [samples B][statistics n_stats]
     // [baselines n_bas][classes D][dbar n_dbar] -- the sample roles start at once (their first ~10 us need no statistics), the
@@ -352,7 +358,8 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         if (!(binary && t < tstar)) { a1 = 0.f; a2 = 0.f; }                  // receiver message: active while m_{t+1} == 1
         if (!(binary && t <= tstar)) { b1 = 0.f; b2 = 0.f; }
         s1w[u] = a1; s2w[u] = a2; s1z[u] = b1; s2z[u] = b2;
-        t_w[i] = a1; t_pw[i] = a2; t_z[i] = b1; t_pz[i] = b2;                // (same thread, same element: in place)
+        const int j = i - t * W;
+        s_sbas[t * SW + j] = a1; s_sbas[(TMAX + t) * SW + j] = a2; s_sbas[(2 * TMAX + t) * SW + j] = b1; s_sbas[(3 * TMAX + t) * SW + j] = b2;
     }
     __syncthreads();
     MMG_BSTAMP(9);
@@ -362,8 +369,8 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     for (int nt = 0; nt < 4; ++nt) { p1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; p2[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int ks = 0; ks < W / 4; ++ks) {
-        const int o = fi * W + 4 * ks + fq;
-        const float aw1 = t_w[o], aw2 = t_pw[o], az1 = t_z[o], az2 = t_pz[o];
+        const int o = fi * SW + 4 * ks + fq;
+        const float aw1 = s_sbas[o], aw2 = s_sbas[TMAX * SW + o], az1 = s_sbas[2 * TMAX * SW + o], az2 = s_sbas[3 * TMAX * SW + o];
         g1 = mfma16(aw1, wwF[ks], g1); g2 = mfma16(aw2, wwF[ks], g2);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) { p1[nt] = mfma16(az1, wbF[nt][ks], p1[nt]); p2[nt] = mfma16(az2, wbF[nt][ks], p2[nt]); }
@@ -389,11 +396,9 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         accy = lane_group_sum<K4>(accy);
         if (p4 == 0) s_dAy[k4] = accy;
     }
-    __syncthreads();                                    // every wave has read the seed bases: their space is reused
-    float* s_G2 = t_msg;                                // [16][R] over t_w | t_pw
-    float* s_H2 = t_msg + 2 * TMAX * W;                 // [16][R] over t_z | t_pz
+    float* s_H2 = t_msg + 2 * TMAX * W;                 // [16][R] over t_z | t_pz (read for the last time before the barrier above)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { t_g[(4 * fq + r) * R + unit] = g1[r]; s_G2[(4 * fq + r) * R + unit] = g2[r]; }
+    for (int r = 0; r < 4; ++r) { s_G1[(4 * fq + r) * SR + unit] = g1[r]; s_G2p[(4 * fq + r) * SR + unit] = g2[r]; }
     __syncthreads();
     MMG_BSTAMP(10);
     // The statistics roles of this launch are normally through by now (8 us after the start): their (value, epoch) pairs are
@@ -412,8 +417,8 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
         f32x4 h1 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < R / 4; ++ks) {
-            h1 = mfma16(t_g[fi * R + 4 * ks + fq], whF[ks], h1);
-            h2 = mfma16(s_G2[fi * R + 4 * ks + fq], whF[ks], h2);
+            h1 = mfma16(s_G1[fi * SR + 4 * ks + fq], whF[ks], h1);
+            h2 = mfma16(s_G2p[fi * SR + 4 * ks + fq], whF[ks], h2);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s_dhin[(4 * fq + r) * R + unit] = h1[r]; s_H2[(4 * fq + r) * R + unit] = h2[r]; }

@@ -58,6 +58,8 @@ struct mmg_handle {
     bool game_ok;              // fused step of the small Adaptive agents: conversation + statistics + baselines + backward in ONE launch (kernels_game.h); MMG_NO_GAME=1: off
     int game_nbas;             // ... its baseline roles (a multiple of 2 * ceil(K / 64), sized by the co-residency budget)
     bool game_step;            // set by mmg_train_step around clip_step_impl: k_opt commits the minibatch counter / launch epoch
+    bool wgrad_opt_ok;         // the clip + optimizer step can run inside k_wgrad's launch (k_wgrad<true>: every block co-resident, no row splits); MMG_NO_WGRAD_OPT=1: off
+    bool wgrad_opt;            // set by mmg_train_step: this step's k_wgrad carries the optimizer (no k_opt launch)
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
     bool basehx_ready;         // this forward pass formed tape.basehx inside the conversation launch
     bool merge_roles;          // MMG_NO_MERGE=1 keeps k_stats / k_dC / basehx as separate launches / in-kernel work
@@ -567,6 +569,15 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         }
     }
     {
+        // the optimizer inside k_wgrad: its blocks spin on the norm role of the same launch, so ALL of them must be resident together
+        int nb = 0;
+        h->wgrad_opt = false;
+        h->wgrad_opt_ok = !h->any_split && h->dm.use_binary && h->d_err != nullptr && !getenv("MMG_NO_WGRAD_OPT") &&
+                          hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_wgrad<true>, MMG_BLOCK, 0) == hipSuccess &&
+                          h->jt.n_wblocks + 2 <= nb * n_cu - 8;
+        if (getenv("MMG_DEBUG")) fprintf(stderr, "mmg_create: wgrad_opt_ok %d (blocks %d, resident %d x %d)\n", (int)h->wgrad_opt_ok, h->jt.n_wblocks + 2, nb, n_cu);
+    }
+    {
         std::vector<float> one(256, 1.0f);
         e = hipMemcpy(h->tp.ones, one.data(), sizeof(float) * one.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) { fail("constant upload failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
@@ -1033,10 +1044,28 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
     }
     {
         Scope sc(h, st, "k_wgrad");
-        hipLaunchKernelGGL(k_wgrad, dim3(h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
+        WgOpt wo;
+        memset(&wo, 0, sizeof(wo));
+        if (h->wgrad_opt) {
+            wo.oa.optim_type = h->cfg.optim_type; wo.oa.only_receiver = 0; wo.oa.lr = h->cfg.learning_rate;
+            wo.oa.from_wgrad = 1; wo.oa.bump_step = 1; wo.oa.bump_mb = h->game_step ? 1 : 0;
+            for (int a = 0; a < 5; ++a) wo.oa.agent_begin[a] = h->pl.agent_begin[a];
+            wo.oa.total = h->pl.total;
+            wo.params = h->params; wo.state = h->opt_state; wo.grads = h->grads; wo.gnll = h->tp.gnll; wo.coefll = h->tp.coefll;
+            wo.counter = h->tp.counter; wo.err_host = h->d_err;
+            hipLaunchKernelGGL(k_wgrad<true>, dim3(h->jt.n_wblocks + 2), dim3(MMG_BLOCK), 0, st,
+                               (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
+                               h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
+                               (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo
+#ifdef MMG_TIMING
+                               , h->tp.dbg2
+#endif
+                               );
+        } else
+        hipLaunchKernelGGL(k_wgrad<false>, dim3(h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
                            (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
                            h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
-                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total
+                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo
 #ifdef MMG_TIMING
                            , h->tp.dbg2
 #endif
@@ -1127,10 +1156,11 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
             else hipLaunchKernelGGL(k_game_fast<32>, dim3(grid), dim3(256), game_lds_bytes(), st, h->dm, h->P, h->tp, ar, ga);
             if (launch_check("k_game_fast")) return -1;
         }
-        if (backward_impl(h, d_x, d_target, d_desc, st, true, true)) return -1;
         h->game_step = true;
-        const int rc = clip_step_impl(h, st, true);
-        h->game_step = false;
+        h->wgrad_opt = h->wgrad_opt_ok;
+        int rc = backward_impl(h, d_x, d_target, d_desc, st, true, true);
+        if (!rc && !h->wgrad_opt) rc = clip_step_impl(h, st, true);
+        h->game_step = false; h->wgrad_opt = false;
         return rc;
     }
     h->defer_bas = true;
@@ -1140,8 +1170,12 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
     const bool merged = merge_stats(h);
     if (h->bas_deferred && !merged) return fail("internal: deferred baselines without the merged backward launch");
     if (!merged && mmg_loss_stats(h, stream)) return -1;
-    if (backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, merged)) return -1;
-    return clip_step_impl(h, (hipStream_t)stream, true);
+    h->wgrad_opt = h->wgrad_opt_ok;
+    const int brc = backward_impl(h, d_x, d_target, d_desc, (hipStream_t)stream, merged);
+    const bool opt_done = h->wgrad_opt;
+    h->wgrad_opt = false;
+    if (brc) return -1;
+    return opt_done ? 0 : clip_step_impl(h, (hipStream_t)stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------
