@@ -55,7 +55,8 @@ def build_library(force=False, verbose=True, out=OUT, extra_flags=()):
 
 def build_timing_library(verbose=True):
     """-DMMG_TIMING build (in-kernel s_memrealtime stamps) for scripts/*timeline.py; built on demand, never shipped."""
-    return build_library(out=os.path.join(HERE, "libmmg_timing.so"), extra_flags=("-DMMG_TIMING",), verbose=verbose)
+    extra = tuple(os.environ.get("MMG_EXTRA_FLAGS", "").split())      # (experiments: scripts/ab_*.sh)
+    return build_library(out=os.path.join(HERE, "libmmg_timing%s.so" % ("_x" if extra else "")), extra_flags=("-DMMG_TIMING",) + extra, verbose=verbose)
 
 
 if __name__ == "__main__":

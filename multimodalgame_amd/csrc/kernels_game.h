@@ -195,7 +195,15 @@ __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp
     // ---------------------------------------------------------------- the other roles
     if (bx >= B) {
         int r = bx - B;
-        if (r < ar.nprep) { prep_body<true, true>(dm, P, tp, ar.desc, ar.x, ar.prep_cpb, r, lds, 0); return; }
+        if (r < ar.nprep) {
+            if (threadIdx.x == 0 && r < 256) { MMG_GT(4608 + 2 * r); }
+            prep_body<true, true>(dm, P, tp, ar.desc, ar.x, ar.prep_cpb, r, lds, 0);
+#ifdef MMG_TIMING
+            __syncthreads();
+            if (threadIdx.x == 0 && r < 256) { MMG_GT(4608 + 2 * r + 1); }
+#endif
+            return;
+        }
         r -= ar.nprep;
         if (r < ar.nbase) {                              // basehx tile: A operand = the h_x pairs, result out as pairs too
             gemm_nt_tile<true, true>(r, tp.prepll, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, B, dm.K, H, tp.basell, epoch, tp.sync);
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp
         for (int i = 0; i < 12; ++i) s_park[i * NT + tid] = whh_tmp[i];
 #pragma unroll
         for (int k = 0; k < (32 * V + NT - 1) / NT; ++k) { const int i = tid + NT * k; if (i < 32 * V) s_desc[i] = dsc[k]; }
+        if (tid == 0) { MMG_GT(2048 + 16 * b + 14); }
         {
             int spins = 0;
             for (;;) {
@@ -342,6 +351,9 @@ __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp
                 bool fresh = true;
 #pragma unroll
                 for (int k = 0; k < 18; ++k) fresh = fresh && ll_fresh(u[k], epoch);
+#ifdef MMG_TIMING
+                if (tid == 0) tp.dbg2[2048 + 16 * b + 15] = (long long)(spins + 1);
+#endif
                 if (!__any(!fresh)) break;
                 if (++spins > (1 << 16)) { if (lane == 0) __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }

@@ -28,9 +28,12 @@ ts = S[:, 12].astype(int)
 lon = int(np.argmax(S[:, 2]))
 print("samples: t* min/mean/max %d / %.2f / %d; the longest conversation: sample %d (t* = %d)" % (ts.min(), ts.mean(), ts.max(), lon, ts[lon]))
 print("%-26s %10s %10s %10s | sample %d" % ("milestone (us after start)", "min", "median", "max", lon))
-for k, nm in [(0, names[0]), (1, names[1]), (2, names[2]), (3, names[3]), (13, names[13])] + [(k, names[k]) for k in range(4, 12)]:
+for k, nm in [(0, names[0]), (14, "weights parked"), (1, names[1]), (2, names[2]), (3, names[3]), (13, names[13])] + [(k, names[k]) for k in range(4, 12)]:
     v = us(S[:, k] - t0)
     print("%-26s %10.2f %10.2f %10.2f | %8.2f" % (nm, v.min(), np.median(v), v.max(), v[lon]))
+print("polls of the prep pairs per sample role: min %d median %d max %d" % (S[:, 15].min(), np.median(S[:, 15]), S[:, 15].max()))
+pr = g[4608:4608 + 512].reshape(256, 2); pr = pr[pr[:, 0] > 0]
+print("prep roles (%d): start %.2f..%.2f | done %.2f..%.2f; slowest %s" % ((len(pr),) + tuple(us(v - t0) for v in (pr[:, 0].min(), pr[:, 0].max(), pr[:, 1].min(), pr[:, 1].max())) + (np.argsort(-pr[:, 1])[:6].tolist(),)))
 st = g[3072:3072 + 4 * 52].reshape(52, 4)
 ok = st[:, 0] > 0
 print("statistics waves: start %.2f..%.2f | forward passes seen %.2f..%.2f | done %.2f..%.2f" % tuple(us(v - t0) for v in (st[ok, 0].min(), st[ok, 0].max(), st[ok, 1].min(), st[ok, 1].max(), st[ok, 2].min(), st[ok, 2].max())))

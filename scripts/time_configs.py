@@ -25,7 +25,7 @@ for name, cfg in CASES.items():
     feats, target, desc = bench.synthetic_dataset(max(3000, B), cfg["n_classes"], 512, 100)
     dev = eng.device
     x = torch.from_numpy(feats[:B]).to(dev); t = torch.from_numpy(target[:B]).to(dev); d = torch.from_numpy(desc).to(dev)
-    n = 50
+    n = int(os.environ.get("N", "50"))
     for _ in range(5): eng.train_step(x, t, d, seed=1)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): eng.train_step(x, t, d, seed=1)
