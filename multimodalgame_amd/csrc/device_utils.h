@@ -394,6 +394,11 @@ __device__ __forceinline__ void st_ll(float* ll, size_t i, float v, uint32_t epo
     const unsigned long long u = ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(ll) + i, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// two consecutive pairs (i even) in ONE 16-byte write-through store: (v0, epoch, v1, epoch); each 8-byte pair lands whole
+__device__ __forceinline__ void st_ll2(float* ll, size_t i, float v0, float v1, uint32_t epoch) {
+    const float e = __builtin_bit_cast(float, epoch);
+    st_wt4(ll + 2 * i, make_float4(v0, e, v1, e));
+}
 __device__ __forceinline__ unsigned long long ld_ll(const float* ll, size_t i) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(ll) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

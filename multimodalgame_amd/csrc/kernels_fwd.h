@@ -197,7 +197,7 @@ __device__ __forceinline__ void prep_body(const Dims& dm, const Params& P, const
         }
         const bool first = blk == nC;
         if (first && tid < dm.T + 2) tp.alive[tid] = (tid == 0) ? 1 : 0;     // per-step live-tile counts (kernels_tile.h)
-        if (first) for (int i = tid; i < (ROLE ? 128 : 4 * 64); i += blockDim.x) tp.pflags[(size_t)i * 64] = 0u;   // role counters of k_conv_persist / the backward launch
+        if (first) for (int i = tid; i < (ROLE ? 128 : 20 * 64); i += blockDim.x) tp.pflags[(size_t)i * 64] = 0u;   // role counters of k_conv_persist / the backward launch
         if (first && mc_shape(dm.H, dm.W, dm.R, dm.V, dm.D, dm.T))                                    // ... and of k_conversation_mc
             for (int i = tid; i < 2 * ((dm.B + 15) / 16); i += blockDim.x) tp.mcflags[(size_t)i * 64] = 0u;
         if (first && tid == 0) {

@@ -507,7 +507,8 @@ struct F2 { float x, y; };
 #endif
 // ---- counters between the roles of k_conv_persist: monotonic (zeroed by k_prep), one per 256-byte block.
 // kind 0: g published by the receiver role of a tile (value = steps done), 1: sender-hidden slices a_t (NS1 per step),
-// 2: message columns + GRU-input partials (NS2 per step), 3: the tile's conversation is over.
+// 2: message columns + GRU-input partials (NS2 per step), 3: the tile's conversation is over, 4 + t (t < 16): per-sample receiver
+// roles that have delivered step t or stopped before it.
 __device__ __forceinline__ uint32_t* pf_ctr(const Tape& tp, int kind, int tile) { return tp.pflags + ((size_t)kind * 64 + tile) * 64; }
 // producer: everything the consumers read was written with agent-scope (write-through) stores
 __device__ __forceinline__ void pf_signal(uint32_t* ctr) {
@@ -1227,8 +1228,11 @@ __device__ __forceinline__ void s1_role(const Dims& dm, const Params& P, const T
                                  : philox_uniform(ar.seed, (uint32_t)(((t - 1) * dm.Bg + dm.boff + b) * W + n), mb_counter, 2u);
             }
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 200);
-            if (!pf_wait(cG, (uint32_t)(ar.rsample ? nb * t : t), done, tp.sync)) return;      // (per-sample receiver roles: one count per sample)
-            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201);
+            // (per-sample receiver roles: one count per sample on the counter OF THE STEP, kind 4 + step -- a sample that has stopped
+            //  counts once on every later step's counter.  Rounds 3-4 kept ONE running counter and let a stopped sample add all its
+            //  remaining steps at once: with enough of them gone the sum passed nb * t before the live samples had delivered.)
+            if (!pf_wait(ar.rsample ? pf_ctr(tp, 4 + (t - 1), tile) : cG, (uint32_t)(ar.rsample ? nb : t), done, tp.sync)) return;
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201); MMG_RSTAMP(tile == 0 && j == 0 && t == 4, 206);
             if (msg_in) {
                 // (per-sample receiver roles that form the message themselves: it arrives ready)
                 batched_for<NT, 8>(MMG_TM * W, [&](int idx) { const int m = idx / W, n = idx - m * W; return tp.w[(rowp + min(b0 + m, B - 1)) * W + n]; },
@@ -1404,7 +1408,23 @@ __device__ __forceinline__ void s2_role(const Dims& dm, const Params& P, const T
 // Against the s1 / s2 roles: no role reads the whole hidden tile (64 KB per role per step) and none runs a K = 1024 chain
 // of dependent MFMAs; the hand-off S1 -> S2 carries 16 x 16 x 16 floats per consumer instead of 16 x 1024.
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+// LL (rounds 5+): every hand-off of the fused roles is the payload itself as (value, tag) pairs (tape.pll_*), tag = (launch
+// epoch << 4) | step: a consumer spins on the pairs it needs -- no store-completion wait and no counter at the producer, no second
+// trip to memory at the consumer (scripts/micro/hop_latency.hip: 8 pairs per lane 0.9-1.2 us per hop as pairs against 1.5-2.1 us
+// as payload + flag, and 190 polling workgroups cost the hop 0.07 us).  ONE slot per buffer: the ring receiver -> SA -> SB ->
+// receiver orders the steps (a producer of step t + 1 has, through the ring, every consumer's step t behind it), and the slots
+// stay hot -- per-step slots (36 MB a minibatch, every line cold) cost the hops 5 us.  A sample that stops publishes a zero
+// message and a zero mask under the FINAL tag (step 15), which every later step accepts; a tile whose 16 masks are all zero is
+// over, and its sender roles return.  (T <= 15; the tag wraps after 2^28 launches into slots rewritten every launch.)
+__device__ __forceinline__ uint32_t pll_tag(uint32_t ep, int t) { return (ep << 4) | (uint32_t)t; }
+__device__ __forceinline__ bool pll_fresh_or_final(unsigned long long u, uint32_t ep, int t) {
+    const uint32_t g = (uint32_t)(u >> 32);
+    return g == pll_tag(ep, t) || g == pll_tag(ep, 15);
+}
+#ifndef MMG_LL_SLEEP
+#define MMG_LL_SLEEP 0          // s_sleep units (64 cycles) between two rounds of a pair poll
+#endif
+template <int NT, bool LL = false>
 __device__ __forceinline__ void sa_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int j) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int nw = NT / 64;
@@ -1431,15 +1451,41 @@ __device__ __forceinline__ void sa_role(const Dims& dm, const Params& P, const T
     wfrag_load<4>(fz0, P.p[S_BIN_W] + n0, H, W, 64, wave, nw);
     wfrag_load<4>(fz1, P.p[S_BIN_W] + n0, H, W, 64, wave + nw, nw);
     float* zp = tp.zpart + ((size_t)tile * (H / 64) + j) * MMG_TM * W;
+    const uint32_t ep = LL ? tp.counter[3] : 0u;                       // (k_prep moved it before this launch; nothing moves it during)
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const size_t rowb = (size_t)t * B, rowp = (size_t)(t > 0 ? t - 1 : 0) * B;
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        if (t >= 1) {
+        if (t >= 1 && LL) {
             MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 200);
-            if (!pf_wait<false>(cG, (uint32_t)(nb * t), done, tp.sync)) return;
-            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201);
+            // the tile's messages w_{t-1} [16][W] and stop masks: 8 pairs per thread (W = 256, 512 threads), spun on directly
+            unsigned long long uw[8], um = 0;
+            size_t iw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int idx = tid + u * NT, m = idx / W, c = idx - m * W; iw[u] = (size_t)min(b0 + m, B - 1) * W + c; }
+            for (int spins = 0;; ) {
+                bool fresh = true;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { uw[u] = ld_ll(tp.pll_w, iw[u]); fresh = fresh && pll_fresh_or_final(uw[u], ep, t - 1); }
+                if (tid < MMG_TM) { um = ld_ll(tp.pll_m, (size_t)min(b0 + tid, B - 1)); fresh = fresh && pll_fresh_or_final(um, ep, t - 1); }
+                if (!__any(!fresh)) break;
+                __builtin_amdgcn_s_sleep(MMG_LL_SLEEP);
+                if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 101u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201); MMG_RSTAMP(tile == 0 && j == 0 && t == 4, 206);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int idx = tid + u * NT, m = idx / W, c = idx - m * W; if (m < MMG_TM) s_w[m * ldW + c] = ll_value(uw[u]); }
+            const bool lv = tid < nb && (!may_stop || ll_value(um) != 0.f);
+            if (tid < MMG_TM) s_live[tid] = lv ? 1.f : 0.f;
+            if (!__syncthreads_or(tid < MMG_TM && lv)) return;          // every sample of the tile has stopped
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 202);
+            wfrag_mma<8>(fc, s_w, ldW, raw, ldA);
+            __syncthreads();
+        } else if (t >= 1) {
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 200);
+            if (!pf_wait<false>(pf_ctr(tp, 4 + (t - 1), tile), (uint32_t)nb, done, tp.sync)) return;      // (the step's own counter: s1_role)
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 201); MMG_RSTAMP(tile == 0 && j == 0 && t == 4, 206);
             {
                 const int W4 = W >> 2;
                 batched_for<NT, 2>(MMG_TM * W4, [&](int idx) { const int m = idx / W4, q = idx - m * W4; return ld_cc4(tp.w + (rowp + min(b0 + m, B - 1)) * W + 4 * q); },
@@ -1466,6 +1512,17 @@ __device__ __forceinline__ void sa_role(const Dims& dm, const Params& P, const T
         MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 203);
         wfrag_mma<4>(fz0, s_a, ldA, raw, ldW); wfrag_mma<4>(fz1, s_a, ldA, raw, ldW);      // partial message logits over this role's K slice
         __syncthreads();
+        if (LL) {
+            const size_t zb = ((size_t)tile * (H / 64) + j) * MMG_TM * W;                        // pair index of this role's [16][W] block
+            for (int idx = tid; idx < MMG_TM * (W >> 1); idx += NT) {
+                const int m = idx / (W >> 1), n = (idx - m * (W >> 1)) * 2;
+                const float2 v = *reinterpret_cast<const float2*>(raw + m * ldW + n);
+                st_ll2(tp.pll_zp, zb + (size_t)m * W + n, v.x, v.y, pll_tag(ep, t));
+            }
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 204);
+            MMG_RSTAMP(tile == 0 && j == 0 && t == 3, 205);
+            continue;                                                    // (raw is rewritten behind the next step's first barrier)
+        }
         for (int idx = tid; idx < MMG_TM * (W >> 2); idx += NT) {
             const int m = idx / (W >> 2), n = (idx - m * (W >> 2)) * 4;
             st_wt4(zp + m * W + n, *reinterpret_cast<const float4*>(raw + m * ldW + n));
@@ -1476,7 +1533,7 @@ __device__ __forceinline__ void sa_role(const Dims& dm, const Params& P, const T
     }
 }
 
-template <int NT>
+template <int NT, bool LL = false>
 __device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int tile, const int k) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int nw = NT / 64;
@@ -1501,6 +1558,7 @@ __device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const T
     const int o = threadIdx.x >> 1, hf = threadIdx.x & 1, om = o >> 4, oc = o & 15;
     const float bbv = P.p[S_BIN_B][c0 + oc];
     const float* zp = tp.zpart + (size_t)tile * ns1 * MMG_TM * W + (size_t)om * W + c0 + oc;
+    const uint32_t ep = LL ? tp.counter[3] : 0u;
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const size_t rowb = (size_t)t * B;
@@ -1511,16 +1569,48 @@ __device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const T
         if (binary && train && hf == 0)
             uz = ar.u_z ? ar.u_z[(rowb + bq) * W + c0 + oc] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + dm.boff + bq) * W + c0 + oc), mb_counter, 0u);
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 210);
-        if (!pf_wait<false>(cA, (uint32_t)(ns1 * (t + 1)), done, tp.sync)) return;
-        MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 211);
         float p8[8], acc = 0.f;
+        if (LL) {
+            // (1) the masks after step t - 1 (long since there: the receiver roles published them before the SA roles even
+            //     started this step) decide whether the tile still runs; (2) the SA roles' partials of this role's 16 bits
+            if (t >= 1) {
+                unsigned long long um = 0;
+                if (tid < MMG_TM) {
+                    for (int spins = 0;; ) {
+                        um = ld_ll(tp.pll_m, (size_t)min(b0 + tid, B - 1));
+                        if (pll_fresh_or_final(um, ep, t - 1)) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 102u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                }
+                const bool lv = tid < nb && (!may_stop || ll_value(um) != 0.f);
+                if (tid < MMG_TM) s_live[tid] = lv ? 1.f : 0.f;
+                if (!__syncthreads_or(tid < MMG_TM && lv)) return;
+            }
+            unsigned long long up[8];
+            const size_t zb = ((size_t)tile * ns1) * MMG_TM * W + (size_t)om * W + c0 + oc;
+            for (int spins = 0;; ) {
+                bool fresh = true;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) p8[u] = ld_cc(zp + (size_t)min(hf + 2 * u, ns1 - 1) * MMG_TM * W);
-        if (t >= 1 && tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || ld_cc(&tp.mstate[min(b0 + tid, B - 1)]) != 0.f)) ? 1.f : 0.f;
+                for (int u = 0; u < 8; ++u) { up[u] = ld_ll(tp.pll_zp, zb + (size_t)min(hf + 2 * u, ns1 - 1) * MMG_TM * W); fresh = fresh && ll_fresh(up[u], pll_tag(ep, t)); }
+                if (!__any(!fresh)) break;
+                __builtin_amdgcn_s_sleep(MMG_LL_SLEEP);
+                if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 103u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 211);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p8[u] = ll_value(up[u]);
+        } else {
+            if (!pf_wait<false>(cA, (uint32_t)(ns1 * (t + 1)), done, tp.sync)) return;
+            MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 211);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p8[u] = ld_cc(zp + (size_t)min(hf + 2 * u, ns1 - 1) * MMG_TM * W);
+            if (t >= 1 && tid < MMG_TM) s_live[tid] = (tid < nb && (!may_stop || ld_cc(&tp.mstate[min(b0 + tid, B - 1)]) != 0.f)) ? 1.f : 0.f;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += (hf + 2 * u < ns1) ? p8[u] : 0.f;
         acc = dpp_group_sum<2>(acc);
-        __syncthreads();                                                 // s_live
+        if (!LL) __syncthreads();                                        // s_live
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 212);
         float zq = 0.f, pq = 0.f;
         if (hf == 0) {
@@ -1533,7 +1623,17 @@ __device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const T
             s_zs[om * ldZ + oc] = zz;
             zq = zz; pq = pp;
         }
-        {
+        if (LL) {
+            // the receiver role of sample om reads (bit, probability) as ONE pair: the probability carries the bit in its sign
+            // (binary mode; continuous messages are not read back).  The tape rows are plain stores (read after the launch).
+            const bool lrow = om < nb && s_live[om] != 0.f;
+            if (hf == 0 && lrow) {
+                const size_t o = (rowb + b0 + om) * W + c0 + oc;
+                if (binary) st_ll(tp.pll_z, (size_t)(b0 + om) * W + c0 + oc, (zq != 0.f) ? pq : -pq, pll_tag(ep, t));
+                tp.z[o] = zq;
+                if (binary) tp.pz[o] = pq;
+            }
+        } else {
             const float4 z4 = gather4_even(zq), p4v = gather4_even(pq);                         // (read back by the receiver roles: write-through)
             if ((tid & 7) == 0 && om < nb && s_live[om] != 0.f) {
                 st_wt4(&tp.z[(rowb + b0 + om) * W + c0 + oc], z4);
@@ -1544,6 +1644,17 @@ __device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const T
         MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 213);
         wfrag_mma<1>(fi0, s_zs, ldZ, raw, ld3R); wfrag_mma<1>(fi1, s_zs, ldZ, raw, ld3R);       // z_slice W_ih[:, slice]^T
         __syncthreads();
+        if (LL) {
+            const size_t gb = ((size_t)k * B + b0) * 3 * R;                                      // pair index of row b0 of this role's [B][3R] block
+            for (int idx = tid; idx < MMG_TM * (3 * R >> 1); idx += NT) {
+                const int m = idx / (3 * R >> 1), n = (idx - m * (3 * R >> 1)) * 2;
+                const float2 v = *reinterpret_cast<const float2*>(raw + m * ld3R + n);
+                if (m < nb) st_ll2(tp.pll_gi, gb + (size_t)m * 3 * R + n, v.x, v.y, pll_tag(ep, t));
+            }
+            MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 214);
+            MMG_RSTAMP(tile == 0 && k == 0 && t == 3, 215);
+            continue;                                                    // (raw / s_zs are rewritten behind the next step's barriers)
+        }
         for (int idx = tid; idx < MMG_TM * (3 * R >> 2); idx += NT) {
             const int m = idx / (3 * R >> 2), n = (idx - m * (3 * R >> 2)) * 4;
             if (m < nb) st_wt4(&tp.gip[((size_t)k * B + b0 + m) * 3 * R + n], *reinterpret_cast<const float4*>(raw + m * ld3R + n));
@@ -1566,8 +1677,9 @@ __device__ __forceinline__ void sb_role(const Dims& dm, const Params& P, const T
 // MW = 256: the role also forms the receiver's message w_t = Bernoulli(sigmoid(W_w g_t + b_w)) (2 lanes per message bit, W_w in
 // registers) and publishes IT instead of g_t: the S1 roles then start from the message (no redundant 16-fold recompute of
 // it, one product less on the per-step chain).  MW = 0: other widths, g_t goes out and the S1 roles form the message.
-template <int NT, int R, int V, int D, int MW>
+template <int NT, int R, int V, int D, int MW, bool LL = false>
 __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const Tape& tp, const ConvArgs& ar, const int b) {
+    static_assert(!LL || MW == 256, "pair hand-offs: the fused sender roles' shape");
     static_assert(NT == 512 && R == 64 && D <= 32 && V <= 200 && (MW == 0 || MW == 256), "receiver shape of the register-resident kernels");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_h = smem; float* s_gi = s_h + R; float* s_gh = s_gi + 3 * R; float* s_A = s_gh + 3 * R;
@@ -1651,6 +1763,7 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
     __syncthreads();
     uint32_t* cG = pf_ctr(tp, 0, tile); uint32_t* cZ = pf_ctr(tp, 2, tile); uint32_t* done = pf_ctr(tp, 3, tile);
     const int ns2 = ar.ns2;
+    const uint32_t ep = LL ? tp.counter[3] : 0u;
     float stop_p = 0.5f, stop_bit = 0.f;
     int signalled = 0;
     int t = 0;
@@ -1667,15 +1780,33 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
             if (binary && train) uwv = ar.u_w ? ar.u_w[row * W + nw] : philox_uniform(ar.seed, (uint32_t)((t * dm.Bg + gb) * W + nw), mb_counter, 2u);
         }
         // ===== the sender roles' message of this step: its GRU input-side product arrives as ns2 partials
-        MMG_RSTAMP(b == 0 && t == 3, 250);
-        if (!pf_wait<false>(cZ, (uint32_t)(ns2 * (t + 1)), nullptr, tp.sync)) return;
-        MMG_RSTAMP(b == 0 && t == 3, 251);
+        MMG_RSTAMP(b == 0 && t == 3, 250); MMG_RSTAMP(t == 3 && b < 64, 256 + 8192 + 8 * b + 0);
+        if (!LL) { if (!pf_wait<false>(cZ, (uint32_t)(ns2 * (t + 1)), nullptr, tp.sync)) return; }
         {
             float p4[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) p4[u] = ld_cc(&tp.gip[((size_t)min(h3 + 2 * u, ns2 - 1) * B + b) * 3 * R + nr]);
             float zz = 0.f, pp = 0.5f;
-            if (binary && tid < W) { zz = ld_cc(&tp.z[row * W + tid]); pp = ld_cc(&tp.pz[row * W + tid]); }
+            if (LL) {
+                // the SB roles' partials of this sample's row (8 per lane) and, binary mode, the message itself: spun on directly
+                unsigned long long ug[8], uzp = 0;
+                const size_t gbase = (size_t)b * 3 * R + nr;
+                for (int spins = 0;; ) {
+                    bool fresh = true;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { ug[u] = ld_ll(tp.pll_gi, gbase + (size_t)min(h3 + 2 * u, ns2 - 1) * B * 3 * R); fresh = fresh && ll_fresh(ug[u], pll_tag(ep, t)); }
+                    if (binary && tid < W) { uzp = ld_ll(tp.pll_z, (size_t)b * W + tid); fresh = fresh && ll_fresh(uzp, pll_tag(ep, t)); }
+                    if (!__any(!fresh)) break;
+                    __builtin_amdgcn_s_sleep(MMG_LL_SLEEP);
+                if (++spins > MMG_SPIN_LIMIT) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 104u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p4[u] = ll_value(ug[u]);
+                if (binary && tid < W) { const float v = ll_value(uzp); zz = (__builtin_bit_cast(unsigned, v) >> 31) ? 0.f : 1.f; pp = fabsf(v); }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p4[u] = ld_cc(&tp.gip[((size_t)min(h3 + 2 * u, ns2 - 1) * B + b) * 3 * R + nr]);
+                if (binary && tid < W) { zz = ld_cc(&tp.z[row * W + tid]); pp = ld_cc(&tp.pz[row * W + tid]); }
+            }
+            MMG_RSTAMP(b == 0 && t == 3, 251); MMG_RSTAMP(t == 3 && b < 64, 256 + 8192 + 8 * b + 1);
             float gp = 0.f;
 #pragma unroll
             for (int u = 0; u < 8; ++u) gp += (h3 + 2 * u < ns2) ? p4[u] : 0.f;
@@ -1692,7 +1823,7 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
             }
         }
         __syncthreads();
-        MMG_RSTAMP(b == 0 && t == 3, 252);
+        MMG_RSTAMP(b == 0 && t == 3, 252); MMG_RSTAMP(t == 3 && b < 64, 256 + 8192 + 8 * b + 2);
         // ===== GRU state update
         if (tid < R) {
             const float rr = fsigmoid(s_gi[tid] + s_gh[tid]);
@@ -1760,14 +1891,22 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
             tp.mask[(size_t)(t + 1) * B + b] = (uint8_t)(m_next != 0.f);
             if (take_out) s_misc[1] = (float)t;
             s_misc[0] = m_next;
-            st_wt(&tp.mstate[b], m_next);                                  // the sender roles store live rows only
+            if (LL) st_ll(tp.pll_m, (size_t)b, m_next, pll_tag(ep, (may_stop && m_next == 0.f) ? 15 : t));   // the sender roles store live rows only; all zero: the tile is over
+            else st_wt(&tp.mstate[b], m_next);
         }
         if (wave == 7 && lane == 0) {
             const float l1 = flog(stop_p + MMG_EPS), l0 = flog(1.f - stop_p + MMG_EPS);
             tp.lp_s[row] = stop_bit * l1 + (1.f - stop_bit) * l0;
             tp.ne_s[row] = stop_p * l1 + (1.f - stop_p) * l0;
         }
-        if (may_stop && m_next == 0.f) { ++t; __syncthreads(); break; }
+        if (may_stop && m_next == 0.f) {
+            if (LL) {
+                // this sample takes no further step: a zero message under the FINAL tag, which every later step of its sender roles
+                // accepts (the zero mask went out above, under the same tag)
+                if (tid < W) st_ll(tp.pll_w, (size_t)b * W + tid, 0.f, pll_tag(ep, 15));
+            }
+            ++t; __syncthreads(); break;
+        }
         // ===== softmax (per wave) -> wave-private LDS -> description mixture (2 lanes per column)
         {
             const float yv = (lane < 32) ? s_y[lane] : -3.0e38f;
@@ -1814,7 +1953,7 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
                 else st_wt(&tp.g[row * R + n4], gv);
             }
         }
-        MMG_RSTAMP(b == 0 && t == 3, 253);
+        MMG_RSTAMP(b == 0 && t == 3, 253); MMG_RSTAMP(t == 3 && b < 64, 256 + 8192 + 8 * b + 3);
         if (MW) {
             __syncthreads();
             // ===== receiver message (model.py:454-475) -> the S1 roles
@@ -1833,7 +1972,9 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
                 s_c[nw] = wv;
                 wq = wv;
             }
-            {
+            if (LL) {
+                if (hw == 0) { st_ll(tp.pll_w, (size_t)b * W + nw, wq, pll_tag(ep, t)); tp.w[row * W + nw] = wq; }   // pair: the SA roles; tape: a plain store
+            } else {
                 const float4 w4 = gather4_even(wq);                         // four message bits per 16-byte write-through store
                 if ((tid & 7) == 0) st_wt4(&tp.w[row * W + nw], w4);
             }
@@ -1842,9 +1983,9 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
                 if (lane == 0) { s_lpw[wave] = lpv; s_lpw[8 + wave] = nev; }
             }
         }
-        MMG_RSTAMP(b == 0 && t == 3, 254);
-        pf_signal(cG);
-        MMG_RSTAMP(b == 0 && t == 3, 255);
+        MMG_RSTAMP(b == 0 && t == 3, 254); MMG_RSTAMP(t == 3 && b < 64, 256 + 8192 + 8 * b + 4);
+        if (LL) __syncthreads(); else pf_signal(pf_ctr(tp, 4 + t, tile));   // (LL: s_lpw is read below; the message went out as pairs)
+        MMG_RSTAMP(b == 0 && t == 3, 255); MMG_RSTAMP(t == 3 && b < 64, 256 + 8192 + 8 * b + 5);
         ++signalled;
         if (MW && binary && tid == 0) {                                    // (after the signal's barrier: off the sender roles' path)
             float a = 0.f, c = 0.f;
@@ -1854,9 +1995,9 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
     }
     __syncthreads();
     // the counts of the steps this sample does not take; the tile's last sample ends the sender roles
-    if (tid == 0) {
+    if (!LL && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the final stop mask is out before the counts move)
-        if (signalled < T) __hip_atomic_fetch_add(cG, (uint32_t)(T - signalled), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int t2 = signalled; t2 < T; ++t2) __hip_atomic_fetch_add(pf_ctr(tp, 4 + t2, tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t fin = __hip_atomic_fetch_add(done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)fin == nb_tile - 1) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1888,9 +2029,27 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
 // SAMPLE_ROLES: the launch of per-sample receiver roles (ar.rsample != 0) and the variant with one 16-sample receiver role per
 // tile are two kernels -- the tile role needs every one of its 256 registers (and spills a few), the per-sample roles do not,
 // and a workgroup should not carry the code of roles its launch never runs (62 k lines of ISA for the union)
-template <int NT, bool SAMPLE_ROLES>
+template <int NT, bool SAMPLE_ROLES, bool LL = false>
 __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles, int xcd_map) {
     int blk = blockIdx.x;
+    if (SAMPLE_ROLES && LL) {                           // fused sender roles with (value, epoch) pair hand-offs (host: ar.rsample == 3 only)
+        const int cb = ar.b_count, ctile0 = ar.b_begin / MMG_TM, ctiles = (cb + MMG_TM - 1) / MMG_TM;
+        const int nrole = cb + ctiles * (ar.ns1 + ar.ns2);
+        if (blk >= nrole) {
+            if (threadIdx.x >= MMG_BLOCK) return;
+            gemm_nt_tile(blk - nrole, tp.hx, dm.H, P.p[BS_L1_W], dm.H + dm.W, nullptr, tp.basehx, dm.K, dm.B, dm.K, dm.H);
+            return;
+        }
+        if (blk < cb) {
+            const int b = ar.b_begin + blk;
+            if (dm.D == 30) rs_role<NT, 64, 100, 30, 256, true>(dm, P, tp, ar, b); else rs_role<NT, 64, 100, 32, 256, true>(dm, P, tp, ar, b);
+            return;
+        }
+        const int r = blk - cb;
+        if (r < ctiles * ar.ns2) sb_role<NT, true>(dm, P, tp, ar, ctile0 + r / ar.ns2, r % ar.ns2);
+        else { const int q = r - ctiles * ar.ns2; sa_role<NT, true>(dm, P, tp, ar, ctile0 + q / ar.ns1, q % ar.ns1); }
+        return;
+    }
     if (SAMPLE_ROLES) {                                 // one receiver role per sample, then the sender roles of the tiles
         // this launch covers the samples [b_begin, b_begin + b_count) = the tiles ctile0 .. ctile0 + ctiles - 1
         const int cb = ar.b_count, ctile0 = ar.b_begin / MMG_TM, ctiles = (cb + MMG_TM - 1) / MMG_TM;

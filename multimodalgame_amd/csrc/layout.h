@@ -106,7 +106,12 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(rcxw, float, 0, 3, NRCZ, 16, 16)   /* ... w_t in fragment order [tile][W/16][16][16] (message slices -> S1 roles)                        */ \
     X(rcxh, float, 0, 3, 2 * NRCH, 16, 16) /* ... h_{t+1} in fragment order [parity][tile][R/16][16][16] (GRU slices -> heads, next GRU step)   */ \
     X(rcst, float, 0, 2, 4, B, 1)        /* ... [0..1] running stop mask m_t, double-buffered by step parity; [2] take-output flag of the step */ \
-    X(pflags, uint32_t, 2, 1, 4 * 64 * 64, 1, 1) /* k_conv_persist: per (kind, sample tile) counters, one per 256-byte block */ \
+    X(pflags, uint32_t, 2, 1, 20 * 64 * 64, 1, 1) /* k_conv_persist: per (kind, sample tile) counters, one per 256-byte block */ \
+    X(pll_w, float, 0, 3, NPLT, B, 2 * W)   /* k_conv_persist<LL>: (value, tag) pairs of the receiver message w_t, tag = (launch epoch << 4) | step: receiver sample roles -> SA roles */ \
+    X(pll_m, float, 0, 2, NPLT, 2 * B, 1)   /* ... pairs of the running stop mask after step t (the sender roles' live rows; all zero: the tile's conversation is over) */ \
+    X(pll_z, float, 0, 3, NPLT, B, 2 * W)   /* ... pairs of the sender message z_t, binary mode: probability with the bit in the SIGN (+p: 1, -p: 0): SB roles -> receiver sample roles */ \
+    X(pll_zp, float, 0, 3, NPLT * NZP, 16, 2 * W) /* ... pairs of the SA roles' partial message logits [tile][role][16][W]: SA -> SB roles */ \
+    X(pll_gi, float, 0, 3, NPLT * NPLS, B, 2 * 3 * R) /* ... pairs of the SB roles' partials of the GRU input product [W / 16][B][3R]: SB -> receiver sample roles */ \
     X(mcA, float, 0, 3, NMC, 16, R + 4)  /* k_conversation_mc: A rows (+ take flag) published by the 16 members of a tile       */ \
     X(mcpart, float, 0, 3, NMC * 16, 16, 104) /* k_conversation_mc: per (tile, class slice): [16 samples][V mixture terms | m | s | pad] */ \
     X(mc3A, float, 0, 3, NMC, 16, 2 * (R + 4)) /* k_conversation_mc3: (value, epoch) pairs of the A rows (+ take flag) of a tile's 16 members */ \
@@ -168,7 +173,7 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(rcount, int32_t, 2, 1, 4, 1, 1)    /* [0] its length (k_wgrad reduces over these rows only)                          */ \
     X(sync, uint32_t, 2, 1, 512, 1, 1)    /* in-launch dependency counters between workgroup roles (device_utils.h: role_signal) */ \
     X(dbg, long long, 3, 1, 256, 1, 1)   /* debug timestamps (MMG_TIMING builds) */ \
-    X(dbg2, long long, 3, 1, 8192, 1, 1) /* per-block start/end stamps of k_wgrad (MMG_TIMING builds) */ \
+    X(dbg2, long long, 3, 1, 16384, 1, 1) /* per-block start/end stamps of k_wgrad (MMG_TIMING builds) */ \
     X(totals, double, 3, 1, 4, 1, 1)     /* running sums over train steps: exchange steps, top-k hits, minibatches, sample-steps */ \
     /* ---- backward ---- */                                                       \
     X(dlz, float, 0, 3, T, B, W)         /* dL/d sender logits                     */ \
@@ -249,6 +254,11 @@ __host__ __device__ inline bool rc_shape(int B, int H, int W, int R, int V, int 
            D <= 32 && V <= 128 && !(V & 3) && !(H & 3);
 }
 
+// k_conv_persist with (value, epoch) pair hand-offs (kernels_tile.h: rs_role / sa_role / sb_role <LL>): the fused sender roles' shape
+__host__ __device__ inline bool persist_ll_shape(int B, int H, int W, int R, int V, int D, int T) {
+    return W == 256 && R == 64 && V == 100 && D <= 32 && T <= 15 && H % 64 == 0 && H / 64 <= 16 && H >= 256 && B <= 512;
+}
+
 __host__ __device__ inline int dc_slices(int B) { return B >= 1024 ? 4 : 1; }
 
 struct TapeLayout {
@@ -263,6 +273,8 @@ inline TapeLayout tape_layout(const mmg_config& c) {
     const int64_t B = c.batch, D = c.n_classes, F = c.feat_dim, H = c.h_dim, W = c.w_dim, R = c.rec_hidden,
                   V = c.wv_dim, K = c.bas_hidden, T = c.max_exchange, T1 = T + 1,
                   NSTAT = stat_count((int)T), NPART = MMG_GN_BLOCKS, NPB = (K + 63) / 64, NDCS = dc_slices((int)B), NS2P = (W + 15) / 16, NTILE = (B + 15) / 16, NZP = ((B + 15) / 16) * ((H + 63) / 64), NHLP = split_helpers((int)B) > 0 ? split_helpers((int)B) : 1,
+                  NPLT = persist_ll_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D, (int)T) ? 1 : 0,   /* the pair buffers of k_conv_persist<LL> exist (zero-sized otherwise) */
+                  NPLS = W / 16,
                   NMC = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) ? (B + 15) / 16 : 1,
                   NRCB = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? B : 1,
                   NRCJ = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? R / 16 : 1,
@@ -275,7 +287,7 @@ inline TapeLayout tape_layout(const mmg_config& c) {
                   NRCW = rc_shape((int)B, (int)H, (int)W, (int)R, (int)V, (int)D) ? W / 16 : 1,
                   NMCB = mc_shape((int)H, (int)W, (int)R, (int)V, (int)D, (int)T) && !c.use_binary ? 16 : 0,
                   NWP = wgrad_any_split((int)(T * B), param_layout(c).total) ? (int64_t)16 * (param_layout(c).total + 512 * 64) : 4;   /* (every job splits <= 16 ways) */
-    (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX; (void)NRCP; (void)NRCA; (void)NRCZ; (void)NRCH; (void)NRCT16;
+    (void)NPLT; (void)NPLS; (void)F; (void)V; (void)NPB; (void)NDCS; (void)NWP; (void)NS2P; (void)NTILE; (void)NHLP; (void)NZP; (void)NMC; (void)NMCB; (void)NRCB; (void)NRCJ; (void)NRCW; (void)NRCX; (void)NRCP; (void)NRCA; (void)NRCZ; (void)NRCH; (void)NRCT16;
     int64_t o = 0;
     const int64_t esz[4] = {4, 1, 4, 8};
 #define X(name_, ctype, code, nd, d0, d1, d2)                                        \

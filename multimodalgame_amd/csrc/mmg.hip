@@ -84,6 +84,7 @@ struct mmg_handle {
     uint32_t* d_err;           // its device-side address
     // debugging switches of the launch paths (environment, read ONCE at mmg_create -- never on the per-minibatch path)
     bool sw_rsample, sw_rmsg, sw_fused_s, sw_xcd_map, rs_capable;
+    bool persist_ll;           // k_conv_persist's fused sender roles hand over (value, epoch) pairs in per-step slots (tape.pll_*); MMG_NO_PERSIST_LL=1: counters
     bool sw_pre_bands, sw_rc_tile_prelude;   // MMG_NO_PRE_BANDS=1 / MMG_RC_TILE_PRELUDE=1 (wide-receiver backward, kernels_rc.h)
     bool mc_ok;                // many-class register-resident conversation (kernels_mc.h); MMG_NO_MC=1: off
     bool mc_never_big, mc_bwd_ok;
@@ -359,6 +360,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     h->use_fast3 = !getenv("MMG_FAST2");
     h->sw_merge_prep = !getenv("MMG_NO_MERGE_PREP");
     h->sw_merge_bas = !getenv("MMG_NO_MERGE_BAS"); h->defer_bas = false; h->bas_deferred = false;
+    h->persist_ll = !getenv("MMG_NO_PERSIST_LL") && persist_ll_shape(cfg->batch, cfg->h_dim, cfg->w_dim, cfg->rec_hidden, cfg->wv_dim, cfg->n_classes, cfg->max_exchange);
     h->sw_rsample = !getenv("MMG_NO_RSAMPLE"); h->sw_rmsg = !getenv("MMG_NO_RMSG"); h->sw_fused_s = !getenv("MMG_NO_FUSED_S");
     h->sw_xcd_map = getenv("MMG_XCD_MAP") != nullptr;
     h->sw_pre_bands = !getenv("MMG_NO_PRE_BANDS"); h->sw_rc_tile_prelude = getenv("MMG_RC_TILE_PRELUDE") != nullptr;
@@ -453,6 +455,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
             if (h->persist_smem > 160 * 1024) h->tile_persist = false;
             else if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_persist<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->persist_smem);
             if (h->tile_persist && e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_persist<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->persist_smem);
+            if (h->tile_persist && e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv_persist<512, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->persist_smem);
             if (h->tile_persist && e == hipSuccess) {
                 h->resident_budget = rs_capable ? budget_of((const void*)k_conv_persist<512, true>, 512, h->persist_smem)
                                                : budget_of((const void*)k_conv_persist<512, false>, 512, h->persist_smem);
@@ -735,6 +738,9 @@ static int launch_conv_tile(mmg_handle* h, hipStream_t st, ConvArgs ar) {
                 ar.b_count = (d.B - ar.b_begin < ct * MMG_TM) ? d.B - ar.b_begin : ct * MMG_TM;
                 if (ar.b_count <= 0) break;
                 const int ctiles = (ar.b_count + MMG_TM - 1) / MMG_TM;
+                if (ar.rsample == 3 && h->persist_ll)
+                    hipLaunchKernelGGL((k_conv_persist<512, true, true>), dim3(ar.b_count + ctiles * (ar.ns1 + ar.ns2) + bt), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
+                else
                 hipLaunchKernelGGL((k_conv_persist<512, true>), dim3(ar.b_count + ctiles * (ar.ns1 + ar.ns2) + bt), dim3(512), h->persist_smem, st, h->dm, h->P, h->tp, ar, tiles, 0);
             }
             h->basehx_ready = want_base;

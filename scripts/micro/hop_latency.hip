@@ -28,10 +28,26 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // its own flag).  FLAG = true: the producer waits for its payload stores to complete, then bumps a flag word; the consumer polls the
 // flag with one lane and then loads the payload (what pf_signal / pf_wait of kernels_tile.h do).
 template <int ST, int LD, int NPL, bool FLAG, int MODE = 0>
-__global__ void k_pingpong(u64* buf, int partner, int iters, int npl, long long* out, int* xcc, int* err) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+__global__ void k_pingpong(u64* buf, int partner, int iters, int npl, long long* out, int* xcc, int* err, int noise) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    if (threadIdx.x >= 64 && (b == 0 || b == partner)) return;
     if (lane == 0) xcc[b] = xcc_id();
-    if (b != 0 && b != partner) return;
+    if (b != 0 && b != partner) {
+        if (!noise) return;
+        const u64* reg = buf + 2 * 64 * 64 + 128 + (size_t)(b % 16) * 8 * 64;      // 16 regions: the pollers of a tile share their lines
+        for (int r = 0; r < 4000000; ++r) {
+            u64 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = ld64<LD>(reg + k * 64 + lane);
+            wait_loads();
+            u64 x = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x |= v[k];
+            if (x != 0) break;                       // workgroup 0 writes every region when it is through
+            if (noise == 4) __builtin_amdgcn_s_sleep(4); else if (noise == 16) __builtin_amdgcn_s_sleep(16);
+        }
+        return;
+    }
     u64* ping = buf; u64* pong = buf + 64 * 64;            // [npl][64]
     const bool me0 = b == 0;
     long long t0 = 0;
@@ -72,16 +88,17 @@ __global__ void k_pingpong(u64* buf, int partner, int iters, int npl, long long*
         if (!me0) publish(pong, fpong);
     }
     if (me0 && lane == 0) out[0] = wall_clock64() - t0;
+    if (me0 && noise) for (int k = 0; k < 16 * 8; ++k) st64<1>(buf + 2 * 64 * 64 + 128 + (size_t)k * 64 + lane, 1ull);
 }
 
 template <int ST, int LD, int NPL, bool FLAG, int MODE = 0>
-static void run(const char* name, int partner) {
+static void run(const char* name, int partner, int noise = 0, int grid = 64) {
     const int npl = NPL;
     u64* buf; long long* out; int *xcc, *err;
-    hipMalloc(&buf, (2 * 64 * 64 + 128) * sizeof(u64)); hipMemset(buf, 0, (2 * 64 * 64 + 128) * sizeof(u64));
+    hipMalloc(&buf, (2 * 64 * 64 + 128 + 16 * 8 * 64) * sizeof(u64)); hipMemset(buf, 0, (2 * 64 * 64 + 128 + 16 * 8 * 64) * sizeof(u64));
     hipMalloc(&out, 8); hipMalloc(&xcc, 64 * 4); hipMalloc(&err, 4); hipMemset(err, 0, 4); hipMemset(out, 0, 8);
     const int iters = 510;
-    hipLaunchKernelGGL((k_pingpong<ST, LD, NPL, FLAG, MODE>), dim3(64), dim3(64), 0, 0, buf, partner, iters, npl, out, xcc, err);
+    hipLaunchKernelGGL((k_pingpong<ST, LD, NPL, FLAG, MODE>), dim3(grid), dim3(64 * (noise ? 8 : 1)), 0, 0, buf, partner, iters, npl, out, xcc, err, noise);
     hipDeviceSynchronize();
     long long o; int e; std::vector<int> x(64);
     hipMemcpy(&o, out, 8, hipMemcpyDeviceToHost); hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost); hipMemcpy(x.data(), xcc, 64 * 4, hipMemcpyDeviceToHost);
@@ -109,6 +126,11 @@ int main(int argc, char** argv) {
             run<1, 1, 20, false>("sc1 / sc1", partner); run<1, 1, 24, false>("sc1 / sc1", partner); run<1, 1, 32, false>("sc1 / sc1", partner);
             run<1, 1, 16, true>("sc1 / sc1", partner); run<1, 1, 24, true>("sc1 / sc1", partner);
         }
+        return 0;
+    }
+    if (argc > 3) {     // 190 workgroups of 8 waves poll 8 pairs per lane all the time (what the roles of k_conv_persist would do between steps)
+        run<1, 1, 8, false>("quiet", 1); run<1, 1, 8, false>("190 polling workgroups", 1, 1, 192); run<1, 1, 8, false>("... with s_sleep 4 between rounds", 1, 4, 192);
+        run<1, 1, 8, false>("... with s_sleep 16 between rounds", 1, 16, 192); run<1, 1, 8, true>("190 polling workgroups", 1, 1, 192);
         return 0;
     }
     if (argc > 2) {

@@ -17,6 +17,7 @@ feats, target, desc = bench.synthetic_dataset(max(3000, B), cfg["n_classes"], 51
 dev = eng.device
 x = torch.from_numpy(feats[:B]).to(dev); t = torch.from_numpy(target[:B]).to(dev); d = torch.from_numpy(desc).to(dev)
 for it in range(4):
+    eng.tape["dbg"].zero_(); eng.tape["dbg2"].zero_()
     eng.train_step(x, t, d, seed=0)
 torch.cuda.synchronize()
 dbg = eng.tape["dbg"].view(torch.int64).cpu().numpy()
@@ -69,3 +70,19 @@ if dbg[224]:
         if dbg[b] and dbg[b + 1] > dbg[b]:
             nxt = dbg[232 + 4 * (t - 1)] if t > 0 else dbg[230]
             print("  bwd step %d: prefetch + cell backward %.2f | dgh W_hh %.2f" % (t, us(b, b + 1), (nxt - dbg[b + 1]) * tick / 1e3))
+
+# rs_role stamps of every sample that reached step 3 (dbg2[1024 + 8 b + k]: wait-start, pairs / counter seen, gi gathered, g out, message out, signalled)
+d2 = eng.tape["dbg2"].view(torch.int64).cpu().numpy()
+rs = d2[8192:8192 + 8 * 64].reshape(64, 8)
+live = np.nonzero(rs[:, 0])[0]
+if len(live):
+    u = lambda a: a * tick / 1e3
+    r = rs[live]
+    print("rs_role at step 3, %d samples: wait %.2f (min %.2f max %.2f) | gather + GRU in %.2f | GRU .. g %.2f | message %.2f | signal %.2f ; last sample in at +%.2f us after the first" % (
+        len(live), u((r[:, 1] - r[:, 0]).mean()), u((r[:, 1] - r[:, 0]).min()), u((r[:, 1] - r[:, 0]).max()), u((r[:, 2] - r[:, 1]).mean()), u((r[:, 3] - r[:, 2]).mean()),
+        u((r[:, 4] - r[:, 3]).mean()), u((r[:, 5] - r[:, 4]).mean()), u(r[:, 1].max() - r[:, 1].min())))
+    if dbg[206] and dbg[201]:
+        print("  SA role 0 of tile 0: messages of step 2 seen -> messages of step 3 seen (one step of the ring): %.2f us" % u(dbg[206] - dbg[201]))
+    if dbg[215] and dbg[201]:
+        print("  tile 0: SB role 0 out at %.2f us before its samples' pairs are seen (mean over tile 0's live samples); SA role 0 sees the messages %.2f us after their mean 'message out'" % (
+            u(rs[live[live < 16], 1].mean() - dbg[215]) if (live < 16).any() else float("nan"), u(dbg[201] - rs[live[live < 16], 4].mean()) if (live < 16).any() else float("nan")))

@@ -48,15 +48,34 @@ def _compare_cached(meta, skip, label, key):
     common.assert_parity(got, want, flips, eng, label, skip=skip)
 
 
-@pytest.mark.parametrize("switch", [None, "MMG_NO_FUSED_S", "MMG_NO_RMSG", "MMG_NO_RSAMPLE", "MMG_NO_PERSIST"])
+@pytest.mark.parametrize("switch", [None, "MMG_NO_PERSIST_LL", "MMG_NO_FUSED_S", "MMG_NO_RMSG", "MMG_NO_RSAMPLE", "MMG_NO_PERSIST"])
 def test_config4_shape_vs_oracle(switch, monkeypatch):
     """Adaptive, W=256, H=1024 (configs[3]): 1 952 852 parameters.  Default: one persistent launch of per-sample receiver
-    roles + fused sender roles.  The switches walk down the fallbacks other agent shapes take: hidden-slice / bit-slice
+    roles + fused sender roles that hand over (value, epoch) pairs; MMG_NO_PERSIST_LL: the same roles with payload + counter
+    hand-offs.  The other switches walk down the fallbacks other agent shapes take: hidden-slice / bit-slice
     sender roles (s1 / s2), receiver roles that publish g instead of the message, one 16-sample receiver role per tile,
     and three launches per step."""
     if switch:
         monkeypatch.setenv(switch, "1")
     _compare_cached(_meta(C4, 30, 64, 2), skip=("y2.bias",), label="config4" + ("-" + switch if switch else ""), key="c4")
+
+
+@pytest.mark.parametrize("switch", [None, "MMG_NO_PERSIST_LL", "MMG_NO_FUSED_S", "MMG_NO_RMSG", "MMG_NO_RSAMPLE", "MMG_NO_PERSIST"])
+def test_config4_fused_train_step_vs_oracle(switch, monkeypatch):
+    """EXACTLY what bench.py's c4 line runs: the FUSED mmg_train_step with early stopping (samples leave their tile's ring of roles
+    at different steps) on config 4's agents, two minibatches against the oracle.  test_config4_shape_vs_oracle runs every
+    sample through every step (run_all), where no role ever has to tell a stopped sample from a slow one -- round 5 found the
+    counter hand-offs of rounds 3-4 letting the sender roles run ahead of live samples once others had stopped."""
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    meta = _meta(dict(C4), 30, 64, 2)
+    got, eng = common.hip_train_case(None, meta, fused=True)
+    key = "c4-fused"
+    if key not in _ORACLE_CACHE:
+        flips = []
+        _ORACLE_CACHE[key] = (common.oracle_train_case(None, meta, flips=flips), flips)
+    want, flips = _ORACLE_CACHE[key]
+    common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused" + ("-" + switch if switch else ""), skip=("y2.bias",))
 
 
 @pytest.mark.parametrize("switch", [None, "MMG_NO_RC_PERSIST", "MMG_NO_RC_BWD", "MMG_RC_TILE_PRELUDE", "MMG_NO_PRE_BANDS"])
