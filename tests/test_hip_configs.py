@@ -78,6 +78,17 @@ def test_config4_fused_train_step_vs_oracle(switch, monkeypatch):
     common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused" + ("-" + switch if switch else ""), skip=("y2.bias",))
 
 
+@pytest.mark.parametrize("batch", [24, 88])
+def test_config4_fused_train_step_ragged_and_chunked(batch):
+    """The same with a ragged last tile (24 samples: rows 8-15 of tile 1 have no receiver role) and with more roles than fit one
+    launch (88 samples: two launches over tile ranges, the pair slots of the other range untouched), early stopping on."""
+    meta = _meta(dict(C4, batch_size=batch), 30, batch, 2)
+    got, eng = common.hip_train_case(None, meta, fused=True)
+    flips = []
+    want = common.oracle_train_case(None, meta, flips=flips)
+    common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused-b%d" % batch, skip=("y2.bias",))
+
+
 @pytest.mark.parametrize("switch", [None, "MMG_NO_RC_PERSIST", "MMG_NO_RC_BWD", "MMG_RC_TILE_PRELUDE", "MMG_NO_PRE_BANDS"])
 def test_config4_with_rec_hidden_256_vs_oracle(switch, monkeypatch):
     """'rec_w_dim 256 / img_h_dim 1024 ... use R = 64 and additionally report R = 256'.  At R = 256 the
