@@ -41,7 +41,9 @@ profile_workload c5 strong
 # caller copies this run's *_kernel_stats.csv / *_pmc_hbm_traffic.json there first when the line is to cite them
 python bench.py > $O/${TAG}_bench_line.json 2> /dev/null
 timeout 300 python scripts/dp_overhead.py 2>&1 | grep -v "^/opt\|^\[W" > $O/${TAG}_dp_overhead.log
-FIXED=0 timeout 300 python scripts/timeline.py 2>&1 | grep -v "^/opt\|hipcc" > $O/${TAG}_timeline_c2.log
+timeout 300 python scripts/game_timeline.py 2>&1 | grep -v "^/opt\|hipcc" > $O/${TAG}_game_timeline_c2.log
+timeout 300 python scripts/tile_timeline.py c4 2>&1 | grep -v "^/opt\|hipcc\|Warning\|print(" > $O/${TAG}_tile_timeline_c4.log
+timeout 300 python scripts/c4_ll_ab.py 40 > $O/${TAG}_c4_handoff_ab.log 2>&1
 timeout 300 python scripts/mc_timeline.py 2>&1 | grep -v "^/opt\|hipcc" > $O/${TAG}_mc_timeline_c5.log
 timeout 300 python scripts/rc_timeline.py 2>&1 | grep -v "^/opt\|hipcc" > $O/${TAG}_rc_timeline_c4r256.log
 python scripts/time_configs.py 2>&1 | grep -v "^/opt" > $O/${TAG}_time_configs.log
