@@ -44,6 +44,7 @@ timeout 300 python scripts/dp_overhead.py 2>&1 | grep -v "^/opt\|^\[W" > $O/${TA
 timeout 300 python scripts/game_timeline.py 2>&1 | grep -v "^/opt\|hipcc" > $O/${TAG}_game_timeline_c2.log
 timeout 300 python scripts/tile_timeline.py c4 2>&1 | grep -v "^/opt\|hipcc\|Warning\|print(" > $O/${TAG}_tile_timeline_c4.log
 timeout 300 python scripts/c4_ll_ab.py 40 > $O/${TAG}_c4_handoff_ab.log 2>&1
+timeout 900 python scripts/path_ab.py 4 > $O/${TAG}_path_ab.log 2>&1
 timeout 300 python scripts/mc_timeline.py 2>&1 | grep -v "^/opt\|hipcc" > $O/${TAG}_mc_timeline_c5.log
 timeout 300 python scripts/rc_timeline.py 2>&1 | grep -v "^/opt\|hipcc" > $O/${TAG}_rc_timeline_c4r256.log
 python scripts/time_configs.py 2>&1 | grep -v "^/opt" > $O/${TAG}_time_configs.log

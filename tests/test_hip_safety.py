@@ -145,3 +145,14 @@ def test_eval_forward_leaves_the_training_sampling_stream_alone(merge_prep, monk
     eng_a.check_sync(); eng_b.check_sync()
     assert int(eng_a.tape["counter"][0]) == int(eng_b.tape["counter"][0]) == 4
     assert torch.equal(eng_a.flat_params, eng_b.flat_params)
+
+
+def test_specialised_paths_agree_with_their_fallbacks_under_early_stopping():
+    """scripts/path_ab.py: every specialised kernel path against its fallbacks (down to the generic per-sample kernels) on the same
+    Philox-sampled first minibatch with early stopping -- identical step / hit counts, losses within 2e-5 relative, and the default
+    path reproducing itself bit for bit.  (Round 5: the check that would have caught k_conv_persist's sender roles running ahead of
+    live samples in rounds 3-4; the oracle tests of that shape ran in run-all mode.)"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "path_ab.py"), "2"], capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
