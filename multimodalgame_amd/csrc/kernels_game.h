@@ -129,6 +129,7 @@ __device__ __forceinline__ void game_baseline_role(const Dims& dm, const Params&
         if (lane == 0) s_nwin = nw > slot ? (nw - slot + nslots - 1) / nslots : 0;
     }
     __syncthreads();
+    if (threadIdx.x == 0) { MMG_GT(5120 + 8 * role + 0); }
     const int nwin = s_nwin;
     float* hid = which ? tp.hid_s : tp.hid_r;
     float* part = which ? tp.bs_part : tp.br_part;
@@ -162,8 +163,12 @@ __device__ __forceinline__ void game_baseline_role(const Dims& dm, const Params&
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = (orow[r] >= 0) ? ll_value(ub[r]) : 0.f;
         }
+        if (threadIdx.x == 0 && kw == 0) { MMG_GT(5120 + 8 * role + 1); }
         frag_mfma(acc, xm, w_msg, W, q);
         if (!which) { frag_mfma(acc2, xt, w_st, R, q); acc += acc2; }
+#ifdef MMG_TIMING
+        if (threadIdx.x == 0 && kw == 0) { asm volatile("" :: "v"(acc[0])); tp.dbg2[5120 + 8 * role + 2] = (long long)wall_clock64(); }
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = fmaxf(acc[r] + bias, 0.f);                                // model.py:514
@@ -172,6 +177,7 @@ __device__ __forceinline__ void game_baseline_role(const Dims& dm, const Params&
             if (i == 0) s_part[wave][q * 4 + r] = v;
         }
         __syncthreads();
+        if (threadIdx.x == 0 && kw == 0) { MMG_GT(5120 + 8 * role + 3); }
         if (threadIdx.x < 16 && rid_w[threadIdx.x] >= 0) {
             const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
             part[(size_t)rid_w[threadIdx.x] * npb + byi] = v;

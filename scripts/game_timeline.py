@@ -51,3 +51,11 @@ print("baseline role duration by slot:", [round(float(dur[np.arange(nb) // 16 ==
 sd = us(st[ok, 2] - st[ok, 1])
 print("statistics waves seen -> done: min %.2f median %.2f max %.2f; slowest waves %s" % (sd.min(), np.median(sd), sd.max(), np.argsort(-sd)[:8].tolist()))
 print("live rows %d -> %d windows" % (int((ts + 1).sum()), (int((ts + 1).sum()) + 15) // 16))
+
+bw = g[5120:5120 + 8 * nb].reshape(nb, 8)
+okb = bw[:, 3] > 0
+print("baseline role, first window (mean over %d roles): forward passes seen -> row list + barrier %.2f | -> row loads issued (+ basehx pairs held) %.2f | -> MFMAs done (the loads have arrived) %.2f | -> hidden stores + partial sums + barrier %.2f | -> role done %.2f" % (
+    okb.sum(), us((bw[okb, 0] - bs[okb, 1]).mean()), us((bw[okb, 1] - bw[okb, 0]).mean()), us((bw[okb, 2] - bw[okb, 1]).mean()), us((bw[okb, 3] - bw[okb, 2]).mean()), us((bs[okb, 2] - bw[okb, 3]).mean())))
+for w in (0, 1):
+    m = okb & ((np.arange(nb) % 16) // 8 == w)
+    print("   which = %d: %.2f | %.2f | %.2f | %.2f | %.2f" % (w, us((bw[m, 0] - bs[m, 1]).mean()), us((bw[m, 1] - bw[m, 0]).mean()), us((bw[m, 2] - bw[m, 1]).mean()), us((bw[m, 3] - bw[m, 2]).mean()), us((bs[m, 2] - bw[m, 3]).mean())))
