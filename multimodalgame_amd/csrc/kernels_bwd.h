@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void k_stats(Dims dm, Params P, Tape tp, int fr
 struct LossCoef { float* cw; float* ce; float* cb; };   // LDS: cw[3*T], ce[3*T], cb[T]
 
 __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* st, LossCoef lc, float* losses_out,
-                                                  double* totals = nullptr) {
+                                                  double* totals = nullptr, bool write_nll = true) {
     // one thread per (stream, step): threads [0,3T) -> cw/ce, [3T,4T) -> cb; block-level sums for the
     // logged losses go through LDS (lc.cw/ce/cb double as staging for the partial losses afterwards)
     const int T = dm.T, tid = threadIdx.x;
@@ -231,7 +231,7 @@ __device__ __forceinline__ void loss_coefficients(const Dims& dm, const double* 
             nsteps += (st[stat_stream(T, 2, t, 0)] > 0) ? 1 : 0;
         }
         if (!dm.use_binary) nsteps = T;
-        losses_out[0] = (float)(-st[stat_glob(T, 0)] / (double)dm.Bg);   // NLL (model.py:1271)
+        if (write_nll) losses_out[0] = (float)(-st[stat_glob(T, 0)] / (double)dm.Bg);   // NLL (model.py:1271); k_wgrad<OPT>: written by the norm role
         losses_out[1] = (float)acc[0];                                   // loss_binary_s
         losses_out[2] = (float)acc[1];                                   // loss_binary_rec
         losses_out[3] = (float)acc[2];                                   // loss_binary_sen
@@ -700,6 +700,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     if (OPT && (int)blockIdx.x == jt->n_wblocks + 1) {
         // ---- the norm role: all n_wblocks sums of squares -> four clip coefficients (k_opt's summation order, bit for bit)
         __shared__ float s_ss[4][4];
+        __shared__ float s_bad[4];
         const int n = jt->n_wblocks;
         float ss[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k0 = threadIdx.x; k0 < n; k0 += 8 * MMG_BLOCK) {
@@ -735,6 +736,17 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             const float tot = (s_ss[a][0] + s_ss[a][1]) + (s_ss[a][2] + s_ss[a][3]);
             const float coef = 1.0f / (sqrtf(tot) + 1e-6f);               // max_norm = 1 (model.py:1310)
             st_ll(wo.coefll, (size_t)a * MMG_COEF_REPL + r, err != 0u ? -1.f : (coef < 1.f ? coef : 1.f), oepoch);
+            // NON-FINITE GUARD: the class-logit ReLU is v_max_f32 (device_utils.h: fmax_nn), which reads a NaN pre-activation as
+            // "unit off" where torch's relu propagates it -- a NaN in W_y1h or in the GRU state would leave the NLL of that step
+            // finite (log D) while every reference loss is NaN.  The backward pass does carry it, so a non-finite gradient norm of
+            // ANY agent makes the logged NLL NaN in the same step, as the reference's would be (scripts/nonfinite_probe.py).
+            // The spare block leaves losses[0] to this role (one writer).
+            if (r == 0) s_bad[a] = (!(tot == tot) || tot > 3.0e38f) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const bool bad = (s_bad[0] + s_bad[1] + s_bad[2] + s_bad[3]) != 0.f;
+            losses[0] = bad ? __builtin_nanf("") : (float)(-stats[stat_glob(dm.T, 0)] / (double)dm.Bg);     // NLL (model.py:1271)
         }
         if (threadIdx.x == 0) {
             if (wo.err_host && (err != 0u || *wo.err_host == 0u)) *wo.err_host = err;
@@ -846,7 +858,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         float* s_lc = &s_b[0][0][0];                       // (7 * 64 floats of the staging area: this block stages nothing -- keeps the
                                                            //  kernel at four workgroups per CU, which k_wgrad<true> needs for co-residency)
         LossCoef lc; lc.cw = s_lc; lc.ce = s_lc + 3 * dm.T; lc.cb = s_lc + 6 * dm.T;
-        loss_coefficients(dm, stats, lc, losses, totals);
+        loss_coefficients(dm, stats, lc, losses, totals, !OPT);
         // the quad behind the gradients (include/mmg.h: mmg_grad_floats): [0] = 1.0 when a dependency wait of this minibatch
         // timed out on THIS rank.  The data-parallel all-reduce sums it with the gradients, so every rank's k_opt sees that
         // some rank's contribution is built from stale data and all of them skip the update together.
@@ -1169,7 +1181,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
                                                    const float* __restrict__ grads, float* __restrict__ state,
                                                    const float* __restrict__ part, const uint32_t* __restrict__ counter,
                                                    const uint32_t* __restrict__ sync, uint32_t* __restrict__ err_host,
-                                                   const float* __restrict__ grad_tail) {
+                                                   const float* __restrict__ grad_tail, float* __restrict__ losses) {
     // An in-launch dependency wait of this minibatch timed out (device_utils.h: role_wait sets sync[MMG_SYNC_ERR]) -- on this
     // rank, or (grad_tail: the flag quad that travelled through the gradient all-reduce) on ANY rank of a data-parallel job:
     // the gradients may be built from stale data -- leave parameters and optimizer state untouched, on every rank alike.
@@ -1226,6 +1238,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
             const float norm = sqrtf(tot);
             const float coef = 1.0f / (norm + 1e-6f);                // max_norm = 1 (model.py:1310)
             s_coef[threadIdx.x] = coef < 1.f ? coef : 1.f;
+            // non-finite guard (k_wgrad<OPT>'s norm role): a non-finite gradient norm of any agent makes the logged NLL NaN
+            if (losses && blockIdx.x == 0 && (!(tot == tot) || tot > 3.0e38f)) losses[0] = __builtin_nanf("");
         }
     }
     __syncthreads();

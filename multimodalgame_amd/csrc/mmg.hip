@@ -1123,7 +1123,7 @@ static int clip_step_impl(mmg_handle* h, hipStream_t st, bool from_wgrad) {
         Scope sc(h, st, "k_opt");
         hipLaunchKernelGGL(k_opt, dim3(blocks), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt, oa, h->params,
                            (const float*)h->grads, h->opt_state, (const float*)part, (const uint32_t*)h->tp.counter, (const uint32_t*)h->tp.sync, h->d_err,
-                           (const float*)(from_wgrad ? nullptr : h->grads + h->pl.total));
+                           (const float*)(from_wgrad ? nullptr : h->grads + h->pl.total), h->tp.losses);
         if (launch_check("k_opt")) return -1;
     }
     return 0;

@@ -156,3 +156,47 @@ def test_specialised_paths_agree_with_their_fallbacks_under_early_stopping():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "path_ab.py"), "2"], capture_output=True, text=True, timeout=1200)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
+
+
+@pytest.mark.parametrize("fused_opt", [True, False])
+@pytest.mark.parametrize("value,key,pos", [(float("inf"), "y1.weight", (3, 5)), (float("-inf"), "y1.weight", (3, 74)),
+                                           (float("nan"), "y1.weight", (3, 74)), (float("nan"), "w_h.weight", (2, 7)),
+                                           (float("nan"), "y1.weight", (3, 5)), (float("nan"), "rnn.weight_hh", (70, 3))])
+def test_non_finite_parameter_shows_up_in_the_losses(value, key, pos, fused_opt, monkeypatch):
+    """A non-finite parameter (a diverged run) must not train on silently.  The class-logit ReLU is v_max_f32 (device_utils.h:
+    fmax_nn), which returns the OTHER operand for a NaN where torch's relu propagates it: a NaN in the h-part of receiver.y1.weight
+    or in the GRU state reads as "unit off", and the NLL of that step would be a plausible log D while every loss of the reference is
+    NaN (scripts/nonfinite_probe.py; ADVICE r04 asked for the behaviour to be pinned).  The backward pass carries the NaN, so the
+    optimizer's norm stage (k_wgrad<OPT>'s norm role / k_opt) makes the logged NLL NaN when any agent's gradient norm is not finite:
+    the NLL is non-finite whenever the oracle's is, in the SAME step, for +-Inf and NaN in and outside that ReLU's operand,
+    and finite whenever all six losses of the oracle are."""
+    from oracle import cpu_ref
+    if not fused_opt:
+        monkeypatch.setenv("MMG_NO_WGRAD_OPT", "1")
+    z, meta = common.load_golden("g2_adaptive_c1")
+    meta = dict(meta, n_minibatches=1)
+    fl = common.flags_from_meta(meta)
+    eng = common.make_engine(meta)
+    eng.params["receiver"][key][pos] = value
+    x, target, desc, (u_z, u_s, u_w) = common.case_inputs(meta, 0, "g2_adaptive_c1")
+    dev = eng.device
+    a = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, target, desc, u_z, u_s[..., 0], u_w)]
+    eng.train_step(*a)
+    hip_nll = float(list(eng.losses().values())[0])
+    torch.manual_seed(0)
+    tape = cpu_ref.UniformTape()
+    models = cpu_ref.build_agents(fl, rng=tape)
+    cpu_ref.load_filled(models, seed=meta["seed_weights"])
+    with torch.no_grad():
+        dict(models["receiver"].named_parameters())[key][pos] = value
+    opt = cpu_ref.build_optimizers(models, fl)
+    tape.u = {"z": u_z, "s": u_s, "w": u_w}; tape.t = {"z": 0, "s": 0, "w": 0}
+    res = cpu_ref.train_minibatch(models, opt, torch.from_numpy(x), torch.from_numpy(target), torch.from_numpy(desc), fl)
+    ora = [float(res[k].detach()) for k in ("nll_loss", "loss_binary_s", "loss_binary_rec", "loss_binary_sen", "loss_bas_rec", "loss_bas_sen")]
+    # never later than the reference ...
+    assert np.isfinite(hip_nll) or not np.isfinite(ora[0]) or not all(np.isfinite(ora)), (hip_nll, ora)
+    assert not np.isfinite(hip_nll) if not np.isfinite(ora[0]) else True, (hip_nll, ora)
+    # ... and only when the reference's own step is broken (w_h feeds the message head only: the reference keeps a finite NLL for
+    # this one step and shows the NaN in loss_binary_rec, then in every parameter of the receiver; the guard reports it one step early)
+    if not np.isfinite(hip_nll):
+        assert not all(np.isfinite(ora)), (hip_nll, ora)
