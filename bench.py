@@ -153,7 +153,7 @@ def traffic_lookup(workload, kernel, strong, profiles_dir=None):
     pat = re.compile(r"^r(\d+)_%sconfig%s_pmc_hbm_traffic\.json$" % ("strong_" if strong else "", num))
     files = sorted((int(pat.match(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(pdir, "r*_pmc_hbm_traffic.json"))
                    if pat.match(os.path.basename(f)))
-    alias = {"k_conversation": ("k_conversation_fast3", "k_conversation_fast2", "k_conversation_mc3", "k_conversation_mc", "k_conversation"),
+    alias = {"k_game": ("k_game_fast",), "k_conversation": ("k_conversation_fast3", "k_conversation_fast2", "k_conversation_mc3", "k_conversation_mc", "k_conversation"),
              "k_conversation_mc": ("k_conversation_mc3", "k_conversation_mc"), "k_bwd_conv": ("k_bwd_conv_fast", "k_bwd_conv"),
              "k_baselines": ("k_baselines3", "k_baselines4", "k_baselines2", "k_baselines")}
     for _, f in reversed(files):
@@ -209,7 +209,8 @@ def rocprof_lookup(workload, strong, profiles_dir=None):
                 continue
             per[m.group(1)] = per.get(m.group(1), 0.0) + float(r["TotalDurationNs"])
             calls[m.group(1)] = calls.get(m.group(1), 0) + int(r["Calls"])
-        n_mb = calls.get("k_opt", 0)
+        # one minibatch = one optimizer step: a k_opt dispatch, or (fused steps: k_wgrad<OPT> carries the optimizer) a k_wgrad one
+        n_mb = calls.get("k_opt", 0) or calls.get("k_wgrad", 0)
         if not n_mb:
             continue
         per_kernel = {k: v / n_mb * 1e-3 for k, v in per.items()}
