@@ -1,5 +1,5 @@
 """Every specialised kernel path against its fallbacks on the SAME Philox-sampled first minibatch (seed-0 weights, early stopping on):
-step counts and top-k hits must be identical, the six losses within 2e-5 relative (other kernels, other summation order), and a path
+step counts and top-k hits must be identical (training step AND a following evaluation pass), the six losses and the evaluation's summed log-likelihood within 2e-5 relative (other kernels, other summation order), and a path
 run twice must reproduce itself bit for bit.  Round 5 added this after finding k_conv_persist's sender roles running ahead of live
 samples (a hand-off that counted stopped samples too generously) -- a bug no oracle test saw because they ran in run-all mode.
 usage: path_ab.py [seeds]      exit code 1 on a mismatch"""
@@ -31,7 +31,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         x = torch.from_numpy(feats[B * seed:B * seed + B]).to(dev); t = torch.from_numpy(target[B * seed:B * seed + B]).to(dev)
         eng.train_step(x, t, torch.from_numpy(desc).to(dev), seed=11 + seed)
         torch.cuda.synchronize()
-        out.append([float(v) for v in eng.losses().values()])
+        res = [float(v) for v in eng.losses().values()]
+        # ... and an evaluation pass (rounded bits, running stop product, no early exit inside the kernels) on the updated weights
+        eng.forward(x, t, torch.from_numpy(desc).to(dev), train=False)
+        torch.cuda.synchronize()
+        eng.check_sync()
+        ts = eng.tape["tstar"][:B].cpu().numpy()
+        res += [float(ts.sum()), float(eng.tape["hit"][:B].sum().item())]           # (counts: compared exactly)
+        res_eval = float(eng.tape["logs"][:B].double().sum().item())
+        out.append(res[:6] + [res_eval] + res[6:])
         del eng
     print("RESULT " + json.dumps(out))
     sys.exit(0)
@@ -50,8 +58,8 @@ for name, (kw, B, variants) in CASES.items():
     for env, r in zip(variants + [dict(variants[0], again="1")], res):
         tag = " ".join("%s=%s" % kv for kv in env.items()) or "default"
         if r is None or ref is None: print("   %-28s FAILED TO RUN" % tag); ok_all = False; continue
-        rel = max(abs(a - b) / max(1.0, abs(b)) for ra, rb in zip(r, ref) for a, b in zip(ra[:6], rb[:6]))
-        counts = sum(1 for ra, rb in zip(r, ref) if ra[6:] != rb[6:])
+        rel = max(abs(a - b) / max(1.0, abs(b)) for ra, rb in zip(r, ref) for a, b in zip(ra[:7], rb[:7]))
+        counts = sum(1 for ra, rb in zip(r, ref) if ra[7:] != rb[7:])
         same_as_default = r == res[0]
         good = rel < 2e-5 and counts == 0 and ("again" not in env or same_as_default)
         ok_all = ok_all and good
