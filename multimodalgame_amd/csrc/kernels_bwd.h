@@ -690,14 +690,19 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                                                      Dims dm, const double* __restrict__ stats, float* __restrict__ losses,
                                                      double* __restrict__ totals, const int* __restrict__ rmap,
                                                      const int* __restrict__ rcount, float* __restrict__ wpart,
-                                                     const uint32_t* __restrict__ sync, float* __restrict__ grad_tail, WgOpt wo
+                                                     const uint32_t* __restrict__ sync, float* __restrict__ grad_tail, WgOpt wo, int gt_stride
 #ifdef MMG_TIMING
                                                      , long long* __restrict__ dbg2
 #endif
                                                      ) {
+    // gt_stride > 0 (agents with more output tiles than resident workgroups: config 4's 3 815): the first gt_stride workgroups
+    // (a multiple of 8: the XCD of a tile stays that of its workgroup) walk the GEMM tiles with that stride -- the live-row list
+    // and the job table are fetched once per workgroup instead of once per tile, and no tile waits for a slot; the other
+    // workgroups (column sums, the special and the spare block) follow them.  bid: the block index of the un-strided launch.
+    const int bid = (gt_stride > 0 && (int)blockIdx.x >= gt_stride) ? (int)blockIdx.x - gt_stride + jt->gemm_tiles : (int)blockIdx.x;
     const uint32_t oepoch = OPT ? wo.counter[3] + 1u : 0u;          // (the norm role bumps the counters when every block has read them)
     const uint32_t ostep = OPT ? wo.counter[1] + 1u : 0u;
-    if (OPT && (int)blockIdx.x == jt->n_wblocks + 1) {
+    if (OPT && bid == jt->n_wblocks + 1) {
         // ---- the norm role: all n_wblocks sums of squares -> four clip coefficients (k_opt's summation order, bit for bit)
         __shared__ float s_ss[4][4];
         __shared__ float s_bad[4];
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     float (*s_acc)[16][33] = reinterpret_cast<float (*)[16][33]>(&s_b[0][0][0]);   // [4][16][33] reused after the row loop
     float* s_part = &s_b[0][0][0];                                                   // column-sum staging
     __shared__ float s_red[8];
-    if ((int)blockIdx.x == jt->special_block) {
+    if (bid == jt->special_block) {
         // (found by ONE scalar load, ahead of the live-row list and the job lookup every other block starts with: this is the launch's
         //  longest block -- 9.0 us next to ~7 -- and those were a dependent memory round trip in front of its two)
         const ColJob& C = jt->c[jt->special_job];
@@ -823,10 +828,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             if (j < Wc && p8 == 0) { const float gsum = acc * C.scale[j]; C.dst[j] = gsum; sq = fmaf(gsum, gsum, sq); }
         }
         sq = block_sum(sq, s_red);
-        if (threadIdx.x == 0) part[blockIdx.x] = sq;
+        if (threadIdx.x == 0) part[bid] = sq;
         if (OPT) {
-            if (threadIdx.x == 0) st_ll(wo.gnll, blockIdx.x, sq, oepoch);
-            const float coef = opt_wait_coef(wo, jt->wblock_agent[blockIdx.x], oepoch, sync);
+            if (threadIdx.x == 0) st_ll(wo.gnll, bid, sq, oepoch);
+            const float coef = opt_wait_coef(wo, jt->wblock_agent[bid], oepoch, sync);
             // (one workgroup, <= 32 elements: read back what it stored -- same thread, same address)
             for (int j0 = 0; j0 < Wc && coef >= 0.f; j0 += MMG_BLOCK / 8) {
                 const int j = j0 + jj;
@@ -852,7 +857,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         nact = rcount[0];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((int)blockIdx.x == jt->n_wblocks) {
+    if (bid == jt->n_wblocks) {
         // spare block: the six logged loss scalars, the semantic step count and the running totals (off every
         // critical path: this launch lasts ~17 us, the bookkeeping ~3)
         float* s_lc = &s_b[0][0][0];                       // (7 * 64 floats of the staging area: this block stages nothing -- keeps the
@@ -873,13 +878,14 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         }
         return;
     }
-    if ((int)blockIdx.x < jt->gemm_tiles) {
+    if (bid < jt->gemm_tiles) {
+      for (int vt = bid; vt < jt->gemm_tiles; vt += (gt_stride > 0 ? gt_stride : jt->gemm_tiles)) {
         // XCD-aware tile order: workgroup b is dispatched to XCD b % 8, and each XCD has its own 4 MB L2.  Giving
         // every XCD a CONTIGUOUS range of tiles (= one or two jobs) keeps the operand tapes it re-reads
         // (16-32 tiles share each of them) inside its L2; with the default order every XCD streams all ~7 MB
         // of tapes through its L2 and the kernel is bound by L2-miss traffic.  (bijective remap, T1)
         const int nwg = jt->gemm_tiles, xq = nwg >> 3, xr = nwg & 7;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = vt & 7, slot = vt >> 3;
         const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
         // job lookup: lane l compares the l-th job's first tile, one ballot (no serial scalar loads)
         const int j = __popcll(__ballot(jt->g_begin[lane] <= tile)) - 1;
@@ -1044,11 +1050,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                     if (gi2[h2] >= 0) opt_update_one(wo.oa, wo.params, wo.state, gi2[h2], gv2[h2], coef, w[h2], s1[h2], s2[h2], ostep);
             }
         }
+        __syncthreads();                                   // (the staging buffers / s_acc are the next tile's)
+      }
         MMG_WG_END();
         return;
     }
     // ---- column sums: 16 columns x 16 row groups per block, 4 independent loads in flight per thread
-    const int cb = blockIdx.x - jt->gemm_tiles;
+    const int cb = bid - jt->gemm_tiles;
     const int j = __popcll(__ballot(jt->c_begin[lane] <= cb)) - 1;
     const ColJob& C = jt->c[j];
     const bool ccmp = use_map && C.compact;
@@ -1098,13 +1106,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         C.dst[c0 + threadIdx.x] = v;
     }
     const float sq = block_sum(v * v, s_red);
-    if (threadIdx.x == 0) part[blockIdx.x] = sq;
+    if (threadIdx.x == 0) part[bid] = sq;
     if (OPT) {
-        if (threadIdx.x == 0) st_ll(wo.gnll, blockIdx.x, sq, oepoch);
+        if (threadIdx.x == 0) st_ll(wo.gnll, bid, sq, oepoch);
         const bool mine = threadIdx.x < 16 && (c0 + (int)threadIdx.x) < C.cols;
         const int64_t idx = mine ? (C.dst - wo.grads) + c0 + threadIdx.x : 0;
         const float w = wo.params[idx], s1 = wo.state[idx], s2 = (wo.oa.optim_type == MMG_OPT_ADAM) ? wo.state[wo.oa.total + idx] : 0.f;
-        const float coef = opt_wait_coef(wo, jt->wblock_agent[blockIdx.x], oepoch, sync);
+        const float coef = opt_wait_coef(wo, jt->wblock_agent[bid], oepoch, sync);
         if (coef >= 0.f && mine) opt_update_one(wo.oa, wo.params, wo.state, idx, v, coef, w, s1, s2, ostep);
     }
     MMG_WG_END();

@@ -58,6 +58,7 @@ struct mmg_handle {
     bool game_ok;              // fused step of the small Adaptive agents: conversation + statistics + baselines + backward in ONE launch (kernels_game.h); MMG_NO_GAME=1: off
     int game_nbas;             // ... its baseline roles (a multiple of 2 * ceil(K / 64), sized by the co-residency budget)
     bool game_step;            // set by mmg_train_step around clip_step_impl: k_opt commits the minibatch counter / launch epoch
+    int wgrad_stride;          // > 0: k_wgrad's GEMM tiles are walked by this many resident workgroups (more tiles than slots); MMG_WGRAD_STRIDE overrides, 0: one workgroup per tile
     bool wgrad_opt_ok;         // the clip + optimizer step can run inside k_wgrad's launch (k_wgrad<true>: every block co-resident, no row splits); MMG_NO_WGRAD_OPT=1: off
     bool wgrad_opt;            // set by mmg_train_step: this step's k_wgrad carries the optimizer (no k_opt launch)
     bool use_fast;             // debugging switches, read once at mmg_create: MMG_NO_FAST=1 forces the generic kernels,
@@ -578,6 +579,20 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         h->wgrad_opt_ok = !h->any_split && h->dm.use_binary && h->d_err != nullptr && !getenv("MMG_NO_WGRAD_OPT") &&
                           hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_wgrad<true>, MMG_BLOCK, 0) == hipSuccess &&
                           h->jt.n_wblocks + 2 <= nb * n_cu - 8;
+        {
+            int nb2 = 0;
+            h->wgrad_stride = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void*)k_wgrad<false>, MMG_BLOCK, 0) == hipSuccess) {
+                const int others = h->jt.n_wblocks + 1 - h->jt.gemm_tiles;
+                const int slots = ((nb2 * n_cu - others) / 8) * 8;
+                // (measured, round 5: 1 336 tiles on 856 slots 289 -> 281 us per minibatch, 3 848 on 672 219 -> 217; 5 120 on 552 388 -> 396 --
+                //  beyond ~6 tiles per workgroup the static split loses more to its ragged last round than the walk saves;
+                //  a balanced stride (tiles / rounds) gave the gain away again: as many workgroups as are resident)
+                if (h->jt.gemm_tiles > slots && slots >= 64 && h->jt.gemm_tiles <= 6 * slots) h->wgrad_stride = slots;
+            }
+            if (getenv("MMG_WGRAD_STRIDE")) { const int v = atoi(getenv("MMG_WGRAD_STRIDE")); h->wgrad_stride = (v > 0 && v < h->jt.gemm_tiles) ? (v / 8) * 8 : 0; }
+        }
+        if (getenv("MMG_DEBUG")) fprintf(stderr, "mmg_create: wgrad_stride %d (gemm tiles %d)\n", h->wgrad_stride, h->jt.gemm_tiles);
         if (getenv("MMG_DEBUG")) fprintf(stderr, "mmg_create: wgrad_opt_ok %d (blocks %d, resident %d x %d)\n", (int)h->wgrad_opt_ok, h->jt.n_wblocks + 2, nb, n_cu);
     }
     {
@@ -1062,16 +1077,16 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             hipLaunchKernelGGL(k_wgrad<true>, dim3(h->jt.n_wblocks + 2), dim3(MMG_BLOCK), 0, st,
                                (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
                                h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
-                               (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo
+                               (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, 0
 #ifdef MMG_TIMING
                                , h->tp.dbg2
 #endif
                                );
         } else
-        hipLaunchKernelGGL(k_wgrad<false>, dim3(h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
+        hipLaunchKernelGGL(k_wgrad<false>, dim3(h->wgrad_stride > 0 ? h->wgrad_stride + h->jt.n_wblocks + 1 - h->jt.gemm_tiles : h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
                            (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
                            h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
-                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo
+                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, h->wgrad_stride
 #ifdef MMG_TIMING
                            , h->tp.dbg2
 #endif
