@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_fast3(Dims dm, Params P
                 *reinterpret_cast<float4*>(tp.z + o) = vz;
                 if (binary) *reinterpret_cast<float4*>(tp.pz + o) = vpz;
                 *reinterpret_cast<float4*>(tp.zr + o) = cv;
-                *reinterpret_cast<float4*>(tp.c + o) = (t == 0) ? sg : cv;             // model.py:199
+                *reinterpret_cast<float4*>(tp.c + o) = make_float4(t == 0 ? sg.x : cv.x, t == 0 ? sg.y : cv.y, t == 0 ? sg.z : cv.z, t == 0 ? sg.w : cv.w);   // model.py:199 (component-wise: a ?: over float4 values goes through scratch)
             }
             if (t < w_done) {
                 *reinterpret_cast<float4*>(tp.w + o) = vw;

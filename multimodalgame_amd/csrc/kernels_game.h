@@ -592,7 +592,8 @@ __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp
             const float4 sg = *reinterpret_cast<const float4*>(s_sig + 4 * c);
             if (t < t_done) {
                 *reinterpret_cast<float4*>(tp.pz + o) = vpz;
-                *reinterpret_cast<float4*>(tp.c + o) = (t == 0) ? sg : cv;             // model.py:199
+                // (component-wise: a ?: over two float4 values went through SCRATCH -- two stores and a dependent load in the epilogue)
+                *reinterpret_cast<float4*>(tp.c + o) = make_float4(t == 0 ? sg.x : cv.x, t == 0 ? sg.y : cv.y, t == 0 ? sg.z : cv.z, t == 0 ? sg.w : cv.w);   // model.py:199
             }
             if (t < w_done) {
                 *reinterpret_cast<float4*>(tp.w + o) = vw;
