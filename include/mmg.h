@@ -151,15 +151,21 @@ int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const
 
 /* Per-agent clip_grad_norm(max_norm=1) + optimizer update on the flat buffers.  In continuous mode
  * (use_binary==0) only the receiver is updated (model.py:1313).  Skips the update (and makes every later training call
- * fail) when the dependency-error flag of this rank or -- through the tail quad of d_grads -- of any rank is set. */
+ * fail) when the dependency-error flag of this rank or -- through the tail quad of d_grads -- of any rank is set.
+ * Non-finite guard: when the gradient norm of ANY agent is not finite, tape "losses"[0] (the NLL) is set to NaN in the same
+ * step.  (The class-logit ReLU is v_max_f32, which reads a NaN pre-activation as "unit off" where torch's relu propagates
+ * it: without the guard a NaN in receiver.y1.weight[:, :R] or in the GRU leaves a plausible NLL = log D while every loss of
+ * the reference is NaN.  The reference's NLL is non-finite => this one is, in the same step; it is finite whenever all six
+ * losses of the reference are.) */
 int mmg_clip_step(mmg_handle* h, void* stream);
 
 /* forward(train, run_all_steps = 2) + stats + backward + clip_step for a single-GPU minibatch; nothing returns to the
- * host.  Equivalent to the four calls above in sequence.  Launches per minibatch depend on the shape: 4 for the agents of
- * BASELINE configs 1-2 (k_conversation_fast3 with k_prep's blocks as roles, k_bwd_conv_fast with the baselines / statistics
- * as roles, k_wgrad, k_opt), 5 for config 3's shard (+ k_baselines3; + k_prep with more samples than CUs), 7 for config 5's
- * shard (k_prep, k_conversation_mc, k_bwd_mc1, k_bwd_mc2, k_wgrad, k_wreduce, k_opt), 10-11 for config 4 (k_prep,
- * k_conv_persist, [k_gemm_nt], k_baselines4, k_stats, k_bwd_pre_send, k_bwd_sample, k_dC_tile, k_wgrad, k_opt), 10 for
+ * host.  Equivalent to the four calls above in sequence.  Launches per minibatch depend on the shape: 2 for the agents of
+ * BASELINE configs 1-2 (k_game_fast: conversation, k_prep's blocks, baselines, statistics and the reverse pass as roles of
+ * one launch; k_wgrad<OPT>: weight gradients + clip + optimizer), 4 for config 3's shard (k_conversation_fast3, k_baselines3,
+ * k_bwd_conv_fast, k_wgrad<OPT>; + k_prep with more samples than CUs, + k_opt with row splits), 7 for config 5's
+ * shard (k_prep, k_conversation_mc, k_bwd_mc1, k_bwd_mc2, k_wgrad, k_wreduce, k_opt), 9 for config 4 (k_prep,
+ * k_conv_persist, k_baselines4, k_stats, k_bwd_pre_send, k_bwd_sample, k_dC_tile, k_wgrad, k_opt), 10 for
  * config 4 with rec_hidden 256 (k_prep, k_rc_persist, k_gemm_nt, k_baselines4, k_stats, k_bwd_pre_send, k_rc_bwd, k_dC_tile,
  * k_wgrad, k_opt). */
 int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
