@@ -260,7 +260,45 @@ def _run(stats, flogger, device, rank, world):
     eval_seconds, n_evals = 0.0, 0
     import time as _time
 
+    # The log block of a minibatch (model.py:1342-1518) is ENQUEUED at its step -- device-side reductions + one non-blocking copy
+    # to pinned memory -- and WRITTEN once the copy has landed, normally a few minibatches later: same lines, same order (every
+    # other writer of the log flushes it first), and the launch queue never drains for it.
+    pending_log = []
+    log_state = dict(hits_at_log=0.0)
+
+    def emit_log(blk):
+        snap = _log_snapshot_end(blk["h"])
+        L, hits_now = snap["losses"], snap["hits_total"]
+        avg_batch_acc = (hits_now - log_state["hits_at_log"]) / float(FLAGS.batch_size) / blk["n_seen"]
+        log_state["hits_at_log"] = hits_now
+        pre = blk["pre"]
+        flogger.Log(pre + "Training Accuracy: {}".format(avg_batch_acc))
+        flogger.Log(pre + "Loss Sender: {}".format(L["loss_binary_sen"]))
+        flogger.Log(pre + "Loss Receiver (Y): {}".format(L["nll_loss"]))
+        if FLAGS.use_binary:
+            flogger.Log(pre + "Loss Receiver (Z): {}".format(L["loss_binary_rec"]))
+            if not FLAGS.fixed_exchange:
+                flogger.Log(pre + "Loss Receiver (S): {}".format(L["loss_binary_s"]))
+            flogger.Log(pre + "Loss Baseline (S): {}".format(L["loss_bas_sen"]))
+            flogger.Log(pre + "Loss Baseline (R): {}".format(L["loss_bas_rec"]))
+        for line in _entropy_lines(blk["eng"], blk["target"], L, snap):    # model.py:1379-1407
+            flogger.Log(line)
+        if "dump" in snap:                                                 # model.py:1411-1461 (train sample dump)
+            flogger.Log(_sample_dump_snap(snap["dump"], "Train:", int(L["n_steps"])))
+        if blk["h_eval"] is not None:                                      # model.py:1463-1518 (the same minibatch in evaluation mode)
+            ev_snap = _log_snapshot_end(blk["h_eval"])
+            flogger.Log(_sample_dump_snap(ev_snap["dump"], "Eval:", _executed_steps_snap(ev_snap["dump"], FLAGS.fixed_exchange, ev_snap["T"])))
+
+    def flush_log(block):
+        while pending_log:
+            blk = pending_log[0]
+            if not block and not (_log_snapshot_ready(blk["h"]) and (blk["h_eval"] is None or _log_snapshot_ready(blk["h_eval"]))):
+                return
+            pending_log.pop(0)
+            emit_log(blk)
+
     def finish():
+        flush_log(True)
         if stats is not None and totals0 is not None:
             _sync(device)
             tot = game._train_engine.tape["totals"].cpu().tolist()
@@ -270,6 +308,7 @@ def _run(stats, flogger, device, rank, world):
     _sync(device)
     t_loop = _time.perf_counter()
     while epoch < FLAGS.max_epoch:
+        flush_log(True)
         flogger.Log("Starting epoch: {}".format(epoch))
         if FLAGS.images != "mammal":
             raise NotImplementedError                                      # model.py:1211 (cifar branch is broken upstream)
@@ -278,35 +317,34 @@ def _run(stats, flogger, device, rank, world):
                                                   with_ids=False, shard=(rank, world))):
             if totals0 is None:                      # (the first minibatch creates the engine)
                 totals0 = game.train_engine_for(batch["target"].size(0), desc_train.size(0)).tape["totals"].cpu().tolist()
-                hits_at_log = totals0[1]
+                log_state["hits_at_log"] = totals0[1]
             # (a minibatch that writes a log block keeps the whole tape: every sample runs all steps -- same update, see Game.train_step)
             eng = game.train_step(batch[FLAGS.img_feat], batch["target"], desc_train,
                                   full_tape=(step % FLAGS.log_interval == 0))                # model.py:1240-1339
             steps_run += 1
+            flush_log(False)                                               # a log block whose snapshot has landed is written now
             if step % FLAGS.log_interval == 0 and rank == 0:               # model.py:1342-1377 (global-minibatch figures)
-                snap = _log_snapshot(eng, batch["target"])              # ONE device -> host copy for the whole block
-                L, hits_now = snap["losses"], snap["hits_total"]
-                n_seen = steps_run - steps_at_log                       # = min(minibatches of this process, log_interval)
-                avg_batch_acc = (hits_now - hits_at_log) / float(FLAGS.batch_size) / n_seen
-                steps_at_log, hits_at_log = steps_run, hits_now
-                pre = "Epoch: {} Step: {} Batch: {} ".format(epoch, step, i_batch)
-                flogger.Log(pre + "Training Accuracy: {}".format(avg_batch_acc))
-                flogger.Log(pre + "Loss Sender: {}".format(L["loss_binary_sen"]))
-                flogger.Log(pre + "Loss Receiver (Y): {}".format(L["nll_loss"]))
-                if FLAGS.use_binary:
-                    flogger.Log(pre + "Loss Receiver (Z): {}".format(L["loss_binary_rec"]))
-                    if not FLAGS.fixed_exchange:
-                        flogger.Log(pre + "Loss Receiver (S): {}".format(L["loss_binary_s"]))
-                    flogger.Log(pre + "Loss Baseline (S): {}".format(L["loss_bas_sen"]))
-                    flogger.Log(pre + "Loss Baseline (R): {}".format(L["loss_bas_rec"]))
-                for line in _entropy_lines(eng, batch["target"], L, snap):  # model.py:1379-1407
-                    flogger.Log(line)
-                if FLAGS.exchange_samples > 0:                             # model.py:1411-1461 (train sample dump)
-                    flogger.Log(_sample_dump(eng, "Train:", int(L["n_steps"])))
+                flush_log(True)
+                n_dump = FLAGS.exchange_samples if FLAGS.exchange_samples > 0 else 0
+                blk = dict(pre="Epoch: {} Step: {} Batch: {} ".format(epoch, step, i_batch), eng=eng, target=batch["target"],
+                           n_seen=steps_run - steps_at_log,                # = min(minibatches of this process, log_interval)
+                           h=_log_snapshot_begin(eng, batch["target"], dump=n_dump), h_eval=None)
+                steps_at_log = steps_run
+                if blk["h"]["event"] is None:                              # (no device queue to keep busy: the block is written at once,
+                    emit_log(blk)                                          #  before the evaluation pass reuses the engine's tape)
+                if n_dump:
                     # model.py:1463-1518: the same minibatch once more in evaluation mode (rounded messages), same layout
                     ev = game.eval_forward(batch[FLAGS.img_feat], batch["target"], desc_train)
-                    flogger.Log(_sample_dump(ev, "Eval:", _executed_steps(ev, FLAGS.fixed_exchange)))
+                    h_eval = _log_snapshot_begin(ev, None, dump=n_dump, losses=False)
+                    if blk["h"]["event"] is None:
+                        ev_snap = _log_snapshot_end(h_eval)
+                        flogger.Log(_sample_dump_snap(ev_snap["dump"], "Eval:", _executed_steps_snap(ev_snap["dump"], FLAGS.fixed_exchange, ev_snap["T"])))
+                    else:
+                        blk["h_eval"] = h_eval
+                if blk["h"]["event"] is not None:
+                    pending_log.append(blk)
             if step % FLAGS.log_dev == 0 and rank == 0:                    # model.py:1545-1576
+                flush_log(True)
                 _sync(device)
                 t_ev = _time.perf_counter()
                 dev_acc, extra = do_eval()
@@ -323,6 +361,7 @@ def _run(stats, flogger, device, rank, world):
                     flogger.Log("Checkpointing with best Development Accuracy: {}".format(best_dev_acc))
                     torch_save(FLAGS.checkpoint + "_best", dict(step=step, best_dev_acc=best_dev_acc, mmg_minibatch_counter=game.counters()[0]), models_dict, optimizers_dict)
             if step >= FLAGS.save_after and step % FLAGS.save_interval == 0 and rank == 0:   # model.py:1579-1584
+                flush_log(True)
                 flogger.Log("Checkpointing.")
                 torch_save(FLAGS.checkpoint, dict(step=step, best_dev_acc=best_dev_acc, mmg_minibatch_counter=game.counters()[0]), models_dict, optimizers_dict)
             step += 1
@@ -350,28 +389,83 @@ def _executed_steps(eng, fixed):
 _LOSS_KEYS = ("nll_loss", "loss_binary_s", "loss_binary_rec", "loss_binary_sen", "loss_bas_rec", "loss_bas_sen", "n_steps", "hits")
 
 
-def _log_snapshot(eng, target):
-    """Everything the log block of a minibatch prints, gathered on the device and copied to the host ONCE (a sync per printed
-    quantity left the GPU idle for the whole block): the eight loss scalars, the running hit count, the batch statistics, the
-    per-step prediction entropies of the run-all tape and targets | argmax predictions."""
+_PINNED = {}
+
+
+def _log_snapshot_begin(eng, target, dump=0, losses=True):
+    """Everything the log block of a minibatch prints, gathered on the device into ONE flat f64 vector and copied to pinned host
+    memory WITHOUT waiting (an event marks the copy): the eight loss scalars, the running hit count, the batch statistics, the
+    per-step prediction entropies of the run-all tape, targets | argmax predictions and -- dump > 0 -- what the sample dump of
+    the first `dump` samples prints (probabilities, bits, stop probabilities, masks of every step) plus the per-step count of
+    live samples.  _log_snapshot_end() waits for the event and parses.  The training loop enqueues a log minibatch's snapshot and
+    formats it a few minibatches later: the GPU never idles for a log block (round 5; the synchronous copy drained the launch
+    queue every -log_interval steps and the host's formatting kept it empty: 79 us per minibatch against 63 resident)."""
     tp = eng.tape
     f64 = torch.float64
-    y = tp["y"].to(torch.float32)
-    p = F.softmax(y, dim=2)
-    ent = (torch.log(p + 1e-8) * p).sum(2).mean(1)                         # [T] (model.py:880-886; the executed steps are picked below)
+    dev = tp["dist"].device
+    T = tp["y"].size(0)
     B = tp["dist"].size(0)
-    parts = [tp["losses"].to(f64).view(-1), tp["totals"].to(f64).view(-1)[1:2], eng.stats.to(f64).view(-1), ent.to(f64).view(-1),
-             tp["dist"].argmax(1).to(f64).view(-1), target.to(tp["dist"].device).to(f64).view(-1)]
-    flat = torch.cat(parts).cpu().tolist()
-    n_stats, T = eng.stats.numel(), y.size(0)
+    parts, n_stats = [], 0
+    if losses:
+        y = tp["y"].to(torch.float32)
+        pr = F.softmax(y, dim=2)
+        ent = (torch.log(pr + 1e-8) * pr).sum(2).mean(1)                   # [T] (model.py:880-886; the executed steps are picked at the end)
+        n_stats = eng.stats.numel()
+        parts += [tp["losses"].to(f64).view(-1), tp["totals"].to(f64).view(-1)[1:2], eng.stats.to(f64).view(-1), ent.to(f64).view(-1),
+                  tp["dist"].argmax(1).to(f64).view(-1), target.to(dev).to(f64).view(-1)]
+    k = min(int(dump), B)
+    W = tp["z"].size(2)
+    if k > 0:
+        parts += [tp["mask"][1:, :, 0].to(f64).sum(1).view(-1)]             # [T] live samples after every step
+        for name in ("pz", "pw", "z", "w"):
+            parts.append(tp[name][:, :k].to(f64).reshape(-1))              # [T, k, W]
+        parts += [tp["ps"][:, :k].to(f64).reshape(-1), tp["mask"][1:, :k, 0].to(f64).reshape(-1)]   # [T, k]
+    flat = torch.cat(parts)
+    ev = None
+    if flat.is_cuda:
+        key = (losses, k, flat.numel())
+        host = _PINNED.get(key)
+        if host is None:
+            host = _PINNED[key] = torch.empty(flat.numel(), dtype=f64, pin_memory=True)
+        host.copy_(flat, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flat.device))
+    else:
+        host = flat
+    return dict(host=host, event=ev, n_stats=n_stats, T=T, B=B, k=k, W=W, losses=losses)
+
+
+def _log_snapshot_ready(h):
+    return h["event"] is None or h["event"].query()
+
+
+def _log_snapshot_end(h):
+    if h["event"] is not None:
+        h["event"].synchronize()
+    flat = h["host"].tolist()
+    T, B, k, W, n_stats = h["T"], h["B"], h["k"], h["W"], h["n_stats"]
+    out = dict(T=T, B=B)
     o = 0
-    losses = dict(zip(_LOSS_KEYS, flat[o:o + 8])); o += 8
-    hits_total = flat[o]; o += 1
-    stats = flat[o:o + n_stats]; o += n_stats
-    ent_y = flat[o:o + T]; o += T
-    argmax = [int(v) for v in flat[o:o + B]]; o += B
-    tgt = [int(v) for v in flat[o:o + B]]
-    return dict(losses=losses, hits_total=hits_total, stats=stats, ent_y=ent_y, argmax=argmax, target=tgt, T=T, B=B)
+    if h["losses"]:
+        out["losses"] = dict(zip(_LOSS_KEYS, flat[o:o + 8])); o += 8
+        out["hits_total"] = flat[o]; o += 1
+        out["stats"] = flat[o:o + n_stats]; o += n_stats
+        out["ent_y"] = flat[o:o + T]; o += T
+        out["argmax"] = [int(v) for v in flat[o:o + B]]; o += B
+        out["target"] = [int(v) for v in flat[o:o + B]]; o += B
+    if k > 0:
+        d = dict(k=k, W=W, alive=flat[o:o + T]); o += T
+        for name in ("pz", "pw", "z", "w"):
+            d[name] = [[flat[o + (t * k + i) * W:o + (t * k + i + 1) * W] for i in range(k)] for t in range(T)]; o += T * k * W
+        d["ps"] = [[flat[o + t * k + i] for i in range(k)] for t in range(T)]; o += T * k
+        d["mask"] = [[flat[o + t * k + i] for i in range(k)] for t in range(T)]; o += T * k
+        out["dump"] = d
+    return out
+
+
+def _log_snapshot(eng, target):
+    """The synchronous form: begin + end (one device -> host copy for the whole block)."""
+    return _log_snapshot_end(_log_snapshot_begin(eng, target))
 
 
 def _entropy_lines(eng, target, L, snap=None):
@@ -407,23 +501,37 @@ def _entropy_lines(eng, target, L, snap=None):
 
 
 def _sample_dump(eng, title, n):
+    """model.py:1415-1461 / 1463-1518 straight from an engine's tape (synchronous): see _sample_dump_snap."""
+    return _sample_dump_snap(_log_snapshot_end(_log_snapshot_begin(eng, None, dump=FLAGS.exchange_samples, losses=False))["dump"], title, n)
+
+
+def _executed_steps_snap(d, fixed, T):
+    """Steps the reference's exchange() executes (model.py:866: break once every sample has stopped), from a snapshot's live counts."""
+    if fixed:
+        return T
+    for t, a in enumerate(d["alive"]):
+        if a == 0:
+            return t + 1
+    return T
+
+
+def _sample_dump_snap(d, title, n):
     """model.py:1415-1461 / 1463-1518: sparkline of the probabilities and the bits of the first samples at every one of the `n`
-    executed steps (the tape of a log minibatch / of an evaluation pass holds all of them)."""
-    tp = eng.tape
-    W = FLAGS.rec_w_dim
+    executed steps, from the dump part of a log snapshot (the tape of a log minibatch / of an evaluation pass holds all of them)."""
+    W = d["W"]
     out = title
-    for i in range(min(FLAGS.exchange_samples, eng.cfg.batch)):
-        prev_sen, prev_rec = torch.zeros(W), torch.zeros(W)
+    for i in range(d["k"]):
+        prev_sen, prev_rec = [0.0] * W, [0.0] * W
         for t in range(n):
-            sp, rp, stp = tp["pz"][t, i].tolist(), tp["pw"][t, i].tolist(), tp["ps"][t, i].tolist()
-            sb, rb = tp["z"][t, i].cpu(), tp["w"][t, i].cpu()
-            sh, rh = float((prev_sen - sb).abs().sum()), float((prev_rec - rb).abs().sum())
+            sp, rp, stp = d["pz"][t][i], d["pw"][t][i], [d["ps"][t][i]]
+            sb, rb = d["z"][t][i], d["w"][t][i]
+            sh, rh = float(sum(abs(a - b) for a, b in zip(prev_sen, sb))), float(sum(abs(a - b) for a, b in zip(prev_rec, rb)))
             prev_sen, prev_rec = sb, rb
             out += ("\n{:>3}".format(i) if t == 0 else "\n   ")
             out += "        {}".format(sparks([1] + sp)[1:]) + "           {}    {}".format(sparks([1] + stp)[1:], sparks([1] + rp)[1:])
-            out += "\n    {:>3} S: {} {:4}".format(t, "".join(str(int(v)) for v in sb.tolist()), sh)
+            out += "\n    {:>3} S: {} {:4}".format(t, "".join(str(int(v)) for v in sb), sh)
             # (the forced zero of the LAST mask, model.py:870)
-            out += "    s={} R: {} {:4}".format(0 if t == n - 1 else int(tp["mask"][t + 1, i, 0].item()), "".join(str(int(v)) for v in rb.tolist()), rh)
+            out += "    s={} R: {} {:4}".format(0 if t == n - 1 else int(d["mask"][t][i]), "".join(str(int(v)) for v in rb), rh)
     return out + "\n"
 
 
