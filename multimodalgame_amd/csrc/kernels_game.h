@@ -88,28 +88,37 @@ __device__ __forceinline__ void frag_load_cc(float4 (&f)[MAXQ], const float* __r
     }
 }
 
-// Baseline role `role` of `n_roles` (a multiple of 2 * npb): (which, byi) = role % (2 npb), window slot = role / (2 npb).
+// Baseline role `role` of `n_roles` (a multiple of 2 * npb / UB): (which, first unit block) = role % (2 npb / UB), window slot =
+// role / (2 npb / UB).  UB = 2 (round 5, npb even): a role owns TWO 64-unit blocks of its baseline -- the rows of a window are loaded
+// once for both, and the same number of roles covers twice as many window slots, so that the longer conversations of a trained
+// pair (180+ live rows: 12+ windows) still cost every role ONE window between the last forward pass and the statistics.
+// Partial scores stay per 64-unit block: the statistics roles add the same npb terms in the same order.
+template <int UB>
 __device__ __forceinline__ void game_baseline_role(const Dims& dm, const Params& P, const Tape& tp, int role, int n_roles, uint32_t epoch) {
     __shared__ int s_rid[64 * 16];                       // live-row ids of this role's windows, 16 per window (-1: none)
     __shared__ int s_nwin;
-    __shared__ float s_part[4][16];
+    __shared__ float s_part[UB][4][16];
     const int B = dm.B, H = dm.H, W = dm.W, R = dm.R, K = dm.K, T = dm.T;
-    const int npb = (K + 63) / 64;
-    const int combo = role % (2 * npb), slot = role / (2 * npb), nslots = n_roles / (2 * npb);
-    const int which = combo / npb, byi = combo - which * npb;
+    const int npb = (K + 63) / 64, cpw = npb / UB;       // unit-block groups per baseline
+    const int combo = role % (2 * cpw), slot = role / (2 * cpw), nslots = n_roles / (2 * cpw);
+    const int which = combo / cpw, byi0 = (combo - which * cpw) * UB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     // ---- weights first (parameters: stable since the previous minibatch's k_opt), while the conversations run
-    const int n = (byi * 4 + wave) * 16 + i;
-    const bool nv = n < K;
     const float* W1 = which ? P.p[BS_L1_W] : P.p[BR_L1_W];
     const int ldw = which ? H + W : W + R;
-    const float* wrow = W1 + (size_t)(nv ? n : 0) * ldw;
-    const float bias = nv ? (which ? P.p[BS_L1_B][n] : P.p[BR_L1_B][n]) : 0.f;
-    const float w2 = nv ? (which ? P.p[BS_L2_W][n] : P.p[BR_L2_W][n]) : 0.f;
-    float4 w_msg[4], w_st[4];
-    frag_load(w_msg, wrow + (which ? H : 0), nv, W, q);
-    if (!which) frag_load(w_st, wrow + W, nv, R, q);
+    int n[UB]; bool nv[UB]; float bias[UB], w2[UB];
+    float4 w_msg[UB][4], w_st[UB][4];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        n[u] = ((byi0 + u) * 4 + wave) * 16 + i;
+        nv[u] = n[u] < K;
+        const float* wrow = W1 + (size_t)(nv[u] ? n[u] : 0) * ldw;
+        bias[u] = nv[u] ? (which ? P.p[BS_L1_B][n[u]] : P.p[BR_L1_B][n[u]]) : 0.f;
+        w2[u] = nv[u] ? (which ? P.p[BS_L2_W][n[u]] : P.p[BR_L2_W][n[u]]) : 0.f;
+        frag_load(w_msg[u], wrow + (which ? H : 0), nv[u], W, q);
+        if (!which) frag_load(w_st[u], wrow + W, nv[u], R, q);
+    }
     for (int k = threadIdx.x; k < 64 * 16; k += blockDim.x) s_rid[k] = -1;
     __syncthreads();
     if (wave == 0) {
@@ -141,54 +150,65 @@ __device__ __forceinline__ void game_baseline_role(const Dims& dm, const Params&
         float4 xm[4], xt[4];
         frag_load_cc(xm, (which ? tp.zr : tp.z) + rr * W, xv, W, q);
         if (!which) frag_load_cc(xt, tp.h + (rr + B) * R, xv, R, q);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
         int orow[4];
-        unsigned long long ub[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            orow[r] = rid_w[q * 4 + r];
-            ub[r] = 0;
-        }
+        for (int r = 0; r < 4; ++r) orow[r] = rid_w[q * 4 + r];
+        f32x4 acc[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (which) {                                      // basehx of the sample as (value, epoch) pairs of this launch's tiles
+            unsigned long long ub[UB][4];
             for (int spins = 0;; ) {
                 bool fresh = true;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ub[r] = ld_ll(tp.basell, (size_t)((orow[r] >= 0 ? orow[r] : 0) % B) * K + min(n, K - 1));
-                    fresh = fresh && ll_fresh(ub[r], epoch);
-                }
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ub[u][r] = ld_ll(tp.basell, (size_t)((orow[r] >= 0 ? orow[r] : 0) % B) * K + min(n[u], K - 1));
+                        fresh = fresh && ll_fresh(ub[u][r], epoch);
+                    }
                 if (!__any(!fresh)) break;
                 if (++spins > (1 << 16)) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = (orow[r] >= 0) ? ll_value(ub[r]) : 0.f;
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[u][r] = (orow[r] >= 0) ? ll_value(ub[u][r]) : 0.f;
         }
         if (threadIdx.x == 0 && kw == 0) { MMG_GT(5120 + 8 * role + 1); }
-        frag_mfma(acc, xm, w_msg, W, q);
-        if (!which) { frag_mfma(acc2, xt, w_st, R, q); acc += acc2; }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            frag_mfma(acc[u], xm, w_msg[u], W, q);
+            if (!which) { f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}; frag_mfma(acc2, xt, w_st[u], R, q); acc[u] += acc2; }
+        }
 #ifdef MMG_TIMING
-        if (threadIdx.x == 0 && kw == 0) { asm volatile("" :: "v"(acc[0])); tp.dbg2[5120 + 8 * role + 2] = (long long)wall_clock64(); }
+        if (threadIdx.x == 0 && kw == 0) { asm volatile("" :: "v"(acc[0][0])); tp.dbg2[5120 + 8 * role + 2] = (long long)wall_clock64(); }
 #endif
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = fmaxf(acc[r] + bias, 0.f);                                // model.py:514
-            if (orow[r] >= 0 && nv) hid[(size_t)orow[r] * K + n] = v; else v = 0.f;
-            v = dpp_group_sum<16>(v * w2);
-            if (i == 0) s_part[wave][q * 4 + r] = v;
-        }
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaxf(acc[u][r] + bias[u], 0.f);                      // model.py:514
+                if (orow[r] >= 0 && nv[u]) hid[(size_t)orow[r] * K + n[u]] = v; else v = 0.f;
+                v = dpp_group_sum<16>(v * w2[u]);
+                if (i == 0) s_part[u][wave][q * 4 + r] = v;
+            }
         __syncthreads();
         if (threadIdx.x == 0 && kw == 0) { MMG_GT(5120 + 8 * role + 3); }
-        if (threadIdx.x < 16 && rid_w[threadIdx.x] >= 0) {
-            const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
-            part[(size_t)rid_w[threadIdx.x] * npb + byi] = v;
-            st_ll(tp.partll, ((size_t)(which ? 0 : 1) * T * B + (size_t)rid_w[threadIdx.x]) * npb + byi, v, epoch);
+        if (threadIdx.x < 16 * UB) {
+            const int u = threadIdx.x >> 4, rw = threadIdx.x & 15;
+            if (rid_w[rw] >= 0) {
+                const float v = (s_part[u][0][rw] + s_part[u][1][rw]) + (s_part[u][2][rw] + s_part[u][3][rw]);
+                part[(size_t)rid_w[rw] * npb + byi0 + u] = v;
+                st_ll(tp.partll, ((size_t)(which ? 0 : 1) * T * B + (size_t)rid_w[rw]) * npb + byi0 + u, v, epoch);
+            }
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) { MMG_GT(3584 + 4 * role + 2); }
 }
 
-struct GameArgs { int n_stats, n_bas; };
+struct GameArgs { int n_stats, n_bas, bas_ub; };   // bas_ub: 64-unit blocks per baseline role (1 | 2)
 
 template <int D>
 __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp, ConvArgs ar, GameArgs ga) {
@@ -223,7 +243,12 @@ __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp
             return;
         }
         r -= ga.n_stats;
-        if (r < ga.n_bas) { game_baseline_role(dm, P, tp, r, ga.n_bas, epoch); return; }
+        if (r < ga.n_bas) {
+            if (ga.bas_ub == 4) game_baseline_role<4>(dm, P, tp, r, ga.n_bas, epoch);
+            else if (ga.bas_ub == 2) game_baseline_role<2>(dm, P, tp, r, ga.n_bas, epoch);
+            else game_baseline_role<1>(dm, P, tp, r, ga.n_bas, epoch);
+            return;
+        }
         r -= ga.n_bas;
         {
             float* s_c = lds; float* s_p = lds + 256;

@@ -56,6 +56,7 @@ struct mmg_handle {
     bool sw_merge_prep;        // k_prep's blocks as roles of k_conversation_fast3's launch (MMG_NO_MERGE_PREP=1: a launch of their own)
     bool use_fast3;            // one-wave-per-SIMD forward kernel of the small agents (kernels_fast3.h); MMG_FAST2=1: the 512-thread one
     bool game_ok;              // fused step of the small Adaptive agents: conversation + statistics + baselines + backward in ONE launch (kernels_game.h); MMG_NO_GAME=1: off
+    int game_bas_ub;           // ... 64-unit blocks of a baseline per role: 2 when the block count is even (MMG_GAME_BAS_UB=1: one)
     int game_nbas;             // ... its baseline roles (a multiple of 2 * ceil(K / 64), sized by the co-residency budget)
     bool game_step;            // set by mmg_train_step around clip_step_impl: k_opt commits the minibatch counter / launch epoch
     int wgrad_stride;          // > 0: k_wgrad's GEMM tiles are walked by this many resident workgroups (more tiles than slots); MMG_WGRAD_STRIDE overrides, 0: one workgroup per tile
@@ -523,7 +524,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
         e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)(k_conversation_fast3<256, 32, 64, 100, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fast3_lds_bytes());
-    h->game_ok = false; h->game_nbas = 0; h->game_step = false;
+    h->game_ok = false; h->game_nbas = 0; h->game_step = false; h->game_bas_ub = 1;
     {
         const Dims& d = h->dm;
         const bool shape = h->use_fast && h->use_fast3 && h->merge_roles && h->sw_merge_prep && h->sw_merge_bas && d.H == 256 && d.W == 32 && d.R == 64 && d.V == 100 &&
@@ -536,7 +537,10 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
                 // every spinning role must be resident together with the sample roles (the sample roles wait for the statistics roles,
                 // those for the baseline roles): B + n_stats + n_bas + D workgroups inside the co-residency budget of this device
                 const int budget = budget_of(fn, 256, game_lds_bytes());
-                const int n_stats = (5 * d.T + 2 + 3) / 4, per = 2 * ((d.K + 63) / 64);
+                const int npb_ = (d.K + 63) / 64;
+                h->game_bas_ub = !(npb_ & 1) ? 2 : 1;
+                if (getenv("MMG_GAME_BAS_UB")) { const int v = atoi(getenv("MMG_GAME_BAS_UB")); if ((v == 1 || v == 2 || v == 4) && npb_ % v == 0) h->game_bas_ub = v; }
+                const int n_stats = (5 * d.T + 2 + 3) / 4, per = 2 * npb_ / h->game_bas_ub;
                 int nb = ((budget - d.B - n_stats - d.D) / per) * per;
                 const int want = ((d.T * d.B + 15) / 16) * per;
                 if (nb > want) nb = want;
@@ -1168,7 +1172,7 @@ extern "C" int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_
         ar.x = d_x; ar.target = d_target; ar.desc = d_desc; ar.u_z = d_u_z; ar.u_s = d_u_s; ar.u_w = d_u_w; ar.seed = seed;
         ar.train = 1; ar.run_all = 0; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
         ar.nprep = prep_blocks(d, h->prep_cpb, true); ar.prep_cpb = h->prep_cpb; ar.nbase = ((d.B + 15) / 16) * ((d.K + 15) / 16);
-        GameArgs ga; ga.n_stats = (5 * d.T + 2 + 3) / 4; ga.n_bas = h->game_nbas;
+        GameArgs ga; ga.n_stats = (5 * d.T + 2 + 3) / 4; ga.n_bas = h->game_nbas; ga.bas_ub = h->game_bas_ub;
         h->basehx_ready = true; h->bas_deferred = false; h->bas_pending = false; h->scores_in_parts = true;
         {
             Scope sc(h, st, "k_game");
