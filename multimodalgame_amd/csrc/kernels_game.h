@@ -142,44 +142,65 @@ __device__ __forceinline__ void game_baseline_role(const Dims& dm, const Params&
     const int nwin = s_nwin;
     float* hid = which ? tp.hid_s : tp.hid_r;
     float* part = which ? tp.bs_part : tp.br_part;
-    for (int kw = 0; kw < nwin; ++kw) {
-        const int* rid_w = s_rid + kw * 16;
-        const int rid = rid_w[i];
+    // Two-stage pipeline over the role's windows: the rows (and the sender baseline's basehx pairs) of window kw + 1 are requested
+    // BEFORE window kw's products, so a second window costs its MFMAs and stores, not another trip to memory (a trained pair
+    // talks for ~7 steps: 440 live rows, 28 windows on 16 slots).
+    float4 xmA[4], xtA[4], xmB[4], xtB[4];                 // (two named buffers: a runtime index would put them in scratch)
+    unsigned long long ubA[UB][4], ubB[UB][4];
+    auto request = [&](int kw, float4 (&xm_)[4], float4 (&xt_)[4], unsigned long long (&ub_)[UB][4]) {
+        const int* rw = s_rid + kw * 16;
+        const int rid = rw[i];
         const bool xv = rid >= 0;
         const size_t rr = (size_t)(xv ? rid : 0);
-        float4 xm[4], xt[4];
-        frag_load_cc(xm, (which ? tp.zr : tp.z) + rr * W, xv, W, q);
-        if (!which) frag_load_cc(xt, tp.h + (rr + B) * R, xv, R, q);
+        frag_load_cc(xm_, (which ? tp.zr : tp.z) + rr * W, xv, W, q);
+        if (!which) frag_load_cc(xt_, tp.h + (rr + B) * R, xv, R, q);
+        if (which) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int o = rw[q * 4 + r]; ub_[u][r] = ld_ll(tp.basell, (size_t)((o >= 0 ? o : 0) % B) * K + min(n[u], K - 1)); }
+        }
+    };
+    auto window = [&](int kw, float4 (&xm_)[4], float4 (&xt_)[4], unsigned long long (&ub_)[UB][4],
+                      float4 (&xmN)[4], float4 (&xtN)[4], unsigned long long (&ubN)[UB][4]) {
+        const int* rid_w = s_rid + kw * 16;
+        if (kw + 1 < nwin) request(kw + 1, xmN, xtN, ubN);
         int orow[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) orow[r] = rid_w[q * 4 + r];
         f32x4 acc[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (which) {                                      // basehx of the sample as (value, epoch) pairs of this launch's tiles
-            unsigned long long ub[UB][4];
-            for (int spins = 0;; ) {
-                bool fresh = true;
+        if (which) {                                      // basehx of the sample: (value, epoch) pairs of this launch's tiles, written ~25 us ago
+            bool fresh = true;
 #pragma unroll
-                for (int u = 0; u < UB; ++u)
+            for (int u = 0; u < UB; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ub[u][r] = ld_ll(tp.basell, (size_t)((orow[r] >= 0 ? orow[r] : 0) % B) * K + min(n[u], K - 1));
-                        fresh = fresh && ll_fresh(ub[u][r], epoch);
-                    }
-                if (!__any(!fresh)) break;
-                if (++spins > (1 << 16)) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                for (int r = 0; r < 4; ++r) fresh = fresh && ll_fresh(ub_[u][r], epoch);
+            if (__any(!fresh)) {                          // (not yet: spin on them)
+                for (int spins = 0;; ) {
+                    fresh = true;
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ub_[u][r] = ld_ll(tp.basell, (size_t)((orow[r] >= 0 ? orow[r] : 0) % B) * K + min(n[u], K - 1));
+                            fresh = fresh && ll_fresh(ub_[u][r], epoch);
+                        }
+                    if (!__any(!fresh)) break;
+                    if (++spins > (1 << 16)) { __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[u][r] = (orow[r] >= 0) ? ll_value(ub[u][r]) : 0.f;
+                for (int r = 0; r < 4; ++r) acc[u][r] = (orow[r] >= 0) ? ll_value(ub_[u][r]) : 0.f;
         }
         if (threadIdx.x == 0 && kw == 0) { MMG_GT(5120 + 8 * role + 1); }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            frag_mfma(acc[u], xm, w_msg[u], W, q);
-            if (!which) { f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}; frag_mfma(acc2, xt, w_st[u], R, q); acc[u] += acc2; }
+            frag_mfma(acc[u], xm_, w_msg[u], W, q);
+            if (!which) { f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}; frag_mfma(acc2, xt_, w_st[u], R, q); acc[u] += acc2; }
         }
 #ifdef MMG_TIMING
         if (threadIdx.x == 0 && kw == 0) { asm volatile("" :: "v"(acc[0][0])); tp.dbg2[5120 + 8 * role + 2] = (long long)wall_clock64(); }
@@ -204,6 +225,11 @@ __device__ __forceinline__ void game_baseline_role(const Dims& dm, const Params&
             }
         }
         __syncthreads();
+    };
+    if (nwin > 0) request(0, xmA, xtA, ubA);
+    for (int kw = 0; kw < nwin; kw += 2) {
+        window(kw, xmA, xtA, ubA, xmB, xtB, ubB);
+        if (kw + 1 < nwin) window(kw + 1, xmB, xtB, ubB, xmA, xtA, ubA);
     }
     if (threadIdx.x == 0) { MMG_GT(3584 + 4 * role + 2); }
 }
@@ -244,8 +270,7 @@ __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp
         }
         r -= ga.n_stats;
         if (r < ga.n_bas) {
-            if (ga.bas_ub == 4) game_baseline_role<4>(dm, P, tp, r, ga.n_bas, epoch);
-            else if (ga.bas_ub == 2) game_baseline_role<2>(dm, P, tp, r, ga.n_bas, epoch);
+            if (ga.bas_ub == 2) game_baseline_role<2>(dm, P, tp, r, ga.n_bas, epoch);
             else game_baseline_role<1>(dm, P, tp, r, ga.n_bas, epoch);
             return;
         }

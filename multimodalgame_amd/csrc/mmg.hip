@@ -539,7 +539,7 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
                 const int budget = budget_of(fn, 256, game_lds_bytes());
                 const int npb_ = (d.K + 63) / 64;
                 h->game_bas_ub = !(npb_ & 1) ? 2 : 1;
-                if (getenv("MMG_GAME_BAS_UB")) { const int v = atoi(getenv("MMG_GAME_BAS_UB")); if ((v == 1 || v == 2 || v == 4) && npb_ % v == 0) h->game_bas_ub = v; }
+                if (getenv("MMG_GAME_BAS_UB")) { const int v = atoi(getenv("MMG_GAME_BAS_UB")); if ((v == 1 || v == 2) && npb_ % v == 0) h->game_bas_ub = v; }
                 const int n_stats = (5 * d.T + 2 + 3) / 4, per = 2 * npb_ / h->game_bas_ub;
                 int nb = ((budget - d.B - n_stats - d.D) / per) * per;
                 const int want = ((d.T * d.B + 15) / 16) * per;

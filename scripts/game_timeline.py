@@ -14,6 +14,10 @@ eng.load_state_dicts(init_state_dicts(eng, 0))
 feats, target, desc = bench.synthetic_dataset(3000, 30, 512, 100)
 dev = eng.device
 d = torch.from_numpy(desc).to(dev)
+# PRETRAIN=n: n untimed minibatches first (cycling over 25 batches as bench.py's window does): the conversations of a trained pair
+for it in range(int(os.environ.get("PRETRAIN", "0"))):
+    k = it % 25
+    eng.train_step(torch.from_numpy(feats[64 * k:64 * k + 64]).to(dev), torch.from_numpy(target[64 * k:64 * k + 64]).to(dev), d, seed=0)
 for it in range(int(os.environ.get("ITERS", "12"))):
     x = torch.from_numpy(feats[64 * it:64 * it + 64]).to(dev); t = torch.from_numpy(target[64 * it:64 * it + 64]).to(dev)
     eng.tape["dbg2"].zero_()
