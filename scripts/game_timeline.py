@@ -63,3 +63,11 @@ print("baseline role, first window (mean over %d roles): forward passes seen -> 
 for w in (0, 1):
     m = okb & ((np.arange(nb) % 16) // 8 == w)
     print("   which = %d: %.2f | %.2f | %.2f | %.2f | %.2f" % (w, us((bw[m, 0] - bs[m, 1]).mean()), us((bw[m, 1] - bw[m, 0]).mean()), us((bw[m, 2] - bw[m, 1]).mean()), us((bw[m, 3] - bw[m, 2]).mean()), us((bs[m, 2] - bw[m, 3]).mean())))
+
+# phases of sample 0's forward steps (tp.dbg[8 + 10 t + k], k = 0..6: the seven barrier-separated phases of kernels_fast3.h's step)
+dbg = eng.tape["dbg"].view(torch.int64).cpu().numpy().astype(np.float64)
+for t in range(10):
+    st = dbg[8 + 10 * t:8 + 10 * t + 7]
+    if st[0] == 0 or st[6] < st[0]: break
+    prev = dbg[8 + 10 * (t - 1) + 6] if t > 0 else dbg[2]
+    print("forward step %d of sample 0: %s | step total %.2f us" % (t, " ".join("%.2f" % us(b - a) for a, b in zip([prev] + list(st[:6]), st)), us(st[6] - prev)))
