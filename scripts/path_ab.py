@@ -12,6 +12,12 @@ CASES = {   # name: (engine kwargs over bench.C2, batch, [environment variants])
     "c4 W=256 H=1024": (dict(w_dim=256, h_dim=1024), 64, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_FUSED_S": "1"}, {"MMG_NO_RMSG": "1"}, {"MMG_NO_RSAMPLE": "1"}, {"MMG_NO_PERSIST": "1"}, {"MMG_NO_TILE": "1"}]),
     "c4 88 samples (two role launches)": (dict(w_dim=256, h_dim=1024), 88, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_PERSIST": "1"}]),
     "c4 W=128 H=2048 (s1 / s2 roles)": (dict(w_dim=128, h_dim=2048), 48, [{}, {"MMG_NO_RSAMPLE": "1"}, {"MMG_NO_PERSIST": "1"}]),
+    "c4 Fixed exchange": (dict(w_dim=256, h_dim=1024, fixed_exchange=True), 64, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_PERSIST": "1"}]),
+    "c4 continuous messages": (dict(w_dim=256, h_dim=1024, use_binary=False, fixed_exchange=True), 64, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_PERSIST": "1"}]),
+    "c4 max_exchange 15": (dict(w_dim=256, h_dim=1024, max_exchange=15), 32, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_PERSIST": "1"}]),
+    "c4 max_exchange 2, 30 samples": (dict(w_dim=256, h_dim=1024, max_exchange=2), 30, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_PERSIST": "1"}]),
+    "c2 max_exchange 15": (dict(max_exchange=15), 64, [{}, {"MMG_NO_GAME": "1"}, {"MMG_NO_FAST": "1"}]),
+    "c2 max_exchange 1": (dict(max_exchange=1), 64, [{}, {"MMG_NO_GAME": "1"}, {"MMG_NO_FAST": "1"}]),
     "c4 R=256 wide receiver": (dict(w_dim=256, h_dim=1024, rec_hidden=256), 64, [{}, {"MMG_NO_RC_PERSIST": "1"}, {"MMG_NO_RC_BWD": "1"}, {"MMG_NO_RC": "1"}]),
     "200 classes, binary, Adaptive": (dict(n_classes=200), 40, [{}, {"MMG_NO_MC": "1"}, {"MMG_TILE": "1"}]),
 }
@@ -58,12 +64,15 @@ for name, (kw, B, variants) in CASES.items():
     for env, r in zip(variants + [dict(variants[0], again="1")], res):
         tag = " ".join("%s=%s" % kv for kv in env.items()) or "default"
         if r is None or ref is None: print("   %-28s FAILED TO RUN" % tag); ok_all = False; continue
-        rel = max(abs(a - b) / max(1.0, abs(b)) for ra, rb in zip(r, ref) for a, b in zip(ra[:7], rb[:7]))
+        rel = max(abs(a - b) / max(1.0, abs(b)) for ra, rb in zip(r, ref) for a, b in zip(ra[:6], rb[:6]))
+        # (the evaluation pass ROUNDS its message bits: a probability within an ulp of 0.5 may round the other way in another
+        #  summation order and the conversation after it differs -- counts must still agree, the summed log-likelihood within 2e-3)
+        rel_ev = max(abs(ra[6] - rb[6]) / max(1.0, abs(rb[6])) for ra, rb in zip(r, ref))
         counts = sum(1 for ra, rb in zip(r, ref) if ra[7:] != rb[7:])
         same_as_default = r == res[0]
-        good = rel < 2e-5 and counts == 0 and ("again" not in env or same_as_default)
+        good = rel < 2e-5 and rel_ev < 2e-3 and counts == 0 and ("again" not in env or same_as_default)
         ok_all = ok_all and good
-        print("   %-28s max relative loss difference %.1e, step / hit counts differ in %d of %d seeds%s%s" % (
-            tag, rel, counts, len(r), (", reproduces the first run: %s" % same_as_default) if "again" in env else "", "" if good else "   <-- MISMATCH"))
+        print("   %-28s max relative loss difference %.1e (evaluation pass %.1e), step / hit counts differ in %d of %d seeds%s%s" % (
+            tag, rel, rel_ev, counts, len(r), (", reproduces the first run: %s" % same_as_default) if "again" in env else "", "" if good else "   <-- MISMATCH"))
 print("OK" if ok_all else "MISMATCH")
 sys.exit(0 if ok_all else 1)
