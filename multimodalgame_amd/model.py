@@ -422,6 +422,8 @@ def _log_snapshot_begin(eng, target, dump=0, losses=True):
         parts += [tp["ps"][:, :k].to(f64).reshape(-1), tp["mask"][1:, :k, 0].to(f64).reshape(-1)]   # [T, k]
     flat = torch.cat(parts)
     ev = None
+    if flat.is_cuda and os.environ.get("MMG_LOG_SYNC"):                    # cross-check switch: the synchronous log block of rounds 1-4
+        flat = flat.cpu()
     if flat.is_cuda:
         key = (losses, k, flat.numel())
         host = _PINNED.get(key)

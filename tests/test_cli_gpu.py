@@ -159,3 +159,26 @@ def test_data_parallel_model_run(mode, tmp_path):
     for la, lb in zip(a, b):
         assert la.rsplit(": ", 1)[0] == lb.rsplit(": ", 1)[0]
         assert abs(float(la.rsplit(": ", 1)[1]) - float(lb.rsplit(": ", 1)[1])) < 1e-4, (la, lb)
+
+
+def test_deferred_log_block_equals_the_synchronous_one(tmp_path, monkeypatch):
+    """model.run() enqueues a log minibatch's block (device-side reductions, sample-dump slices, one non-blocking copy to pinned
+    memory) and writes it when the copy has landed, a few minibatches later; MMG_LOG_SYNC=1 copies and writes at once, as rounds
+    1-4 did.  Same seed, same data: the two log files must be identical line by line -- loss lines, Predictions, the three
+    Entropy blocks, Train / Eval sample dumps, dev evaluation and checkpoint lines in between, in the same order."""
+    from multimodalgame_amd import model, flags
+    logs = {}
+    for name, sync in (("deferred", None), ("sync", "1")):
+        tmp = str(tmp_path / name)
+        if sync:
+            monkeypatch.setenv("MMG_LOG_SYNC", sync)
+        flags.define_flags(); flags.FLAGS.Reset()
+        model.main(_argv(tmp, "run", ["-max_steps", "23", "-log_interval", "3"]))
+        flags.FLAGS.Reset()
+        text = open(os.path.join(tmp, "logs", "run.log")).read()
+        logs[name] = [re.sub(r"^\d\d-\d\d-\d\d \d\d:\d\d:\d\d ", "", l) for l in text.replace(tmp, "<tmp>").splitlines() if "Flag Values" not in l]   # (FileLogger's time stamp)
+    a, b = logs["deferred"], logs["sync"]
+    assert len(a) == len(b) and len(a) > 200
+    diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y and "<tmp>" not in x]
+    assert not diff, diff[:5]
+    assert sum(1 for l in a if "Training Accuracy" in l) == 8 and any("Eval:" in l for l in a)
