@@ -831,6 +831,12 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         if (threadIdx.x == 0) part[bid] = sq;
         if (OPT) {
             if (threadIdx.x == 0) st_ll(wo.gnll, bid, sq, oepoch);
+#ifdef MMG_TIMING
+        if (threadIdx.x == 0 && bid < 2000) dbg2[8192 + 4 * bid + 2] = (long long)wall_clock64();
+#endif
+#ifdef MMG_TIMING
+            if (threadIdx.x == 0 && bid < 2000) dbg2[8192 + 4 * bid + 2] = (long long)wall_clock64();
+#endif
             const float coef = opt_wait_coef(wo, jt->wblock_agent[bid], oepoch, sync);
             // (one workgroup, <= 32 elements: read back what it stored -- same thread, same address)
             for (int j0 = 0; j0 < Wc && coef >= 0.f; j0 += MMG_BLOCK / 8) {
@@ -903,6 +909,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const bool cmp = use_map && G.compact;
         const int rows = cmp ? nact : G.rows, lda = G.lda, ldb = G.ldb, bmod = G.bmod, N = G.N, K = G.K;
         if (use_map) __syncthreads();                      // s_map is complete
+#ifdef MMG_TIMING
+        if (threadIdx.x == 0 && tile < 2000) dbg2[8192 + 4 * tile + 0] = (long long)wall_clock64();
+#endif
         const bool veca = ((lda & 3) == 0) && ((((uintptr_t)Abase) & 15) == 0);
         const bool vecb = ((ldb & 3) == 0) && ((((uintptr_t)Bbase) & 15) == 0);
         // loader roles: A row la, columns lac..+3 (64 rows x 16 cols); B row lb0 / lb0+32, columns lbc..+3 (64 x 32)
@@ -1013,6 +1022,9 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             }
         }
         __syncthreads();                                   // every wave is done reading the staging buffers
+#ifdef MMG_TIMING
+        if (threadIdx.x == 0 && tile < 2000) dbg2[8192 + 4 * tile + 1] = (long long)wall_clock64();
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s_acc[wave][q * 4 + r][i] = acc0[r]; s_acc[wave][q * 4 + r][16 + i] = acc1[r]; }
         __syncthreads();
@@ -1043,7 +1055,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                 w[h2] = wo.params[ic]; s1[h2] = wo.state[ic];
                 s2[h2] = (wo.oa.optim_type == MMG_OPT_ADAM) ? wo.state[wo.oa.total + ic] : 0.f;
             }
+#ifdef MMG_TIMING
+            if (threadIdx.x == 0 && tile < 2000) dbg2[8192 + 4 * tile + 2] = (long long)wall_clock64();
+#endif
             const float coef = opt_wait_coef(wo, jt->wblock_agent[tile], oepoch, sync);
+#ifdef MMG_TIMING
+            if (threadIdx.x == 0 && tile < 2000) dbg2[8192 + 4 * tile + 3] = (long long)wall_clock64();
+#endif
             if (coef >= 0.f) {
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2)

@@ -13,10 +13,35 @@ eng.load_state_dicts(init_state_dicts(eng, 0))
 feats, target, desc = bench.synthetic_dataset(3000, 30, 512, 100)
 dev = eng.device
 x = torch.from_numpy(feats[:64]).to(dev); t = torch.from_numpy(target[:64]).to(dev); d = torch.from_numpy(desc).to(dev)
+for it in range(int(os.environ.get("PRETRAIN", "0"))):          # PRETRAIN=n: the conversations of a trained pair (bench.py's window)
+    k = it % 25
+    eng.train_step(torch.from_numpy(feats[64 * k:64 * k + 64]).to(dev), torch.from_numpy(target[64 * k:64 * k + 64]).to(dev), d, seed=0)
 for it in range(6):
+    eng.tape["dbg2"].zero_()
     eng.train_step(x, t, d, seed=0)
 torch.cuda.synchronize()
-st = eng.tape["dbg2"].view(torch.int64).cpu().numpy().reshape(-1, 2)
+raw = eng.tape["dbg2"].view(torch.int64).cpu().numpy()
+ph = raw[8192:8192 + 8000].reshape(-1, 4).astype(np.float64)
+okp = (ph[:, 0] > 0) & (ph[:, 3] > 0)
+if okp.any():
+    g0 = raw[:8192].reshape(-1, 2)
+    g0 = g0[g0[:, 0] > 0][:, 0].min()
+    u = lambda v: v * 0.01
+    print("GEMM tiles (%d): job + row list held at %.2f us after the first block started | rows reduced +%.2f | sum of squares out +%.2f | coefficient held +%.2f (mean); last pair out at %.2f, first coefficient at %.2f" % (
+        okp.sum(), u((ph[okp, 0] - g0).mean()), u((ph[okp, 1] - ph[okp, 0]).mean()), u((ph[okp, 2] - ph[okp, 1]).mean()), u((ph[okp, 3] - ph[okp, 2]).mean()),
+        u(ph[okp, 2].max() - g0), u(ph[okp, 3].min() - g0)))
+pub = ph[:, 2]
+okb = pub > 0
+if okb.any():
+    first = pub[okb].min()
+    order = np.argsort(-pub)[:16]
+    print("blocks by the time their sum of squares went out (us after the first one): median %.2f, p90 %.2f, last %.2f; the latest: %s" % (
+        u(np.median(pub[okb]) - first), u(np.percentile(pub[okb], 90) - first), u(pub[okb].max() - first), [(int(b), round(float(u(pub[b] - first)), 2)) for b in order]))
+red = u(ph[:, 1] - ph[:, 0]); held = ph[:, 0] > 0
+nt = int(np.nonzero(held & (ph[:, 1] > 0))[0].max()) + 1
+print("rows-reduced time by tile range (us, mean):", " ".join("%d-%d:%.1f" % (lo, min(lo + 24, nt) - 1, red[lo:lo + 25][(ph[lo:lo + 25, 1] > 0)].mean()) for lo in range(0, nt, 25)))
+print("job + row list held, by tile range (us after the first):", " ".join("%d:%.1f" % (lo, u(ph[lo:lo + 25, 0][ph[lo:lo + 25, 0] > 0].mean() - ph[held, 0].min())) for lo in range(0, nt, 50)))
+st = raw[:8192].reshape(-1, 2)
 nz = st[:, 0] > 0
 st = st[nz]
 t0 = st[:, 0].min()
