@@ -12,6 +12,9 @@
  *   mmg_backward           <- the four loss.backward()      model.py:1309, 1316, 1322, 1328
  *   mmg_clip_step          <- clip_grad_norm + optimizer    model.py:1310-1311, 1317-1318, 1323-1324, 1329-1330
  *   mmg_train_step         <- the whole per-minibatch block model.py:1240-1339 (single GPU)
+ *   mmg_train_steps        <- n iterations of the epoch loop's body, model.py:1218-1240 (batches of misc.py:257-302)
+ *   mmg_dp_train_step[s]   <- the same block on one rank of a data-parallel job (statistics + gradient
+ *                             all-reduce; couplings model.py:912-915, 947-961, 1310)
  *   mmg_sender_forward     <- Sender.forward                model.py:144-238 (non-attention, sender_mix=sum)
  *   mmg_receiver_forward   <- Receiver.forward              model.py:303-477 (non-desc_attn)
  *   mmg_baseline_forward   <- Baseline.forward              model.py:496-516
@@ -22,8 +25,9 @@
  *     it one workspace of mmg_workspace_bytes() bytes at mmg_create().
  *   - all work is enqueued on the hipStream_t passed as `stream` (void*, 0 = null stream) and is
  *     asynchronous w.r.t. the host; no host synchronisation happens inside any call.
- *   - return value: 0 = ok, negative = error (message via mmg_last_error()); nothing throws
- *     across the ABI.  One handle per device per process; not thread-safe (the reference is
+ *   - return value: 0 = ok, negative = error (message via mmg_last_error()), 1 = ok with a warning in
+ *     mmg_last_error() (training entry points only: the library recovered from a timed-out in-launch
+ *     dependency, see mmg_clear_error); nothing throws across the ABI.  One handle per device per process; not thread-safe (the reference is
  *     single-threaded).
  *   - all floating-point data is fp32, row-major, PyTorch [out,in] weight layout; masks are
  *     uint8; targets int64 (as the reference's LongTensor).
@@ -38,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MMG_VERSION 2
+#define MMG_VERSION 3
 #define MMG_GRAD_TAIL 4       /* floats behind the gradients in d_grads, owned by the library (see mmg_grad_floats) */
 
 enum { MMG_OPT_RMSPROP = 0, MMG_OPT_ADAM = 1, MMG_OPT_SGD = 2 };          /* model.py:1725 */
@@ -66,6 +70,11 @@ typedef struct mmg_config {
     int32_t optim_type;       /* MMG_OPT_*                                                           */
     float   learning_rate;    /* -learning_rate                                                      */
     int32_t top_k;            /* -top_k_train                                                        */
+    int32_t cu_budget;        /* compute units this process can count on (0 = the whole device).  The persistent
+                                 "role" launches need their workgroups co-resident; their budgets are sized from this
+                                 number, and a budget they do not fit selects launches without in-launch waits up front.
+                                 Set it when the GPU is shared or the process runs under a CU mask (no reference
+                                 counterpart: additive)                                                              */
 } mmg_config;
 
 /* One parameter tensor inside the flat parameter / gradient / optimizer-state buffers. */
@@ -150,8 +159,9 @@ int mmg_loss_stats(mmg_handle* h, void* stream);
 int mmg_backward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc, void* stream);
 
 /* Per-agent clip_grad_norm(max_norm=1) + optimizer update on the flat buffers.  In continuous mode
- * (use_binary==0) only the receiver is updated (model.py:1313).  Skips the update (and makes every later training call
- * fail) when the dependency-error flag of this rank or -- through the tail quad of d_grads -- of any rank is set.
+ * (use_binary==0) only the receiver is updated (model.py:1313).  Skips the update when the dependency-error flag of this
+ * rank or -- through the tail quad of d_grads -- of any rank is set; the next call that starts a minibatch recovers
+ * (mmg_clear_error).
  * Non-finite guard: when the gradient norm of ANY agent is not finite, tape "losses"[0] (the NLL) is set to NaN in the same
  * step.  (The class-logit ReLU is v_max_f32, which reads a NaN pre-activation as "unit off" where torch's relu propagates
  * it: without the guard a NaN in receiver.y1.weight[:, :R] or in the GRU leaves a plausible NLL = log D while every loss of
@@ -170,6 +180,42 @@ int mmg_clip_step(mmg_handle* h, void* stream);
  * k_wgrad, k_opt). */
 int mmg_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
                    const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed, void* stream);
+
+/* n consecutive minibatches of the epoch loop (model.py:1218-1240) enqueued by ONE call: minibatch i reads rows
+ * [i * B, (i + 1) * B) of d_x [n * B, F] / d_target [n * B] -- the epoch's samples laid out in the reference's batch order
+ * (misc.py:257-302: random.seed(11 + epoch) shuffle, consecutive slices, indices sorted inside a batch), which the caller
+ * gathers once per epoch.  Philox sampling only (the device-side minibatch counter advances as under n mmg_train_step
+ * calls: bit-identical results).  The caller runs the minibatches that write a log block / evaluate / checkpoint itself. */
+int mmg_train_steps(mmg_handle* h, const float* d_x, const int64_t* d_target, int64_t n, const float* d_desc,
+                    uint64_t seed, void* stream);
+
+/* Data-parallel minibatch in ONE call (one rank; batch < global_batch): forward + mmg_loss_stats | all-reduce(sum) of the
+ * f64 "stats" array (binary messages only) | mmg_backward | ONE all-reduce of all mmg_grad_floats() floats of d_grads |
+ * mmg_clip_step on the reduced gradient.  The collectives are RCCL's
+ *     ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream)
+ * called through the ADDRESS the caller registers (libmmg does not link RCCL) on the caller's communicator, in place, on
+ * `stream`.  reduce == 0 skips both (a one-rank job).  full_tape != 0: every sample runs all steps (run_all_steps = 1: the
+ * minibatches whose log block reads the whole tape), same update.  mmg_dp_train_steps: n minibatches laid out as for
+ * mmg_train_steps (this rank's B rows of each). */
+int mmg_dp_set_allreduce(mmg_handle* h, void* nccl_all_reduce, void* comm);
+int mmg_dp_train_step(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
+                      const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed,
+                      int full_tape, int reduce, void* stream);
+int mmg_dp_train_steps(mmg_handle* h, const float* d_x, const int64_t* d_target, int64_t n, const float* d_desc,
+                       uint64_t seed, int reduce, void* stream);
+
+/* Fail-soft.  The persistent launches hold workgroup "roles" that wait on each other inside one launch; every wait is
+ * bounded.  A wait that expires (fewer compute units than mmg_create assumed: shared or CU-masked GPU) makes that minibatch's
+ * optimizer update a no-op on every rank, and the NEXT call that starts a minibatch (mmg_train_step[s],
+ * mmg_exchange_forward(train), mmg_dp_train_step[s]) recovers by itself: it drains `stream`, clears the error words,
+ * re-selects the kernels WITHOUT in-launch waits for the rest of the handle's life (what MMG_NO_ROLES=1, a CU mask in the
+ * environment or a too-small cu_budget select up front), and returns 1 with the warning in mmg_last_error().  The reference
+ * has no such failure mode (model.py:1218-1330 keeps training) -- neither has the caller of this library.
+ *   mmg_clear_error: the same clearing on request, without changing the selected kernels (drains `stream`).
+ *   mmg_degraded:    0 = role launches in use, 1 = launches without in-launch waits selected at mmg_create,
+ *                    2 = ... selected by a recovery. */
+int mmg_clear_error(mmg_handle* h, void* stream);
+int mmg_degraded(const mmg_handle* h);
 
 /* Agent-level entry points (forward only; one exchange step), mirroring the reference modules.
  *   sender:   x[B,F], w[B,W] (ignored when t==0), t -> message[B,W], probs[B,W] (NULL if continuous),

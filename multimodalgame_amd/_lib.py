@@ -16,7 +16,8 @@ class MmgConfig(C.Structure):
         "wv_dim", "bas_hidden", "max_exchange", "use_binary", "fixed_exchange", "s_prob_prod",
         "has_entropy_s", "has_entropy_sen", "has_entropy_rec")] + [
         ("entropy_s", C.c_float), ("entropy_sen", C.c_float), ("entropy_rec", C.c_float),
-        ("first_rec", C.c_float), ("optim_type", C.c_int32), ("learning_rate", C.c_float), ("top_k", C.c_int32)]
+        ("first_rec", C.c_float), ("optim_type", C.c_int32), ("learning_rate", C.c_float), ("top_k", C.c_int32),
+        ("cu_budget", C.c_int32)]
 
 
 class ParamEntry(C.Structure):
@@ -33,13 +34,18 @@ class MmgError(RuntimeError):
     pass
 
 
+class MmgWarning(RuntimeWarning):
+    """A training call returned 1: the library recovered from a timed-out in-launch dependency (include/mmg.h: fail-soft)."""
+
+
 _lib = None
 
 # every symbol include/mmg.h declares (tests check that the library exports all of them)
 SYMBOLS = ["mmg_last_error", "mmg_version", "mmg_param_count", "mmg_grad_floats", "mmg_param_table", "mmg_workspace_bytes",
            "mmg_tape_table", "mmg_create", "mmg_destroy", "mmg_exchange_forward", "mmg_loss_stats",
            "mmg_backward", "mmg_clip_step", "mmg_train_step", "mmg_sender_forward", "mmg_receiver_forward",
-           "mmg_baseline_forward", "mmg_set_profiling", "mmg_get_kernel_times", "mmg_host_shuffle"]
+           "mmg_baseline_forward", "mmg_set_profiling", "mmg_get_kernel_times", "mmg_host_shuffle", "mmg_train_steps",
+           "mmg_dp_set_allreduce", "mmg_dp_train_step", "mmg_dp_train_steps", "mmg_clear_error", "mmg_degraded"]
 
 
 def load():
@@ -68,6 +74,12 @@ def load():
     lib.mmg_backward.restype = i32; lib.mmg_backward.argtypes = [vp, fp, vp, fp, vp]
     lib.mmg_clip_step.restype = i32; lib.mmg_clip_step.argtypes = [vp, vp]
     lib.mmg_train_step.restype = i32; lib.mmg_train_step.argtypes = [vp, fp, vp, fp, fp, fp, fp, u64, vp]
+    lib.mmg_train_steps.restype = i32; lib.mmg_train_steps.argtypes = [vp, fp, vp, i64, fp, u64, vp]
+    lib.mmg_dp_set_allreduce.restype = i32; lib.mmg_dp_set_allreduce.argtypes = [vp, vp, vp]
+    lib.mmg_dp_train_step.restype = i32; lib.mmg_dp_train_step.argtypes = [vp, fp, vp, fp, fp, fp, fp, u64, i32, i32, vp]
+    lib.mmg_dp_train_steps.restype = i32; lib.mmg_dp_train_steps.argtypes = [vp, fp, vp, i64, fp, u64, i32, vp]
+    lib.mmg_clear_error.restype = i32; lib.mmg_clear_error.argtypes = [vp, vp]
+    lib.mmg_degraded.restype = i32; lib.mmg_degraded.argtypes = [vp]
     lib.mmg_sender_forward.restype = i32
     lib.mmg_sender_forward.argtypes = [vp, fp, fp, i32, i32, fp, u64, fp, fp, fp, vp]
     lib.mmg_receiver_forward.restype = i32
@@ -82,14 +94,22 @@ def load():
 
 
 def check(status):
-    if status != 0:
-        raise MmgError(load().mmg_last_error().decode())
+    """0 = ok; 1 = ok with a warning (the library recovered from a timed-out in-launch dependency and continues on the launches
+    without in-launch waits: reported once per event as MmgWarning); negative = error."""
+    if status == 0:
+        return
+    if status > 0:
+        import warnings
+        warnings.warn(MmgWarning(load().mmg_last_error().decode()), stacklevel=3)
+        return
+    raise MmgError(load().mmg_last_error().decode())
 
 
 def make_config(batch, n_classes, feat_dim, h_dim, w_dim, rec_hidden, wv_dim, bas_hidden, max_exchange,
                 use_binary=True, fixed_exchange=True, s_prob_prod=True, entropy_s=None, entropy_sen=None,
                 entropy_rec=None, first_rec=0.0, optim_type="RMSprop", learning_rate=1e-4, top_k=6,
-                global_batch=None, batch_offset=0):
+                global_batch=None, batch_offset=0, cu_budget=0):
+    """cu_budget: compute units this process can count on (0 = the whole device; include/mmg.h)."""
     c = MmgConfig()
     c.batch, c.global_batch, c.batch_offset = batch, global_batch or batch, batch_offset
     c.n_classes, c.feat_dim, c.h_dim, c.w_dim = n_classes, feat_dim, h_dim, w_dim
@@ -98,6 +118,7 @@ def make_config(batch, n_classes, feat_dim, h_dim, w_dim, rec_hidden, wv_dim, ba
     c.has_entropy_s, c.has_entropy_sen, c.has_entropy_rec = [int(v is not None) for v in (entropy_s, entropy_sen, entropy_rec)]
     c.entropy_s, c.entropy_sen, c.entropy_rec = [float(v or 0.0) for v in (entropy_s, entropy_sen, entropy_rec)]
     c.first_rec, c.optim_type, c.learning_rate, c.top_k = float(first_rec), MMG_OPT[optim_type], float(learning_rate), int(top_k)
+    c.cu_budget = int(cu_budget or 0)
     return c
 
 

@@ -7,8 +7,8 @@
 // the per-step weights ONCE into registers, every layer with a fixed lane->weight mapping chosen at compile
 // time, and then runs the T steps with activations in LDS: no global load sits on the critical path of the
 // recurrence; tape stores are fire-and-forget.  The lane mappings are listed at each kernel.
-// (A first 256-thread / one-wave-per-SIMD forward kernel, ~270 weight registers per lane, was replaced by the
-// 512-thread k_conversation_fast2: 37 -> 27 us.)
+// This file holds the BACKWARD kernel of that shape (k_bwd_conv_fast) and k_bas_stats; the forward conversation is
+// kernels_fast3.h (one wave per SIMD; rounds 1-3's 512-thread k_conversation_fast2 was deleted in round 6).
 #pragma once
 #include "device_utils.h"
 #include "kernels_fwd.h"
@@ -551,406 +551,6 @@ __global__ __launch_bounds__(256, 1) void k_bwd_conv_fast(Dims dm, Params P, Tap
     }
     MMG_BSTAMP(4);
     // (code_bias: k_wgrad's special column job forms dsig * W_c^T (sum_b dpre_0) once, instead of W_c^T dpre_0 per sample here)
-}
-
-}  // namespace mmg
-
-namespace mmg {
-
-// ---------------------------------------------------------------------------------------------
-// k_conversation_fast2: the same register-resident conversation on 512 threads (8 waves = TWO per SIMD).
-// One wave per SIMD (256 threads) is bound by dependent-instruction issue (~5 cycles per instruction, ~1800
-// instructions per step).  Spreading every layer over twice the lanes halves the
-// per-lane FMA/operand work (136 weight registers per lane instead of ~270, no AGPR spill traffic) and gives
-// each SIMD a second wave to issue from while the first waits on LDS / DPP / transcendental latency.
-//   code_layer  2 lanes per row (16 regs)      binary_layer 16 lanes per row (16 regs)
-//   GRU         2 lanes per row (16 + 32 regs) y1[:, :R], w_h  8 lanes per row (8 + 8 regs)
-//   y head      16 lanes per class (4 + 4)     softmax.desc  2 lanes per column (15 regs), softmax via wave-private LDS
-//   w_d         8 lanes per row (13 regs)      w  16 lanes per row (4 regs)
-// ---------------------------------------------------------------------------------------------
-// Workgroups beyond the B sample roles (training launches only) are independent 16x16 tiles of
-//   basehx = h_x . baseline_sen.linear1.weight[:, :H]^T   [B, K]
-// -- work k_baselines2 needs next and that depends on nothing this launch produces: it runs on CUs the B <= 64 sample
-// roles leave idle instead of as a 4.7 us prologue of every sender-baseline workgroup of the next launch.
-template <int H, int W, int R, int V, int D>
-__global__ __launch_bounds__(512, 2) void k_conversation_fast2(Dims dm, Params P, Tape tp, ConvArgs ar) {
-    constexpr int NT = 512;
-    if ((int)blockIdx.x >= dm.B) {
-        if (threadIdx.x >= MMG_BLOCK) return;            // gemm_nt_tile is a 4-wave routine
-        gemm_nt_tile((int)blockIdx.x - dm.B, tp.hx, H, P.p[BS_L1_W], H + W, nullptr, tp.basehx, dm.K, dm.B, dm.K, H);
-        return;
-    }
-    static_assert(FastDims<H, W, R, V, D>::ok && D <= 32 && V <= 200, "unsupported fast shape");
-    __shared__ __attribute__((aligned(16))) float s_a[H];
-    __shared__ __attribute__((aligned(16))) float s_c[W];
-    __shared__ __attribute__((aligned(16))) float s_z[W];
-    __shared__ __attribute__((aligned(16))) float s_h[R];
-    __shared__ __attribute__((aligned(16))) float s_A[R];
-    __shared__ __attribute__((aligned(16))) float s_y[32];
-    __shared__ __attribute__((aligned(16))) float s_yout[32];
-    __shared__ __attribute__((aligned(16))) float s_dbar[V];
-    __shared__ __attribute__((aligned(16))) float s_g[R];
-    __shared__ float s_pi[8][32];
-    // bits and probabilities of every step: their log-likelihood / neg-entropy sums (model.py:908-922) are formed for ALL steps in
-    // one pass after the conversation -- inside the step loop they were 0.2 us per step on one straggling wave
-    constexpr int TMAXL = 16;
-    static_assert(W == 32 && TMAXL * W == 512, "one (step, bit) per thread in the log-likelihood pass");
-    __shared__ float s_pzT[TMAXL * W], s_zT[TMAXL * W], s_pwT[TMAXL * W], s_wT[TMAXL * W], s_psT[TMAXL], s_sbT[TMAXL];
-    __shared__ float s_misc[8];
-    constexpr int TMAX = 16;
-    __shared__ float s_uz[TMAX * W], s_uw[TMAX * W], s_us[TMAX];
-
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int B = dm.B, T = dm.T;
-    const int Dr = dm.D;                                // classes of this run (<= D, the compile-time capacity)
-    const bool binary = dm.use_binary != 0, train = ar.train != 0;
-    const bool inject = ar.u_s != nullptr;
-    MMG_STAMP(0);
-#ifdef MMG_TIMING
-    if (b == 0 && tid == 0) tp.dbg[4] = (long long)__builtin_readcyclecounter();      // s_memtime: shader cycles on gfx950
-#endif
-    const uint32_t mb_counter = tp.counter[0];
-    const uint32_t gb = (uint32_t)(dm.boff + b);
-    if (train && inject) {
-        for (int i = tid; i < T * W; i += NT) {
-            const int t = i / W, j = i - t * W;
-            if (ar.u_z) s_uz[i] = ar.u_z[((size_t)t * B + b) * W + j];
-            if (ar.u_w) s_uw[i] = ar.u_w[((size_t)t * B + b) * W + j];
-        }
-        if (tid < T) s_us[tid] = ar.u_s[(size_t)tid * B + b];
-    }
-
-    // ------------------------------------------------------------ weights -> registers (once)
-    // (1) code_layer: row n1 = tid/2, half h1: k = (h1 + 2j)*4 + {0..3}
-    const int n1 = tid >> 1, h1 = tid & 1;
-    constexpr int J1 = W / 8;
-    float wc[4 * J1];
-#pragma unroll
-    for (int j = 0; j < J1; ++j) {
-        const float4 v = *reinterpret_cast<const float4*>(P.p[S_CODE_W] + (size_t)n1 * W + (h1 + 2 * j) * 4);
-        wc[4 * j] = v.x; wc[4 * j + 1] = v.y; wc[4 * j + 2] = v.z; wc[4 * j + 3] = v.w;
-    }
-    const float bc = P.p[S_CODE_B][n1];
-    const float hw0 = tp.hw0[n1];
-    const float hx = tp.hx[(size_t)b * H + n1];
-    // (2) binary_layer and (9) w: 16 lanes per row
-    constexpr int LB = NT / W;                     // 16
-    constexpr int JB = H / (4 * LB);               // 4
-    constexpr int JW = R / (4 * LB);               // 1
-    const int nb = tid / LB, kpb = tid % LB;
-    float wb[4 * JB], ww[4 * JW];
-#pragma unroll
-    for (int j = 0; j < JB; ++j) {
-        const float4 v = *reinterpret_cast<const float4*>(P.p[S_BIN_W] + (size_t)nb * H + kpb * 4 + 4 * LB * j);
-        wb[4 * j] = v.x; wb[4 * j + 1] = v.y; wb[4 * j + 2] = v.z; wb[4 * j + 3] = v.w;
-    }
-#pragma unroll
-    for (int j = 0; j < JW; ++j) {
-        const float4 v = *reinterpret_cast<const float4*>(P.p[R_W_W] + (size_t)nb * R + kpb * 4 + 4 * LB * j);
-        ww[4 * j] = v.x; ww[4 * j + 1] = v.y; ww[4 * j + 2] = v.z; ww[4 * j + 3] = v.w;
-    }
-    const float bb = P.p[S_BIN_B][nb];
-    const float bw = P.p[R_W_B][nb];
-    // (3) GRU: unit j3 = tid / 8 owns eight lanes: slot q3 = 2 * gate + half (gates r, u, n; slots 6, 7 idle), so that the three
-    // gate pre-activations of a unit meet inside one DPP row and the state update needs no LDS round trip
-    static_assert(NT == 8 * R, "eight lanes per GRU unit");
-    const int j3 = tid >> 3, q3 = tid & 7, h3 = q3 & 1;
-    constexpr int J3I = W / 8, J3H = R / 8;
-    float wih[4 * J3I], whh[4 * J3H];
-    float bih = 0.f, bhh = 0.f;
-    {
-        const int nr = min(q3 >> 1, 2) * R + j3;
-#pragma unroll
-        for (int j = 0; j < J3I; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(P.p[R_WIH] + (size_t)nr * W + (h3 + 2 * j) * 4);
-            wih[4 * j] = v.x; wih[4 * j + 1] = v.y; wih[4 * j + 2] = v.z; wih[4 * j + 3] = v.w;
-        }
-#pragma unroll
-        for (int j = 0; j < J3H; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(P.p[R_WHH] + (size_t)nr * R + (h3 + 2 * j) * 4);
-            whh[4 * j] = v.x; whh[4 * j + 1] = v.y; whh[4 * j + 2] = v.z; whh[4 * j + 3] = v.w;
-        }
-        bih = P.p[R_BIH][nr]; bhh = P.p[R_BHH][nr];
-    }
-    // (5) y1[:, :R], w_h and (8) w_d: 8 lanes per row
-    constexpr int L4 = NT / R;                     // 8
-    constexpr int J4 = R / (4 * L4);               // 2
-    const int n4 = tid / L4, kp4 = tid % L4;
-    float wy1[4 * J4], wh[4 * J4];
-#pragma unroll
-    for (int j = 0; j < J4; ++j) {
-        const float4 v = *reinterpret_cast<const float4*>(P.p[R_Y1_W] + (size_t)n4 * (R + V) + kp4 * 4 + 4 * L4 * j);
-        wy1[4 * j] = v.x; wy1[4 * j + 1] = v.y; wy1[4 * j + 2] = v.z; wy1[4 * j + 3] = v.w;
-        const float4 u = *reinterpret_cast<const float4*>(P.p[R_WH_W] + (size_t)n4 * R + kp4 * 4 + 4 * L4 * j);
-        wh[4 * j] = u.x; wh[4 * j + 1] = u.y; wh[4 * j + 2] = u.z; wh[4 * j + 3] = u.w;
-    }
-    const float bh = P.p[R_WH_B][n4];
-    constexpr int JD = (V + L4 - 1) / L4;          // 13
-    float wd[JD];
-#pragma unroll
-    for (int j = 0; j < JD; ++j) { const int k = kp4 + L4 * j; wd[j] = (k < V) ? P.p[R_WD_W][(size_t)n4 * V + k] : 0.f; }
-    const float ws = P.p[R_S_W][lane];
-    const float bs = P.p[R_S_B][0];
-    // (6) y head: 16 lanes per class, k = kpy*4 + {0..3}
-    constexpr int LY = 16;
-    static_assert(R == 4 * LY, "y-head mapping assumes R == 64");
-    const int dy = tid / LY, kpy = tid % LY;
-    float cd[4], w2[4];
-    {
-        const float4 v = *reinterpret_cast<const float4*>(tp.Cd + (size_t)(dy < Dr ? dy : 0) * R + kpy * 4);
-        cd[0] = v.x; cd[1] = v.y; cd[2] = v.z; cd[3] = v.w;
-        const float4 u = *reinterpret_cast<const float4*>(P.p[R_Y2_W] + kpy * 4);
-        w2[0] = u.x; w2[1] = u.y; w2[2] = u.z; w2[3] = u.w;
-    }
-    const float b2 = P.p[R_Y2_B][0];
-    // (7) desc column v7 = tid/2 (< V), half h7 covers classes h7*DH .. h7*DH + DH-1
-    constexpr int DH = (D + 1) / 2;                // 15
-    const int v7 = tid >> 1, h7 = tid & 1;
-    float dcol[DH];
-#pragma unroll
-    for (int j = 0; j < DH; ++j) { const int d = h7 * DH + j; dcol[j] = (v7 < V && d < Dr) ? ar.desc[(size_t)d * V + v7] : 0.f; }
-    const float sig_cb = (tid < W) ? fsigmoid(P.p[S_CODE_BIAS][tid]) : 0.f;
-    if (train && !inject) {                        // Philox draws of the whole conversation, while the weight loads are in flight
-        for (int i = tid; i < T * W; i += NT) {
-            const int t = i / W, j = i - t * W;
-            const uint32_t e = (uint32_t)((t * dm.Bg + gb) * W + j);
-            s_uz[i] = philox_uniform(ar.seed, e, mb_counter, 0u);
-            s_uw[i] = philox_uniform(ar.seed, e, mb_counter, 2u);
-        }
-        if (tid < T) s_us[tid] = philox_uniform(ar.seed, (uint32_t)(tid * dm.Bg + gb), mb_counter, 1u);
-    }
-
-    MMG_STAMP(1);
-    // ------------------------------------------------------------ conversation state
-    if (tid < R) { s_h[tid] = 0.f; tp.h[(size_t)b * R + tid] = 0.f; }
-    if (tid < W) s_c[tid] = dm.first_rec;
-    if (tid == 0) { s_misc[0] = 1.f; s_misc[1] = -1.f; s_misc[2] = 1.f; tp.mask[b] = 1; }
-    __syncthreads();
-
-    int t_done = T, w_done = T;                         // steps executed / steps whose receiver message was formed
-    MMG_STAMP(2);
-    for (int t = 0; t < T; ++t) {
-        const size_t row = (size_t)t * B + b;
-        MMG_STAMP(8 + 10 * t + 9);
-        // ===== (1) sender: h_w = code_layer(c), a = tanh(h_x + h_w)
-        {
-            float hw = hw0;
-            if (t > 0) hw = bc + dpp_group_sum<2>(dot4<J1>(wc, s_c + h1 * 4, 8));
-            const float av = ftanh(hx + hw);
-            if (h1 == 0) { s_a[n1] = av; tp.a[row * H + n1] = av; }
-            if (tid < W) {
-                const float cv = s_c[tid];
-                tp.zr[row * W + tid] = cv;
-                tp.c[row * W + tid] = (t == 0) ? sig_cb : cv;
-            }
-        }
-        float ghv = bhh + dpp_group_sum<2>(dot4<J3H>(whh, s_h + h3 * 4, 8));      // GRU hidden-side product (independent of z)
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 0);                       // B1
-        // ===== (2) sender logits + sample
-        {
-            float acc = dpp_group_sum<LB>(dot4<JB>(wb, s_a + kpb * 4, 4 * LB));
-            if (kpb == 0) {
-                const float lz = acc + bb;
-                float zz = lz, pp = 0.f;
-                if (binary) {
-                    pp = fsigmoid(lz);
-                    zz = train ? ((s_uz[t * W + nb] < pp) ? 1.f : 0.f) : rintf(pp);
-                    tp.pz[row * W + nb] = pp;
-                }
-                s_z[nb] = zz; s_zT[t * W + nb] = zz; s_pzT[t * W + nb] = pp;
-                tp.z[row * W + nb] = zz;
-            }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 1);                       // B2
-        // ===== (3 + 4) GRU gate pre-activations and state update in ONE phase: the r / u sums travel to the unit's n lane by DPP
-        // row shifts (slots 0, 2 -> slot 4), which then forms the new state
-        {
-            const float giv = bih + dpp_group_sum<2>(dot4<J3I>(wih, s_z + h3 * 4, 8));
-            const float xs = giv + ghv;
-            const float xr = dpp_f<0x114>(xs);                             // row_shr:4  (slot 4 <- slot 0)
-            const float xu = dpp_f<0x112>(xs);                             // row_shr:2  (slot 4 <- slot 2)
-            if (q3 == 4) {
-                const float rr = fsigmoid(xr);
-                const float uu = fsigmoid(xu);
-                const float ghn = ghv;
-                const float nn = ftanh(giv + rr * ghn);
-                const float hv = nn + uu * (s_h[j3] - nn);
-                float* gr = tp.gru + row * 4 * R;
-                gr[j3] = rr; gr[R + j3] = uu; gr[2 * R + j3] = nn; gr[3 * R + j3] = ghn;
-                tp.h[((size_t)(t + 1) * B + b) * R + j3] = hv;
-                s_h[j3] = hv;
-            }
-        }
-        MMG_STAMP(8 + 10 * t + 2);
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 3);                       // B4
-        // ===== (5) heads on h
-        float gpre_h;
-        {
-            const float accA = dpp_group_sum<L4>(dot4<J4>(wy1, s_h + kp4 * 4, 4 * L4));
-            const float accH = dpp_group_sum<L4>(dot4<J4>(wh, s_h + kp4 * 4, 4 * L4));
-            if (kp4 == 0) s_A[n4] = accA;
-            gpre_h = accH + bh;
-        }
-        if (wave == 7) {                                                   // stop head on an otherwise lightly loaded wave
-            const float sv = dpp_wave_sum(ws * s_h[lane]);
-            if (lane == 0) {
-                const float p = fsigmoid(sv + bs);
-                float sbit;
-                if (train) {
-                    sbit = (s_us[t] < p) ? 1.f : 0.f;
-                } else {
-                    const float prod = dm.s_prob_prod ? s_misc[2] * p : p;
-                    s_misc[2] = prod;
-                    sbit = rintf(prod);
-                }
-                s_misc[3] = sbit;                                          // (the barrier is waiting for this wave)
-                tp.s[row] = sbit; tp.ps[row] = p;
-                s_psT[t] = p; s_sbT[t] = sbit;                             // (log terms: after the conversation)
-            }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 4);                       // B5
-        // ===== (6) class logits
-        {
-            const float4 a4 = *reinterpret_cast<const float4*>(s_A + kpy * 4);
-            float acc = w2[0] * fmax_nn(a4.x + cd[0], 0.f);
-            acc = fmaf(w2[1], fmax_nn(a4.y + cd[1], 0.f), acc);
-            acc = fmaf(w2[2], fmax_nn(a4.z + cd[2], 0.f), acc);
-            acc = fmaf(w2[3], fmax_nn(a4.w + cd[3], 0.f), acc);
-            acc = dpp_group_sum<LY>(acc);
-            if (kpy == 0) {
-                const float yv = (dy < Dr) ? acc + b2 : -3.0e38f;
-                s_y[dy] = yv;
-                if (dy < Dr) tp.y[row * Dr + dy] = yv;
-            }
-        }
-        const float m_t = s_misc[0], sbit = s_misc[3];
-        const float m_next = fminf(m_t, sbit);
-        const bool first_stop = (m_next == 0.f) && (s_misc[1] < 0.f);
-        const bool take_out = dm.fixed ? (t == T - 1) : (first_stop || ((t == T - 1) && (s_misc[1] < 0.f)));
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 5);                       // B6
-        if (take_out && tid < 32) s_yout[tid] = s_y[tid];
-        if (tid == 0) {
-            tp.mask[(size_t)(t + 1) * B + b] = (uint8_t)(m_next != 0.f);
-            if (take_out) s_misc[1] = (float)t;
-            s_misc[0] = m_next;
-        }
-        if (!ar.run_all && !dm.fixed && train && m_next == 0.f) { t_done = t + 1; w_done = t; __syncthreads(); break; }
-        // ===== (7) softmax (per wave, lanes < 32) -> wave-private LDS -> description mixture (2 lanes per column)
-        {
-            const float yv = (lane < 32) ? s_y[lane] : -3.0e38f;
-            float mx = fmaxf(yv, dpp_f<MMG_DPP_QUAD_1032>(yv)); mx = fmaxf(mx, dpp_f<MMG_DPP_QUAD_2301>(mx));
-            mx = fmaxf(mx, dpp_f<MMG_DPP_ROW_HALF_MIRROR>(mx)); mx = fmaxf(mx, dpp_f<MMG_DPP_ROW_MIRROR>(mx));   // per 16-lane row
-            const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 0));
-            const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 16));
-            const float mxx = fmaxf(m0, m1);                               // classes live in lanes 0..31 only
-            const float e = (lane < Dr) ? __expf(yv - mxx) : 0.f;
-            const float rs = dpp_group_sum<16>(e);
-            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 0));
-            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 16));
-            const float inv = __builtin_amdgcn_rcpf(s0 + s1);
-            if (lane < 32) s_pi[wave][lane] = e * inv;
-            __builtin_amdgcn_wave_barrier();
-            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-#pragma unroll
-            for (int j = 0; j + 2 < DH; j += 3) {
-                q0 = fmaf(s_pi[wave][h7 * DH + j], dcol[j], q0);
-                q1 = fmaf(s_pi[wave][h7 * DH + j + 1], dcol[j + 1], q1);
-                q2 = fmaf(s_pi[wave][h7 * DH + j + 2], dcol[j + 2], q2);
-            }
-#pragma unroll
-            for (int j = DH - DH % 3; j < DH; ++j) q0 = fmaf(s_pi[wave][min(h7 * DH + j, 31)], dcol[j], q0);
-            const float acc = dpp_group_sum<2>((q0 + q1) + q2);
-            if (h7 == 0 && v7 < V) { s_dbar[v7] = acc; tp.dbar[row * V + v7] = acc; }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 6);                       // B7
-        // ===== (8) h_w = tanh(w_h h + b_h + w_d dbar)
-        {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int j = 0; j + 3 < JD; j += 4) {
-                a0 = fmaf(wd[j], s_dbar[min(kp4 + L4 * j, V - 1)], a0); a1 = fmaf(wd[j + 1], s_dbar[min(kp4 + L4 * (j + 1), V - 1)], a1);
-                a2 = fmaf(wd[j + 2], s_dbar[min(kp4 + L4 * (j + 2), V - 1)], a2); a3 = fmaf(wd[j + 3], s_dbar[min(kp4 + L4 * (j + 3), V - 1)], a3);
-            }
-#pragma unroll
-            for (int j = JD & ~3; j < JD; ++j) a0 = fmaf(wd[j], s_dbar[min(kp4 + L4 * j, V - 1)], a0);
-            const float acc = dpp_group_sum<L4>((a0 + a1) + (a2 + a3));
-            if (kp4 == 0) {
-                const float gv = ftanh(gpre_h + acc);
-                s_g[n4] = gv;
-                tp.g[row * R + n4] = gv;
-            }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 7);                       // B8
-        // ===== (9) receiver message
-        {
-            float acc = dpp_group_sum<LB>(dot4<JW>(ww, s_g + kpb * 4, 4 * LB));
-            if (kpb == 0) {
-                const float lw = acc + bw;
-                float wv = lw, pp = 0.f;
-                if (binary) {
-                    pp = fsigmoid(lw);
-                    wv = train ? ((s_uw[t * W + nb] < pp) ? 1.f : 0.f) : rintf(pp);
-                    tp.pw[row * W + nb] = pp;
-                }
-                s_c[nb] = wv; s_wT[t * W + nb] = wv; s_pwT[t * W + nb] = pp;
-                tp.w[row * W + nb] = wv;
-            }
-        }
-        __syncthreads(); MMG_STAMP(8 + 10 * t + 8);                       // B9
-    }
-    __syncthreads();
-    MMG_STAMP(3);
-#ifdef MMG_TIMING
-    if (b == 0 && tid == 0) tp.dbg[5] = (long long)__builtin_readcyclecounter();
-#endif
-    // ------------------------------------------------------------ log-likelihood / neg-entropy sums of all steps (model.py:908-922)
-    {
-        const int tt = tid >> 5, j = tid & 31;                              // one (step, bit) per thread
-        if (binary) {
-            float lz = 0.f, nz = 0.f, lw = 0.f, nw = 0.f;
-            if (tt < t_done) {
-                const float p = s_pzT[tid], q = s_zT[tid];
-                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                lz = q * l1 + (1.f - q) * l0; nz = p * l1 + (1.f - p) * l0;
-            }
-            if (tt < w_done) {
-                const float p = s_pwT[tid], q = s_wT[tid];
-                const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-                lw = q * l1 + (1.f - q) * l0; nw = p * l1 + (1.f - p) * l0;
-            }
-            lz = group_sum(lz, 32); nz = group_sum(nz, 32); lw = group_sum(lw, 32); nw = group_sum(nw, 32);
-            if (j == 0 && tt < t_done) { tp.lp_z[(size_t)tt * B + b] = lz; tp.ne_z[(size_t)tt * B + b] = nz; }
-            if (j == 0 && tt < w_done) { tp.lp_w[(size_t)tt * B + b] = lw; tp.ne_w[(size_t)tt * B + b] = nw; }
-        }
-        if (tid < t_done) {
-            const float p = s_psT[tid], sb = s_sbT[tid];
-            const float l1 = flog(p + MMG_EPS), l0 = flog(1.f - p + MMG_EPS);
-            tp.lp_s[(size_t)tid * B + b] = sb * l1 + (1.f - sb) * l0;
-            tp.ne_s[(size_t)tid * B + b] = p * l1 + (1.f - p) * l0;
-        }
-    }
-    // ------------------------------------------------------------ output selection / reward / top-k
-    const int tstar = dm.fixed ? (T - 1) : (int)s_misc[1];
-    if (tid < 64) {
-        const float o = (lane < 32) ? s_yout[lane] : -3.0e38f;
-        const float mx = dpp_wave_max(o);
-        const float e = (lane < Dr) ? __expf(o - mx) : 0.f;
-        const float lse = mx + flog(dpp_wave_sum(e));
-        const int tgt = ar.target ? (int)ar.target[b] : -1;
-        const float dt = (tgt >= 0) ? (__shfl(o, tgt, 64) - lse) : 0.f;
-        const float ld = o - lse;
-        if (lane < Dr) {
-            tp.outp[(size_t)b * Dr + lane] = o;
-            tp.dist[(size_t)b * Dr + lane] = ld;
-            tp.sm[(size_t)b * Dr + lane] = __expf(ld);
-        }
-        const float above = dpp_wave_sum((lane < Dr && tgt >= 0 && ld > dt) ? 1.f : 0.f);
-        if (lane == 0) {
-            tp.tstar[b] = tstar;
-            tp.logs[b] = dt;
-            tp.hit[b] = (tgt >= 0 && above < (float)dm.top_k) ? 1 : 0;
-        }
-    }
 }
 
 }  // namespace mmg

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp
     // ================================================================ the reverse pass's weight fragments: requested NOW, in the order
     // of their use (sweep 1: W_w, binary_layer; y1^T; sweep 2: W_h; the recurrence: W_hh^T -- loads return in order, so the first
     // sweep starts on a third of the bytes), they arrive under epilogue 2.  `wrep` was written through by prep roles of this
-    // launch ~20 us ago; their "through" pairs are checked below.
+    // launch ~20 us ago; their "through" pairs are awaited first.
     constexpr int K4 = NT / R;
     const int k4 = tid / K4, p4 = tid % K4;
     float whhT[3 * R / K4], wwF[W / 4], whF[R / 4], wbF[4][W / 4], y1T[R / K4];
@@ -671,7 +671,15 @@ __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp
     constexpr int NTILE_V = (V + 15) / 16;
     {
         static_assert(3 * R / K4 == 48 && R / K4 == 16 && W / 4 == 8 && R / 4 == 16 && MMG_REPACK_F4 == 30, "layout of tape.wrep");
+        // The repack blocks' "through" pairs FIRST (written ~20 us ago: one trip), the plain fragment loads only behind them: a
+        // workgroup that fetched tape.wrep before the repack was through would park the PREVIOUS minibatch's fragments in this
+        // XCD's L2 for every later sample role of the XCD, whose own pair check then passes.  Nothing is in flight
+        // here (the vmcnt(0) above), and the sweeps these fragments feed run in the shadow of the statistics chain.
         u_rep = ld_ll(tp.gamell, (size_t)B + (lane & 7));
+        for (int spins = 0; __any(!ll_fresh(u_rep, epoch)); ) {
+            u_rep = ld_ll(tp.gamell, (size_t)B + (lane & 7));
+            if (++spins > (1 << 16)) { if (lane == 0) __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 9u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
         const float4* wr = reinterpret_cast<const float4*>(tp.wrep) + tid;
         float4 q[MMG_REPACK_F4];
 #pragma unroll
@@ -803,24 +811,6 @@ __global__ __launch_bounds__(256, 1) void k_game_fast(Dims dm, Params P, Tape tp
         s_sbas[t * G::SW + j] = a1; s_sbas[(TMAX + t) * G::SW + j] = a2; s_sbas[(2 * TMAX + t) * G::SW + j] = b1; s_sbas[(3 * TMAX + t) * G::SW + j] = b2;
     }
     __syncthreads();
-    // ---- the "through" pairs of the repack blocks (fresh ~20 us ago in every run; a stale one: the fragments are reloaded)
-    {
-        int spins = 0;
-        while (__any(!ll_fresh(u_rep, epoch))) {
-            u_rep = ld_ll(tp.gamell, (size_t)B + (lane & 7));
-            if (++spins > (1 << 16)) { if (lane == 0) __hip_atomic_store(tp.sync + MMG_SYNC_ERR, 9u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-        if (spins > 0) {      // (never taken in practice) the fragments may predate the repack: fetch them again, past the caches
-            const float* wr = tp.wrep + (size_t)tid * 4;
-            auto get = [&](int j) { return ld_cc4(wr + (size_t)j * NT * 4); };
-            auto put = [](float* dst, const float4& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; };
-            for (int j = 0; j < 12; ++j) put(whhT + 4 * j, get(j));
-            for (int j = 0; j < 4; ++j) put(y1T + 4 * j, get(12 + j));
-            for (int j = 0; j < 2; ++j) put(wwF + 4 * j, get(16 + j));
-            for (int j = 0; j < 4; ++j) put(whF + 4 * j, get(18 + j));
-            for (int j = 0; j < 8; ++j) put(&wbF[j >> 1][4 * (j & 1)], get(22 + j));
-        }
-    }
     MMG_GSTAMP(9);
     f32x4 g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f}, p1[4], p2[4];
 #pragma unroll

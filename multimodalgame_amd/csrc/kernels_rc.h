@@ -939,25 +939,16 @@ __global__ __launch_bounds__(256) void k_rc_persist(Dims dm, Params P, Tape tp, 
     }
 }
 
-#ifdef MMG_ROLE_DIAG
-// diagnosis only (scripts/isa_stats.py -D MMG_ROLE_DIAG --kernel k_diag_rc): the roles / bodies of k_rc_persist as kernels of their own,
-// so that register counts and spills can be attributed
-__global__ __launch_bounds__(256) void k_diag_rc_s1(Dims dm, Params P, Tape tp, ConvArgs ar) { rc_s1_role(dm, P, tp, ar, blockIdx.x, 0, 16); }
-__global__ __launch_bounds__(256) void k_diag_rc_s2(Dims dm, Params P, Tape tp, ConvArgs ar) { rc_s2_role(dm, P, tp, ar, blockIdx.x, 0, 16); }
-__global__ __launch_bounds__(256) void k_diag_rc_gru(Dims dm, Params P, Tape tp, ConvArgs ar) { RcGruW w; rc_gru_w(w, dm, P, 0); for (int t = 0; t < dm.T; ++t) rc_gru_body<true>(dm, P, tp, ar, t, blockIdx.x, 0, w); }
-__global__ __launch_bounds__(256) void k_diag_rc_heads(Dims dm, Params P, Tape tp, ConvArgs ar) { RcHeadsW w; rc_heads_w(w, dm, P, tp, 0, true); for (int t = 0; t < dm.T; ++t) rc_heads_body<true>(dm, P, tp, ar, t, blockIdx.x, 0, w); }
-__global__ __launch_bounds__(256) void k_diag_rc_query(Dims dm, Params P, Tape tp, ConvArgs ar) { RcQueryW w; rc_query_w(w, dm, P, 0); for (int t = 0; t < dm.T; ++t) rc_query_body<true>(dm, P, tp, ar, t, blockIdx.x, 0, 0, w); }
-#endif
+// (scripts/isa_stats.py -D MMG_ROLE_DIAG: the roles of k_rc_persist as kernels of their own -- diag_kernels.h)
 
 // ---------------------------------------------------------------------------------------------
 // k_rc_bwd: the reverse-time loop of k_bwd_tile (same math and tape contract) with a tile's hidden units split over R/16
 // co-resident roles.  A role keeps ITS 16 columns of W_hh (3R x 16 = 48 KB) as MFMA B fragments in registers and the carried
 // dh of its units in a register per thread; per reverse step it gathers the tile's gate gradients dgh_{t+1} (16 x 3R, published
 // by all roles: ONE counter hand-off per step), forms dgh_{t+1} W_hh for its columns, runs the GRU cell backward of its units
-// (model.py:340) and publishes its slice of dgh_t.  The output-step prelude (dy, h*, A*, dA, dA W_y1h) stays k_bwd_tile's
-// (make_map & 2), which also zeroes the tile's counter.
+// (model.py:340) and publishes its slice of dgh_t.
 // ---------------------------------------------------------------------------------------------
-// prelude != 0: the output-step prelude runs HERE too, per 16-unit slice (k_bwd_tile is not launched): every role forms dy of the
+// The output-step prelude (dy, h*, A*, dA, dA W_y1h) runs HERE too, per 16-unit slice (k_bwd_tile is not launched): every role forms dy of the
 // tile (role 0 stores it), ITS 16 columns of A* = W_y1[:, :R] h* and of dA[m][r] = w_y2[r] sum_d dy[m][d] 1[A*[m][r] + Cd[d][r] > 0]
 // -- both local to the slice -- then the roles all-gather dA (hand-off 0) and each forms its columns of dA W_y1h (what enters dh at
 // the sample's output step).  The tile's counter is zeroed by the forward launch (k_rc_persist / k_rc_tail).  prelude & 2: role 0 of
@@ -977,7 +968,7 @@ __global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, cons
     const int ts = (m < nb) ? tp.tstar[b] : -1;                         // padded rows: never live
     float dam;
     int step = 0;
-    if (prelude) {
+    {
         const int D = dm.D, V = dm.V;
         if ((prelude & 2) && blockIdx.x == 0 && tid < 64) build_row_map(dm, tp);        // live (step, sample) rows for k_wgrad / k_send_bwd
         // ---- dNLL/d outp (model.py:1264-1275): thread (m, d = c), (m, c + 16)
@@ -1049,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_rc_bwd(Dims dm, Params P, Tape tp, cons
         __syncthreads();
         dam = (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]);
         __syncthreads();                                                // (s_acc is rewritten by the time loop)
-    } else dam = tp.rcdam[(size_t)b * R + unit];
+    }
     // this wave's K share of the role's 16 columns of W_hh ("NN" form: the PyTorch [out, in] matrix IS [K, N])
     const int kg = R3 >> 4, per = (kg + 3) >> 2, g0 = wave * per, n = max(0, min(kg, g0 + per) - g0);
     float4 wf[12];

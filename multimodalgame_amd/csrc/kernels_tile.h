@@ -2030,7 +2030,7 @@ __device__ __forceinline__ void rs_role(const Dims& dm, const Params& P, const T
 // tile are two kernels -- the tile role needs every one of its 256 registers (and spills a few), the per-sample roles do not,
 // and a workgroup should not carry the code of roles its launch never runs (62 k lines of ISA for the union)
 template <int NT, bool SAMPLE_ROLES, bool LL = false>
-__global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles, int xcd_map) {
+__global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp, ConvArgs ar, int tiles) {
     int blk = blockIdx.x;
     if (SAMPLE_ROLES && LL) {                           // fused sender roles with (value, epoch) pair hand-offs (host: ar.rsample == 3 only)
         const int cb = ar.b_count, ctile0 = ar.b_begin / MMG_TM, ctiles = (cb + MMG_TM - 1) / MMG_TM;
@@ -2077,16 +2077,8 @@ __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp,
         }
         return;
     }
-    if (xcd_map) {
-        // at most 8 tiles: workgroup i runs on XCD i % 8, so tile x takes the workgroups with i % 8 == x -- all roles of a
-        // tile share one L2 and their hand-offs (payload + counter) never leave it.  grid = 8 x roles per tile.
-        const int tile = blk & 7, slot = blk >> 3;
-        if (tile >= tiles) return;
-        if (slot == 0) conv_tile_body<NT, true>(dm, P, tp, ar, tile);
-        else if (slot <= ar.ns2) s2_role<NT>(dm, P, tp, ar, tile, slot - 1);
-        else s1_role<NT>(dm, P, tp, ar, tile, slot - 1 - ar.ns2);
-        return;
-    }
+    // (a per-XCD placement of a tile's roles -- all hand-offs inside one L2 -- measured SLOWER at config 4, 575 against 527 us per
+    //  minibatch: a load that follows a write-through store in the same L2 took 5-8 us instead of 2.3; deleted in round 6)
     if (blk < tiles) { conv_tile_body<NT, true>(dm, P, tp, ar, blk); return; }
     const int r = blk - tiles;
     if (r < tiles * ar.ns2) { s2_role<NT>(dm, P, tp, ar, r / ar.ns2, r % ar.ns2); return; }
@@ -2094,24 +2086,7 @@ __global__ __launch_bounds__(NT) void k_conv_persist(Dims dm, Params P, Tape tp,
     s1_role<NT>(dm, P, tp, ar, q / ar.ns1, q % ar.ns1);
 }
 
-#ifdef MMG_ROLE_DIAG
-// diagnosis only (scripts/isa_stats.py -D MMG_ROLE_DIAG --kernel k_diag): every role of k_conv_persist as a kernel of its own,
-// so that register counts / spills can be attributed to a role
-template <int NT> __global__ __launch_bounds__(NT) void k_diag_sa(Dims dm, Params P, Tape tp, ConvArgs ar) { sa_role<NT>(dm, P, tp, ar, blockIdx.x, 0); }
-template <int NT> __global__ __launch_bounds__(NT) void k_diag_sb(Dims dm, Params P, Tape tp, ConvArgs ar) { sb_role<NT>(dm, P, tp, ar, blockIdx.x, 0); }
-template <int NT> __global__ __launch_bounds__(NT) void k_diag_s1(Dims dm, Params P, Tape tp, ConvArgs ar) { s1_role<NT>(dm, P, tp, ar, blockIdx.x, 0); }
-template <int NT> __global__ __launch_bounds__(NT) void k_diag_s2(Dims dm, Params P, Tape tp, ConvArgs ar) { s2_role<NT>(dm, P, tp, ar, blockIdx.x, 0); }
-template <int NT> __global__ __launch_bounds__(NT) void k_diag_rs256(Dims dm, Params P, Tape tp, ConvArgs ar) { rs_role<NT, 64, 100, 30, 256>(dm, P, tp, ar, blockIdx.x); }
-template <int NT> __global__ __launch_bounds__(NT) void k_diag_rs0(Dims dm, Params P, Tape tp, ConvArgs ar) { rs_role<NT, 64, 100, 30, 0>(dm, P, tp, ar, blockIdx.x); }
-template <int NT> __global__ __launch_bounds__(NT) void k_diag_body(Dims dm, Params P, Tape tp, ConvArgs ar) { conv_tile_body<NT, true>(dm, P, tp, ar, blockIdx.x); }
-template __global__ void k_diag_sa<512>(Dims, Params, Tape, ConvArgs);
-template __global__ void k_diag_sb<512>(Dims, Params, Tape, ConvArgs);
-template __global__ void k_diag_s1<512>(Dims, Params, Tape, ConvArgs);
-template __global__ void k_diag_s2<512>(Dims, Params, Tape, ConvArgs);
-template __global__ void k_diag_rs256<512>(Dims, Params, Tape, ConvArgs);
-template __global__ void k_diag_rs0<512>(Dims, Params, Tape, ConvArgs);
-template __global__ void k_diag_body<512>(Dims, Params, Tape, ConvArgs);
-#endif
+// (scripts/isa_stats.py -D MMG_ROLE_DIAG: every role of k_conv_persist as a kernel of its own -- diag_kernels.h)
 
 // ---------------------------------------------------------------------------------------------
 // Per-step sender launches (large sender MLP, few samples: BASELINE config 4).  One workgroup per 16x16 output tile,
@@ -2302,7 +2277,7 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
         const int tid = threadIdx.x;
         for (int i = tid; i < L.total; i += NT) smem[i] = 0.f;
         __syncthreads();
-        if ((make_map & 1) && blockIdx.x == 0 && tid < 64) build_row_map(dm, tp);       // live (step, sample) rows for k_wgrad / k_send_bwd
+        if (make_map && blockIdx.x == 0 && tid < 64) build_row_map(dm, tp);       // live (step, sample) rows for k_wgrad / k_send_bwd
         if (tid < MMG_TM) {
             const int b = min(b0 + tid, B - 1);
             misc[BL_TSTAR + tid] = (tid < nb) ? (float)tp.tstar[b] : -1.f;          // padded rows: never live
@@ -2448,13 +2423,9 @@ __global__ __launch_bounds__(NT) void k_bwd_tile(Dims dm, Params P, Tape tp, con
         for (int idx = tid; idx < MMG_TM * R; idx += NT) {
             const int m = idx / R, i = idx - m * R;
             s_dAm[m * L.ldR + i] = raw_sum(raw0, L.ldR, kp, m, i);
-            // (make_map & 2: the reverse-time loop runs as k_rc_bwd's roles, kernels_rc.h -- dAy and a zeroed hand-off counter go out)
-            if ((make_map & 2) && m < nb) tp.rcdam[(size_t)(b0 + m) * R + i] = s_dAm[m * L.ldR + i];
         }
-        if ((make_map & 2) && tid == 0) tp.rcflags[(size_t)blockIdx.x * 64] = 0u;
         __syncthreads();
     }
-    if (make_map & 2) return;
     // ---------------- W_hh in [K][N + 4] layout in LDS (the dy tile is dead now): the loop's only product reads no weight from L2
     if (L.whh >= 0) {
         const int stride = R + 4, n4 = R >> 2;

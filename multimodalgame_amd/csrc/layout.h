@@ -98,9 +98,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(rcgw, float, 0, 2, NRCT16, R, 1)   /* wide receiver (kernels_rc.h): w_h h + b_h of the step, [tile][R/16][r][q][16]: the query phase's MFMA accumulator order */ \
     X(rcyp, float, 0, 3, NRCT16, 32, 16) /* ... per-slice partial class logits [tile][slice quad][16 samples][32 classes][4], added in slice order by k_rc_query */ \
     X(rclw, float, 0, 3, 2 * NRCW, NRCB, 2)  /* ... per-16-bit-slice partial (log-likelihood, neg-entropy) of the receiver's message            */ \
-    X(rcdam, float, 0, 2, NRCB, R, 1)    /* ... backward: dA W_y1h of the output step (k_bwd_tile's prelude -> k_rc_bwd)                                */ \
     X(rcx, float, 0, 3, NRCX, 16, 3 * R) /* ... backward: the tile's gate gradients dgh_t, double-buffered by step parity (all-gather between k_rc_bwd's roles) */ \
-    X(rcflags, uint32_t, 2, 1, 64 * 64, 1, 1) /* ... backward: one hand-off counter per sample tile (256-byte blocks), zeroed by k_bwd_tile's prelude */ \
+    X(rcflags, uint32_t, 2, 1, 64 * 64, 1, 1) /* ... backward: one hand-off counter per sample tile (256-byte blocks), zeroed by the forward launch (k_rc_persist / k_rc_tail) */ \
     X(rcxa, float, 0, 3, NRCA, 16, 16)   /* ... the sender's hidden tile a_t in FRAGMENT order [tile][H/16 k-groups][16 samples][16]: a wave of an S2 role reads a k-group's 1 KB contiguously */ \
     X(rcxz, float, 0, 3, NRCZ, 16, 16)   /* ... z_t in fragment order [tile][W/16][16][16] (S2 roles -> GRU slices)                              */ \
     X(rcxw, float, 0, 3, NRCZ, 16, 16)   /* ... w_t in fragment order [tile][W/16][16][16] (message slices -> S1 roles)                        */ \

@@ -33,6 +33,11 @@ class DataParallel(object):
         if direct:
             from . import rccl
             self.comm = rccl.try_create(engine.device, group)
+        # the whole step in ONE C call when the collectives are RCCL's on the engine's stream (include/mmg.h: mmg_dp_train_step)
+        self.in_library = False
+        if self.comm is not None and hasattr(engine, "set_allreduce"):
+            engine.set_allreduce(self.comm.all_reduce_address(), self.comm.comm)
+            self.in_library = True
 
     def _all_reduce(self, tensor):
         if self.comm is not None:
@@ -44,6 +49,9 @@ class DataParallel(object):
         """full_tape: every sample runs all steps and the whole tape is stored (the minibatches whose log block reads it,
         model.py:1342-1542); same update."""
         e = self.engine
+        if self.in_library:
+            e.dp_train_step(x, target, desc, u_z, u_s, u_w, seed=seed, full_tape=full_tape, reduce=self.world > 1)
+            return
         e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=bool(full_tape), minimal=not full_tape)
         if e.use_binary:
             e.loss_stats()
@@ -53,6 +61,17 @@ class DataParallel(object):
         if self.world > 1:
             self._all_reduce(e.flat_grads)
         e.clip_step()
+
+
+    def train_steps(self, x, target, desc, n, seed=0):
+        """n consecutive minibatches (this rank's rows of each, batch-ordered) -- one C call when the collectives run in the library."""
+        e = self.engine
+        if self.in_library:
+            e.dp_train_steps(x, target, desc, n, seed=seed, reduce=self.world > 1)
+            return
+        B = x.size(0) // n
+        for i in range(n):
+            self.train_step(x[i * B:(i + 1) * B], target[i * B:(i + 1) * B], desc, seed=seed)
 
 
 def shard_range(global_batch, rank, world):

@@ -123,6 +123,39 @@ class Engine(object):
             self.handle, self._ptr(x, f32), self._ptr(target, torch.int64), self._ptr(desc, f32),
             self._ptr(u_z, f32), self._ptr(u_s, f32), self._ptr(u_w, f32), C.c_uint64(seed), self._stream()))
 
+    def train_steps(self, x, target, desc, n, seed=0):
+        """n consecutive minibatches enqueued by ONE C call: x [n * B, F], target [n * B] = the epoch's samples in batch order
+        (include/mmg.h: mmg_train_steps)."""
+        B = self.cfg.batch
+        assert x.size(0) >= n * B and target.size(0) >= n * B
+        _lib.check(self.lib.mmg_train_steps(self.handle, self._ptr(x, torch.float32), self._ptr(target, torch.int64), int(n),
+                                            self._ptr(desc, torch.float32), C.c_uint64(seed), self._stream()))
+
+    def set_allreduce(self, fn_address, comm):
+        """RCCL's ncclAllReduce by address + a communicator: the data-parallel step then runs inside ONE C call (dp_train_step)."""
+        _lib.check(self.lib.mmg_dp_set_allreduce(self.handle, C.c_void_p(fn_address), comm))
+
+    def dp_train_step(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0, full_tape=False, reduce=True):
+        f32 = torch.float32
+        _lib.check(self.lib.mmg_dp_train_step(
+            self.handle, self._ptr(x, f32), self._ptr(target, torch.int64), self._ptr(desc, f32),
+            self._ptr(u_z, f32), self._ptr(u_s, f32), self._ptr(u_w, f32), C.c_uint64(seed), int(bool(full_tape)), int(bool(reduce)),
+            self._stream()))
+
+    def dp_train_steps(self, x, target, desc, n, seed=0, reduce=True):
+        B = self.cfg.batch
+        assert x.size(0) >= n * B and target.size(0) >= n * B
+        _lib.check(self.lib.mmg_dp_train_steps(self.handle, self._ptr(x, torch.float32), self._ptr(target, torch.int64), int(n),
+                                               self._ptr(desc, torch.float32), C.c_uint64(seed), int(bool(reduce)), self._stream()))
+
+    def clear_error(self):
+        """Clear a recorded in-launch dependency error (drains the stream; the selected kernels stay)."""
+        _lib.check(self.lib.mmg_clear_error(self.handle, self._stream()))
+
+    def degraded(self):
+        """0: role launches in use; 1: launches without in-launch waits since mmg_create; 2: ... since a recovery."""
+        return int(self.lib.mmg_degraded(self.handle))
+
     # ------------------------------------------------------------------ agent-level steps
     def sender_forward(self, x, w, t, train, u_z=None, seed=0):
         B, W, H = self.cfg.batch, self.cfg.w_dim, self.cfg.h_dim

@@ -243,6 +243,28 @@ class Game(object):
             eng.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed)
         return eng
 
+    def train_steps(self, data, target, desc, n):
+        """n consecutive plain minibatches (no log block) enqueued by ONE library call: data [n * B, F] / target [n * B] in batch
+        order (misc.Epoch).  Same updates, same sampling streams as n train_step() calls (tests/test_cli_gpu.py)."""
+        B = data.size(0) // n
+        eng = self.train_engine_for(B, desc.size(0))
+        last = getattr(self, "_train_engine", None)
+        if last is not None and last is not eng:
+            eng.tape["counter"][:3].copy_(last.tape["counter"][:3])
+        self._train_engine = eng
+        if self.world > 1:
+            dp = self._dp.get(id(eng))
+            if dp is None:
+                from .dist import DataParallel
+                dp = self._dp[id(eng)] = DataParallel(eng, group=self.group)
+            dp.train_steps(data, target, desc, n, seed=self.seed)
+        elif hasattr(eng, "train_steps"):
+            eng.train_steps(data, target, desc, n, seed=self.seed)
+        else:                                            # (an engine stand-in without the C loop: tests/oracle_engine.py)
+            for i in range(n):
+                eng.train_step(data[i * B:(i + 1) * B], target[i * B:(i + 1) * B], desc, seed=self.seed)
+        return eng
+
     def counters(self):
         """[minibatch counter (Philox stream), optimizer step] of the engine that trained last (checkpointed by model.py)."""
         eng = getattr(self, "_train_engine", None) or self.engine

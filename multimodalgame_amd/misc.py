@@ -328,6 +328,43 @@ def _fits_on_device(data, feats, device, hdf5_file=None):
     return fits
 
 
+class Epoch(object):
+    """One epoch of a device-resident file in the reference's batch order (misc.py:257-302): `feats[name]` [n * B, F] and
+    `target` [n * B] hold the samples of minibatch i in rows [i * B, (i + 1) * B) -- ONE gather per epoch -- so a minibatch is two
+    tensor views and a run of consecutive minibatches is two pointers (include/mmg.h: mmg_train_steps).  Only whole batches
+    (training drops the ragged last one, misc.py:279)."""
+
+    def __init__(self, feats, target, batch):
+        self.feats, self.target, self.B = feats, target, int(batch)
+        self.n = int(target.size(0)) // self.B if self.B else 0
+
+    def batch(self, i):
+        lo, hi = i * self.B, (i + 1) * self.B
+        out = {"target": self.target[lo:hi]}
+        for name, t in self.feats.items():
+            out[name] = t[lo:hi]
+        return out
+
+
+def load_epoch(hdf5_file, batch_size, random_seed, shuffle, map_labels=int, feats=("avgpool_512",), device=None, shard=None):
+    """The training epoch as an Epoch (device-resident loop), or None when the file has to stream from the host
+    (_fits_on_device) -- the caller then iterates load_hdf5.  Same order, same shard rule as load_hdf5."""
+    if device is None:
+        return None
+    data = _dataset(hdf5_file, feats)
+    if not _fits_on_device(data, feats, device, hdf5_file):
+        return None
+    batches = _epoch_order(int(data["Target"].shape[0]), batch_size, random_seed, shuffle, False)
+    per = batch_size
+    if shard is not None and shard[1] > 1:
+        from .dist import shard_range
+        lo, per = shard_range(batch_size, shard[0], shard[1])
+        batches = [idx[lo:lo + per] for idx in batches]
+    res = _resident(hdf5_file, feats, torch.device(device))
+    flat = torch.from_numpy(np.concatenate(batches) if batches else np.zeros(0, np.int64)).to(res.device)
+    return Epoch({name: res.feats[name].index_select(0, flat) for name in feats}, res.targets(map_labels).index_select(0, flat), per)
+
+
 def load_hdf5(hdf5_file, batch_size, random_seed, shuffle, truncate_final_batch=False, map_labels=int,
               feats=("avgpool_512",), device=None, with_ids=True, shard=None):
     """Generator of batch dicts with the reference's order semantics (misc.py:257-302): random.seed(11 + epoch) shuffle of

@@ -15,7 +15,7 @@ from . import flags as _flags
 from .agents import Baseline, Receiver, Sender
 from .flags import FLAGS
 from .game import Game, exchange, get_rec_outp
-from .misc import (FileLogger, VisdomLogger, cbow, embed, load_hdf5, read_data, torch_load, torch_save,
+from .misc import (FileLogger, VisdomLogger, cbow, embed, load_epoch, load_hdf5, read_data, torch_load, torch_save,
                    write_synthetic_dataset)
 from .sparks import sparks
 
@@ -27,6 +27,49 @@ def _desc_matrix(csv_path, glove_path, wv_dim):
     descr = cbow(descr, word_dict)
     desc = torch.cat([descr[i]["cbow"].view(1, -1) for i in descr.keys()], 0)
     return desc, (lambda x: label_id_to_idx.get(x))
+
+
+EVAL_FLUSH_BATCHES = 64     # eval_dev reduces the stacked tape slices every this many dev batches (device memory bound)
+
+
+def _eval_reduce(groups, acc, conv_lens, ham_sen, ham_rec, T, W, n_cls, top_k):
+    """Pass 2 of eval_dev: the reference's per-batch host arithmetic (model.py:648-691) on the device, batched over the dev
+    batches stacked since the last call; accumulates into acc (hit count, confusion matrix, classes seen) and the three lists."""
+    for _bs, g in groups.items():
+        mask = torch.stack(g["mask"]).to(torch.float32)                      # [NB, T + 1, B]: m_0 .. m_T, running minimum of the stop bits
+        NB = mask.size(0)
+        dv = mask.device
+        steps = torch.arange(T, device=dv)
+        if FLAGS.fixed_exchange:
+            n = torch.full((NB,), T, dtype=torch.int64, device=dv)
+            tsel = torch.full((NB, _bs), T - 1, dtype=torch.int64, device=dv)
+        else:
+            dead = mask[:, 1:].sum(2) == 0                                   # [NB, T]: step after which nobody is alive (model.py:866)
+            n = torch.where(dead.any(1), torch.argmax(dead.to(torch.int8), 1) + 1, torch.full((NB,), T, dtype=torch.int64, device=dv))
+            # y_masks[t] = min(1 - m'_{t+1}, m'_t) with m'_n forced to 0 (model.py:870, 1261): the masks are a running minimum
+            # that starts at 1, so the selected step of a sample is the number of t in 1..n-1 with m_t = 1
+            tsel = (mask[:, 1:] * (steps.view(1, T) + 1 < n.view(NB, 1)).to(mask.dtype).view(NB, T, 1)).sum(1).to(torch.int64)
+        live = (steps.view(1, T) < n.view(NB, 1)).to(torch.float32)          # [NB, T]: the steps the reference executed
+        y = torch.stack(g["y"]).to(torch.float32)                            # [NB, T, B, D]
+        outp = y.gather(1, tsel.view(NB, 1, _bs, 1).expand(NB, 1, _bs, y.size(3)))[:, 0]
+        dist = F.log_softmax(outp, dim=2)                                    # [NB, B, D]
+        tgt = torch.stack(g["target"]).to(dv)                                # [NB, B]
+        top_k_ind = dist.topk(min(top_k, dist.size(2)), dim=2).indices       # (= argsort()[:, -top_k:] as a set, model.py:658)
+        c = (top_k_ind == tgt.unsqueeze(2)).sum()
+        acc["correct"] = c if acc["correct"] is None else acc["correct"] + c.to(acc["correct"].device)
+        pred = dist.argmax(2)
+        if acc["conf_flat"] is None:
+            acc["conf_flat"] = torch.zeros(n_cls * n_cls, dtype=torch.int64, device=dv)
+            acc["seen"] = torch.zeros(n_cls, dtype=torch.int64, device=dv)
+        conf_flat, seen = acc["conf_flat"], acc["seen"]
+        conf_flat.index_add_(0, (tgt * n_cls + pred).view(-1), torch.ones(NB * _bs, dtype=torch.int64, device=dv))
+        seen.index_add_(0, torch.cat([tgt.view(-1), pred.view(-1)]), torch.ones(2 * NB * _bs, dtype=torch.int64, device=dv))
+        conv_lens.append((torch.stack(g["s"]).to(torch.float32) * live.view(NB, T, 1)).sum(1).view(-1))
+        for name, hl in (("z", ham_sen), ("w", ham_rec)):
+            msg = torch.stack(g[name]).to(torch.float32)                     # [NB, T, B, W]
+            prev = torch.cat([torch.zeros(NB, 1, _bs, W, device=dv), msg[:, :-1]], 1)
+            per_step = (msg - prev).abs().sum(3).mean(2)                     # [NB, T]: mean over the batch of the Hamming distance
+            hl.append((per_step * live).sum(1) / n.to(torch.float32))       # [NB]: mean over the executed steps (model.py:679, 684)
 
 
 def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels, conf_mat_path, device, dump=None):
@@ -52,6 +95,9 @@ def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels
     groups = {}                                        # batch size -> dict of lists
     total = 0.0
     eng = None
+    acc = dict(correct=None, conf_flat=None, seen=None)
+    conv_lens, ham_sen, ham_rec = [], [], []
+    pending = 0
     for batch in load_hdf5(dev_file, batch_size, epoch, shuffle, truncate_final_batch=True, map_labels=map_labels,
                            feats=(FLAGS.img_feat,), device=device):
         target, data = batch["target"], batch[FLAGS.img_feat]
@@ -63,44 +109,12 @@ def eval_dev(dev_file, batch_size, epoch, shuffle, top_k, game, desc, map_labels
         g["z"].append(tp["z"].view(T, _bs, W).clone()); g["w"].append(tp["w"].view(T, _bs, W).clone())
         g["y"].append(tp["y"].view(T, _bs, -1).clone()); g["target"].append(target.view(-1))
         total += float(batch_size)                                           # model.py:667: the NOMINAL batch size
-    # ---- pass 2: the reference's per-batch host arithmetic (model.py:648-691), batched over all batches of one size
-    correct = None
-    conf_flat, seen = None, None
-    conv_lens, ham_sen, ham_rec = [], [], []
-    for _bs, g in groups.items():
-        mask = torch.stack(g["mask"]).to(torch.float32)                      # [NB, T + 1, B]: m_0 .. m_T, running minimum of the stop bits
-        NB = mask.size(0)
-        dv = mask.device
-        steps = torch.arange(T, device=dv)
-        if FLAGS.fixed_exchange:
-            n = torch.full((NB,), T, dtype=torch.int64, device=dv)
-            tsel = torch.full((NB, _bs), T - 1, dtype=torch.int64, device=dv)
-        else:
-            dead = mask[:, 1:].sum(2) == 0                                   # [NB, T]: step after which nobody is alive (model.py:866)
-            n = torch.where(dead.any(1), torch.argmax(dead.to(torch.int8), 1) + 1, torch.full((NB,), T, dtype=torch.int64, device=dv))
-            # y_masks[t] = min(1 - m'_{t+1}, m'_t) with m'_n forced to 0 (model.py:870, 1261): the masks are a running minimum
-            # that starts at 1, so the selected step of a sample is the number of t in 1..n-1 with m_t = 1
-            tsel = (mask[:, 1:] * (steps.view(1, T) + 1 < n.view(NB, 1)).to(mask.dtype).view(NB, T, 1)).sum(1).to(torch.int64)
-        live = (steps.view(1, T) < n.view(NB, 1)).to(torch.float32)          # [NB, T]: the steps the reference executed
-        y = torch.stack(g["y"]).to(torch.float32)                            # [NB, T, B, D]
-        outp = y.gather(1, tsel.view(NB, 1, _bs, 1).expand(NB, 1, _bs, y.size(3)))[:, 0]
-        dist = F.log_softmax(outp, dim=2)                                    # [NB, B, D]
-        tgt = torch.stack(g["target"]).to(dv)                                # [NB, B]
-        top_k_ind = dist.topk(min(top_k, dist.size(2)), dim=2).indices       # (= argsort()[:, -top_k:] as a set, model.py:658)
-        c = (top_k_ind == tgt.unsqueeze(2)).sum()
-        correct = c if correct is None else correct + c.to(correct.device)
-        pred = dist.argmax(2)
-        if conf_flat is None:
-            conf_flat = torch.zeros(n_cls * n_cls, dtype=torch.int64, device=dv)
-            seen = torch.zeros(n_cls, dtype=torch.int64, device=dv)
-        conf_flat.index_add_(0, (tgt * n_cls + pred).view(-1), torch.ones(NB * _bs, dtype=torch.int64, device=dv))
-        seen.index_add_(0, torch.cat([tgt.view(-1), pred.view(-1)]), torch.ones(2 * NB * _bs, dtype=torch.int64, device=dv))
-        conv_lens.append((torch.stack(g["s"]).to(torch.float32) * live.view(NB, T, 1)).sum(1).view(-1))
-        for name, acc in (("z", ham_sen), ("w", ham_rec)):
-            msg = torch.stack(g[name]).to(torch.float32)                     # [NB, T, B, W]
-            prev = torch.cat([torch.zeros(NB, 1, _bs, W, device=dv), msg[:, :-1]], 1)
-            per_step = (msg - prev).abs().sum(3).mean(2)                     # [NB, T]: mean over the batch of the Hamming distance
-            acc.append((per_step * live).sum(1) / n.to(torch.float32))       # [NB]: mean over the executed steps (model.py:679, 684)
+        pending += 1
+        if pending >= EVAL_FLUSH_BATCHES:              # bound the stacked tape copies (a 1000-class dev set of 50k samples would hold GBs)
+            _eval_reduce(groups, acc, conv_lens, ham_sen, ham_rec, T, W, n_cls, top_k)
+            groups, pending = {}, 0
+    _eval_reduce(groups, acc, conv_lens, ham_sen, ham_rec, T, W, n_cls, top_k)
+    correct, conf_flat, seen = acc["correct"], acc["conf_flat"], acc["seen"]
     # ---- ONE copy to the host
     correct_h = int(correct.item()) if correct is not None else 0
     conf_full = conf_flat.view(n_cls, n_cls).cpu().numpy() if conf_flat is not None else np.zeros((n_cls, n_cls), np.int64)
@@ -305,6 +319,40 @@ def _run(stats, flogger, device, rank, world):
             stats.update(train_seconds=_time.perf_counter() - t_loop - eval_seconds, minibatches=steps_run,
                          exchange_steps=tot[0] - totals0[0], sample_steps=tot[3] - totals0[3],
                          eval_seconds=eval_seconds, evals=n_evals)
+    def special(s):
+        """A minibatch the host handles itself: it writes a log block (run-all tape), is followed by a dev evaluation or by a
+        checkpoint (model.py:1342, 1545, 1579) -- evaluated identically on every rank."""
+        return (s % FLAGS.log_interval == 0 or s % FLAGS.log_dev == 0
+                or (s >= FLAGS.save_after and s % FLAGS.save_interval == 0))
+
+    def epoch_items():
+        """(i_batch, batch, n) in the reference's order (misc.py:257-302).  Device-resident epoch (misc.load_epoch): a RUN of n
+        consecutive plain minibatches comes as ONE item -- batch = (features [n * B, F], targets [n * B]) -- and is enqueued by
+        one library call (include/mmg.h: mmg_train_steps); the special minibatches come one by one (n = 0) as batch dicts.
+        A file that streams from the host yields every minibatch as a dict, as rounds 1-5 did."""
+        ep = None if os.environ.get("MMG_LOOP_PER_STEP") else load_epoch(
+            FLAGS.train_file, FLAGS.batch_size, epoch, FLAGS.shuffle_train, map_labels=map_labels_train,
+            feats=(FLAGS.img_feat,), device=device, shard=(rank, world))
+        if ep is None:
+            for i, b in enumerate(load_hdf5(FLAGS.train_file, FLAGS.batch_size, epoch, FLAGS.shuffle_train,
+                                            map_labels=map_labels_train, feats=(FLAGS.img_feat,), device=device,
+                                            with_ids=False, shard=(rank, world))):
+                yield i, b, 0
+            return
+        i, x_ep, B = 0, ep.feats[FLAGS.img_feat], ep.B
+        while i < ep.n:
+            if special(step):
+                yield i, ep.batch(i), 0
+                i += 1
+                continue
+            n, limit = 1, ep.n - i
+            if FLAGS.max_steps:
+                limit = min(limit, FLAGS.max_steps - step)
+            while n < limit and not special(step + n):
+                n += 1
+            yield i, (x_ep[i * B:(i + n) * B], ep.target[i * B:(i + n) * B]), n
+            i += n
+
     _sync(device)
     t_loop = _time.perf_counter()
     while epoch < FLAGS.max_epoch:
@@ -312,12 +360,21 @@ def _run(stats, flogger, device, rank, world):
         flogger.Log("Starting epoch: {}".format(epoch))
         if FLAGS.images != "mammal":
             raise NotImplementedError                                      # model.py:1211 (cifar branch is broken upstream)
-        for i_batch, batch in enumerate(load_hdf5(FLAGS.train_file, FLAGS.batch_size, epoch, FLAGS.shuffle_train,
-                                                  map_labels=map_labels_train, feats=(FLAGS.img_feat,), device=device,
-                                                  with_ids=False, shard=(rank, world))):
+        for i_batch, batch, n_run in epoch_items():
             if totals0 is None:                      # (the first minibatch creates the engine)
-                totals0 = game.train_engine_for(batch["target"].size(0), desc_train.size(0)).tape["totals"].cpu().tolist()
+                b0 = batch[1].size(0) // n_run if n_run else batch["target"].size(0)
+                totals0 = game.train_engine_for(b0, desc_train.size(0)).tape["totals"].cpu().tolist()
                 log_state["hits_at_log"] = totals0[1]
+            if n_run:                                # a run of plain minibatches: one library call, nothing else to do for them
+                game.train_steps(batch[0], batch[1], desc_train, n_run)
+                steps_run += n_run
+                step += n_run
+                flush_log(False)
+                if FLAGS.max_steps and step >= FLAGS.max_steps:
+                    finish()
+                    flogger.Log("Finished training.")
+                    return
+                continue
             # (a minibatch that writes a log block keeps the whole tape: every sample runs all steps -- same update, see Game.train_step)
             eng = game.train_step(batch[FLAGS.img_feat], batch["target"], desc_train,
                                   full_tape=(step % FLAGS.log_interval == 0))                # model.py:1240-1339
@@ -374,22 +431,10 @@ def _run(stats, flogger, device, rank, world):
     flogger.Log("Finished training.")
 
 
-def _executed_steps(eng, fixed):
-    """Steps the reference's exchange() executes on this batch (model.py:866: break once every sample has stopped)."""
-    T = eng.tape["mask"].size(0) - 1
-    if fixed:
-        return T
-    alive = eng.tape["mask"][1:, :, 0].sum(1).tolist()
-    for t, a in enumerate(alive):
-        if a == 0:
-            return t + 1
-    return T
-
-
 _LOSS_KEYS = ("nll_loss", "loss_binary_s", "loss_binary_rec", "loss_binary_sen", "loss_bas_rec", "loss_bas_sen", "n_steps", "hits")
 
 
-_PINNED = {}
+_PINNED = {}        # (losses, k, numel) -> FREE pinned host buffers; a snapshot handle owns its buffer from begin to end
 
 
 def _log_snapshot_begin(eng, target, dump=0, losses=True):
@@ -426,15 +471,14 @@ def _log_snapshot_begin(eng, target, dump=0, losses=True):
         flat = flat.cpu()
     if flat.is_cuda:
         key = (losses, k, flat.numel())
-        host = _PINNED.get(key)
-        if host is None:
-            host = _PINNED[key] = torch.empty(flat.numel(), dtype=f64, pin_memory=True)
+        free = _PINNED.setdefault(key, [])
+        host = free.pop() if free else torch.empty(flat.numel(), dtype=f64, pin_memory=True)
         host.copy_(flat, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(flat.device))
     else:
         host = flat
-    return dict(host=host, event=ev, n_stats=n_stats, T=T, B=B, k=k, W=W, losses=losses)
+    return dict(host=host, event=ev, n_stats=n_stats, T=T, B=B, k=k, W=W, losses=losses, key=(losses, k, flat.numel()) if ev is not None else None)
 
 
 def _log_snapshot_ready(h):
@@ -445,6 +489,9 @@ def _log_snapshot_end(h):
     if h["event"] is not None:
         h["event"].synchronize()
     flat = h["host"].tolist()
+    if h.get("key") is not None:                       # the pinned buffer goes back to the pool: two pending blocks never share one
+        _PINNED.setdefault(h["key"], []).append(h["host"])
+        h["key"] = None
     T, B, k, W, n_stats = h["T"], h["B"], h["k"], h["W"], h["n_stats"]
     out = dict(T=T, B=B)
     o = 0
@@ -500,11 +547,6 @@ def _entropy_lines(eng, target, L, snap=None):
             msg += "\n{}. {}".format(i, -e)
         out.append(msg + "\n")
     return out
-
-
-def _sample_dump(eng, title, n):
-    """model.py:1415-1461 / 1463-1518 straight from an engine's tape (synchronous): see _sample_dump_snap."""
-    return _sample_dump_snap(_log_snapshot_end(_log_snapshot_begin(eng, None, dump=FLAGS.exchange_samples, losses=False))["dump"], title, n)
 
 
 def _executed_steps_snap(d, fixed, T):

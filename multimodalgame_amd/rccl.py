@@ -61,6 +61,10 @@ class RcclComm(object):
         self._check(self.lib.ncclAllReduce(C.c_void_p(tensor.data_ptr()), C.c_void_p(tensor.data_ptr()), tensor.numel(),
                                            _DTYPES[tensor.dtype], _NCCL_SUM, self.comm, C.c_void_p(stream)), "ncclAllReduce")
 
+    def all_reduce_address(self):
+        """Address of RCCL's ncclAllReduce: libmmg calls it on this communicator from inside mmg_dp_train_step."""
+        return C.cast(self.lib.ncclAllReduce, C.c_void_p).value
+
     def close(self):
         if self.comm:
             self.lib.ncclCommDestroy(self.comm)

@@ -27,9 +27,7 @@ print("tstar[0] =", int(eng.tape["tstar"][0]), " prologue(weights->regs) %.2f us
 if dbg[126] > t0:
     print("   reloads of the (value, epoch) pairs, all waves of all sample roles, 6 launches: %d" % dbg[118])
     print("   prep roles of the launch, relative to sample role 0's start: class block 0 done %+.2f us | hw0 block 0 %+.2f | h_x tile 0 %+.2f | last h_x tile %+.2f | sample 0 holds their pairs %+.2f" % tuple((dbg[k] - t0) * tick / 1e3 for k in (123, 127, 124, 125, 126)))
-names = ["(1)sender a", "(2)logits+sample", "(3)gates", "(4)h", "(5)heads", "(6)y", "(7)softmax.desc", "(8)g", "(9)w"]
-if not os.environ.get("MMG_FAST2"):      # k_conversation_fast3: seven phases
-    names = ["P1 code->a", "P2 bin->z", "P3 GRU", "P4 A|w_h h", "P5 y+stop+gh_r", "P6 softmax->g+gh_u", "P7 w+gh_n"]
+names = ["P1 code->a", "P2 bin->z", "P3 GRU", "P4 A|w_h h", "P5 y+stop+gh_r", "P6 softmax->g+gh_u", "P7 w+gh_n"]
 for st in range(int(eng.tape["tstar"][0]) + 1):
     base = 8 + 10 * st
     prev = dbg[base + 9]

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), "libmmg.so does not export " + sym
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    assert lib.mmg_version() == 2
+    assert lib.mmg_version() == 3
 
 
 def test_param_table_matches_reference_inventory():

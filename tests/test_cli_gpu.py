@@ -182,3 +182,35 @@ def test_deferred_log_block_equals_the_synchronous_one(tmp_path, monkeypatch):
     diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y and "<tmp>" not in x]
     assert not diff, diff[:5]
     assert sum(1 for l in a if "Training Accuracy" in l) == 8 and any("Eval:" in l for l in a)
+
+
+def test_runs_of_minibatches_in_one_library_call_write_the_same_log(tmp_path, monkeypatch):
+    """Round 6: model.run() hands every run of plain minibatches between two log / evaluation / checkpoint steps to ONE library call
+    (mmg_train_steps over the epoch's batch-ordered gather, misc.Epoch); MMG_LOOP_PER_STEP=1 keeps the per-minibatch loop of rounds
+    1-5 (a Python generator step + one ctypes call per minibatch).  Same seed, same data: identical log files line by line and
+    identical checkpoints, across an epoch boundary (46 minibatches per epoch) and a resume."""
+    from multimodalgame_amd import model, flags
+    logs, cks = {}, {}
+    for name, per_step in (("runs", None), ("per_step", "1")):
+        tmp = str(tmp_path / name)
+        if per_step:
+            monkeypatch.setenv("MMG_LOOP_PER_STEP", per_step)
+        flags.define_flags(); flags.FLAGS.Reset()
+        extra = ["-max_epoch", "3", "-log_interval", "7", "-log_dev", "40", "-save_after", "20", "-save_interval", "20"]
+        model.main(_argv(tmp, "run", extra + ["-max_steps", "61"]))
+        flags.FLAGS.Reset()
+        model.main(_argv(tmp, "run", extra + ["-max_steps", "75"]))           # resumes from step 60's checkpoint
+        flags.FLAGS.Reset()
+        text = open(os.path.join(tmp, "logs", "run.log")).read()
+        logs[name] = [re.sub(r"^\d\d-\d\d-\d\d \d\d:\d\d:\d\d ", "", l) for l in text.replace(tmp, "<tmp>").splitlines() if "Flag Values" not in l]
+        cks[name] = torch.load(os.path.join(tmp, "logs", "run.pt"), weights_only=False)
+    monkeypatch.delenv("MMG_LOOP_PER_STEP")
+    a, b = logs["runs"], logs["per_step"]
+    assert len(a) == len(b) and len(a) > 200
+    diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y and "<tmp>" not in x]
+    assert not diff, diff[:5]
+    assert any("Starting epoch: 1" in l for l in a) and any("Loaded at step: 60" in l for l in a)
+    assert cks["runs"]["data"] == cks["per_step"]["data"]
+    for agent, sd in cks["runs"]["models"].items():
+        for k, v in sd.items():
+            assert torch.equal(v, cks["per_step"]["models"][agent][k]), (agent, k)

@@ -89,15 +89,14 @@ def test_config4_fused_train_step_ragged_and_chunked(batch):
     common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused-b%d" % batch, skip=("y2.bias",))
 
 
-@pytest.mark.parametrize("switch", [None, "MMG_NO_RC_PERSIST", "MMG_NO_RC_BWD", "MMG_RC_TILE_PRELUDE", "MMG_NO_PRE_BANDS"])
+@pytest.mark.parametrize("switch", [None, "MMG_NO_RC_PERSIST", "MMG_NO_RC_BWD"])
 def test_config4_with_rec_hidden_256_vs_oracle(switch, monkeypatch):
     """'rec_w_dim 256 / img_h_dim 1024 ... use R = 64 and additionally report R = 256'.  At R = 256 the
     one-workgroup-per-tile forward does not fit its LDS plan: the receiver of a tile is split over workgroups by 16-unit slices on
     the matrix cores (kernels_rc.h) -- one launch of co-resident roles (k_rc_persist), or with the switch k_rc_gru / k_rc_heads /
     k_rc_query between the per-step sender launches; the backward on the tile kernels, its reverse-time loop as roles over
-    16-unit slices (k_rc_bwd, which also runs the output-step prelude per slice; MMG_RC_TILE_PRELUDE: the prelude as k_bwd_tile's
-    launch; MMG_NO_RC_BWD: all of it inside k_bwd_tile; MMG_NO_PRE_BANDS: k_bwd_pre without its column bands); B = 64 as the bench
-    times it."""
+    16-unit slices (k_rc_bwd, which also runs the output-step prelude per slice; MMG_NO_RC_BWD: all of it inside k_bwd_tile);
+    B = 64 as the bench times it."""
     if switch:
         monkeypatch.setenv(switch, "1")
     meta = _meta(dict(C4, rec_hidden=256, batch_size=64), 30, 64, 2)
