@@ -146,7 +146,7 @@ class Sender(nn.Module):
             if self.training:                                     # model.py:224-227
                 probs_ = probs.detach().cpu().numpy()
                 binary = torch.from_numpy(
-                    (self.rng.rand("z", *probs_.shape) < probs_).astype("float32"))
+                    (self.rng.rand("z", *probs_.shape) < probs_).astype(probs_.dtype))      # (float32; float64 in a double re-run)
             else:
                 binary = torch.round(probs).detach()              # model.py:229
             return binary, probs
@@ -216,7 +216,7 @@ class Receiver(nn.Module):
         if self.training:                                         # model.py:416-420
             prob_ = s_prob.detach().cpu().numpy()
             s_binary = torch.from_numpy(
-                (self.rng.rand("s", *prob_.shape) < prob_).astype("float32"))
+                (self.rng.rand("s", *prob_.shape) < prob_).astype(prob_.dtype))
         else:                                                     # model.py:421-427
             if self.s_prob_prod is None or not self.flags.s_prob_prod:
                 self.s_prob_prod = s_prob
@@ -240,7 +240,7 @@ class Receiver(nn.Module):
             if self.training:                                     # model.py:457-460
                 probs_ = w_probs.detach().cpu().numpy()
                 w_feats = torch.from_numpy(
-                    (self.rng.rand("w", *probs_.shape) < probs_).astype("float32"))
+                    (self.rng.rand("w", *probs_.shape) < probs_).astype(probs_.dtype))
             else:
                 w_feats = torch.round(w_probs).detach()           # model.py:462
             if self.flags.ignore_receiver:                        # model.py:470-472

@@ -161,11 +161,14 @@ def test_n_gt_1_line_shape_under_gloo(tmp_path):
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rccl_world"] == 2 and d["config"]["global_batch"] == 128
-    assert d["value"] == 2 * 400 * 8.0 / 2.0 and d["value_first_pass"] > 0
+    # value = the exact --steps pass (2 ranks x 4 x 7.0 exchange steps in 4 x 70 us); the long window is reported beside it
+    assert abs(d["value"] - 2 * (4 * 7.0) / (4 * 7e-5)) < 1e-6 * d["value"] and d["value_first_pass"] == d["value"]
+    assert d["value_window"] == 2 * 400 * 8.0 / 2.0 and d["config"]["window"]["value"] == d["value_window"]
+    assert abs(d["ms_per_step"] - 0.07) < 1e-9
     assert d["config"]["collective_us"]["grads_f32_allreduce_us"] == 22.0
     sc = d["strong_configs"]
     assert set(sc) == {"c3s", "c5s"}
     assert sc["c3s"]["global_batch"] == 512 and sc["c3s"]["per_gpu_batch"] == 256 and sc["c3s"]["scaling"] == "strong" and sc["c3s"]["rccl_world"] == 2
     assert sc["c5s"]["global_batch"] == 2048 and sc["c5s"]["per_gpu_batch"] == 1024
-    assert sc["c5s"]["value"] == 30 * 100 * 8.0 / 2.0 and "collective_us" in sc["c5s"]
+    assert sc["c5s"]["value_window"] == 30 * 100 * 8.0 / 2.0 and abs(sc["c5s"]["value"] - 1e5) < 1e-3 and "collective_us" in sc["c5s"]
     assert "other_configs" not in d and "cpu_baseline" not in d

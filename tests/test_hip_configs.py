@@ -26,26 +26,34 @@ def _meta(flags_kw, n_classes, batch, n_mb, seeds=(5, 6, 7)):
     return meta
 
 
-def _compare(meta, skip, label):
-    """Forward quantities and losses: the 1e-4 gate of common.assert_parity.  A gradient entry beyond its tolerance passes only
-    if a ReLU unit on the threshold (|pre| < RELU_EPS in the oracle's own run) feeds it."""
-    got, eng = common.hip_train_case(None, meta)
-    flips = []
-    want = common.oracle_train_case(None, meta, flips=flips)
-    common.assert_parity(got, want, flips, eng, label, skip=skip)
-
-
 _ORACLE_CACHE = {}
 
 
-def _compare_cached(meta, skip, label, key):
-    """_compare with the oracle's result of `key` computed once per session (it takes seconds at config 4)."""
+def _oracle(meta, key=None, f64=False):
+    """(want, flips, f64 losses): the oracle's fp32 run of the case (cached per session under `key`: it takes seconds at config 4)
+    and -- f64=True, the cases with config 4's 256-bit agents -- the six losses of its float64 re-run on the same discrete
+    trajectory (common.oracle_losses_f64), against which the GPU's losses are gated there."""
+    if key is not None and key in _ORACLE_CACHE:
+        return _ORACLE_CACHE[key]
+    flips = []
+    want = common.oracle_train_case(None, meta, flips=flips)
+    out = (want, flips, common.oracle_losses_f64(None, meta, want) if f64 else None)
+    if key is not None:
+        _ORACLE_CACHE[key] = out
+    return out
+
+
+def _compare(meta, skip, label, key=None):
+    """Forward quantities and losses: the 1e-4 gate of common.assert_parity (config 4's losses: against the float64 oracle).  A
+    gradient entry beyond its tolerance passes only if a ReLU unit on the threshold (|pre| < RELU_EPS in the oracle's own run)
+    feeds it."""
     got, eng = common.hip_train_case(None, meta)
-    if key not in _ORACLE_CACHE:
-        flips = []
-        _ORACLE_CACHE[key] = (common.oracle_train_case(None, meta, flips=flips), flips)
-    want, flips = _ORACLE_CACHE[key]
-    common.assert_parity(got, want, flips, eng, label, skip=skip)
+    want, flips, f64 = _oracle(meta, key, f64=label.startswith("config4"))
+    common.assert_parity(got, want, flips, eng, label, skip=skip, f64=f64)
+
+
+def _compare_cached(meta, skip, label, key):
+    _compare(meta, skip, label, key)
 
 
 @pytest.mark.parametrize("switch", [None, "MMG_NO_PERSIST_LL", "MMG_NO_FUSED_S", "MMG_NO_RMSG", "MMG_NO_RSAMPLE", "MMG_NO_PERSIST"])
@@ -70,12 +78,8 @@ def test_config4_fused_train_step_vs_oracle(switch, monkeypatch):
         monkeypatch.setenv(switch, "1")
     meta = _meta(dict(C4), 30, 64, 2)
     got, eng = common.hip_train_case(None, meta, fused=True)
-    key = "c4-fused"
-    if key not in _ORACLE_CACHE:
-        flips = []
-        _ORACLE_CACHE[key] = (common.oracle_train_case(None, meta, flips=flips), flips)
-    want, flips = _ORACLE_CACHE[key]
-    common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused" + ("-" + switch if switch else ""), skip=("y2.bias",))
+    want, flips, f64 = _oracle(meta, "c4-fused", f64=True)
+    common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused" + ("-" + switch if switch else ""), skip=("y2.bias",), f64=f64)
 
 
 @pytest.mark.parametrize("batch", [24, 88])
@@ -84,9 +88,8 @@ def test_config4_fused_train_step_ragged_and_chunked(batch):
     launch (88 samples: two launches over tile ranges, the pair slots of the other range untouched), early stopping on."""
     meta = _meta(dict(C4, batch_size=batch), 30, batch, 2)
     got, eng = common.hip_train_case(None, meta, fused=True)
-    flips = []
-    want = common.oracle_train_case(None, meta, flips=flips)
-    common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused-b%d" % batch, skip=("y2.bias",))
+    want, flips, f64 = _oracle(meta, f64=True)
+    common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused-b%d" % batch, skip=("y2.bias",), f64=f64)
 
 
 @pytest.mark.parametrize("switch", [None, "MMG_NO_RC_PERSIST", "MMG_NO_RC_BWD"])
@@ -101,9 +104,8 @@ def test_config4_with_rec_hidden_256_vs_oracle(switch, monkeypatch):
         monkeypatch.setenv(switch, "1")
     meta = _meta(dict(C4, rec_hidden=256, batch_size=64), 30, 64, 2)
     got, eng = common.hip_train_case(None, meta)
-    flips = []
-    want = common.oracle_train_case(None, meta, flips=flips)
-    common.assert_parity(got, want, flips, eng, "config4-R256", skip=("y2.bias",))
+    want, flips, f64 = _oracle(meta, "c4-R256", f64=True)
+    common.assert_parity(got, want, flips, eng, "config4-R256", skip=("y2.bias",), f64=f64)
     names = _kernel_names(eng, meta)
     assert "k_conv_rc" in names and "k_bwd_tile" in names, names
 
@@ -122,9 +124,8 @@ def test_wide_receiver_fused_train_step_vs_oracle(flavour):
         skip = ("y2.bias", ".bs", ".br")
     meta = _meta(kw, 30, 64, 2)
     got, eng = common.hip_train_case(None, meta, fused=True)
-    flips = []
-    want = common.oracle_train_case(None, meta, flips=flips)
-    common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-wide-fused-" + flavour, skip=skip)
+    want, flips, f64 = _oracle(meta, f64=True)
+    common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-wide-fused-" + flavour, skip=skip, f64=f64)
     names = _kernel_names(eng, meta)
     assert "k_conv_rc" in names and "k_bwd_tile" in names and "k_conversation" not in names, names
 
@@ -151,9 +152,8 @@ def test_wide_receiver_other_modes_vs_oracle(flavour):
         kw.update(rec_hidden=192)
     meta = _meta(kw, 30, B, 2)
     got, eng = common.hip_train_case(None, meta)
-    flips = []
-    want = common.oracle_train_case(None, meta, flips=flips)
-    common.assert_parity(got, want, flips, eng, "config4-wide-" + flavour, skip=skip)      # (config 4's 256-bit agents: RELATIVE_ALLOW's ulp gate on the six losses)
+    want, flips, f64 = _oracle(meta, f64=True)
+    common.assert_parity(got, want, flips, eng, "config4-wide-" + flavour, skip=skip, f64=f64)      # (config 4's 256-bit agents: the six losses against the float64 oracle)
     assert "k_conv_rc" in _kernel_names(eng, meta)
 
 
@@ -531,3 +531,19 @@ def test_many_class_binary_adaptive_vs_oracle(n_classes, batch):
     names = [n for n, _ in eng.kernel_times()]
     eng.set_profiling(False)
     assert "k_conversation_mc" in names, names
+
+
+@pytest.mark.parametrize("optim", ["Adam", "SGD"])
+def test_fused_step_with_adam_and_sgd_at_config1_shape_vs_oracle(optim):
+    """k_wgrad<OPT>'s in-launch clip + optimizer at config 1's shape (k_game_fast + k_wgrad<true>, the
+    two launches of the metric config) met the oracle for RMSprop only; Adam / SGD were covered at tiny dimensions on the phased
+    path (g3_tiny_*).  Two fused minibatches with -optim_type Adam and SGD against the oracle's torch.optim.Adam / SGD
+    (model.py:1127-1135): post-update parameters of the first step feed the second."""
+    z, meta = common.load_golden("g2_adaptive_c1")
+    meta = dict(meta, optim_type=optim, learning_rate=1e-3 if optim == "SGD" else 1e-4)
+    got, eng = common.hip_train_case(None, meta, fused=True)
+    names = _kernel_names(eng, meta)
+    assert names == ["k_game", "k_wgrad"], names                           # the optimizer ran inside k_wgrad's launch
+    flips = []
+    want = common.oracle_train_case(None, meta, flips=flips)
+    common.assert_parity(_pick(got), _pick(want), flips, eng, "config1-fused-" + optim, skip=("y2.bias",))

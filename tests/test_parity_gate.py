@@ -101,12 +101,16 @@ def _flipped_unit_case():
         common.assert_parity(bad, want, flips, eng, None, skip=("y2.bias",))
 
 
-def test_forward_gate_is_absolute_with_an_explicit_allow_list():
+def test_forward_gate_is_absolute_and_losses_beyond_fp32_resolution_are_gated_against_float64():
     want = {"mb0.losses": np.array([600.0, 0.5]), "mb0.logs": np.array([80.0])}
     got = {"mb0.losses": np.array([600.0005, 0.5]), "mb0.logs": np.array([80.0])}
-    assert common.compare_packed(got, want, label="config2")                          # 5e-4 on a loss: fails everywhere ...
-    assert not common.compare_packed(got, want, label="config4-b88")                  # ... but on config 4's losses (16 ulp of 600 = 1.1e-3)
+    assert common.compare_packed(got, want, label="config2")                          # 5e-4 on a loss: fails, whatever the label ...
+    assert common.compare_packed(got, want, label="config4-b88")
+    # ... unless the float64 oracle says the fp32 oracle itself is that far from the exact value: |got - f64| <= |want - f64| + 1e-4
+    f64 = {"mb0.losses": np.array([600.00045, 0.5])}
+    assert not common.compare_packed(got, want, label="config4-b88", f64=f64)         # got is 5e-5 from exact, the fp32 oracle 4.5e-4
+    assert common.compare_packed(got, want, label="config4-b88", f64={"mb0.losses": np.array([599.9999, 0.5])})   # got 6e-4 from exact, the oracle 1e-4
     got["mb0.logs"] = np.array([80.0005])
-    assert common.compare_packed(got, want, label="config4-b88")                      # only `.losses` is on the allow-list
+    assert common.compare_packed(got, want, label="config4-b88", f64=f64)             # only the entries f64 holds are gated that way
     got = {"mb0.losses": np.array([600.0, 0.5002]), "mb0.logs": np.array([80.0])}
-    assert common.compare_packed(got, want, label="config4")                          # small entries keep 1e-4 there too
+    assert common.compare_packed(got, want, label="config4", f64=f64)                 # a small entry: 2e-4 from exact fails
