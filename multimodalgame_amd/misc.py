@@ -361,8 +361,29 @@ def load_epoch(hdf5_file, batch_size, random_seed, shuffle, map_labels=int, feat
         lo, per = shard_range(batch_size, shard[0], shard[1])
         batches = [idx[lo:lo + per] for idx in batches]
     res = _resident(hdf5_file, feats, torch.device(device))
-    flat = torch.from_numpy(np.concatenate(batches) if batches else np.zeros(0, np.int64)).to(res.device)
+    perm = np.concatenate(batches) if batches else np.zeros(0, np.int64)
+    if res.device.type == "cuda":
+        # the permutation goes up from PINNED memory without blocking the host: a pageable copy waits, in stream order, for every
+        # minibatch still queued -- the launch queue then runs dry once per epoch (46 minibatches at config 1) while the host forms
+        # the gather, logs "Starting epoch" and enqueues the first run
+        key = (str(res.device), perm.size)
+        ring = _PERM_PINNED.setdefault(key, dict(buf=[torch.empty(perm.size, dtype=torch.int64, pin_memory=True) for _ in range(2)],
+                                                 ev=[None, None], n=0))
+        k = ring["n"] & 1                                # two buffers: the previous epoch's copy may still be queued
+        ring["n"] += 1
+        if ring["ev"][k] is not None:
+            ring["ev"][k].synchronize()                  # (the copy of two epochs ago: long done unless the host ran far ahead)
+        host = ring["buf"][k]
+        host.numpy()[:] = perm
+        flat = host.to(res.device, non_blocking=True)
+        ring["ev"][k] = torch.cuda.Event()
+        ring["ev"][k].record(torch.cuda.current_stream(res.device))
+    else:
+        flat = torch.from_numpy(perm).to(res.device)
     return Epoch({name: res.feats[name].index_select(0, flat) for name in feats}, res.targets(map_labels).index_select(0, flat), per)
+
+
+_PERM_PINNED = {}
 
 
 def load_hdf5(hdf5_file, batch_size, random_seed, shuffle, truncate_final_batch=False, map_labels=int,

@@ -108,7 +108,7 @@ def _relu_flips(res, y1_out, bas_out, n_classes, binary=True, fixed=False):
 _FORCE_TINY = 1e-30       # a forced unit's pre-activation: +tiny (mask on, value ~0) / -tiny (mask off)
 
 
-def oracle_train_case(name, meta, flips=None, force=None):
+def oracle_train_case(name, meta, flips=None, force=None, params_before=None):
     """Re-run a golden train case with the CPU oracle; returns the packed dict.
     flips: a list that receives, per minibatch, the near-threshold ReLU units (_relu_flips) and the case they belong to.
     force: per minibatch, a set of positions ("y", t, b, d, r, side) / ("bas_*", t, b, k, side) whose ReLU mask is forced to
@@ -150,6 +150,8 @@ def oracle_train_case(name, meta, flips=None, force=None):
         tape.u = {"z": u_z, "s": u_s, "w": u_w}
         tape.t = {"z": 0, "s": 0, "w": 0}
         state["mb"] = i
+        if params_before is not None:                               # (oracle_losses_f64: the parameters minibatch i starts from)
+            params_before.append({a: {k: v.detach().clone() for k, v in m.state_dict().items()} for a, m in models.items()})
         del y1_out[:], bas_out["bas_rec"][:], bas_out["bas_sen"][:]
         res = cpu_ref.train_minibatch(models, optimizers, torch.from_numpy(x), torch.from_numpy(target),
                                       torch.from_numpy(desc), fl)
@@ -163,27 +165,23 @@ def oracle_train_case(name, meta, flips=None, force=None):
     return out
 
 
-def oracle_losses_f64(name, meta, want):
-    """The six losses of every minibatch from the oracle re-run in FLOAT64 on the DISCRETE trajectory of its fp32 run (`want`:
-    the packed result of oracle_train_case): the sampled bits of the fp32 run are injected as uniforms 0 / 1 (u < p gives the
-    same bit at any precision), so both runs take the same conversations and differ by rounding alone.  Returns
-    {"mb<i>.losses": float64[6]}.  For shapes whose losses are far above fp32's absolute resolution (config 4: means of
-    256-bit log-likelihood sums times a reward weight, |loss| ~ 600, one fp32 ulp = 6e-5) the GPU is gated against THIS:
-    |HIP - f64| <= |fp32 oracle - f64| + 1e-4 -- "at least as close to the exact value as the reference's own fp32 arithmetic,
-    plus the 1e-4 of north_star" (replaces round 4's 16-ulp allow-list)."""
+def oracle_losses_f64(name, meta, want, params_oracle, params_gpu):
+    """The float64 gate of the six losses (shapes whose losses are far above fp32's absolute resolution: config 4's means of
+    256-bit log-likelihood sums times a reward weight, |loss| ~ 600, one fp32 ulp = 6e-5).  For every minibatch i the oracle's
+    loss computation is re-run in FLOAT64 on the DISCRETE trajectory of the fp32 run (`want`: its sampled bits are injected as
+    uniforms 0 / 1 -- u < p gives the same bit at any precision) TWICE: from the parameters the fp32 ORACLE held before
+    minibatch i (params_oracle[i]) and from the parameters the GPU held (params_gpu[i]; equal for i = 0, later they differ by
+    the two implementations' own update noise -- RMSprop turns rounding-level gradients into +-lr steps).  Returns
+    {"mb<i>.losses": (exact at the GPU's parameters, exact at the oracle's parameters)}; compare_packed gates
+        |GPU - exact(GPU params)| <= |fp32 oracle - exact(oracle params)| + 1e-4
+    i.e. each implementation against the exact value of ITS OWN forward pass: "at least as close to exact as the reference's
+    fp32 arithmetic, plus north_star's 1e-4" (replaces round 4's 16-ulp allow-list)."""
     fl = flags_from_meta(meta)
     old = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
+    keys6 = ("nll_loss", "loss_binary_s", "loss_binary_rec", "loss_binary_sen", "loss_bas_rec", "loss_bas_sen")
     try:
-        torch.manual_seed(0)
-        tape = cpu_ref.UniformTape()
-        models = cpu_ref.build_agents(fl, rng=tape)
-        cpu_ref.load_filled(models, seed=meta["seed_weights"])
-        for m in models.values():
-            m.double()
-        optimizers = cpu_ref.build_optimizers(models, fl)
         out = {}
-        T = int(meta["max_exchange"])
         for i in range(meta["n_minibatches"]):
             x, target, desc, (u_z, u_s, u_w) = case_inputs(meta, i, name)
             u = {"z": np.array(u_z, np.float64), "s": np.array(u_s, np.float64), "w": np.array(u_w, np.float64)}
@@ -192,13 +190,21 @@ def oracle_losses_f64(name, meta, want):
                     bits = np.asarray(want["mb%d.%s" % (i, key)])                    # [n, B, .] of the executed steps
                     n = bits.shape[0]
                     u[kind][:n] = np.where(bits.reshape(u[kind][:n].shape) != 0, 0.0, 1.0)
-            tape.u = u
-            tape.t = {"z": 0, "s": 0, "w": 0}
-            res = cpu_ref.train_minibatch(models, optimizers, torch.from_numpy(x).double(), torch.from_numpy(target),
-                                          torch.from_numpy(desc).double(), fl)
-            assert int(res["n_steps"]) == int(want["mb%d.n_steps" % i]), "the float64 re-run left the fp32 run's trajectory"
-            out["mb%d.losses" % i] = np.array([float(res[k].detach()) for k in (
-                "nll_loss", "loss_binary_s", "loss_binary_rec", "loss_binary_sen", "loss_bas_rec", "loss_bas_sen")], np.float64)
+            both = []
+            for params in ((params_gpu[i], params_oracle[i]) if i > 0 else (params_oracle[i],)):
+                tape = cpu_ref.UniformTape()
+                models = cpu_ref.build_agents(fl, rng=tape)
+                for a, m in models.items():
+                    m.double()
+                    m.load_state_dict({k: torch.as_tensor(v).double() for k, v in params[a].items()})
+                optimizers = cpu_ref.build_optimizers(models, fl)
+                tape.u = {k: v.copy() for k, v in u.items()}
+                tape.t = {"z": 0, "s": 0, "w": 0}
+                res = cpu_ref.train_minibatch(models, optimizers, torch.from_numpy(x).double(), torch.from_numpy(target),
+                                              torch.from_numpy(desc).double(), fl, update=False)
+                assert int(res["n_steps"]) == int(want["mb%d.n_steps" % i]), "the float64 re-run left the fp32 run's trajectory"
+                both.append(np.array([float(res[k].detach()) for k in keys6], np.float64))
+            out["mb%d.losses" % i] = (both[0], both[-1])
         return out
     finally:
         torch.set_default_dtype(old)
@@ -278,8 +284,9 @@ SHIFT_INVARIANT = ("y", "outp")
 # probabilities, rewards, baseline scores and the six loss scalars -- are compared with an ABSOLUTE tolerance of 1e-4, whatever
 # their magnitude.  The REINFORCE losses of config 4 are means of 256-bit log-likelihood sums times a reward weight,
 # |loss| ~ 600, where ONE fp32 ulp is 6.1e-5 and the fp32 oracle itself moves by 4e-4 between hosts: a caller that passes
-# `f64` (oracle_losses_f64: the oracle re-run in float64 on the same discrete trajectory) gets those entries gated as
-# |got - f64| <= |fp32 oracle - f64| + 1e-4 -- against the exact value, with the reference's own fp32 error as the allowance
+# `f64` (oracle_losses_f64: the oracle's losses re-computed in float64 on the same discrete trajectory, from each side's own
+# parameters) gets those entries gated as |got - exact(got's parameters)| <= |fp32 oracle - exact(its parameters)| + 1e-4
+# -- against the exact value, with the reference's own fp32 error as the allowance
 # (round 6; rounds 4-5 allowed 16 ulp of |want| there, which only said "as noisy as fp32").  Gradients / updated parameters /
 # gradient norms (sums over up to 10^4 products) keep atol + rtol.
 FORWARD_ATOL = 1e-4
@@ -340,9 +347,10 @@ def compare_packed(got, want, atol=1e-5, rtol=1e-4, skip=(), only_prefix=None, s
             if is_grad_key(k):
                 tol = atol + rtol * np.abs(b.astype(np.float64))
             elif gate64:
-                exact = np.asarray(f64[k], np.float64).reshape(b.shape)
-                err = np.abs(a.astype(np.float64) - exact)
-                tol = np.abs(b.astype(np.float64) - exact) + min(atol, FORWARD_ATOL)
+                ex_got, ex_want = [np.asarray(v, np.float64).reshape(b.shape) for v in
+                                   (f64[k] if isinstance(f64[k], tuple) else (f64[k], f64[k]))]
+                err = np.abs(a.astype(np.float64) - ex_got)          # each side against the exact value of ITS OWN forward pass
+                tol = np.abs(b.astype(np.float64) - ex_want) + min(atol, FORWARD_ATOL)
             else:
                 tol = np.full(b.shape, min(atol, FORWARD_ATOL), dtype=np.float64)
             if a.size:
@@ -492,7 +500,9 @@ def hip_train_case(name, meta, early_exit=False, fused=False):
     out = {}
     agents = ("receiver", "sender", "baseline_rec", "baseline_sen") if fl.use_binary else ("receiver",)
     eng.relu_capture = []
+    eng.param_snapshots = []                                        # the parameters every minibatch starts from (oracle_losses_f64)
     for i in range(meta["n_minibatches"]):
+        eng.param_snapshots.append({a: {k: v.detach().cpu().clone() for k, v in eng.params[a].items()} for a in _lib_agents()})
         x, target, desc, (u_z, u_s, u_w) = case_inputs(meta, i, name)
         xd, td, dd = torch.from_numpy(x).to(dev), torch.from_numpy(target).to(dev), torch.from_numpy(desc).to(dev)
         uz, us, uw = [torch.from_numpy(np.ascontiguousarray(u)).to(dev) for u in (u_z, u_s[..., 0], u_w)]

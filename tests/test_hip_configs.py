@@ -29,18 +29,19 @@ def _meta(flags_kw, n_classes, batch, n_mb, seeds=(5, 6, 7)):
 _ORACLE_CACHE = {}
 
 
-def _oracle(meta, key=None, f64=False):
-    """(want, flips, f64 losses): the oracle's fp32 run of the case (cached per session under `key`: it takes seconds at config 4)
-    and -- f64=True, the cases with config 4's 256-bit agents -- the six losses of its float64 re-run on the same discrete
-    trajectory (common.oracle_losses_f64), against which the GPU's losses are gated there."""
+def _oracle(meta, key=None, f64=False, eng=None):
+    """(want, flips, f64 gate): the oracle's fp32 run of the case (cached per session under `key`: it takes seconds at config 4)
+    and -- f64=True, the cases with config 4's 256-bit agents -- the float64 values of the six losses on the same discrete
+    trajectory from the oracle's AND from the GPU's own parameters (common.oracle_losses_f64; eng: the engine
+    common.hip_train_case returned), against which the losses are gated there."""
     if key is not None and key in _ORACLE_CACHE:
-        return _ORACLE_CACHE[key]
-    flips = []
-    want = common.oracle_train_case(None, meta, flips=flips)
-    out = (want, flips, common.oracle_losses_f64(None, meta, want) if f64 else None)
-    if key is not None:
-        _ORACLE_CACHE[key] = out
-    return out
+        want, flips, params = _ORACLE_CACHE[key]
+    else:
+        flips, params = [], []
+        want = common.oracle_train_case(None, meta, flips=flips, params_before=params)
+        if key is not None:
+            _ORACLE_CACHE[key] = (want, flips, params)
+    return want, flips, (common.oracle_losses_f64(None, meta, want, params, eng.param_snapshots) if f64 else None)
 
 
 def _compare(meta, skip, label, key=None):
@@ -48,7 +49,7 @@ def _compare(meta, skip, label, key=None):
     gradient entry beyond its tolerance passes only if a ReLU unit on the threshold (|pre| < RELU_EPS in the oracle's own run)
     feeds it."""
     got, eng = common.hip_train_case(None, meta)
-    want, flips, f64 = _oracle(meta, key, f64=label.startswith("config4"))
+    want, flips, f64 = _oracle(meta, key, f64=label.startswith("config4"), eng=eng)
     common.assert_parity(got, want, flips, eng, label, skip=skip, f64=f64)
 
 
@@ -78,7 +79,7 @@ def test_config4_fused_train_step_vs_oracle(switch, monkeypatch):
         monkeypatch.setenv(switch, "1")
     meta = _meta(dict(C4), 30, 64, 2)
     got, eng = common.hip_train_case(None, meta, fused=True)
-    want, flips, f64 = _oracle(meta, "c4-fused", f64=True)
+    want, flips, f64 = _oracle(meta, "c4-fused", f64=True, eng=eng)
     common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused" + ("-" + switch if switch else ""), skip=("y2.bias",), f64=f64)
 
 
@@ -88,7 +89,7 @@ def test_config4_fused_train_step_ragged_and_chunked(batch):
     launch (88 samples: two launches over tile ranges, the pair slots of the other range untouched), early stopping on."""
     meta = _meta(dict(C4, batch_size=batch), 30, batch, 2)
     got, eng = common.hip_train_case(None, meta, fused=True)
-    want, flips, f64 = _oracle(meta, f64=True)
+    want, flips, f64 = _oracle(meta, f64=True, eng=eng)
     common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-fused-b%d" % batch, skip=("y2.bias",), f64=f64)
 
 
@@ -104,7 +105,7 @@ def test_config4_with_rec_hidden_256_vs_oracle(switch, monkeypatch):
         monkeypatch.setenv(switch, "1")
     meta = _meta(dict(C4, rec_hidden=256, batch_size=64), 30, 64, 2)
     got, eng = common.hip_train_case(None, meta)
-    want, flips, f64 = _oracle(meta, "c4-R256", f64=True)
+    want, flips, f64 = _oracle(meta, "c4-R256", f64=True, eng=eng)
     common.assert_parity(got, want, flips, eng, "config4-R256", skip=("y2.bias",), f64=f64)
     names = _kernel_names(eng, meta)
     assert "k_conv_rc" in names and "k_bwd_tile" in names, names
@@ -124,7 +125,7 @@ def test_wide_receiver_fused_train_step_vs_oracle(flavour):
         skip = ("y2.bias", ".bs", ".br")
     meta = _meta(kw, 30, 64, 2)
     got, eng = common.hip_train_case(None, meta, fused=True)
-    want, flips, f64 = _oracle(meta, f64=True)
+    want, flips, f64 = _oracle(meta, f64=True, eng=eng)
     common.assert_parity(_pick(got), _pick(want), flips, eng, "config4-wide-fused-" + flavour, skip=skip, f64=f64)
     names = _kernel_names(eng, meta)
     assert "k_conv_rc" in names and "k_bwd_tile" in names and "k_conversation" not in names, names
@@ -152,7 +153,7 @@ def test_wide_receiver_other_modes_vs_oracle(flavour):
         kw.update(rec_hidden=192)
     meta = _meta(kw, 30, B, 2)
     got, eng = common.hip_train_case(None, meta)
-    want, flips, f64 = _oracle(meta, f64=True)
+    want, flips, f64 = _oracle(meta, f64=True, eng=eng)
     common.assert_parity(got, want, flips, eng, "config4-wide-" + flavour, skip=skip, f64=f64)      # (config 4's 256-bit agents: the six losses against the float64 oracle)
     assert "k_conv_rc" in _kernel_names(eng, meta)
 
