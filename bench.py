@@ -552,6 +552,7 @@ def run_cli(seconds=2.0, epochs=None, dist_backend=None, log_dev=10 ** 9):
                 "-top_k_train", "6"] + [a for k, v in paths.items() for a in ("-" + k, v)]
         if dist_backend:
             argv += ["-dist_backend", dist_backend]
+        argv += os.environ.get("MMG_CLI_EXTRA", "").split()          # (experiments: scripts/cli_run.py)
         _flags.define_flags()
         _flags.FLAGS.Reset()
         _flags.FLAGS(argv)

@@ -632,6 +632,15 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, si
     return v;
 }
 
+// What every block of k_wgrad needs BEFORE it can look anything else up -- the launch geometry and the first tile / block of
+// every job -- travels in the kernel arguments (one s_load burst with the pointers) instead of behind the JobTable pointer:
+// job lookup = unrolled scalar compares, and the job's fields (jt->g[j]) are the FIRST dependent memory trip of the block, not
+// the second (round 6: 3.0 -> ~2.2 us from block start to the first operand load issued; profiles/r06_wgrad_timeline*.log)
+struct WgHead {
+    int gemm_tiles, n_wblocks, special_block, special_job;
+    int g_begin[MMG_MAX_GEMM], c_begin[MMG_MAX_COL];    // INT_MAX padded
+};
+
 struct OptArgs {
     int optim_type, only_receiver, from_wgrad, bump_step, bump_mb;
     float lr;
@@ -642,9 +651,10 @@ struct OptArgs {
 // OPT (k_wgrad<true>): the clip + optimizer step of model.py:1310-1330 INSIDE the weight-gradient launch.  Every workgroup still
 // holds the gradient elements it just stored in registers; what it lacks is the four per-agent clip coefficients, which need the
 // squared norm of ALL blocks.  So: each block publishes its sum of squares as a (value, epoch) pair (tape.gnll) and requests its
-// parameter / optimizer-state elements; ONE extra workgroup (the norm role) spins on all n_wblocks pairs, adds them in k_opt's
-// fixed order, and publishes the four coefficients (64 replicas each: no word has more than ~16 pollers); the blocks spin on
+// parameter / optimizer-state elements; FOUR extra workgroups (one norm role per agent) spin on their agent's pairs, add them in
+// k_opt's fixed order, and publish the agent's coefficient (64 replicas: no word has more than ~16 pollers); the blocks spin on
 // their replica, update their elements and store parameters + state.  No k_opt launch (6 us), and the gradients are never re-read.
+// The spare block closes the launch (NLL / non-finite guard, error word, counters) once the four totals are out.
 // A block's phase 2 starts only after EVERY block has published, i.e. finished reading -- some jobs read parameters
 // (linear2.weight, code_layer.weight).  All blocks of the launch must be co-resident (the host checks the occupancy budget).
 struct WgOpt {
@@ -690,7 +700,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                                                      Dims dm, const double* __restrict__ stats, float* __restrict__ losses,
                                                      double* __restrict__ totals, const int* __restrict__ rmap,
                                                      const int* __restrict__ rcount, float* __restrict__ wpart,
-                                                     const uint32_t* __restrict__ sync, float* __restrict__ grad_tail, WgOpt wo, int gt_stride
+                                                     const uint32_t* __restrict__ sync, float* __restrict__ grad_tail, WgOpt wo, int gt_stride, WgHead hd
 #ifdef MMG_TIMING
                                                      , long long* __restrict__ dbg2
 #endif
@@ -699,64 +709,54 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     // (a multiple of 8: the XCD of a tile stays that of its workgroup) walk the GEMM tiles with that stride -- the live-row list
     // and the job table are fetched once per workgroup instead of once per tile, and no tile waits for a slot; the other
     // workgroups (column sums, the special and the spare block) follow them.  bid: the block index of the un-strided launch.
-    const int bid = (gt_stride > 0 && (int)blockIdx.x >= gt_stride) ? (int)blockIdx.x - gt_stride + jt->gemm_tiles : (int)blockIdx.x;
+    const int bid = (gt_stride > 0 && (int)blockIdx.x >= gt_stride) ? (int)blockIdx.x - gt_stride + hd.gemm_tiles : (int)blockIdx.x;
     const uint32_t oepoch = OPT ? wo.counter[3] + 1u : 0u;          // (the norm role bumps the counters when every block has read them)
     const uint32_t ostep = OPT ? wo.counter[1] + 1u : 0u;
-    if (OPT && bid == jt->n_wblocks + 1) {
-        // ---- the norm role: all n_wblocks sums of squares -> four clip coefficients (k_opt's summation order, bit for bit)
-        __shared__ float s_ss[4][4];
-        __shared__ float s_bad[4];
-        const int n = jt->n_wblocks;
-        float ss[4] = {0.f, 0.f, 0.f, 0.f};
+    if (OPT && bid > hd.n_wblocks) {
+        // ---- a norm role: ONE PER AGENT (round 6; one workgroup for all four polled 8 pairs per lane, ~0.9 us per poll round).  It
+        // spins on the sums of squares of ITS agent's blocks only -- two or three of the eight pair slots of a lane -- adds them in
+        // k_opt's order (the other agents' entries are skipped where k_opt adds zeros: bit for bit the same sum) and publishes the
+        // agent's clip coefficient (64 replicas) and its total (the closing role below reads the four totals).  An agent's
+        // blocks update as soon as THEIR coefficient is out: the receiver's and sender's do not wait for the baselines' tiles.
+        __shared__ float s_ss[4];
+        const int agent = bid - hd.n_wblocks - 1;
+        const int n = hd.n_wblocks;
+        float ss = 0.f;
         for (int k0 = threadIdx.x; k0 < n; k0 += 8 * MMG_BLOCK) {
-            unsigned long long u[8]; int a[8];
+            unsigned long long u[8]; bool mine[8], any[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int k = k0 + q * MMG_BLOCK; a[q] = (k < n) ? (int)jt->wblock_agent[k] : -1; }
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + q * MMG_BLOCK;
+                mine[q] = (k < n) && ((int)jt->wblock_agent[min(k, n - 1)] == agent);
+                any[q] = __any(mine[q]);
+                u[q] = 0ull;
+            }
             for (int spins = 0;; ) {
                 bool fresh = true;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const int k = k0 + q * MMG_BLOCK; u[q] = ld_ll(wo.gnll, (size_t)min(k, n - 1)); fresh = fresh && (k >= n || ll_fresh(u[q], oepoch)); }
-                if (fresh) break;
-                __builtin_amdgcn_s_sleep(2);
+                for (int q = 0; q < 8; ++q)
+                    if (any[q]) {                            // (wave-uniform: slots without a block of this agent cost nothing)
+                        const unsigned long long v = ld_ll(wo.gnll, (size_t)min(k0 + q * MMG_BLOCK, n - 1));
+                        if (mine[q]) { u[q] = v; fresh = fresh && ll_fresh(v, oepoch); }
+                    }
+                if (!__any(!fresh)) break;
+                __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1 << 20)) { __hip_atomic_store(const_cast<uint32_t*>(sync) + MMG_SYNC_ERR, 11u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float v = (a[q] >= 0) ? ll_value(u[q]) : 0.f;
-                ss[0] += (a[q] == 0) ? v : 0.f; ss[1] += (a[q] == 1) ? v : 0.f;
-                ss[2] += (a[q] == 2) ? v : 0.f; ss[3] += (a[q] == 3) ? v : 0.f;
-            }
+            for (int q = 0; q < 8; ++q) ss += mine[q] ? ll_value(u[q]) : 0.f;
         }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float wsum = dpp_wave_sum(ss[a]);
-            if ((threadIdx.x & 63) == 0) s_ss[a][threadIdx.x >> 6] = wsum;
-        }
+        const float wsum = dpp_wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) s_ss[threadIdx.x >> 6] = wsum;
         __syncthreads();
         // an in-launch dependency wait of this minibatch timed out (sync[MMG_SYNC_ERR]): parameters and optimizer state stay
-        // untouched (coefficient -1), the word goes to the pinned host word -- exactly k_opt's contract
+        // untouched (coefficient -1) -- exactly k_opt's contract; the closing role posts the word to the host
         const uint32_t err = __hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        {
-            const int a = threadIdx.x >> 6, r = threadIdx.x & 63;          // 4 agents x 64 replicas
-            const float tot = (s_ss[a][0] + s_ss[a][1]) + (s_ss[a][2] + s_ss[a][3]);
+        if (threadIdx.x < MMG_COEF_REPL + 1) {
+            const float tot = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
             const float coef = 1.0f / (sqrtf(tot) + 1e-6f);               // max_norm = 1 (model.py:1310)
-            st_ll(wo.coefll, (size_t)a * MMG_COEF_REPL + r, err != 0u ? -1.f : (coef < 1.f ? coef : 1.f), oepoch);
-            // NON-FINITE GUARD: the class-logit ReLU is v_max_f32 (device_utils.h: fmax_nn), which reads a NaN pre-activation as
-            // "unit off" where torch's relu propagates it -- a NaN in W_y1h or in the GRU state would leave the NLL of that step
-            // finite (log D) while every reference loss is NaN.  The backward pass does carry it, so a non-finite gradient norm of
-            // ANY agent makes the logged NLL NaN in the same step, as the reference's would be (scripts/nonfinite_probe.py).
-            // The spare block leaves losses[0] to this role (one writer).
-            if (r == 0) s_bad[a] = (!(tot == tot) || tot > 3.0e38f) ? 1.f : 0.f;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const bool bad = (s_bad[0] + s_bad[1] + s_bad[2] + s_bad[3]) != 0.f;
-            losses[0] = bad ? __builtin_nanf("") : (float)(-stats[stat_glob(dm.T, 0)] / (double)dm.Bg);     // NLL (model.py:1271)
-        }
-        if (threadIdx.x == 0) {
-            if (wo.err_host && (err != 0u || *wo.err_host == 0u)) *wo.err_host = err;
-            if (err == 0u) wo.counter[2] = ostep;                           // committed to counter[1] by the next k_prep
-            if (wo.oa.bump_mb) { wo.counter[0] += 1u; wo.counter[3] += 1u; }
+            if (threadIdx.x < MMG_COEF_REPL) st_ll(wo.coefll, (size_t)agent * MMG_COEF_REPL + threadIdx.x, err != 0u ? -1.f : (coef < 1.f ? coef : 1.f), oepoch);
+            else st_ll(wo.coefll, (size_t)4 * MMG_COEF_REPL + agent, tot, oepoch);
         }
         return;
     }
@@ -782,10 +782,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     float (*s_acc)[16][33] = reinterpret_cast<float (*)[16][33]>(&s_b[0][0][0]);   // [4][16][33] reused after the row loop
     float* s_part = &s_b[0][0][0];                                                   // column-sum staging
     __shared__ float s_red[8];
-    if (bid == jt->special_block) {
+    if (bid == hd.special_block) {
         // (found by ONE scalar load, ahead of the live-row list and the job lookup every other block starts with: this is the launch's
         //  longest block -- 9.0 us next to ~7 -- and those were a dependent memory round trip in front of its two)
-        const ColJob& C = jt->c[jt->special_job];
+        const ColJob& C = jt->c[hd.special_job];
         // code_bias gradient: dst[j] = scale[j] * sum_h wrow[h*cols + j] * v[h],  v[h] = sum_{b < rows} src[b*ld + h]
         // (src = dpre rows of step 0, wrow = code_layer.weight [ld, cols], scale = sigmoid'(code_bias))
         float* s_v = &s_b[0][0][0];                        // ld <= 4224 floats of staging
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         nact = rcount[0];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (bid == jt->n_wblocks) {
+    if (bid == hd.n_wblocks) {
         // spare block: the six logged loss scalars, the semantic step count and the running totals (off every
         // critical path: this launch lasts ~17 us, the bookkeeping ~3)
         float* s_lc = &s_b[0][0][0];                       // (7 * 64 floats of the staging area: this block stages nothing -- keeps the
@@ -882,19 +882,51 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             grad_tail[2] = (float)stats[stat_glob(dm.T, 1)];
             grad_tail[3] = 0.f;
         }
+        if (OPT) {
+            // ---- the CLOSING role of the launch: once the four norm roles have published their totals, every block of the launch
+            // has published its sum of squares, i.e. has read the launch epoch / optimizer step counters -- they may move now.
+            // NON-FINITE GUARD: the class-logit ReLU is v_max_f32 (device_utils.h: fmax_nn), which reads a NaN pre-activation as
+            // "unit off" where torch's relu propagates it -- a NaN in W_y1h or in the GRU state would leave the NLL of that step
+            // finite (log D) while every reference loss is NaN.  The backward pass does carry it, so a non-finite gradient norm of
+            // ANY agent makes the logged NLL NaN in the same step, as the reference's would be (scripts/nonfinite_probe.py).
+            __shared__ float s_tot[4];
+            if (threadIdx.x < 4) {
+                unsigned long long u;
+                for (int spins = 0;; ) {
+                    u = ld_ll(wo.coefll, (size_t)4 * MMG_COEF_REPL + threadIdx.x);
+                    if (ll_fresh(u, oepoch)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 20)) { __hip_atomic_store(const_cast<uint32_t*>(sync) + MMG_SYNC_ERR, 11u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                s_tot[threadIdx.x] = ll_value(u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                bool bad = false;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) bad = bad || !(s_tot[a] == s_tot[a]) || s_tot[a] > 3.0e38f;
+                losses[0] = bad ? __builtin_nanf("") : (float)(-stats[stat_glob(dm.T, 0)] / (double)dm.Bg);     // NLL (model.py:1271)
+                const uint32_t err = __hip_atomic_load(sync + MMG_SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wo.err_host && (err != 0u || *wo.err_host == 0u)) *wo.err_host = err;
+                if (err == 0u) wo.counter[2] = ostep;                           // committed to counter[1] by the next k_prep
+                if (wo.oa.bump_mb) { wo.counter[0] += 1u; wo.counter[3] += 1u; }
+            }
+        }
         return;
     }
-    if (bid < jt->gemm_tiles) {
-      for (int vt = bid; vt < jt->gemm_tiles; vt += (gt_stride > 0 ? gt_stride : jt->gemm_tiles)) {
+    if (bid < hd.gemm_tiles) {
+      for (int vt = bid; vt < hd.gemm_tiles; vt += (gt_stride > 0 ? gt_stride : hd.gemm_tiles)) {
         // XCD-aware tile order: workgroup b is dispatched to XCD b % 8, and each XCD has its own 4 MB L2.  Giving
         // every XCD a CONTIGUOUS range of tiles (= one or two jobs) keeps the operand tapes it re-reads
         // (16-32 tiles share each of them) inside its L2; with the default order every XCD streams all ~7 MB
         // of tapes through its L2 and the kernel is bound by L2-miss traffic.  (bijective remap, T1)
-        const int nwg = jt->gemm_tiles, xq = nwg >> 3, xr = nwg & 7;
+        const int nwg = hd.gemm_tiles, xq = nwg >> 3, xr = nwg & 7;
         const int xcd = vt & 7, slot = vt >> 3;
         const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-        // job lookup: lane l compares the l-th job's first tile, one ballot (no serial scalar loads)
-        const int j = __popcll(__ballot(jt->g_begin[lane] <= tile)) - 1;
+        // job lookup: scalar compares against the jobs' first tiles in the kernel arguments (no memory trip)
+        int j = 0;
+#pragma unroll
+        for (int k = 1; k < MMG_MAX_GEMM; ++k) j += (tile >= hd.g_begin[k]) ? 1 : 0;
         const GemmJob& G = jt->g[j];
         // many rows, few output tiles (thousands of samples): the rows of a tile are split over nsplit workgroups whose raw
         // partial tiles k_wreduce adds in a fixed order
@@ -907,11 +939,14 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const bool virt = G.vhid != nullptr;
         const float* Abase = virt ? G.vhid : G.A;
         const bool cmp = use_map && G.compact;
-        const int rows = cmp ? nact : G.rows, lda = G.lda, ldb = G.ldb, bmod = G.bmod, N = G.N, K = G.K;
-        if (use_map) __syncthreads();                      // s_map is complete
-#ifdef MMG_TIMING
-        if (threadIdx.x == 0 && tile < 2000) dbg2[8192 + 4 * tile + 0] = (long long)wall_clock64();
-#endif
+        const int lda = G.lda, ldb = G.ldb, bmod = G.bmod, N = G.N, K = G.K;
+        // The live-row list (s_map, nact) is a memory trip to what the previous launch just wrote -- ~2-3 us -- and so is the first
+        // operand chunk.  Round 6: the two trips overlap.  Jobs over plain rows (image_layer, the class jobs) never needed the list;
+        // and the compacted list BEGINS with the B rows of step 0 in order (build_row_map: every sample is live at t = 0), so
+        // with B >= 64 chunk 0 of a live-row job is rows 0..63 -- both kinds issue their first loads BEFORE the barrier that
+        // waits for the list (`early`), the rest of the prefetch ring behind it.  Nothing below may read nact ahead of that barrier.
+        const bool ident0 = cmp && dm.B >= 64 && sp == 0;
+        int rows = cmp ? 0 : G.rows;                       // (live-row jobs: set behind the barrier)
         const bool veca = ((lda & 3) == 0) && ((((uintptr_t)Abase) & 15) == 0);
         const bool vecb = ((ldb & 3) == 0) && ((((uintptr_t)Bbase) & 15) == 0);
         // loader roles: A row la, columns lac..+3 (64 rows x 16 cols); B row lb0 / lb0+32, columns lbc..+3 (64 x 32)
@@ -919,9 +954,15 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const int lb0 = threadIdx.x >> 3, lbc = (threadIdx.x & 7) * 4;
         float4 vw = make_float4(0.f, 0.f, 0.f, 0.f);
         if (virt) vw = load4_guard(G.vw2, 0, n0 + lac, N, true, false);
-        const int nchunks_all = (rows + CH - 1) / CH, cps = (nchunks_all + ns - 1) / ns;
-        const int cbeg = sp * cps, cend = min(nchunks_all, cbeg + cps), nchunks = max(cend - cbeg, 0);
-        const int rows_end = min(rows, cend * CH);               // rows of this slice: [cbeg * CH, rows_end)
+        int nchunks_all = 0, cps = 0, cbeg = 0, cend = 0, nchunks = 0, rows_end = 0, rlast = 0;
+        auto set_rows = [&](int r) {
+            rows = r;
+            nchunks_all = (rows + CH - 1) / CH; cps = (nchunks_all + ns - 1) / ns;
+            cbeg = sp * cps; cend = min(nchunks_all, cbeg + cps); nchunks = max(cend - cbeg, 0);
+            rows_end = min(rows, cend * CH);                     // rows of this slice: [cbeg * CH, rows_end)
+            rlast = rows - 1;
+        };
+        if (!cmp) set_rows(G.rows);
         constexpr int DEPTH = 3;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         // Branch-free steady state: every load is unconditional (indices clamped, values masked afterwards), so the
@@ -932,7 +973,6 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         // Tile tails may over-read: columns beyond N (A) / K (B) only feed output elements that are never stored, and
         // every operand except x lives inside the workspace (the job tables follow the last operand array).
         const bool interior = veca && vecb && ((G.bsrc != SRC_X) || (k0 + 32 <= K));
-        const int rlast = rows - 1;
         const int bmodv = bmod ? bmod : 0x7fffffff;          // branch-free "row % bmod" (identity when unused)
         const float* betap = G.A;                            // virt: d score per row; otherwise any valid address
         auto run = [&](auto vec_tag) {
@@ -948,17 +988,32 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             };
             float4 ra[DEPTH], rb0[DEPTH], rb1[DEPTH];
             float beta[DEPTH];
-            auto fetch = [&](int c, int u) {
-                const int r_ = c * CH + la, r0_ = c * CH + lb0, r1_ = r0_ + 32;
-                int rc_ = min(r_, rlast), c0_ = min(r0_, rlast), c1_ = min(r1_, rlast);
-                if (cmp) { rc_ = s_map[rc_]; c0_ = s_map[c0_]; c1_ = s_map[c1_]; }      // (LDS reads: the global loads stay branch-free)
+            auto issue = [&](int rc_, int c0_, int c1_, int u) {                         // (row indices already mapped)
                 ra[u] = ld4(Abase + (size_t)rc_ * lda, n0 + lac, N);
                 beta[u] = betap[virt ? rc_ : 0];
                 rb0[u] = ld4(Bbase + (size_t)(c0_ % bmodv) * ldb, k0 + lbc, K);
                 rb1[u] = ld4(Bbase + (size_t)(c1_ % bmodv) * ldb, k0 + lbc, K);
             };
+            auto fetch = [&](int c, int u) {
+                const int r_ = c * CH + la, r0_ = c * CH + lb0, r1_ = r0_ + 32;
+                int rc_ = min(r_, rlast), c0_ = min(r0_, rlast), c1_ = min(r1_, rlast);
+                if (cmp) { rc_ = s_map[rc_]; c0_ = s_map[c0_]; c1_ = s_map[c1_]; }      // (LDS reads: the global loads stay branch-free)
+                issue(rc_, c0_, c1_, u);
+            };
+            // the prefetch ring's first loads: ahead of the list where they do not need it (see `early` above)
+            if (!cmp) {
 #pragma unroll
-            for (int u = 0; u < DEPTH - 1; ++u) fetch(cbeg + u, u);
+                for (int u = 0; u < DEPTH - 1; ++u) fetch(cbeg + u, u);
+            } else if (ident0) issue(la, lb0, lb0 + 32, 0);
+            if (use_map) __syncthreads();                      // s_map is complete
+#ifdef MMG_TIMING
+            if (threadIdx.x == 0 && tile < 2000) dbg2[8192 + 4 * tile + 0] = (long long)wall_clock64();
+#endif
+            if (cmp) {
+                set_rows(nact);
+#pragma unroll
+                for (int u = 0; u < DEPTH - 1; ++u) if (u > 0 || !ident0) fetch(cbeg + u, u);
+            }
             const int nouter = (nchunks + DEPTH - 1) / DEPTH;
             for (int o = 0; o < nouter; ++o) {
 #pragma unroll
@@ -991,6 +1046,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             run(std::true_type{});
         } else {
             // edge tiles (N or K tail inside the tile, unaligned rows): guarded loads, one chunk at a time
+            if (use_map) __syncthreads();                      // s_map is complete
+            if (cmp) set_rows(nact);
             for (int c = cbeg; c < cend; ++c) {
                 const int buf = c & 1;
                 const int rl = c * CH + la;
@@ -1074,8 +1131,10 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         return;
     }
     // ---- column sums: 16 columns x 16 row groups per block, 4 independent loads in flight per thread
-    const int cb = bid - jt->gemm_tiles;
-    const int j = __popcll(__ballot(jt->c_begin[lane] <= cb)) - 1;
+    const int cb = bid - hd.gemm_tiles;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < MMG_MAX_COL; ++k) j += (cb >= hd.c_begin[k]) ? 1 : 0;
     const ColJob& C = jt->c[j];
     const bool ccmp = use_map && C.compact;
     if (use_map) __syncthreads();                          // s_map is complete

@@ -20,6 +20,7 @@
 #include "kernels_tile.h"
 #include "kernels_mc.h"
 #include "kernels_mc3.h"
+#include "kernels_mc3p.h"
 #include "kernels_rc.h"
 #ifdef MMG_ROLE_DIAG
 #include "diag_kernels.h"
@@ -90,6 +91,7 @@ struct mmg_handle {
     bool sw_rsample, sw_rmsg, sw_fused_s, rs_capable;
     bool persist_ll;           // k_conv_persist's fused sender roles hand over (value, epoch) pairs in per-step slots (tape.pll_*); MMG_NO_PERSIST_LL=1: counters
     bool mc_ok;                // many-class register-resident conversation (kernels_mc.h); MMG_NO_MC=1: off
+    bool mc3p_ok;              // ... for batches of several rounds of workgroups: two sample tiles per workgroup, pipelined (kernels_mc3p.h); MMG_NO_MC3P=1: off
     bool mc3_ok;               // continuous messages: the one-wave-per-SIMD many-class kernel (kernels_mc3.h); binary messages: k_conversation_mc
     bool any_split;            // some k_wgrad job splits its rows over workgroups (k_wreduce adds the partial tiles)
     bool wgrad_small_split;    // jobs with few output tiles split their (step, sample) rows further (layout.h: wgrad_job_nsplit)
@@ -397,7 +399,7 @@ static int select_paths(mmg_handle* h) {
     h->mc_ok = h->use_fast && mc_shape(h->dm.H, h->dm.W, h->dm.R, h->dm.V, h->dm.D, h->dm.T) && !getenv("MMG_NO_MC") && !no_roles;
     h->mc_per = (((h->dm.D + 15) / 16) + 3) & ~3;
     h->mc_xcd = 1;                                  // a tile's 16 workgroups on one XCD (measured at config 5, 256 samples: 192 us per minibatch against 201); cleared below on a device without room for it
-    h->mc3_ok = false;
+    h->mc3_ok = false; h->mc3p_ok = false;
     h->wgrad_small_split = true;
     int n_cu = 0;
     {
@@ -544,6 +546,11 @@ static int select_paths(mmg_handle* h) {
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k_conversation_mc3<256, 32, 64, 100, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, mc3_lds_bytes());
             const int b3 = budget_of((const void*)(k_conversation_mc3<256, 32, 64, 100, 64>), 256, mc3_lds_bytes());
             if (b3 < (h->mc_xcd ? 128 : 16)) h->mc3_ok = false;
+            // two tiles per workgroup (kernels_mc3p.h): from 512 samples on, where the one-tile kernel needs several rounds of workgroups
+            if (h->mc3_ok && h->mc_xcd && mc3p_shape(h->dm.B, h->dm.T, h->dm.D) && !getenv("MMG_NO_MC3P")) {
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k_conversation_mc3p<256, 32, 64, 100, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, mc3p_lds_bytes(h->dm.T));
+                h->mc3p_ok = e == hipSuccess && budget_of((const void*)(k_conversation_mc3p<256, 32, 64, 100, 64>), 256, mc3p_lds_bytes(h->dm.T)) >= 128;
+            }
         }
     }
     if (e == hipSuccess)
@@ -573,12 +580,14 @@ static int select_paths(mmg_handle* h) {
             }
         }
     }
-    if (getenv("MMG_DEBUG"))
+#ifdef MMG_DEBUG_CREATE                                  // (compile with -DMMG_DEBUG_CREATE: what select_paths decided)
+    if (true)
         fprintf(stderr, "mmg_create: game_ok %d game_nbas %d\n", (int)h->game_ok, h->game_nbas);
-    if (getenv("MMG_DEBUG"))
+    if (true)
         fprintf(stderr, "mmg_create: tile_ok %d tile_nt %d tile_smem %d tile_ext %d tile_persist %d persist_smem %d resident_budget %d tile_bwd_smem %d bwd_pre %d send_bwd %d split %d mc %d fast %d rc %d rc_persist %d rc_budget %d rc_bwd %d\n",
                 (int)h->tile_ok, h->tile_nt, h->tile_smem, (int)h->tile_ext, (int)h->tile_persist, h->persist_smem, h->resident_budget, h->tile_bwd_smem,
                 bwd_pre_lds_floats(h->dm) * 4, h->send_bwd_smem, (int)h->tile_split, (int)h->mc_ok, (int)h->use_fast, (int)h->rc_fwd, (int)h->rc_persist, h->rc_budget, (int)h->rc_bwd);
+#endif
     if (h->conv_smem > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_conversation<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conversation<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->conv_smem);
@@ -604,7 +613,7 @@ static int select_paths(mmg_handle* h) {
         h->wgrad_opt = false;
         h->wgrad_opt_ok = !h->any_split && h->dm.use_binary && h->d_err != nullptr && !getenv("MMG_NO_WGRAD_OPT") && !no_roles &&
                           hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_wgrad<true>, MMG_BLOCK, 0) == hipSuccess &&
-                          h->jt.n_wblocks + 2 <= nb * n_cu - 8;
+                          h->jt.n_wblocks + 5 <= nb * n_cu - 8;
         {
             int nb2 = 0;
             h->wgrad_stride = 0;
@@ -617,8 +626,10 @@ static int select_paths(mmg_handle* h) {
                 if (h->jt.gemm_tiles > slots && slots >= 64 && h->jt.gemm_tiles <= 6 * slots) h->wgrad_stride = slots;
             }
         }
-        if (getenv("MMG_DEBUG")) fprintf(stderr, "mmg_create: wgrad_stride %d (gemm tiles %d)\n", h->wgrad_stride, h->jt.gemm_tiles);
-        if (getenv("MMG_DEBUG")) fprintf(stderr, "mmg_create: wgrad_opt_ok %d (blocks %d, resident %d x %d)\n", (int)h->wgrad_opt_ok, h->jt.n_wblocks + 2, nb, n_cu);
+#ifdef MMG_DEBUG_CREATE
+        fprintf(stderr, "mmg_create: wgrad_stride %d (gemm tiles %d)\n", h->wgrad_stride, h->jt.gemm_tiles);
+        fprintf(stderr, "mmg_create: wgrad_opt_ok %d (blocks %d, resident %d x %d)\n", (int)h->wgrad_opt_ok, h->jt.n_wblocks + 5, nb, n_cu);
+#endif
     }
     if (no_roles) {
         // nothing that spins on another workgroup of its own launch: per-step / per-phase launches only
@@ -925,7 +936,11 @@ static int exchange_forward_impl(mmg_handle* h, const float* d_x, const int64_t*
         const int ntile = (d.B + 15) / 16;
         ar.per = h->mc_per;
         const int grid = h->mc_xcd ? ((ntile + 7) / 8) * 128 : ntile * 16;     // (mc_xcd assumes the 8 XCDs of an unpartitioned MI355X; mmg_create clears it otherwise)
-        if (h->mc3_ok)
+        if (h->mc3_ok && h->mc3p_ok && lean) {
+            // two sample tiles per workgroup, half a step apart (kernels_mc3p.h): 128 consecutive workgroups = 8 pairs of tiles x 16 members
+            const int npair = (ntile + 1) / 2;
+            hipLaunchKernelGGL((k_conversation_mc3p<256, 32, 64, 100, 64>), dim3(((npair + 7) / 8) * 128), dim3(256), mc3p_lds_bytes(d.T), st, h->dm, h->P, h->tp, ar, ntile, y_last_only);
+        } else if (h->mc3_ok)
             hipLaunchKernelGGL((k_conversation_mc3<256, 32, 64, 100, 64>), dim3(grid), dim3(256), mc3_lds_bytes(), st, h->dm, h->P, h->tp, ar, ntile, h->mc_xcd, y_last_only);
         else
             hipLaunchKernelGGL((k_conversation_mc<256, 32, 64, 100, 64>), dim3(grid), dim3(512), 0, st, h->dm, h->P, h->tp, ar, ntile, h->mc_xcd, y_last_only);
@@ -1131,6 +1146,10 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         Scope sc(h, st, "k_wgrad");
         WgOpt wo;
         memset(&wo, 0, sizeof(wo));
+        WgHead hd;
+        hd.gemm_tiles = h->jt.gemm_tiles; hd.n_wblocks = h->jt.n_wblocks; hd.special_block = h->jt.special_block; hd.special_job = h->jt.special_job;
+        for (int k = 0; k < MMG_MAX_GEMM; ++k) hd.g_begin[k] = k < h->jt.n_gemm ? h->jt.g[k].tile_begin : 0x7fffffff;
+        for (int k = 0; k < MMG_MAX_COL; ++k) hd.c_begin[k] = k < h->jt.n_col ? h->jt.c[k].blk_begin : 0x7fffffff;
         if (h->wgrad_opt) {
             wo.oa.optim_type = h->cfg.optim_type; wo.oa.only_receiver = 0; wo.oa.lr = h->cfg.learning_rate;
             wo.oa.from_wgrad = 1; wo.oa.bump_step = 1; wo.oa.bump_mb = h->game_step ? 1 : 0;
@@ -1138,10 +1157,10 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             wo.oa.total = h->pl.total;
             wo.params = h->params; wo.state = h->opt_state; wo.grads = h->grads; wo.gnll = h->tp.gnll; wo.coefll = h->tp.coefll;
             wo.counter = h->tp.counter; wo.err_host = h->d_err;
-            hipLaunchKernelGGL(k_wgrad<true>, dim3(h->jt.n_wblocks + 2), dim3(MMG_BLOCK), 0, st,
+            hipLaunchKernelGGL(k_wgrad<true>, dim3(h->jt.n_wblocks + 1 + 4), dim3(MMG_BLOCK), 0, st,     // tiles + column blocks | spare / closing block | four norm roles
                                (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
                                h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
-                               (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, 0
+                               (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, 0, hd
 #ifdef MMG_TIMING
                                , h->tp.dbg2
 #endif
@@ -1150,7 +1169,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         hipLaunchKernelGGL(k_wgrad<false>, dim3(h->wgrad_stride > 0 ? h->wgrad_stride + h->jt.n_wblocks + 1 - h->jt.gemm_tiles : h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
                            (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
                            h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
-                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, h->wgrad_stride
+                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, h->wgrad_stride, hd
 #ifdef MMG_TIMING
                            , h->tp.dbg2
 #endif
