@@ -138,6 +138,10 @@ void    mmg_destroy(mmg_handle* h);
  *   are kept for the output step (T-1) only -- the losses read nothing else of them (model.py:885-904, 1264-1275) -- and in
  *   continuous mode (only the receiver is trained, model.py:1313) the sender-side and message arrays (a, c, zr, dbar, g, w)
  *   may be left unwritten.  This is what mmg_train_step runs.
+ *   ==3 (train == 1): every sample runs all T steps, as with 1 -- messages, probabilities, stop bits, masks and class logits
+ *   of every (step, sample) are on the tape -- but the baselines are the training step's: their scores "bs" / "br" are defined
+ *   on the live rows only.  For the minibatches whose log block prints the whole conversation (model.py:1342-1518), which
+ *   prints no baseline score.
  * Results land in the workspace arrays listed by mmg_tape_table(). */
 int mmg_exchange_forward(mmg_handle* h, const float* d_x, const int64_t* d_target, const float* d_desc,
                          const float* d_u_z, const float* d_u_s, const float* d_u_w, uint64_t seed,
@@ -236,6 +240,19 @@ int mmg_receiver_forward(mmg_handle* h, const float* d_z, const float* d_desc, f
                          float* d_h_w, void* stream);
 int mmg_baseline_forward(mmg_handle* h, int which, const float* d_x, const float* d_binary,
                          const float* d_inp, int rows, float* d_score, void* stream);
+
+/* The log block of a minibatch (model.py:1342-1461) gathered on the device: ONE launch writes one flat float64 vector the
+ * caller copies to the host (asynchronously) and formats.  Layout (mmg_log_snapshot_count() doubles):
+ *   with_losses != 0:  the tape's losses[8] | running top-k hit count totals[1] | the batch statistics "stats" |
+ *                      ent[T]: mean over the WHOLE batch of sum_d softmax(y_t) log(softmax(y_t) + 1e-8) at every step ("Entropy
+ *                      Receiver Predictions", model.py:880-886 -- meaningful on the tape of a run_all_steps = 1 minibatch) |
+ *                      argmax[B] of the selected log-probabilities | target[B]                    ("Predictions", model.py:1379)
+ *   dump = k > 0:      what the sample dump of the first k samples prints at every step (model.py:1411-1461): live samples
+ *                      after each step [T] | sender probs, receiver probs, sender bits, receiver bits [T, k, W] each | stop
+ *                      probabilities [T, k] | stop masks after each step [T, k]
+ * Call it after the minibatch whose block is to be logged, on the same stream. */
+int64_t mmg_log_snapshot_count(const mmg_config* cfg, int dump, int with_losses);
+int mmg_log_snapshot(mmg_handle* h, const int64_t* d_target, int dump, int with_losses, double* d_out, void* stream);
 
 /* Host-only helper of the epoch loop (no GPU work): shuffles perm[0..n) in place exactly as CPython's
  * `random.shuffle` would from the Mersenne-Twister state (624 words + position, `random.getstate()[1]`) -- the batch order of

@@ -45,7 +45,8 @@ SYMBOLS = ["mmg_last_error", "mmg_version", "mmg_param_count", "mmg_grad_floats"
            "mmg_tape_table", "mmg_create", "mmg_destroy", "mmg_exchange_forward", "mmg_loss_stats",
            "mmg_backward", "mmg_clip_step", "mmg_train_step", "mmg_sender_forward", "mmg_receiver_forward",
            "mmg_baseline_forward", "mmg_set_profiling", "mmg_get_kernel_times", "mmg_host_shuffle", "mmg_train_steps",
-           "mmg_dp_set_allreduce", "mmg_dp_train_step", "mmg_dp_train_steps", "mmg_clear_error", "mmg_degraded"]
+           "mmg_dp_set_allreduce", "mmg_dp_train_step", "mmg_dp_train_steps", "mmg_clear_error", "mmg_degraded",
+           "mmg_log_snapshot_count", "mmg_log_snapshot"]
 
 
 def load():
@@ -80,6 +81,8 @@ def load():
     lib.mmg_dp_train_steps.restype = i32; lib.mmg_dp_train_steps.argtypes = [vp, fp, vp, i64, fp, u64, i32, vp]
     lib.mmg_clear_error.restype = i32; lib.mmg_clear_error.argtypes = [vp, vp]
     lib.mmg_degraded.restype = i32; lib.mmg_degraded.argtypes = [vp]
+    lib.mmg_log_snapshot_count.restype = i64; lib.mmg_log_snapshot_count.argtypes = [cfgp, i32, i32]
+    lib.mmg_log_snapshot.restype = i32; lib.mmg_log_snapshot.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.mmg_sender_forward.restype = i32
     lib.mmg_sender_forward.argtypes = [vp, fp, fp, i32, i32, fp, u64, fp, fp, fp, vp]
     lib.mmg_receiver_forward.restype = i32

@@ -1380,4 +1380,84 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_opt(const JobTable* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_log_snapshot: everything the log block of a minibatch prints (model.py:1342-1461) gathered into ONE flat f64 vector by ONE
+// launch (round 6; the host ran ~16 small torch kernels for it -- softmax / log / sums over [T, B, D], six dtype casts, a cat --
+// 0.2 ms of GPU time per log block, 4 us per minibatch at -log_interval 50).  Layout (include/mmg.h: mmg_log_snapshot):
+//   with_losses: losses[8] | totals[1] | stats[NSTAT] | ent[T] | argmax[B] | target[B]
+//     ent[t] = mean_b sum_d softmax(y_t)[b, d] log(softmax(y_t)[b, d] + 1e-8)   ("Entropy Receiver Predictions", model.py:880-886,
+//     over the WHOLE batch: the tape of a run-all minibatch); argmax[b] = first maximum of dist[b, :] ("Predictions")
+//   dump = k > 0:  alive[T] | pz[T, k, W] | pw[T, k, W] | z[T, k, W] | w[T, k, W] | ps[T, k] | mask[1:, :k][T, k]
+// grid = T + 2 workgroups: one per step's entropy, one for the scalars / predictions, one for the dump.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int64_t log_snapshot_count(int T, int B, int W, int k, bool with_losses) {
+    return (with_losses ? 8 + 1 + (int64_t)stat_count(T) + T + 2 * (int64_t)B : 0) + (k > 0 ? (int64_t)T + 4 * (int64_t)T * k * W + 2 * (int64_t)T * k : 0);
+}
+__global__ __launch_bounds__(MMG_BLOCK) void k_log_snapshot(Dims dm, Tape tp, const int64_t* __restrict__ target, int k, int with_losses, double* __restrict__ out) {
+    __shared__ float s_red[8];
+    const int T = dm.T, B = dm.B, D = dm.D, W = dm.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nst = stat_count(T);
+    const int64_t o_ent = 9 + nst, o_arg = o_ent + T, o_tgt = o_arg + B, o_dump = with_losses ? o_tgt + B : 0;
+    const int blk = blockIdx.x;
+    if (blk < T) {
+        if (!with_losses) return;
+        // one wave per row, lanes over the classes
+        float acc = 0.f;
+        for (int b = wave; b < B; b += MMG_BLOCK / 64) {
+            const float* yr = tp.y + ((size_t)blk * B + b) * D;
+            float m = -3.0e38f;
+            for (int d = lane; d < D; d += 64) m = fmaxf(m, yr[d]);
+            m = wave_max(m);
+            float se = 0.f;
+            for (int d = lane; d < D; d += 64) se += __expf(yr[d] - m);
+            se = wave_sum(se);
+            const float inv = 1.0f / se;
+            float e = 0.f;
+            for (int d = lane; d < D; d += 64) { const float p = __expf(yr[d] - m) * inv; e += p * __logf(p + 1e-8f); }
+            acc += wave_sum(e);
+        }
+        if (lane == 0) s_red[wave] = acc;
+        __syncthreads();
+        if (tid == 0) out[o_ent + blk] = (double)(((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)B);
+        return;
+    }
+    if (blk == T) {
+        if (!with_losses) return;
+        if (tid < 8) out[tid] = (double)tp.losses[tid];
+        if (tid == 8) out[8] = tp.totals[1];
+        for (int i = tid; i < nst; i += MMG_BLOCK) out[9 + i] = tp.stats[i];
+        for (int b = tid; b < B; b += MMG_BLOCK) {
+            const float* dr = tp.dist + (size_t)b * D;
+            float best = dr[0]; int arg = 0;
+            for (int d = 1; d < D; ++d) { const float v = dr[d]; if (v > best) { best = v; arg = d; } }
+            out[o_arg + b] = (double)arg;
+            out[o_tgt + b] = target ? (double)target[b] : 0.0;
+        }
+        return;
+    }
+    if (k <= 0) return;
+    // ---- the sample dump of the first k samples (model.py:1411-1461): every step, stopped samples too (run-all tape)
+    double* od = out + o_dump;
+    for (int t = wave; t < T; t += MMG_BLOCK / 64) {                          // live samples after every step
+        float a = 0.f;
+        for (int b = lane; b < B; b += 64) a += (float)tp.mask[(size_t)(t + 1) * B + b];
+        a = wave_sum(a);
+        if (lane == 0) od[t] = (double)a;
+    }
+    const int64_t nW = (int64_t)T * k * W;
+    const float* src[4] = {tp.pz, tp.pw, tp.z, tp.w};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        for (int64_t i = tid; i < nW; i += MMG_BLOCK) {
+            const int t = (int)(i / ((int64_t)k * W)), r = (int)(i % ((int64_t)k * W)), b = r / W, j = r % W;
+            od[T + a * nW + i] = (double)src[a][((size_t)t * B + b) * W + j];
+        }
+    for (int i = tid; i < T * k; i += MMG_BLOCK) {
+        const int t = i / k, b = i % k;
+        od[T + 4 * nW + i] = (double)tp.ps[(size_t)t * B + b];
+        od[T + 4 * nW + T * k + i] = (double)tp.mask[(size_t)(t + 1) * B + b];
+    }
+}
+
 }  // namespace mmg

@@ -29,6 +29,36 @@ namespace mmg {
 
 #define MMG_MC3_LDP 68                              // floats per (slice, sample) row of the partial buffer: R mixture terms | m | s | pad
 
+// The y head of one (sample row, class, r-quarter): sum_j w2[j] max(A[j], -Cd[j]) over the quarter's 16 hidden units, as two
+// chains over the even / the odd units kept in ONE packed accumulator (v_pk_fma_f32: half the FMA issue slots of the scalar
+// form; the same products in the same order, so the sum is bit for bit that of p0 + p1 of rounds 3-5).
+__device__ __forceinline__ float yhead16(const float4& a0, const float4& a1, const float4& a2, const float4& a3,
+                                         const float (&ncd)[16], const float (&w2e)[16]) {
+    f32x2 acc = {0.f, 0.f};
+#define MMG_YH(ax, ay, j) acc = __builtin_elementwise_fma(f32x2{w2e[j], w2e[j + 1]}, f32x2{fmax_nn(ax, ncd[j]), fmax_nn(ay, ncd[j + 1])}, acc)
+    MMG_YH(a0.x, a0.y, 0); MMG_YH(a0.z, a0.w, 2); MMG_YH(a1.x, a1.y, 4); MMG_YH(a1.z, a1.w, 6);
+    MMG_YH(a2.x, a2.y, 8); MMG_YH(a2.z, a2.w, 10); MMG_YH(a3.x, a3.y, 12); MMG_YH(a3.z, a3.w, 14);
+#undef MMG_YH
+    return acc.x + acc.y;
+}
+// ... for the 16 rows of a tile: rows are fetched one ahead of their use (LDS latency under the previous row's 30 VALU slots; at
+// one wave per SIMD nothing else hides it), two rows in flight keep the register footprint at 32 floats
+template <int TM, int LDA, int LDY>
+__device__ __forceinline__ void yhead_tile(const float* s_At, float* s_y, int e4, int cls, float cyv, const float (&ncd)[16], const float (&w2e)[16]) {
+    const float* ar_ = s_At + 16 * e4;
+    float4 c0 = *reinterpret_cast<const float4*>(ar_), c1 = *reinterpret_cast<const float4*>(ar_ + 4);
+    float4 c2 = *reinterpret_cast<const float4*>(ar_ + 8), c3 = *reinterpret_cast<const float4*>(ar_ + 12);
+#pragma unroll 2
+    for (int i = 0; i < TM; ++i) {
+        const float* nx = s_At + min(i + 1, TM - 1) * LDA + 16 * e4;
+        const float4 n0 = *reinterpret_cast<const float4*>(nx), n1 = *reinterpret_cast<const float4*>(nx + 4);
+        const float4 n2 = *reinterpret_cast<const float4*>(nx + 8), n3 = *reinterpret_cast<const float4*>(nx + 12);
+        const float tot = dpp_group_sum<4>(yhead16(c0, c1, c2, c3, ncd, w2e));
+        if (e4 == 0) s_y[i * LDY + cls] = tot + cyv;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+}
+
 struct Mc3Lds {
     static constexpr int R = 64, W = 32, H = 256, TM = 16, LDA = R + 4, LDY = 64 + 4;
     static constexpr int a = 0;                          // [H]
@@ -155,6 +185,8 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
             w2e[4 * j] = q.x; w2e[4 * j + 1] = q.y; w2e[4 * j + 2] = q.z; w2e[4 * j + 3] = q.w;
         }
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(ncd[j]));        // (keep -Cd itself in the registers: hipcc re-negates Cd inside the y-head loop otherwise)
     const float cyv = cls_ok ? tp.cy[min(c0 + cls, D - 1)] : -3.0e38f;
     // mixture: wave w owns the columns 16 w .. 16 w + 15 of [16 samples, CAP classes] x Dd_k [CAP, R]; B fragment of k-step ks:
     // lane (fi = lane & 15, fq = lane >> 4) holds Dd[c0 + 4 ks + fq][16 w + fi]
@@ -291,22 +323,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
         __syncthreads();
         MMG_MSTAMP(16 + 8 * t + 2);
         // ===== C1 slice logits for the 16 samples of the tile
-#pragma unroll 8
-        for (int i = 0; i < TM; ++i) {
-            const float* ar_ = s_At + i * LDA + 16 * e4;
-            const float4 a0 = *reinterpret_cast<const float4*>(ar_), a1 = *reinterpret_cast<const float4*>(ar_ + 4);
-            const float4 a2 = *reinterpret_cast<const float4*>(ar_ + 8), a3 = *reinterpret_cast<const float4*>(ar_ + 12);
-            float p0 = w2e[0] * fmax_nn(a0.x, ncd[0]), p1 = w2e[1] * fmax_nn(a0.y, ncd[1]);
-            p0 = fmaf(w2e[2], fmax_nn(a0.z, ncd[2]), p0); p1 = fmaf(w2e[3], fmax_nn(a0.w, ncd[3]), p1);
-            p0 = fmaf(w2e[4], fmax_nn(a1.x, ncd[4]), p0); p1 = fmaf(w2e[5], fmax_nn(a1.y, ncd[5]), p1);
-            p0 = fmaf(w2e[6], fmax_nn(a1.z, ncd[6]), p0); p1 = fmaf(w2e[7], fmax_nn(a1.w, ncd[7]), p1);
-            p0 = fmaf(w2e[8], fmax_nn(a2.x, ncd[8]), p0); p1 = fmaf(w2e[9], fmax_nn(a2.y, ncd[9]), p1);
-            p0 = fmaf(w2e[10], fmax_nn(a2.z, ncd[10]), p0); p1 = fmaf(w2e[11], fmax_nn(a2.w, ncd[11]), p1);
-            p0 = fmaf(w2e[12], fmax_nn(a3.x, ncd[12]), p0); p1 = fmaf(w2e[13], fmax_nn(a3.y, ncd[13]), p1);
-            p0 = fmaf(w2e[14], fmax_nn(a3.z, ncd[14]), p0); p1 = fmaf(w2e[15], fmax_nn(a3.w, ncd[15]), p1);
-            const float tot = dpp_group_sum<4>(p0 + p1);
-            if (e4 == 0) s_y[i * LDY + cls] = tot + cyv;
-        }
+        yhead_tile<TM, LDA, LDY>(s_At, s_y, e4, cls, cyv, ncd, w2e);
         __syncthreads();
         MMG_MSTAMP(16 + 8 * t + 7);
         // logits -> tape (every step: exchange() returns them; y_last_only: the output step's) and the selected rows -> outp;

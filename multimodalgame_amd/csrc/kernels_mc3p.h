@@ -12,6 +12,8 @@
 //   S(0,t) pubA | pollP K(1,t-1) | S(1,t) pubA | pollA C(0,t) pubP | pollA C(1,t) pubP | pollP K(0,t) | S(0,t+1) pubA | ...
 // every poll comes one or two compute blocks (1.4 - 3.6 us) after its publication: the hand-offs cost their LDS gather only.
 // A pair of steps takes ~12.5 us instead of 2 x 9.2 and the batch needs half the rounds (measured: profiles/r06_*config5*).
+// The launch is PERSISTENT: 256 workgroups (16 pairs x 16 members) walk the batch's pairs, so the 188 KB of weights and the class
+// slice are fetched once per workgroup, not once per round, and a pair's 16 members stay in step from pair to pair.
 // Same lane maps, arithmetic, tape contract and sampling streams as k_conversation_mc3 (bit-identical results: tests/test_hip_configs.py);
 // lean tape only (the fused training step); the host selects it for B >= 512, T <= 13.
 #pragma once
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
     // workgroup -> (pair of tiles, member): the 16 members of a pair are the workgroups i = x (mod 8) of a block of 128 (one XCD)
     const int npair = (ntile + 1) >> 1;
     const int wg = blockIdx.x, blk = wg >> 7, x = wg & 7, member = (wg & 127) >> 3;
-    const int pair = blk * 8 + x;
-    if (pair >= npair) return;
+    const int pair0 = blk * 8 + x, pair_stride = (int)(gridDim.x >> 7) * 8;      // PERSISTENT: this workgroup walks pairs pair0, pair0 + stride, ...
+    if (pair0 >= npair) return;
     const bool train = ar.train != 0, inject = ar.u_s != nullptr;
     const int per = ar.per, c0 = member * per;
     const uint32_t mb_counter = tp.counter[0];
@@ -79,6 +81,9 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
         Slot& S = sl[s];
         S.base = lds + L::slots + s * slotf;
         S.t_gru = S.base + L::tape; S.t_h = S.t_gru + T * 4 * R; S.t_z = S.t_h + (T + 1) * R; S.t_sp = S.t_z + T * W;
+    }
+    // a pair's samples: what changes from pair to pair (the weights, the class slice and the park stay)
+    auto slot_begin = [&](Slot& S, int pair, int s) __attribute__((always_inline)) {
         S.tile = 2 * pair + s;
         S.on = S.tile < ntile;
         const int tl = S.on ? S.tile : 2 * pair;
@@ -93,7 +98,8 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
         const uint32_t gb = (uint32_t)(dm.boff + S.b);
         float* s_us = S.base + L::small;
         if (tid < T) s_us[tid] = (train && inject) ? ar.u_s[(size_t)tid * B + S.b] : philox_uniform(ar.seed, (uint32_t)(tid * dm.Bg + gb), mb_counter, 1u);
-    }
+    };
+    slot_begin(sl[0], pair0, 0); slot_begin(sl[1], pair0, 1);
     // ------------------------------------------------------------ agent weights -> registers / LDS park (kernels_mc3.h lane maps)
     float4 park_tmp[20];
 #pragma unroll
@@ -153,6 +159,8 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
             w2e[4 * j] = q.x; w2e[4 * j + 1] = q.y; w2e[4 * j + 2] = q.z; w2e[4 * j + 3] = q.w;
         }
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(ncd[j]));        // (keep -Cd itself in the registers: hipcc re-negates Cd inside the y-head loop otherwise)
     const float cyv = cls_ok ? tp.cy[min(c0 + cls, D - 1)] : -3.0e38f;
     const int fi = lane & 15, fq = lane >> 4;
     float bfrag[CAP / 4];
@@ -164,15 +172,14 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
     }
 #pragma unroll
     for (int i = 0; i < 20; ++i) s_park[i * NT + tid] = park_tmp[i];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        Slot& S = sl[s];
+    auto slot_state = [&](Slot& S) __attribute__((always_inline)) {
         S.ghn = b_hn;
         float* s_h = S.base + L::h; float* s_w = S.base + L::w; float* s_mask = S.base + L::small + 16;
         if (tid < R) { s_h[tid] = 0.f; S.t_h[tid] = 0.f; }
         if (tid < W) s_w[tid] = dm.first_rec;
         if (tid == 0) s_mask[0] = 1.f;
-    }
+    };
+    slot_state(sl[0]); slot_state(sl[1]);
     const float fixedm = dm.fixed ? 1.f : 0.f;
     const bool sprodm = dm.s_prob_prod != 0;
     __syncthreads();
@@ -284,22 +291,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
             for (int r = 0; r < NA; ++r) if (tid + NT * r < TM * LDA) s_At[tid + NT * r] = ll_value(ua[r]);
         }
         __syncthreads();
-#pragma unroll 8
-        for (int i = 0; i < TM; ++i) {
-            const float* ar_ = s_At + i * LDA + 16 * e4;
-            const float4 a0 = *reinterpret_cast<const float4*>(ar_), a1 = *reinterpret_cast<const float4*>(ar_ + 4);
-            const float4 a2 = *reinterpret_cast<const float4*>(ar_ + 8), a3 = *reinterpret_cast<const float4*>(ar_ + 12);
-            float p0 = w2e[0] * fmax_nn(a0.x, ncd[0]), p1 = w2e[1] * fmax_nn(a0.y, ncd[1]);
-            p0 = fmaf(w2e[2], fmax_nn(a0.z, ncd[2]), p0); p1 = fmaf(w2e[3], fmax_nn(a0.w, ncd[3]), p1);
-            p0 = fmaf(w2e[4], fmax_nn(a1.x, ncd[4]), p0); p1 = fmaf(w2e[5], fmax_nn(a1.y, ncd[5]), p1);
-            p0 = fmaf(w2e[6], fmax_nn(a1.z, ncd[6]), p0); p1 = fmaf(w2e[7], fmax_nn(a1.w, ncd[7]), p1);
-            p0 = fmaf(w2e[8], fmax_nn(a2.x, ncd[8]), p0); p1 = fmaf(w2e[9], fmax_nn(a2.y, ncd[9]), p1);
-            p0 = fmaf(w2e[10], fmax_nn(a2.z, ncd[10]), p0); p1 = fmaf(w2e[11], fmax_nn(a2.w, ncd[11]), p1);
-            p0 = fmaf(w2e[12], fmax_nn(a3.x, ncd[12]), p0); p1 = fmaf(w2e[13], fmax_nn(a3.y, ncd[13]), p1);
-            p0 = fmaf(w2e[14], fmax_nn(a3.z, ncd[14]), p0); p1 = fmaf(w2e[15], fmax_nn(a3.w, ncd[15]), p1);
-            const float tot = dpp_group_sum<4>(p0 + p1);
-            if (e4 == 0) s_y[i * LDY + cls] = tot + cyv;
-        }
+        yhead_tile<TM, LDA, LDY>(s_At, s_y, e4, cls, cyv, ncd, w2e);
         __syncthreads();
         {
             const bool keep_y = !y_last_only || t == T - 1;
@@ -404,6 +396,12 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
     // ... written so that each block is instantiated once per slot (six inlined bodies): iteration t runs
     //     S(0,t) | K(1,t-1) | S(1,t) | C(0,t) | C(1,t) | K(0,t)        (t = T: only K(1,T-1) is left)
     const bool two = sl[1].on;
+  for (int pair = pair0; pair < npair; pair += pair_stride) {
+    if (pair != pair0) {                                     // the next pair of this workgroup: fresh samples on the same weights
+        slot_begin(sl[0], pair, 0); slot_begin(sl[1], pair, 1);
+        slot_state(sl[0]); slot_state(sl[1]);
+        __syncthreads();
+    }
     // (timing build: stamps 16 + 16 t + k of workgroup 0 -- block starts k = 0..5, the ends of the four polls k = 8..11)
     MMG_MSTAMP(2);
     for (int t = 0; t <= T; ++t) {
@@ -493,6 +491,8 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
             tp.hit[b] = (S.tgt >= 0 && above < (float)dm.top_k) ? 1 : 0;
         }
     }
+    __syncthreads();                                         // (the slots' LDS is the next pair's)
+  }
 }
 
 }  // namespace mmg

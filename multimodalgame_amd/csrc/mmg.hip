@@ -729,6 +729,22 @@ static int launch_check(const char* what) {
     return 0;
 }
 
+extern "C" int64_t mmg_log_snapshot_count(const mmg_config* cfg, int dump, int with_losses) {
+    if (validate(cfg)) return -1;
+    const int k = dump < cfg->batch ? (dump > 0 ? dump : 0) : cfg->batch;
+    return log_snapshot_count(cfg->max_exchange, cfg->batch, cfg->w_dim, k, with_losses != 0);
+}
+
+extern "C" int mmg_log_snapshot(mmg_handle* h, const int64_t* d_target, int dump, int with_losses, double* d_out, void* stream) {
+    if (!h) return fail("NULL handle");
+    if (!d_out) return fail("out must not be NULL");
+    const int k = dump < h->dm.B ? (dump > 0 ? dump : 0) : h->dm.B;
+    if (!with_losses && k == 0) return 0;
+    Scope sc(h, (hipStream_t)stream, "k_log_snapshot");
+    hipLaunchKernelGGL(k_log_snapshot, dim3(h->dm.T + 2), dim3(MMG_BLOCK), 0, (hipStream_t)stream, h->dm, h->tp, d_target, k, with_losses ? 1 : 0, d_out);
+    return launch_check("k_log_snapshot");
+}
+
 static int launch_gemm_nt(mmg_handle* h, hipStream_t st, const char* name, const float* X, int ldx, const float* Wm, int ldw,
                           const float* bias, float* out, int ldo, int M, int N, int K) {
     Scope sc(h, st, name);
@@ -923,8 +939,14 @@ static int exchange_forward_impl(mmg_handle* h, const float* d_x, const int64_t*
     const int y_last_only = (run_all_steps == 2 && d.fixed) ? 1 : 0;
     const int lean = (run_all_steps == 2 && !d.use_binary) ? 1 : 0;
     if (run_all_steps == 2) run_all_steps = 0;
+    // run_all_steps == 3 (the minibatches whose log block reads the whole tape): the CONVERSATION runs every sample through all
+    // steps, everything else is the training step's -- the baselines over the live rows only, in the statistics / backward launch
+    // (the log block prints no baseline score; the generic all-rows baselines launch of mode 1 costs 55 us at config 2).
+    // Register-resident agents of a training pass only: other paths take it as mode 1.
+    const bool tape_all = run_all_steps == 3 && train && d.use_binary && fast_shape(h) && !tile_path(h) && !mc_path(h);
+    if (run_all_steps == 3) run_all_steps = tape_all ? 0 : 1;
     ar.y_last_only = y_last_only; ar.lean = lean;
-    ar.train = train; ar.run_all = run_all_steps; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
+    ar.train = train; ar.run_all = (run_all_steps || tape_all) ? 1 : 0; ar.t_begin = 0; ar.t_end = d.T; ar.phases = 3; ar.sprod_first = 1;
     bool base_ready = false;
     h->basehx_ready = false;
     h->bas_deferred = false;
@@ -936,10 +958,15 @@ static int exchange_forward_impl(mmg_handle* h, const float* d_x, const int64_t*
         const int ntile = (d.B + 15) / 16;
         ar.per = h->mc_per;
         const int grid = h->mc_xcd ? ((ntile + 7) / 8) * 128 : ntile * 16;     // (mc_xcd assumes the 8 XCDs of an unpartitioned MI355X; mmg_create clears it otherwise)
-        if (h->mc3_ok && h->mc3p_ok && lean) {
+        // ... when it needs fewer rounds: a round of 16 pairs takes ~1.55x a round of 16 single tiles (measured, scripts/mc3p_ab.py:
+        // 768 samples = 24 pairs = two rounds lose to three rounds of single tiles, every other multiple of 256 from 512 on wins)
+        const int mc3p_rounds = (((ntile + 1) / 2) + h->n_cu / 16 - 1) / (h->n_cu / 16 > 0 ? h->n_cu / 16 : 1), mc3_rounds = (ntile * 16 + h->n_cu - 1) / h->n_cu;
+        if (h->mc3_ok && h->mc3p_ok && lean && 31 * mc3p_rounds < 20 * mc3_rounds) {
             // two sample tiles per workgroup, half a step apart (kernels_mc3p.h): 128 consecutive workgroups = 8 pairs of tiles x 16 members
             const int npair = (ntile + 1) / 2;
-            hipLaunchKernelGGL((k_conversation_mc3p<256, 32, 64, 100, 64>), dim3(((npair + 7) / 8) * 128), dim3(256), mc3p_lds_bytes(d.T), st, h->dm, h->P, h->tp, ar, ntile, y_last_only);
+            int nblk = (npair + 7) / 8;                     // blocks of 128 workgroups = 8 pairs x 16 members; one workgroup per CU: the launch is persistent
+            if (nblk > h->n_cu / 128) nblk = h->n_cu / 128 > 0 ? h->n_cu / 128 : 1;
+            hipLaunchKernelGGL((k_conversation_mc3p<256, 32, 64, 100, 64>), dim3(nblk * 128), dim3(256), mc3p_lds_bytes(d.T), st, h->dm, h->P, h->tp, ar, ntile, y_last_only);
         } else if (h->mc3_ok)
             hipLaunchKernelGGL((k_conversation_mc3<256, 32, 64, 100, 64>), dim3(grid), dim3(256), mc3_lds_bytes(), st, h->dm, h->P, h->tp, ar, ntile, h->mc_xcd, y_last_only);
         else
@@ -1323,7 +1350,7 @@ static int dp_step_impl(mmg_handle* h, const float* d_x, const int64_t* d_target
     hipStream_t st = (hipStream_t)stream;
     mmg_allreduce_fn ar = (mmg_allreduce_fn)h->ar_fn;
     if (reduce && !ar) return fail("mmg_dp_train_step: no collective set (mmg_dp_set_allreduce)");
-    if (exchange_forward_impl(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, full_tape ? 1 : 2, stream)) return -1;
+    if (exchange_forward_impl(h, d_x, d_target, d_desc, d_u_z, d_u_s, d_u_w, seed, 1, full_tape ? 3 : 2, stream)) return -1;
     if (h->dm.use_binary) {
         if (mmg_loss_stats(h, stream)) return -1;
         if (reduce) {

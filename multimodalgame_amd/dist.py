@@ -52,7 +52,7 @@ class DataParallel(object):
         if self.in_library:
             e.dp_train_step(x, target, desc, u_z, u_s, u_w, seed=seed, full_tape=full_tape, reduce=self.world > 1)
             return
-        e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=bool(full_tape), minimal=not full_tape)
+        e.forward(x, target, desc, u_z, u_s, u_w, seed=seed, train=True, run_all=bool(full_tape), minimal=not full_tape, log_tape=True)
         if e.use_binary:
             e.loss_stats()
             if self.world > 1:

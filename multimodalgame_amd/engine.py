@@ -98,14 +98,15 @@ class Engine(object):
         return {a: {k: v.detach().cpu().clone() for k, v in d.items()} for a, d in self.params.items()}
 
     # ------------------------------------------------------------------ phases
-    def forward(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0, train=True, run_all=False, minimal=False):
+    def forward(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0, train=True, run_all=False, minimal=False, log_tape=False):
         """run_all: every sample runs all T steps (what exchange() returns).  minimal (training only): store just what the
-        backward pass reads (include/mmg.h: run_all_steps == 2) -- what the fused mmg_train_step does."""
+        backward pass reads (include/mmg.h: run_all_steps == 2) -- what the fused mmg_train_step does.  log_tape (training
+        only): run_all for the conversation, the baselines on the live rows only (run_all_steps == 3: a log minibatch)."""
         f32 = torch.float32
         _lib.check(self.lib.mmg_exchange_forward(
             self.handle, self._ptr(x, f32), self._ptr(target, torch.int64), self._ptr(desc, f32),
             self._ptr(u_z, f32), self._ptr(u_s, f32), self._ptr(u_w, f32), C.c_uint64(seed),
-            int(bool(train)), 1 if run_all else (2 if minimal and train else 0), self._stream()))
+            int(bool(train)), (3 if log_tape and train else 1) if run_all else (2 if minimal and train else 0), self._stream()))
 
     def loss_stats(self):
         _lib.check(self.lib.mmg_loss_stats(self.handle, self._stream()))
@@ -147,6 +148,15 @@ class Engine(object):
         assert x.size(0) >= n * B and target.size(0) >= n * B
         _lib.check(self.lib.mmg_dp_train_steps(self.handle, self._ptr(x, torch.float32), self._ptr(target, torch.int64), int(n),
                                                self._ptr(desc, torch.float32), C.c_uint64(seed), int(bool(reduce)), self._stream()))
+
+    def log_snapshot(self, target, dump=0, losses=True):
+        """What the log block of the last minibatch prints, as ONE flat float64 device vector written by one launch
+        (include/mmg.h: mmg_log_snapshot)."""
+        n = int(self.lib.mmg_log_snapshot_count(C.byref(self.cfg), int(dump), int(bool(losses))))
+        out = torch.empty(max(n, 1), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mmg_log_snapshot(self.handle, self._ptr(target, torch.int64) if target is not None else None, int(dump),
+                                             int(bool(losses)), C.c_void_p(out.data_ptr()), self._stream()))
+        return out[:n]
 
     def clear_error(self):
         """Clear a recorded in-launch dependency error (drains the stream; the selected kernels stay)."""

@@ -235,7 +235,7 @@ class Game(object):
                 dp = self._dp[id(eng)] = DataParallel(eng, group=self.group)
             dp.train_step(data, target, desc, u[0], u[1], u[2], seed=self.seed, full_tape=full_tape)
         elif full_tape:
-            eng.forward(data, target, desc, u[0], u[1], u[2], seed=self.seed, train=True, run_all=True)
+            eng.forward(data, target, desc, u[0], u[1], u[2], seed=self.seed, train=True, run_all=True, log_tape=True)
             eng.loss_stats()
             eng.backward(data, target, desc)
             eng.clip_step()

@@ -71,7 +71,7 @@ class ShardEngine(object):
         self.optimizers = cpu_ref.build_optimizers(models, flags)
         self.use_binary = bool(flags.use_binary)
 
-    def forward(self, x, target, desc, u_z, u_s, u_w, seed=0, train=True, run_all=False, minimal=False):
+    def forward(self, x, target, desc, u_z, u_s, u_w, seed=0, train=True, run_all=False, minimal=False, log_tape=False):
         fl, m = self.fl, self.models
         tape = cpu_ref.UniformTape(u_z, u_s, u_w)
         for a in ("sender", "receiver"):

@@ -40,3 +40,17 @@ def runs_of_23(e):
     x, t = ep.feats["avgpool_512"], ep.target
     eng.train_steps(x, t, d, 23, seed=0); eng.train_steps(x[23 * 64:], t[23 * 64:], d, 23, seed=0)
 timed("C  ... as two runs of 23", runs_of_23)
+# ---- the log minibatches of model.run(): a special step (phased, run-all tape) + the log snapshot every 50 steps
+from multimodalgame_amd import model as M, flags as F
+F.define_flags(); F.FLAGS.Reset(); F.FLAGS(["x", "-model_type", "Adaptive", "-use_binary", "-exchange_samples", "0"]); 
+xs, ts = x0[:64], t0[:64]
+def special(e, snap):
+    eng.train_steps(x0, t0, d, 46, seed=0)
+    eng.forward(xs, ts, d, seed=0, train=True, run_all=True); eng.loss_stats(); eng.backward(xs, ts, d); eng.clip_step()
+    if snap:
+        h = M._log_snapshot_begin(eng, ts, dump=0)
+        pend.append(h)
+        while len(pend) > 1: M._log_snapshot_end(pend.pop(0))
+pend = []
+timed("D  46 fused steps + ONE phased run-all step (a log minibatch's update)", lambda e: special(e, False))
+timed("E  ... + the log snapshot enqueued (formatted one interval later)", lambda e: special(e, True))

@@ -29,12 +29,20 @@ for B in [int(a) for a in sys.argv[1:]] or [512, 528, 2048]:
         for n, ms in eng.kernel_times():
             times[n] = times.get(n, 0.0) + ms * 500.0       # us per minibatch (2 minibatches)
         eng.set_profiling(False)
+        x = torch.from_numpy(feats[:B]).to(dev); t = torch.from_numpy(target[:B]).to(dev)
+        for i in range(5): eng.train_step(x, t, d, seed=7)
+        torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
+        for i in range(30): eng.train_step(x, t, d, seed=7)
+        torch.cuda.synchronize()
+        times["minibatch"] = 1e6 * (time.perf_counter() - t0) / 30
         res.append((eng.flat_params.clone(), {k: eng.tape[k].clone() for k in ("tstar", "logs", "dist", "hit", "gru", "h", "z", "s", "ps", "mask", "Astar", "hstar", "losses", "outp")}, times))
         del eng
     same = torch.equal(res[0][0], res[1][0]) and all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
     bad = [k for k in res[0][1] if not torch.equal(res[0][1][k], res[1][1][k])]
     ok_all = ok_all and same
-    print("B = %4d: pair kernel == single-tile kernel: %s %s | conversation %.1f us (pair) vs %.1f us (single) per minibatch" % (
-        B, same, bad, res[0][2].get("k_conversation_mc", 0.0), res[1][2].get("k_conversation_mc", 0.0)))
+    print("B = %4d: pair kernel == single-tile kernel: %s %s | training minibatch %.1f us (pair) vs %.1f us (single), 30 steady-state steps" % (
+        B, same, bad, res[0][2]["minibatch"], res[1][2]["minibatch"]))
 print("OK" if ok_all else "MISMATCH")
 sys.exit(0 if ok_all else 1)

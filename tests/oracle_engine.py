@@ -77,7 +77,7 @@ class OracleEngine(dp_ref.ShardEngine):
         u_w = rs.rand(self.T, self.Bg, fl.rec_w_dim)[:, lo:hi]
         return u_z, u_s, u_w
 
-    def forward(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0, train=True, run_all=False, minimal=False):
+    def forward(self, x, target, desc, u_z=None, u_s=None, u_w=None, seed=0, train=True, run_all=False, minimal=False, log_tape=False):
         if not train:
             return self._eval_forward(x, target, desc)
         if u_z is None:

@@ -100,3 +100,31 @@ def test_dp_train_step_calls_rccl_by_address_on_the_engine_stream(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
     assert open(out).read() == "ok"
+
+
+@pytest.mark.parametrize("name,dump", [("g2_adaptive_c1", 3), ("g2_adaptive_c1", 0), ("g3_fixed_c3shard", 2), ("g3_continuous", 0)])
+def test_log_snapshot_kernel_equals_the_torch_form(name, dump, monkeypatch):
+    """mmg_log_snapshot (ONE launch: the log block's losses, statistics, per-step prediction entropies over the whole batch,
+    predictions and sample-dump slices as one flat f64 vector, model.py:1342-1461) against the ~16 torch ops model.run() used
+    through round 5 (MMG_LOG_TORCH=1) on the same run-all tape: copied values exact, entropies within float32 rounding."""
+    from multimodalgame_amd import model
+    z, meta = common.load_golden(name)
+    eng = common.make_engine(meta)
+    x, t, desc = _epoch(meta, 1, eng.device, seed=4)
+    eng.forward(x, t, desc, seed=3, train=True, run_all=True)
+    if eng.use_binary:
+        eng.loss_stats()
+    eng.backward(x, t, desc)
+    eng.clip_step()
+    a = model._log_snapshot_end(model._log_snapshot_begin(eng, t, dump=dump))
+    b_eval = model._log_snapshot_end(model._log_snapshot_begin(eng, None, dump=max(dump, 1), losses=False))
+    monkeypatch.setenv("MMG_LOG_TORCH", "1")
+    want = model._log_snapshot_end(model._log_snapshot_begin(eng, t, dump=dump))
+    want_eval = model._log_snapshot_end(model._log_snapshot_begin(eng, None, dump=max(dump, 1), losses=False))
+    assert a["losses"] == want["losses"] and a["hits_total"] == want["hits_total"] and a["stats"] == want["stats"]
+    assert a["argmax"] == want["argmax"] and a["target"] == want["target"]
+    np.testing.assert_allclose(a["ent_y"], want["ent_y"], rtol=2e-5, atol=2e-6)
+    assert ("dump" in a) == (dump > 0)
+    for got, ref in ((a, want), (b_eval, want_eval)):
+        if "dump" in ref:
+            assert got["dump"] == ref["dump"]
