@@ -632,14 +632,11 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, si
     return v;
 }
 
-// What every block of k_wgrad needs BEFORE it can look anything else up -- the launch geometry and the first tile / block of
-// every job -- travels in the kernel arguments (one s_load burst with the pointers) instead of behind the JobTable pointer:
-// job lookup = unrolled scalar compares, and the job's fields (jt->g[j]) are the FIRST dependent memory trip of the block, not
-// the second (round 6: 3.0 -> ~2.2 us from block start to the first operand load issued; profiles/r06_wgrad_timeline*.log)
-struct WgHead {
-    int gemm_tiles, n_wblocks, special_block, special_job;
-    int g_begin[MMG_MAX_GEMM], c_begin[MMG_MAX_COL];    // INT_MAX padded
-};
+// The launch geometry of k_wgrad travels in the kernel arguments (with the pointers) instead of behind the JobTable pointer: a
+// block knows its role without a memory trip.  (Round 6 also tried the jobs' first tiles there -- job lookup by 40 scalar
+// compares instead of a lane-parallel load + ballot: no gain at config 2, and the 80 extra SGPRs cost the tile-walking launches
+// of config 4 8 us, 35 -> 43: reverted.)
+struct WgHead { int gemm_tiles, n_wblocks, special_block, special_job; };
 
 struct OptArgs {
     int optim_type, only_receiver, from_wgrad, bump_step, bump_mb;
@@ -923,10 +920,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const int nwg = hd.gemm_tiles, xq = nwg >> 3, xr = nwg & 7;
         const int xcd = vt & 7, slot = vt >> 3;
         const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-        // job lookup: scalar compares against the jobs' first tiles in the kernel arguments (no memory trip)
-        int j = 0;
-#pragma unroll
-        for (int k = 1; k < MMG_MAX_GEMM; ++k) j += (tile >= hd.g_begin[k]) ? 1 : 0;
+        // job lookup: lane l compares the l-th job's first tile, one ballot (no serial scalar loads)
+        const int j = __popcll(__ballot(jt->g_begin[lane] <= tile)) - 1;
         const GemmJob& G = jt->g[j];
         // many rows, few output tiles (thousands of samples): the rows of a tile are split over nsplit workgroups whose raw
         // partial tiles k_wreduce adds in a fixed order
@@ -1132,9 +1127,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     }
     // ---- column sums: 16 columns x 16 row groups per block, 4 independent loads in flight per thread
     const int cb = bid - hd.gemm_tiles;
-    int j = 0;
-#pragma unroll
-    for (int k = 1; k < MMG_MAX_COL; ++k) j += (cb >= hd.c_begin[k]) ? 1 : 0;
+    const int j = __popcll(__ballot(jt->c_begin[lane] <= cb)) - 1;
     const ColJob& C = jt->c[j];
     const bool ccmp = use_map && C.compact;
     if (use_map) __syncthreads();                          // s_map is complete

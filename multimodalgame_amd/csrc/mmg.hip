@@ -1175,8 +1175,6 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         memset(&wo, 0, sizeof(wo));
         WgHead hd;
         hd.gemm_tiles = h->jt.gemm_tiles; hd.n_wblocks = h->jt.n_wblocks; hd.special_block = h->jt.special_block; hd.special_job = h->jt.special_job;
-        for (int k = 0; k < MMG_MAX_GEMM; ++k) hd.g_begin[k] = k < h->jt.n_gemm ? h->jt.g[k].tile_begin : 0x7fffffff;
-        for (int k = 0; k < MMG_MAX_COL; ++k) hd.c_begin[k] = k < h->jt.n_col ? h->jt.c[k].blk_begin : 0x7fffffff;
         if (h->wgrad_opt) {
             wo.oa.optim_type = h->cfg.optim_type; wo.oa.only_receiver = 0; wo.oa.lr = h->cfg.learning_rate;
             wo.oa.from_wgrad = 1; wo.oa.bump_step = 1; wo.oa.bump_mb = h->game_step ? 1 : 0;

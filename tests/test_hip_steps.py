@@ -51,7 +51,7 @@ def test_dp_train_step_in_the_library_equals_the_phased_calls(name):
         xs, ts = x[i * B:(i + 1) * B], t[i * B:(i + 1) * B]
         full = i == 2
         a.dp_train_step(xs, ts, desc, seed=5, full_tape=full, reduce=False)
-        b.forward(xs, ts, desc, seed=5, train=True, run_all=full, minimal=not full)
+        b.forward(xs, ts, desc, seed=5, train=True, run_all=full, minimal=not full, log_tape=True)
         if b.use_binary:
             b.loss_stats()
         b.backward(xs, ts, desc)
