@@ -153,8 +153,8 @@ def traffic_lookup(workload, kernel, strong, profiles_dir=None):
     pat = re.compile(r"^r(\d+)_%sconfig%s_pmc_hbm_traffic\.json$" % ("strong_" if strong else "", num))
     files = sorted((int(pat.match(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(pdir, "r*_pmc_hbm_traffic.json"))
                    if pat.match(os.path.basename(f)))
-    alias = {"k_game": ("k_game_fast",), "k_conversation": ("k_conversation_fast3", "k_conversation_fast2", "k_conversation_mc3", "k_conversation_mc", "k_conversation"),
-             "k_conversation_mc": ("k_conversation_mc3", "k_conversation_mc"), "k_bwd_conv": ("k_bwd_conv_fast", "k_bwd_conv"),
+    alias = {"k_game": ("k_game_fast",), "k_conversation": ("k_conversation_fast3", "k_conversation_fast2", "k_conversation_mc3p", "k_conversation_mc3", "k_conversation_mc", "k_conversation"),
+             "k_conversation_mc": ("k_conversation_mc3p", "k_conversation_mc3", "k_conversation_mc"), "k_bwd_conv": ("k_bwd_conv_fast", "k_bwd_conv"),
              "k_baselines": ("k_baselines3", "k_baselines4", "k_baselines2", "k_baselines")}
     for _, f in reversed(files):
         try:
@@ -171,7 +171,7 @@ def traffic_lookup(workload, kernel, strong, profiles_dir=None):
 GROUP_OF = {
     "k_conversation_fast3": "k_conversation", "k_conversation_fast2": "k_conversation", "k_conversation": "k_conversation",
     "k_game_fast": "k_game",
-    "k_conversation_mc3": "k_conversation_mc", "k_conversation_mc": "k_conversation_mc",
+    "k_conversation_mc3p": "k_conversation_mc", "k_conversation_mc3": "k_conversation_mc", "k_conversation_mc": "k_conversation_mc",
     "k_conv_persist": "k_conv_persist", "k_conv_tile": "k_conv_tile", "k_conv_split": "k_conv_split",
     "k_rc_persist": "k_conv_rc", "k_rc_gru": "k_conv_rc", "k_rc_heads": "k_conv_rc", "k_rc_query": "k_conv_rc", "k_rc_tail": "k_conv_rc",
     "k_send_s1": "k_send_s1", "k_send_s2": "k_send_s2",

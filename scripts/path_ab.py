@@ -6,10 +6,10 @@ usage: path_ab.py [seeds]      exit code 1 on a mismatch"""
 import os, sys, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CASES = {   # name: (engine kwargs over bench.C2, batch, [environment variants])
-    "c2 small agents, Adaptive": (dict(), 64, [{}, {"MMG_NO_GAME": "1"}, {"MMG_NO_WGRAD_OPT": "1"}, {"MMG_NO_MERGE": "1"}, {"MMG_NO_FAST": "1"}]),
+    "c2 small agents, Adaptive": (dict(), 64, [{}, {"MMG_NO_GAME": "1"}, {"MMG_NO_WGRAD_OPT": "1"}, {"MMG_NO_MERGE_PREP": "1"}, {"MMG_NO_MERGE": "1"}, {"MMG_NO_ROLES": "1"}, {"MMG_NO_FAST": "1"}]),
     "c2 ragged batch 50": (dict(), 50, [{}, {"MMG_NO_GAME": "1"}, {"MMG_NO_FAST": "1"}]),
-    "c3 Fixed": (dict(fixed_exchange=True), 64, [{}, {"MMG_NO_MERGE": "1"}, {"MMG_NO_FAST": "1"}]),
-    "c4 W=256 H=1024": (dict(w_dim=256, h_dim=1024), 64, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_FUSED_S": "1"}, {"MMG_NO_RMSG": "1"}, {"MMG_NO_RSAMPLE": "1"}, {"MMG_NO_PERSIST": "1"}, {"MMG_NO_TILE": "1"}]),
+    "c3 Fixed": (dict(fixed_exchange=True), 64, [{}, {"MMG_NO_MERGE": "1"}, {"MMG_NO_ROLES": "1"}, {"MMG_NO_FAST": "1"}]),
+    "c4 W=256 H=1024": (dict(w_dim=256, h_dim=1024), 64, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_FUSED_S": "1"}, {"MMG_NO_RMSG": "1"}, {"MMG_NO_RSAMPLE": "1"}, {"MMG_NO_PERSIST": "1"}, {"MMG_NO_ROLES": "1"}, {"MMG_NO_TILE": "1"}]),
     "c4 88 samples (two role launches)": (dict(w_dim=256, h_dim=1024), 88, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_PERSIST": "1"}]),
     "c4 W=128 H=2048 (s1 / s2 roles)": (dict(w_dim=128, h_dim=2048), 48, [{}, {"MMG_NO_RSAMPLE": "1"}, {"MMG_NO_PERSIST": "1"}]),
     "c4 Fixed exchange": (dict(w_dim=256, h_dim=1024, fixed_exchange=True), 64, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_PERSIST": "1"}]),
@@ -18,8 +18,10 @@ CASES = {   # name: (engine kwargs over bench.C2, batch, [environment variants])
     "c4 max_exchange 2, 30 samples": (dict(w_dim=256, h_dim=1024, max_exchange=2), 30, [{}, {"MMG_NO_PERSIST_LL": "1"}, {"MMG_NO_PERSIST": "1"}]),
     "c2 max_exchange 15": (dict(max_exchange=15), 64, [{}, {"MMG_NO_GAME": "1"}, {"MMG_NO_FAST": "1"}]),
     "c2 max_exchange 1": (dict(max_exchange=1), 64, [{}, {"MMG_NO_GAME": "1"}, {"MMG_NO_FAST": "1"}]),
-    "c4 R=256 wide receiver": (dict(w_dim=256, h_dim=1024, rec_hidden=256), 64, [{}, {"MMG_NO_RC_PERSIST": "1"}, {"MMG_NO_RC_BWD": "1"}, {"MMG_NO_RC": "1"}]),
+    "c4 R=256 wide receiver": (dict(w_dim=256, h_dim=1024, rec_hidden=256), 64, [{}, {"MMG_NO_RC_PERSIST": "1"}, {"MMG_NO_RC_BWD": "1"}, {"MMG_NO_ROLES": "1"}, {"MMG_NO_RC": "1"}]),
     "200 classes, binary, Adaptive": (dict(n_classes=200), 40, [{}, {"MMG_NO_MC": "1"}, {"MMG_TILE": "1"}]),
+    "1000 classes, continuous, on the sample tiles (class helpers)": (dict(n_classes=1000, use_binary=False, fixed_exchange=True), 128, [{"MMG_TILE": "1"}, {"MMG_TILE": "1", "MMG_NO_SPLIT": "1"}, {}]),
+    "c5 continuous, 512 samples (two tiles per workgroup)": (dict(n_classes=1000, use_binary=False, fixed_exchange=True), 512, [{}, {"MMG_NO_MC3P": "1"}, {"MMG_NO_ROLES": "1"}]),
 }
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import numpy as np, torch
