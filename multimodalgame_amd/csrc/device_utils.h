@@ -399,6 +399,17 @@ __device__ __forceinline__ void st_ll2(float* ll, size_t i, float v0, float v1, 
     const float e = __builtin_bit_cast(float, epoch);
     st_wt4(ll + 2 * i, make_float4(v0, e, v1, e));
 }
+// ... the same pair kept INSIDE the XCD's L2 (round 6): a plain 8-byte store goes through the CU's write-through L1 into the L2 of
+// ITS XCD and stays there (written back when the line is evicted or the launch ends); the agent-scope (sc1) loads of consumers on
+// the SAME XCD hit it there (scripts/micro/hop_latency.hip: "a plain store is visible to sc1 loads of the same XCD only").  Only
+// for hand-offs whose producer and consumers the launch places on one XCD, and only when mmg_create's probe (k_xcc_probe)
+// confirmed that placement rule on this device: the payload then never reaches the HBM-side counters.
+__device__ __forceinline__ void st_ll_l2(float* ll, size_t i, float v, uint32_t epoch) {
+    const unsigned long long u = ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(ll) + i, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the XCD (XCC) this wave runs on: HW_REG_XCC_ID (id 20), bits [3:0]
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 0xfu; }
 __device__ __forceinline__ unsigned long long ld_ll(const float* ll, size_t i) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(ll) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

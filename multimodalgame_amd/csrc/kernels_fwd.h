@@ -372,6 +372,7 @@ struct ConvArgs {
     int lean;                  // training-minimal call in continuous mode: tape arrays the receiver-only backward never reads are not stored
     int nprep, prep_cpb;       // k_conversation_fast3: leading workgroups that run k_prep's blocks as roles of the launch (0: k_prep ran before), classes per class block
     int nbase;                 // ... and trailing basehx tiles
+    int l2_handoff;            // kernels_mc3.h / kernels_mc3p.h: the tile's members share an XCD (probed at mmg_create): pairs as plain stores, inside its L2
 };
 
 struct ConvSmem {
@@ -387,6 +388,12 @@ __host__ __device__ inline int conv_smem_floats(const Dims& d, int nthreads) {
 
 // NT = 256 (many samples: occupancy) or 512 with deeper load batches (few samples, large weight matrices: the weights
 // stream from L2 every step, so what counts is bytes in flight per CU).
+// k_xcc_probe: which XCD runs workgroup i of a launch?  mmg_create checks the rule the XCD-aware launches rely on -- workgroup
+// i goes to XCD i % 8 -- before it lets a hand-off stay inside one XCD's L2 (st_ll_l2).
+__global__ __launch_bounds__(64) void k_xcc_probe(uint32_t* __restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_conversation(Dims dm, Params P, Tape tp, ConvArgs ar) {
     constexpr int GU = NT == 512 ? 8 : 4;               // row passes per load batch of gemv_rows

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
     const bool have_full = have && !ar.lean;            // (lean: the fused training step keeps what its backward reads: z, h, gates, output step)
     const int b = have ? b_raw : B - 1;
     const bool train = ar.train != 0, inject = ar.u_s != nullptr;
+    const bool l2h = ar.l2_handoff != 0 && xcd_map != 0;     // the tile's 16 members share this XCD's L2: the pairs stay there (device_utils.h: st_ll_l2)
     const int per = ar.per, c0 = member * per;
     const uint32_t mb_counter = tp.counter[0];
     const uint32_t ll_base = tp.counter[3] * 32u;          // epochs of this launch's pair hand-offs: launch epoch, step
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
         }
         // ----- hand-off 1: publish A (17 x 16 bytes); the hidden-side GRU product of the next step fills the wait
         const uint32_t ep = ll_base + (uint32_t)t + 1u;
-        if (tid < LDA) st_ll(llA, (size_t)member * LDA + tid, s_Aown[tid], ep);
+        if (tid < LDA) { if (l2h) st_ll_l2(llA, (size_t)member * LDA + tid, s_Aown[tid], ep); else st_ll(llA, (size_t)member * LDA + tid, s_Aown[tid], ep); }
         {
             float4 pk[4], hq[4];
             park_load(pk, hq, s_park, 0, tid, hn + q3 * 16); ghp_r = park_fma(pk, hq);
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3(Dims dm, Params P, 
         {
             constexpr int NP = (TM * LDP + NT - 1) / NT;                     // pairs per thread, out and in
 #pragma unroll
-            for (int r = 0; r < NP; ++r) if (tid + NT * r < TM * LDP) st_ll(llP, p_mine + tid + NT * r, s_P[tid + NT * r], ep);
+            for (int r = 0; r < NP; ++r) if (tid + NT * r < TM * LDP) { if (l2h) st_ll_l2(llP, p_mine + tid + NT * r, s_P[tid + NT * r], ep); else st_ll(llP, p_mine + tid + NT * r, s_P[tid + NT * r], ep); }
             unsigned long long up[NP];
             int kq[NP];
 #pragma unroll

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
     const int pair0 = blk * 8 + x, pair_stride = (int)(gridDim.x >> 7) * 8;      // PERSISTENT: this workgroup walks pairs pair0, pair0 + stride, ...
     if (pair0 >= npair) return;
     const bool train = ar.train != 0, inject = ar.u_s != nullptr;
+    const bool l2h = ar.l2_handoff != 0;                     // a pair's 16 members share this XCD's L2: the pairs stay there (device_utils.h: st_ll_l2)
     const int per = ar.per, c0 = member * per;
     const uint32_t mb_counter = tp.counter[0];
     const uint32_t ll_base = tp.counter[3] * 32u;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
             tp.hstar[(size_t)S.b * R + tid] = hn[tid];
         }
         const uint32_t ep = ll_base + (uint32_t)t + 1u;
-        if (tid < LDA) st_ll(S.llA, (size_t)member * LDA + tid, s_Aown[tid], ep);
+        if (tid < LDA) { if (l2h) st_ll_l2(S.llA, (size_t)member * LDA + tid, s_Aown[tid], ep); else st_ll(S.llA, (size_t)member * LDA + tid, s_Aown[tid], ep); }
         {
             float4 pk[4], hq[4];
             park_load(pk, hq, s_park, 0, tid, hn + q3 * 16); S.ghp_r = park_fma(pk, hq);
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void k_conversation_mc3p(Dims dm, Params P,
             constexpr int NP = (TM * LDP + NT - 1) / NT;
             const size_t p_mine = (size_t)member * TM * LDP;
 #pragma unroll
-            for (int r = 0; r < NP; ++r) if (tid + NT * r < TM * LDP) st_ll(S.llP, p_mine + tid + NT * r, s_P[tid + NT * r], ep);
+            for (int r = 0; r < NP; ++r) if (tid + NT * r < TM * LDP) { if (l2h) st_ll_l2(S.llP, p_mine + tid + NT * r, s_P[tid + NT * r], ep); else st_ll(S.llP, p_mine + tid + NT * r, s_P[tid + NT * r], ep); }
         }
     };
     // ---- K: the 16 slices' partials of this sample in, combined into g; the receiver's message

@@ -96,6 +96,7 @@ struct mmg_handle {
     bool any_split;            // some k_wgrad job splits its rows over workgroups (k_wreduce adds the partial tiles)
     bool wgrad_small_split;    // jobs with few output tiles split their (step, sample) rows further (layout.h: wgrad_job_nsplit)
     int mc_per, mc_xcd;        // classes per member of a tile; mc_xcd: a tile's 16 workgroups on one XCD
+    bool xcd_rule_ok;          // probed at mmg_create (k_xcc_probe): workgroup i of a launch runs on XCD i % 8 -- a hand-off between workgroups of one XCD may stay in its L2
     // workgroups of 512 threads that are guaranteed to be resident together on this device (occupancy query at mmg_create,
     // minus a margin): the role launches (k_conv_persist / k_conv_split / k_conversation_mc) spin on each other, so a launch
     // may never hold more roles than this
@@ -669,6 +670,23 @@ extern "C" mmg_handle* mmg_create(const mmg_config* cfg, void* d_workspace, int6
     if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) h->no_roles = true;
     if (select_paths(h)) { delete h; return nullptr; }
     {
+        // does this device place workgroup i of a launch on XCD i % 8 (8 distinct XCDs)?  The XCD-aware launches only PREFER that
+        // placement; the many-class conversation may additionally keep its hand-off pairs inside the XCD's L2 when it holds.
+        h->xcd_rule_ok = false;
+        if (h->mc_ok && h->mc_xcd) {
+            const int n = 2048;
+            uint32_t* d_probe = reinterpret_cast<uint32_t*>(h->tp.tables);      // (the job-table slot: uploaded below)
+            if (hipMemset(d_probe, 0xff, n * sizeof(uint32_t)) == hipSuccess) {
+                hipLaunchKernelGGL(k_xcc_probe, dim3(n), dim3(64), 0, 0, d_probe);
+                std::vector<uint32_t> got(n);
+                if (hipMemcpy(got.data(), d_probe, n * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+                    bool ok = true;
+                    for (int i = 0; i < n && ok; ++i) ok = got[i] < 8u && got[i] == got[i & 7];
+                    for (int a = 0; a < 8 && ok; ++a) for (int b = a + 1; b < 8 && ok; ++b) ok = got[a] != got[b];
+                    h->xcd_rule_ok = ok;
+                }
+            }
+        }
         hipError_t e = hipMemset(d_workspace, 0, h->tl.total);
         if (e == hipSuccess) e = hipMemset(d_grads, 0, sizeof(float) * (h->pl.total + MMG_GRAD_TAIL));
         if (e != hipSuccess) { fail("device init failed: %s", hipGetErrorString(e)); delete h; return nullptr; }
@@ -957,6 +975,7 @@ static int exchange_forward_impl(mmg_handle* h, const float* d_x, const int64_t*
         Scope sc(h, st, "k_conversation_mc");
         const int ntile = (d.B + 15) / 16;
         ar.per = h->mc_per;
+        ar.l2_handoff = (h->mc_xcd && h->xcd_rule_ok) ? 1 : 0;
         const int grid = h->mc_xcd ? ((ntile + 7) / 8) * 128 : ntile * 16;     // (mc_xcd assumes the 8 XCDs of an unpartitioned MI355X; mmg_create clears it otherwise)
         // ... when it needs fewer rounds: a round of 16 pairs takes ~1.55x a round of 16 single tiles (measured, scripts/mc3p_ab.py:
         // 768 samples = 24 pairs = two rounds lose to three rounds of single tiles, every other multiple of 256 from 512 on wins)
