@@ -968,7 +968,18 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         // Tile tails may over-read: columns beyond N (A) / K (B) only feed output elements that are never stored, and
         // every operand except x lives inside the workspace (the job tables follow the last operand array).
         const bool interior = veca && vecb && ((G.bsrc != SRC_X) || (k0 + 32 <= K));
-        const int bmodv = bmod ? bmod : 0x7fffffff;          // branch-free "row % bmod" (identity when unused)
+        // branch-free "row % bmod" (identity when unused) WITHOUT a runtime division (~9 instructions apiece, two per chunk and
+        // thread: the loop around the eight MFMAs of a chunk is issue-bound): row < 2^16, so q = (row * ceil(2^32 / bmod)) >> 32 is
+        // floor(row / bmod) or one more -- one conditional correction
+        const int bmodv = bmod ? bmod : 0x7fffffff;
+        const uint32_t bmagic = bmod > 1 ? (uint32_t)((0x100000000ull + (unsigned)bmod - 1ull) / (unsigned)bmod) : 0u;
+        const bool bmod_one = bmod == 1;                     // (its magic number is 2^32: every row is row 0)
+        (void)bmodv;
+        auto rowmod = [&](int r) -> int {
+            const int q = (int)__umulhi((uint32_t)r, bmagic);
+            const int m = r - q * bmod;                      // (bmod = 0: q = 0, m = r)
+            return bmod_one ? 0 : (m < 0 ? m + bmod : m);
+        };
         const float* betap = G.A;                            // virt: d score per row; otherwise any valid address
         auto run = [&](auto vec_tag) {
             constexpr bool VEC = decltype(vec_tag)::value;
@@ -986,8 +997,8 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             auto issue = [&](int rc_, int c0_, int c1_, int u) {                         // (row indices already mapped)
                 ra[u] = ld4(Abase + (size_t)rc_ * lda, n0 + lac, N);
                 beta[u] = betap[virt ? rc_ : 0];
-                rb0[u] = ld4(Bbase + (size_t)(c0_ % bmodv) * ldb, k0 + lbc, K);
-                rb1[u] = ld4(Bbase + (size_t)(c1_ % bmodv) * ldb, k0 + lbc, K);
+                rb0[u] = ld4(Bbase + (size_t)rowmod(c0_) * ldb, k0 + lbc, K);
+                rb1[u] = ld4(Bbase + (size_t)rowmod(c1_) * ldb, k0 + lbc, K);
             };
             auto fetch = [&](int c, int u) {
                 const int r_ = c * CH + la, r0_ = c * CH + lb0, r1_ = r0_ + 32;
@@ -1021,10 +1032,13 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                         av.x = av.x > 0.f ? beta[u] * vw.x : 0.f; av.y = av.y > 0.f ? beta[u] * vw.y : 0.f;
                         av.z = av.z > 0.f ? beta[u] * vw.z : 0.f; av.w = av.w > 0.f ? beta[u] * vw.w : 0.f;
                     }
-                    const float ma = va ? 1.f : 0.f, m0 = v0 ? 1.f : 0.f, m1 = v1 ? 1.f : 0.f;
+                    // rows beyond the slice: the A slice is zeroed; the B slice may stay what the clamped load fetched -- a LIVE row's
+                    // finite values times zero (eight multiplies per chunk and thread less)
+                    const float ma = va ? 1.f : 0.f;
+                    (void)v0; (void)v1;
                     *reinterpret_cast<float4*>(&s_a[buf][la][lac]) = make_float4(av.x * ma, av.y * ma, av.z * ma, av.w * ma);
-                    *reinterpret_cast<float4*>(&s_b[buf][lb0][lbc]) = make_float4(rb0[u].x * m0, rb0[u].y * m0, rb0[u].z * m0, rb0[u].w * m0);
-                    *reinterpret_cast<float4*>(&s_b[buf][lb0 + 32][lbc]) = make_float4(rb1[u].x * m1, rb1[u].y * m1, rb1[u].z * m1, rb1[u].w * m1);
+                    *reinterpret_cast<float4*>(&s_b[buf][lb0][lbc]) = rb0[u];
+                    *reinterpret_cast<float4*>(&s_b[buf][lb0 + 32][lbc]) = rb1[u];
                     __syncthreads();
                     fetch(c + DEPTH - 1, (u + DEPTH - 1) % DEPTH);        // unconditional: clamped beyond the last row
 #pragma unroll
