@@ -6,6 +6,18 @@
 namespace mmg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Pointers a kernel reads out of a TABLE in memory (k_wgrad's job table) are generic to the compiler, which then emits flat_load
+// with 64-bit address arithmetic per access; these casts state what the host guarantees (device memory): global_load, half the
+// address instructions.
+typedef __attribute__((address_space(1))) const float gfloat;
+typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+__device__ __forceinline__ gfloat* as_global(const float* p) { return (gfloat*)p; }
+typedef __attribute__((address_space(1))) float gfloat_w;
+__device__ __forceinline__ gfloat_w* as_global_w(float* p) { return (gfloat_w*)p; }
+__device__ __forceinline__ float4 ldg4(gfloat* p) {
+    const f32x4 v = *(gf32x4*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 #define MMG_BLOCK 256          // 4 wave64 per workgroup everywhere
 #define MMG_EPS 1e-8f          // the reference's log(p + 1e-8)   model.py:908

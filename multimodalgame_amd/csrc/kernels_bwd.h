@@ -620,11 +620,11 @@ struct JobTable {
 };
 
 // load 4 consecutive floats of one row with bounds / alignment handling (zeros outside)
-__device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, size_t row_off, int col, int ncols, bool row_ok, bool vec_ok) {
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ base_, size_t row_off, int col, int ncols, bool row_ok, bool vec_ok) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!row_ok) return v;
-    const float* p = base + row_off + col;
-    if (vec_ok && col + 3 < ncols) return *reinterpret_cast<const float4*>(p);
+    gfloat* p = as_global(base_) + row_off + col;          // (device memory: see as_global)
+    if (vec_ok && col + 3 < ncols) return ldg4(p);
     if (col < ncols) v.x = p[0];
     if (col + 1 < ncols) v.y = p[1];
     if (col + 2 < ncols) v.z = p[2];
@@ -980,34 +980,37 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             const int m = r - q * bmod;                      // (bmod = 0: q = 0, m = r)
             return bmod_one ? 0 : (m < 0 ? m + bmod : m);
         };
-        const float* betap = G.A;                            // virt: d score per row; otherwise any valid address
-        auto run = [&](auto vec_tag) {
-            constexpr bool VEC = decltype(vec_tag)::value;
-            auto ld4 = [&](const float* rowp, int col, int ncols) -> float4 {
-                if (VEC) return *reinterpret_cast<const float4*>(rowp + col);
-                const int cm = ncols - 1;
-                float4 v;
-                v.x = rowp[min(col, cm)]; v.y = rowp[min(col + 1, cm)]; v.z = rowp[min(col + 2, cm)]; v.w = rowp[min(col + 3, cm)];
-                v.x = (col < ncols) ? v.x : 0.f; v.y = (col + 1 < ncols) ? v.y : 0.f;
-                v.z = (col + 2 < ncols) ? v.z : 0.f; v.w = (col + 3 < ncols) ? v.w : 0.f;
-                return v;
-            };
+        // (global address space stated: pointers out of the job table are generic to the compiler -- flat loads with 64-bit address
+        //  arithmetic per access; as_global: 125 -> 65 instructions per chunk and thread around the eight MFMAs, and the loop is
+        //  bound by the SIMDs' instruction issue: four workgroups per CU x ~500 issue cycles per chunk of 2 400)
+        gfloat* const Ag = as_global(Abase);
+        gfloat* const Bg = as_global(Bbase);
+        gfloat* const betag = as_global(G.A);                // virt: d score per row; otherwise any valid address
+        // One instantiation of the steady loop per KIND of job -- virtual A operand or not, live-row list or plain rows, a
+        // per-sample B operand (row % B) or not -- because the loop is bound by the SIMDs' instruction issue (round-6 counters at
+        // config 3, 512 samples: 42 % of the wave cycles stalled on issue, 20 % issuing, MFMA pipes 23 % busy): what a job does
+        // not use must not be in its loop.  The commonest kind (live rows, plain operands) drops the score load, the ReLU mask
+        // arithmetic and two magic modulos: ~65 -> ~40 instructions per chunk and thread.
+        auto run = [&](auto virt_tag, auto cmp_tag, auto bmod_tag) {
+            constexpr bool VIRT = decltype(virt_tag)::value, CMPJ = decltype(cmp_tag)::value, BMOD = decltype(bmod_tag)::value;
             float4 ra[DEPTH], rb0[DEPTH], rb1[DEPTH];
             float beta[DEPTH];
+            // (32-bit element offsets from the job's base pointers: every operand array is far below 2^32 floats)
+            const uint32_t acol = (uint32_t)(n0 + lac), bcol = (uint32_t)(k0 + lbc), ulda = (uint32_t)lda, uldb = (uint32_t)ldb;
             auto issue = [&](int rc_, int c0_, int c1_, int u) {                         // (row indices already mapped)
-                ra[u] = ld4(Abase + (size_t)rc_ * lda, n0 + lac, N);
-                beta[u] = betap[virt ? rc_ : 0];
-                rb0[u] = ld4(Bbase + (size_t)rowmod(c0_) * ldb, k0 + lbc, K);
-                rb1[u] = ld4(Bbase + (size_t)rowmod(c1_) * ldb, k0 + lbc, K);
+                ra[u] = ldg4(Ag + ((uint32_t)rc_ * ulda + acol));
+                if (VIRT) beta[u] = betag[(uint32_t)rc_];
+                rb0[u] = ldg4(Bg + ((uint32_t)(BMOD ? rowmod(c0_) : c0_) * uldb + bcol));
+                rb1[u] = ldg4(Bg + ((uint32_t)(BMOD ? rowmod(c1_) : c1_) * uldb + bcol));
             };
             auto fetch = [&](int c, int u) {
                 const int r_ = c * CH + la, r0_ = c * CH + lb0, r1_ = r0_ + 32;
                 int rc_ = min(r_, rlast), c0_ = min(r0_, rlast), c1_ = min(r1_, rlast);
-                if (cmp) { rc_ = s_map[rc_]; c0_ = s_map[c0_]; c1_ = s_map[c1_]; }      // (LDS reads: the global loads stay branch-free)
+                if (CMPJ) { rc_ = s_map[rc_]; c0_ = s_map[c0_]; c1_ = s_map[c1_]; }     // (LDS reads: the global loads stay branch-free)
                 issue(rc_, c0_, c1_, u);
             };
             // the prefetch ring's first loads: ahead of the list where they do not need it (see `early` above)
-            if (!cmp) {
+            if (!CMPJ) {
 #pragma unroll
                 for (int u = 0; u < DEPTH - 1; ++u) fetch(cbeg + u, u);
             } else if (ident0) issue(la, lb0, lb0 + 32, 0);
@@ -1015,7 +1018,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
 #ifdef MMG_TIMING
             if (threadIdx.x == 0 && tile < 2000) dbg2[8192 + 4 * tile + 0] = (long long)wall_clock64();
 #endif
-            if (cmp) {
+            if (CMPJ) {
                 set_rows(nact);
 #pragma unroll
                 for (int u = 0; u < DEPTH - 1; ++u) if (u > 0 || !ident0) fetch(cbeg + u, u);
@@ -1026,16 +1029,15 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                 for (int u = 0; u < DEPTH; ++u) {
                     const int c = cbeg + o * DEPTH + u;
                     const int buf = (o * DEPTH + u) & 1;
-                    const bool va = (c * CH + la) < rows_end, v0 = (c * CH + lb0) < rows_end, v1 = (c * CH + lb0 + 32) < rows_end;
+                    const bool va = (c * CH + la) < rows_end;
                     float4 av = ra[u];
-                    if (virt) {
+                    if (VIRT) {
                         av.x = av.x > 0.f ? beta[u] * vw.x : 0.f; av.y = av.y > 0.f ? beta[u] * vw.y : 0.f;
                         av.z = av.z > 0.f ? beta[u] * vw.z : 0.f; av.w = av.w > 0.f ? beta[u] * vw.w : 0.f;
                     }
                     // rows beyond the slice: the A slice is zeroed; the B slice may stay what the clamped load fetched -- a LIVE row's
                     // finite values times zero (eight multiplies per chunk and thread less)
                     const float ma = va ? 1.f : 0.f;
-                    (void)v0; (void)v1;
                     *reinterpret_cast<float4*>(&s_a[buf][la][lac]) = make_float4(av.x * ma, av.y * ma, av.z * ma, av.w * ma);
                     *reinterpret_cast<float4*>(&s_b[buf][lb0][lbc]) = rb0[u];
                     *reinterpret_cast<float4*>(&s_b[buf][lb0 + 32][lbc]) = rb1[u];
@@ -1051,8 +1053,12 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                 }
             }
         };
+        auto run_b = [&](auto virt_tag, auto cmp_tag) {
+            if (bmod != 0) run(virt_tag, cmp_tag, std::true_type{}); else run(virt_tag, cmp_tag, std::false_type{});
+        };
+        auto run_c = [&](auto virt_tag) { if (cmp) run_b(virt_tag, std::true_type{}); else run_b(virt_tag, std::false_type{}); };
         if (interior) {
-            run(std::true_type{});
+            if (virt) run_c(std::true_type{}); else run_c(std::false_type{});
         } else {
             // edge tiles (N or K tail inside the tile, unaligned rows): guarded loads, one chunk at a time
             if (use_map) __syncthreads();                      // s_map is complete
@@ -1064,7 +1070,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                 const int r = cmp ? (int)s_map[min(rl, rlast)] : rl;
                 float4 av = load4_guard(Abase, (size_t)(rv ? r : 0) * lda, n0 + lac, N, rv, veca);
                 if (virt) {
-                    const float be = rv ? G.A[r] : 0.f;
+                    const float be = rv ? betag[r] : 0.f;
                     av.x = av.x > 0.f ? be * vw.x : 0.f; av.y = av.y > 0.f ? be * vw.y : 0.f;
                     av.z = av.z > 0.f ? be * vw.z : 0.f; av.w = av.w > 0.f ? be * vw.w : 0.f;
                 }
@@ -1104,7 +1110,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             gv2[h2] = v; gi2[h2] = -1;
             if (ns > 1) wpart[(size_t)tile * 512 + rr * 32 + cc] = v;       // raw partial tile (k_wreduce)
             else if (n < N && k < K) {
-                G.C[(size_t)n * G.ldc + k] = v;
+                as_global_w(G.C)[(size_t)n * G.ldc + k] = v;
                 sq = fmaf(v, v, sq);
                 gi2[h2] = (G.C - wo.grads) + (int64_t)n * G.ldc + k;
             }
@@ -1146,46 +1152,98 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
     const bool ccmp = use_map && C.compact;
     if (use_map) __syncthreads();                          // s_map is complete
     const int c0 = (cb - C.blk_begin) * 16;
-    const int cc = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const bool cv = (c0 + cc) < C.cols;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (cv) {
-        const float* sp = C.src + c0 + cc;
-        const int rows = ccmp ? nact : C.rows, ld = C.ld;
-        constexpr int UN = 16;                         // rows in flight per thread (one round trip per 256 rows)
-        const bool virt = C.vbeta != nullptr;
-        const bool wsum = C.wrow != nullptr;
-        const float* rowv = virt ? C.vbeta : C.wrow;
-        const float vw = virt ? C.vw2[c0 + cc] : 0.f;
-        for (int r0 = g; r0 < rows; r0 += 16 * UN) {
-            float hv[UN], bv[UN];
+    const int rows = ccmp ? nact : C.rows, ld = C.ld;
+    const bool virt = C.vbeta != nullptr;
+    const bool wsum = C.wrow != nullptr;
+    gfloat* const rowv = as_global(virt ? C.vbeta : wsum ? C.wrow : C.src);      // (neither: any valid address, the value is unused)
+    // Sixteen whole columns of 16-byte-aligned rows (every job but a ragged last block): FOUR columns per thread, 64 row groups,
+    // eight rows in flight per thread -- 512 rows per memory trip and 16-byte loads; the scalar form below (one column per
+    // thread, 256 rows per trip, 64-byte segments) kept config 3 at 512 samples waiting for its 141 column blocks: 5 632 rows,
+    // 22 trips, 88 us while the GEMM tiles were through after 77 (round-6 timeline).  Loads are unconditional (rows clamped,
+    // contributions masked): the compiler keeps them all in flight.
+    const bool vec4 = (c0 + 16 <= C.cols) && !(ld & 3) && !(((uintptr_t)(C.src + c0)) & 15) && rows > 0;
+    int ngroups = 16;
+    if (vec4) {
+        ngroups = 64;
+        const int cq = (threadIdx.x & 3) * 4, g = threadIdx.x >> 2;
+        gfloat* const sp = as_global(C.src) + (c0 + cq);
+        float4 vw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (virt) vw = make_float4(C.vw2[c0 + cq], C.vw2[c0 + cq + 1], C.vw2[c0 + cq + 2], C.vw2[c0 + cq + 3]);
+        float4 A0 = make_float4(0.f, 0.f, 0.f, 0.f), A1 = A0;
+        constexpr int UN = 8;
+        const int rlast = rows - 1;
+        for (int r0 = g; r0 < rows; r0 += 64 * UN) {
+            float4 hv[UN]; float bv[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int rl = r0 + 16 * u;
-                const bool ok = rl < rows;
-                const int r = (ccmp && ok) ? (int)s_map[rl] : rl;
-                hv[u] = ok ? sp[(size_t)r * ld] : 0.f;
-                bv[u] = (ok && (virt || wsum)) ? rowv[r] : 0.f;
+                const int rl = min(r0 + 64 * u, rlast);
+                const int r = ccmp ? (int)s_map[rl] : rl;
+                hv[u] = ldg4(sp + (size_t)r * ld);
+                bv[u] = rowv[(virt || wsum) ? r : 0];
             }
 #pragma unroll
-            for (int u = 0; u < UN; u += 4) {
+            for (int u = 0; u < UN; ++u) {
+                const bool ok = (r0 + 64 * u) < rows;
+                float4& A = (u & 1) ? A1 : A0;
                 if (wsum) {
-                    a0 = fmaf(hv[u], bv[u], a0); a1 = fmaf(hv[u + 1], bv[u + 1], a1);
-                    a2 = fmaf(hv[u + 2], bv[u + 2], a2); a3 = fmaf(hv[u + 3], bv[u + 3], a3);
+                    const float w = ok ? bv[u] : 0.f;
+                    A.x = fmaf(hv[u].x, w, A.x); A.y = fmaf(hv[u].y, w, A.y); A.z = fmaf(hv[u].z, w, A.z); A.w = fmaf(hv[u].w, w, A.w);
                 } else if (virt) {
-                    a0 += hv[u] > 0.f ? bv[u] * vw : 0.f; a1 += hv[u + 1] > 0.f ? bv[u + 1] * vw : 0.f;
-                    a2 += hv[u + 2] > 0.f ? bv[u + 2] * vw : 0.f; a3 += hv[u + 3] > 0.f ? bv[u + 3] * vw : 0.f;
+                    const float w = ok ? bv[u] : 0.f;
+                    A.x += hv[u].x > 0.f ? w * vw.x : 0.f; A.y += hv[u].y > 0.f ? w * vw.y : 0.f;
+                    A.z += hv[u].z > 0.f ? w * vw.z : 0.f; A.w += hv[u].w > 0.f ? w * vw.w : 0.f;
                 } else {
-                    a0 += hv[u]; a1 += hv[u + 1]; a2 += hv[u + 2]; a3 += hv[u + 3];
+                    A.x += ok ? hv[u].x : 0.f; A.y += ok ? hv[u].y : 0.f; A.z += ok ? hv[u].z : 0.f; A.w += ok ? hv[u].w : 0.f;
                 }
             }
         }
+        *reinterpret_cast<float4*>(&s_part[g * 16 + cq]) = make_float4(A0.x + A1.x, A0.y + A1.y, A0.z + A1.z, A0.w + A1.w);
+    } else {
+        // a ragged last block or a narrow job (the N = 1 products: ONE column over all (step, sample) rows): the columns on the
+        // low lane bits, every other thread of the workgroup a row group of its own -- 256 row groups for one column instead of 16
+        const int ncol = min(16, C.cols - c0);
+        const int lp = ncol > 8 ? 4 : ncol > 4 ? 3 : ncol > 2 ? 2 : ncol > 1 ? 1 : 0, P = 1 << lp, NG = MMG_BLOCK >> lp;
+        const int cc = threadIdx.x & (P - 1), g = threadIdx.x >> lp;
+        const bool cv = cc < ncol;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (cv) {
+            const float* sp = C.src + c0 + cc;
+            constexpr int UN = 16;                         // rows in flight per thread
+            const float vw = virt ? C.vw2[c0 + cc] : 0.f;
+            for (int r0 = g; r0 < rows; r0 += NG * UN) {
+                float hv[UN], bv[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int rl = r0 + NG * u;
+                    const bool ok = rl < rows;
+                    const int r = (ccmp && ok) ? (int)s_map[rl] : rl;
+                    hv[u] = ok ? sp[(size_t)r * ld] : 0.f;
+                    bv[u] = (ok && (virt || wsum)) ? rowv[r] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < UN; u += 4) {
+                    if (wsum) {
+                        a0 = fmaf(hv[u], bv[u], a0); a1 = fmaf(hv[u + 1], bv[u + 1], a1);
+                        a2 = fmaf(hv[u + 2], bv[u + 2], a2); a3 = fmaf(hv[u + 3], bv[u + 3], a3);
+                    } else if (virt) {
+                        a0 += hv[u] > 0.f ? bv[u] * vw : 0.f; a1 += hv[u + 1] > 0.f ? bv[u + 1] * vw : 0.f;
+                        a2 += hv[u + 2] > 0.f ? bv[u + 2] * vw : 0.f; a3 += hv[u + 3] > 0.f ? bv[u + 3] * vw : 0.f;
+                    } else {
+                        a0 += hv[u]; a1 += hv[u + 1]; a2 += hv[u + 2]; a3 += hv[u + 3];
+                    }
+                }
+            }
+        }
+        // across the row groups: the lanes P apart within a wave (fixed butterfly), then the four waves below
+        float av = (a0 + a1) + (a2 + a3);
+        for (int off = 32; off >= P; off >>= 1) av += __shfl_xor(av, off);
+        ngroups = 4;
+        if ((threadIdx.x & 63) < P) s_part[(threadIdx.x >> 6) * 16 + cc] = av;
     }
-    s_part[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     float v = 0.f;
     if (threadIdx.x < 16 && (c0 + (int)threadIdx.x) < C.cols) {
-        for (int k = 0; k < 16; ++k) v += s_part[k * 16 + threadIdx.x];
+        for (int k = 0; k < ngroups; ++k) v += s_part[k * 16 + threadIdx.x];
         if (C.scale) v *= C.scale[c0 + threadIdx.x];
         C.dst[c0 + threadIdx.x] = v;
     }
@@ -1231,7 +1289,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wreduce(const JobTable* __restric
             for (int u = 0; u < 8; ++u) v += (s0 + u < ns) ? p[u] : 0.f;
         }
         const int n = n0 + rr, k = k0 + cc;
-        if (n < G.N && k < G.K) { G.C[(size_t)n * G.ldc + k] = v; sq = fmaf(v, v, sq); }
+        if (n < G.N && k < G.K) { as_global_w(G.C)[(size_t)n * G.ldc + k] = v; sq = fmaf(v, v, sq); }
     }
     sq = block_sum(sq, s_red);
     if (threadIdx.x == 0) part[tile] = sq;

@@ -8,20 +8,25 @@ _lib.LIB_PATH = _build.build_timing_library()      # -DMMG_TIMING build, compile
 from multimodalgame_amd.engine import Engine
 from multimodalgame_amd.agents import init_state_dicts
 import bench
-eng = Engine(batch=64, **bench.C2)
+CASES = {"c2": dict(bench.C2), "c3": dict(bench.C2, fixed_exchange=True), "c3s": dict(bench.C2, fixed_exchange=True, batch=512),
+         "c4": dict(bench.C2, w_dim=256, h_dim=1024), "c5s": dict(bench.C2, use_binary=False, fixed_exchange=True, n_classes=1000, batch=2048)}
+cfg = CASES[os.environ.get("CASE", "c2")]            # CASE=c3s: config 3 with all 512 samples on one GPU, ...
+NB = cfg.pop("batch", 64)
+eng = Engine(batch=NB, **cfg)
 eng.load_state_dicts(init_state_dicts(eng, 0))
-feats, target, desc = bench.synthetic_dataset(3000, 30, 512, 100)
+feats, target, desc = bench.synthetic_dataset(max(3000, NB), cfg["n_classes"], 512, 100)
 dev = eng.device
-x = torch.from_numpy(feats[:64]).to(dev); t = torch.from_numpy(target[:64]).to(dev); d = torch.from_numpy(desc).to(dev)
+x = torch.from_numpy(feats[:NB]).to(dev); t = torch.from_numpy(target[:NB]).to(dev); d = torch.from_numpy(desc).to(dev)
 for it in range(int(os.environ.get("PRETRAIN", "0"))):          # PRETRAIN=n: the conversations of a trained pair (bench.py's window)
-    k = it % 25
-    eng.train_step(torch.from_numpy(feats[64 * k:64 * k + 64]).to(dev), torch.from_numpy(target[64 * k:64 * k + 64]).to(dev), d, seed=0)
+    k = it % max(len(feats) // NB - 1, 1)
+    eng.train_step(torch.from_numpy(feats[NB * k:NB * k + NB]).to(dev), torch.from_numpy(target[NB * k:NB * k + NB]).to(dev), d, seed=0)
 for it in range(6):
     eng.tape["dbg2"].zero_()
     eng.train_step(x, t, d, seed=0)
 torch.cuda.synchronize()
 raw = eng.tape["dbg2"].view(torch.int64).cpu().numpy()
 ph = raw[8192:8192 + 8000].reshape(-1, 4).astype(np.float64)
+u = lambda v: v * 0.01
 okp = (ph[:, 0] > 0) & (ph[:, 3] > 0)
 if okp.any():
     g0 = raw[:8192].reshape(-1, 2)
@@ -57,3 +62,8 @@ for i in order:
 for lo in range(0, len(st), 128):
     sl = slice(lo, lo + 128)
     print("blocks %4d-%4d: start %.2f..%.2f  dur mean %.2f max %.2f  end max %.2f" % (lo, lo + 127, start[sl].min(), start[sl].max(), dur[sl].mean(), dur[sl].max(), end[sl].max()))
+# the trailing blocks (column sums, spare block) one by one when asked: TAIL=n
+ntail = int(os.environ.get("TAIL", "0"))
+if ntail:
+    ids = np.nonzero(nz)[0]
+    print("last %d blocks (id:dur):" % ntail, " ".join("%d:%.0f" % (ids[i], dur[i]) for i in range(len(ids) - ntail, len(ids))))
