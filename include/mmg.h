@@ -177,8 +177,8 @@ int mmg_clip_step(mmg_handle* h, void* stream);
  * host.  Equivalent to the four calls above in sequence.  Launches per minibatch depend on the shape: 2 for the agents of
  * BASELINE configs 1-2 (k_game_fast: conversation, k_prep's blocks, baselines, statistics and the reverse pass as roles of
  * one launch; k_wgrad<OPT>: weight gradients + clip + optimizer), 4 for config 3's shard (k_conversation_fast3, k_baselines3,
- * k_bwd_conv_fast, k_wgrad<OPT>; + k_prep with more samples than CUs, + k_opt with row splits), 7 for config 5's
- * shard (k_prep, k_conversation_mc, k_bwd_mc1, k_bwd_mc2, k_wgrad, k_wreduce, k_opt), 9 for config 4 (k_prep,
+ * k_bwd_conv_fast, k_wgrad<OPT>; + k_prep with more samples than CUs, + k_opt with row splits), 6 for config 5's
+ * shard (k_prep, k_conversation_mc, k_bwd_mc1, k_bwd_mc2, k_wgrad, k_opt), 9 for config 4 (k_prep,
  * k_conv_persist, k_baselines4, k_stats, k_bwd_pre_send, k_bwd_sample, k_dC_tile, k_wgrad, k_opt), 10 for
  * config 4 with rec_hidden 256 (k_prep, k_rc_persist, k_gemm_nt, k_baselines4, k_stats, k_bwd_pre_send, k_rc_bwd, k_dC_tile,
  * k_wgrad, k_opt). */

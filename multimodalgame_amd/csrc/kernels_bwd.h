@@ -696,7 +696,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
                                                      const float* __restrict__ desc, float* __restrict__ part,
                                                      Dims dm, const double* __restrict__ stats, float* __restrict__ losses,
                                                      double* __restrict__ totals, const int* __restrict__ rmap,
-                                                     const int* __restrict__ rcount, float* __restrict__ wpart,
+                                                     const int* __restrict__ rcount, float* __restrict__ wpart, uint32_t* __restrict__ wcnt,
                                                      const uint32_t* __restrict__ sync, float* __restrict__ grad_tail, WgOpt wo, int gt_stride, WgHead hd
 #ifdef MMG_TIMING
                                                      , long long* __restrict__ dbg2
@@ -912,6 +912,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         return;
     }
     if (bid < hd.gemm_tiles) {
+      __shared__ int s_arrived;
       for (int vt = bid; vt < hd.gemm_tiles; vt += (gt_stride > 0 ? gt_stride : hd.gemm_tiles)) {
         // XCD-aware tile order: workgroup b is dispatched to XCD b % 8, and each XCD has its own 4 MB L2.  Giving
         // every XCD a CONTIGUOUS range of tiles (= one or two jobs) keeps the operand tapes it re-reads
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         const int j = __popcll(__ballot(jt->g_begin[lane] <= tile)) - 1;
         const GemmJob& G = jt->g[j];
         // many rows, few output tiles (thousands of samples): the rows of a tile are split over nsplit workgroups whose raw
-        // partial tiles k_wreduce adds in a fixed order
+        // partial tiles the last of them to arrive adds in slice order
         const int ns = G.nsplit > 1 ? G.nsplit : 1;
         const int lts = tile - G.tile_begin, sp = lts % ns, lt = lts / ns;
         const int tn = lt / G.tiles_k, tk = lt - tn * G.tiles_k;
@@ -1108,15 +1109,52 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
             const int n = n0 + rr, k = k0 + cc;
             const float v = (s_acc[0][rr][cc] + s_acc[1][rr][cc]) + (s_acc[2][rr][cc] + s_acc[3][rr][cc]);
             gv2[h2] = v; gi2[h2] = -1;
-            if (ns > 1) wpart[(size_t)tile * 512 + rr * 32 + cc] = v;       // raw partial tile (k_wreduce)
+            if (ns > 1) st_wt(&wpart[(size_t)tile * 512 + rr * 32 + cc], v);       // raw partial tile, written through
             else if (n < N && k < K) {
                 as_global_w(G.C)[(size_t)n * G.ldc + k] = v;
                 sq = fmaf(v, v, sq);
                 gi2[h2] = (G.C - wo.grads) + (int64_t)n * G.ldc + k;
             }
         }
+        bool adds_up = false;
+        if (ns > 1) {
+            // Row slices of one output tile (thousands of (step, sample) rows): the slice that ARRIVES LAST adds the ns raw partial
+            // tiles -- in slice order whoever it is, so the sum does not depend on the arrival order -- and stores the gradient tile
+            // and its sum of squares.  (Through round 5 a second launch, k_wreduce, did that: ~5 us per minibatch of configs 3 / 5
+            // at full batch and of config 5's shard.)  Nobody waits: the count is a returning atomic behind the workgroup's own
+            // write-through stores, the partial tiles are read with agent-scope loads, and the last slice zeroes the count.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int tile0 = tile - sp;
+            if (threadIdx.x == 0) s_arrived = (int)__hip_atomic_fetch_add(wcnt + tile0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            adds_up = __builtin_amdgcn_readfirstlane(s_arrived) == ns - 1;
+            if (adds_up) {
+                if (threadIdx.x == 0) __hip_atomic_store(wcnt + tile0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int rr = threadIdx.x >> 4, cc = (threadIdx.x & 15) + 16 * h2;
+                    float v = 0.f;
+                    for (int s0 = 0; s0 < ns; s0 += 8) {
+                        float pv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) pv[u] = ld_cc(&wpart[(size_t)(tile0 + min(s0 + u, ns - 1)) * 512 + rr * 32 + cc]);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v += (s0 + u < ns) ? pv[u] : 0.f;
+                    }
+                    const int n = n0 + rr, k = k0 + cc;
+                    if (n < N && k < K) { as_global_w(G.C)[(size_t)n * G.ldc + k] = v; sq = fmaf(v, v, sq); }
+                }
+            }
+        }
         sq = block_sum(sq, s_red);
-        if (threadIdx.x == 0) part[tile] = sq;
+        if (threadIdx.x == 0) {
+            if (ns == 1) part[tile] = sq;
+            else {                                         // (the tile's sum of squares sits in its FIRST slice's entry, the others are zero)
+                if (sp != 0) part[tile] = 0.f;
+                if (adds_up) part[tile - sp] = sq;
+            }
+        }
         if (OPT) {
             if (threadIdx.x == 0) st_ll(wo.gnll, tile, sq, oepoch);
             // parameter / state elements of this thread: requested now, they arrive while the norm role adds up
@@ -1258,41 +1296,6 @@ __global__ __launch_bounds__(MMG_BLOCK) void k_wgrad(const JobTable* __restrict_
         if (coef >= 0.f && mine) opt_update_one(wo.oa, wo.params, wo.state, idx, v, coef, w, s1, s2, ostep);
     }
     MMG_WG_END();
-}
-
-// k_wreduce: output tiles whose rows k_wgrad split over several workgroups -- the first slice's block adds the raw partial
-// tiles in slice order, stores the gradient tile and its sum of squares (clip-norm partial).  grid = gemm tiles.
-__global__ __launch_bounds__(MMG_BLOCK) void k_wreduce(const JobTable* __restrict__ jt, const float* __restrict__ wpart, float* __restrict__ part) {
-    __shared__ float s_red[8];
-    const int nwg = jt->gemm_tiles, xq = nwg >> 3, xr = nwg & 7;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;      // same order as k_wgrad
-    const int lane = threadIdx.x & 63;
-    const int j = __popcll(__ballot(jt->g_begin[lane] <= tile)) - 1;
-    const GemmJob& G = jt->g[j];
-    const int ns = G.nsplit;
-    if (ns <= 1) return;
-    const int lts = tile - G.tile_begin, sp = lts % ns, lt = lts / ns;
-    if (sp != 0) return;
-    const int tn = lt / G.tiles_k, tk = lt - tn * G.tiles_k;
-    const int n0 = tn * 16, k0 = tk * 32;
-    float sq = 0.f;
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        const int rr = threadIdx.x >> 4, cc = (threadIdx.x & 15) + 16 * h2;
-        float v = 0.f;
-        for (int s0 = 0; s0 < ns; s0 += 8) {
-            float p[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] = wpart[(size_t)(tile + min(s0 + u, ns - 1)) * 512 + rr * 32 + cc];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v += (s0 + u < ns) ? p[u] : 0.f;
-        }
-        const int n = n0 + rr, k = k0 + cc;
-        if (n < G.N && k < G.K) { as_global_w(G.C)[(size_t)n * G.ldc + k] = v; sq = fmaf(v, v, sq); }
-    }
-    sq = block_sum(sq, s_red);
-    if (threadIdx.x == 0) part[tile] = sq;
 }
 
 // ---------------------------------------------------------------------------------------------

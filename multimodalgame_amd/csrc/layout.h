@@ -201,7 +201,8 @@ inline Params resolve_params(const ParamLayout& L, float* base) {
     X(gnll, float, 0, 1, 2 * 16384, 1, 1) /* k_wgrad<OPT>: (value, epoch) pairs of the blocks' sums of squares (hand-off to the norm role of the same launch) */ \
     X(coefll, float, 0, 1, 2 * (4 * 64 + 4), 1, 1) /* k_wgrad<OPT>: (value, epoch) pairs of the four clip coefficients, 64 replicas each, then the four agents' squared norms */ \
     X(ones, float, 0, 1, 256, 1, 1)      /* 1.0f: B operand of bias gradients run as K = 1 GEMM jobs (many (step, sample) rows) */ \
-    X(wpart, float, 0, 1, NWP, 1, 1)     /* raw partial tiles of weight gradients whose rows are split over workgroups (k_wgrad / k_wreduce) */ \
+    X(wcnt, int32_t, 2, 1, 16384, 1, 1)  /* k_wgrad: slices of an output tile that have written their partial tile (the last one adds them up and zeroes the count) */ \
+    X(wpart, float, 0, 1, NWP, 1, 1)     /* raw partial tiles of weight gradients whose rows are split over workgroups (k_wgrad) */ \
     X(tables, uint8_t, 1, 1, 98304, 1, 1) /* GEMM / column-sum job descriptors      */
 
 // statistics vector (f64).  Per stream (0 = stop bits, 1 = receiver msgs, 2 = sender msgs) and

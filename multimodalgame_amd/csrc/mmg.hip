@@ -93,7 +93,7 @@ struct mmg_handle {
     bool mc_ok;                // many-class register-resident conversation (kernels_mc.h); MMG_NO_MC=1: off
     bool mc3p_ok;              // ... for batches of several rounds of workgroups: two sample tiles per workgroup, pipelined (kernels_mc3p.h); MMG_NO_MC3P=1: off
     bool mc3_ok;               // continuous messages: the one-wave-per-SIMD many-class kernel (kernels_mc3.h); binary messages: k_conversation_mc
-    bool any_split;            // some k_wgrad job splits its rows over workgroups (k_wreduce adds the partial tiles)
+    bool any_split;            // some k_wgrad job splits its rows over workgroups (the last slice to arrive adds the partial tiles)
     bool wgrad_small_split;    // jobs with few output tiles split their (step, sample) rows further (layout.h: wgrad_job_nsplit)
     int mc_per, mc_xcd;        // classes per member of a tile; mc_xcd: a tile's 16 workgroups on one XCD
     bool xcd_rule_ok;          // probed at mmg_create (k_xcc_probe): workgroup i of a launch runs on XCD i % 8 -- a hand-off between workgroups of one XCD may stay in its L2
@@ -1204,7 +1204,7 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
             hipLaunchKernelGGL(k_wgrad<true>, dim3(h->jt.n_wblocks + 1 + 4), dim3(MMG_BLOCK), 0, st,     // tiles + column blocks | spare / closing block | four norm roles
                                (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
                                h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
-                               (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, 0, hd
+                               (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, reinterpret_cast<uint32_t*>(h->tp.wcnt), (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, 0, hd
 #ifdef MMG_TIMING
                                , h->tp.dbg2
 #endif
@@ -1213,16 +1213,12 @@ static int backward_impl(mmg_handle* h, const float* d_x, const int64_t* d_targe
         hipLaunchKernelGGL(k_wgrad<false>, dim3(h->wgrad_stride > 0 ? h->wgrad_stride + h->jt.n_wblocks + 1 - h->jt.gemm_tiles : h->jt.n_wblocks + 1), dim3(MMG_BLOCK), 0, st,
                            (const JobTable*)h->d_jt, d_x, d_desc, h->tp.gnpart, h->dm, (const double*)h->tp.stats,
                            h->tp.losses, h->tp.totals, (const int*)(row_map ? h->tp.rmap : nullptr),
-                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, h->wgrad_stride, hd
+                           (const int*)(row_map ? h->tp.rcount : nullptr), h->tp.wpart, reinterpret_cast<uint32_t*>(h->tp.wcnt), (const uint32_t*)h->tp.sync, h->grads + h->pl.total, wo, h->wgrad_stride, hd
 #ifdef MMG_TIMING
                            , h->tp.dbg2
 #endif
                            );
         if (launch_check("k_wgrad")) return -1;
-        if (h->any_split) {
-            hipLaunchKernelGGL(k_wreduce, dim3(h->jt.gemm_tiles), dim3(MMG_BLOCK), 0, st, (const JobTable*)h->d_jt, (const float*)h->tp.wpart, h->tp.gnpart);
-            if (launch_check("k_wreduce")) return -1;
-        }
     }
     return 0;
 }

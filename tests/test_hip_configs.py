@@ -242,7 +242,7 @@ def _kernel_names(eng, meta, fused=True):
 def test_config5_shard_fused_vs_oracle():
     """EXACTLY what bench.py's c5 line and each GPU of the 8-GPU job run (configs[4]: D = 1000, continuous, Fixed, 256 samples
     per GPU): the FUSED mmg_train_step -- lean tape (run_all_steps = 2: y of the output step only, no a / c / zr / dbar / g /
-    w), k_conversation_mc, k_bwd_mc1, k_bwd_mc2 with the statistics workgroup riding along, k_wgrad (+ k_wreduce), k_opt --
+    w), k_conversation_mc, k_bwd_mc1, k_bwd_mc2 with the statistics workgroup riding along, k_wgrad (row slices added up by the last one to arrive), k_opt --
     two minibatches against the oracle (model.py:1297-1305, 1313: only the receiver is trained, loss = NLL)."""
     meta = _meta(dict(C5, batch_size=256), 1000, 256, 2)
     got, eng = common.hip_train_case(None, meta, fused=True)
@@ -443,8 +443,8 @@ def test_wide_receiver_sharded_equals_unsharded():
 
 
 def test_config3_global_batch_512_single_engine_vs_oracle():
-    """configs[2] as the N = 1 point of strong scaling runs it: all 512 samples on ONE engine (k_baselines2, row-split k_wgrad +
-    k_wreduce -- kernels the 64-sample shards never take), two minibatches, against the CPU oracle itself."""
+    """configs[2] as the N = 1 point of strong scaling runs it: all 512 samples on ONE engine (k_baselines2, row-split k_wgrad
+    -- paths the 64-sample shards never take), two minibatches, against the CPU oracle itself."""
     fl_kw = dict(use_binary=True, fixed_exchange=True, max_exchange=10, batch_size=512, learning_rate=1e-4,
                  entropy_rec=0.01, entropy_sen=0.01, img_feat_dim=512, img_h_dim=256, rec_w_dim=32, sender_out_dim=32,
                  rec_hidden=64, wv_dim=100, baseline_hid_dim=500, top_k_train=6)
