@@ -6,6 +6,14 @@
 namespace mmg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// clamp(a * k + c) to [0, 1] on two floats at once: v_pk_fma_f32 with the clamp output modifier (k: one scalar for both halves)
+__device__ __forceinline__ f32x2 pk_fma_clamp(f32x2 a, float k, f32x2 c) {
+    f32x2 r;
+    const f32x2 k2 = {k, k};
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(k2), "v"(c));
+    return r;
+}
 // Pointers a kernel reads out of a TABLE in memory (k_wgrad's job table) are generic to the compiler, which then emits flat_load
 // with 64-bit address arithmetic per access; these casts state what the host guarantees (device memory): global_load, half the
 // address instructions.

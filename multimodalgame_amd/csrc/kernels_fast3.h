@@ -35,7 +35,6 @@
 
 namespace mmg {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // dot product of 4 * NV register weights with float4 operands read from LDS at base + stride * j: two packed accumulators
 // (v_pk_fma_f32: two FMAs per issue slot), i.e. four independent chains

@@ -541,7 +541,14 @@ __global__ __launch_bounds__(512, 2) void k_bwd_mc1(Dims dm, Params P, Tape tp, 
     const int c0 = cb * per;
     const int cls = tid >> 3, e8 = tid & 7;
     const bool cls_ok = cls < per && c0 + cls < D;
-    float cd[8], w2e[8], dCacc[8], Pacc[8];
+    // Both passes on PACKED fp32 (v_pk_fma_f32, two units per issue slot).  The indicator 1[A + Cd > 0] is one packed
+    // fused multiply-add with the clamp modifier, clamp((A + Cd) 2^100) -- exactly 0 or 1 unless 0 < |A + Cd| < 2^-100, which a
+    // sum of two O(1) floats never is (kernels_tile.h uses the scalar form) -- and with it  dC += ind dy,  Py2 += dy ((A + Cd) ind):
+    // the same values added in the same order as the compare / select / max form (x 1 and x 0 are exact), 5 packed instructions per
+    // unit pair instead of 12 scalar ones; the sample side 2 instead of 8.  (Round 6; config 5 at 2 048 samples: 52.9 -> see DESIGN 3g)
+    constexpr float BIG = 1.2676506e30f;                                     // 2^100
+    float cd[8], w2e[8];
+    f32x2 cd2[4], cdk2[4], dC2[4], P2[4];
     {
         const float* crow = tp.Cd + (size_t)min(c0 + cls, D - 1) * R + 8 * e8;
         const float4 u0 = *reinterpret_cast<const float4*>(crow), u1 = *reinterpret_cast<const float4*>(crow + 4);
@@ -549,7 +556,12 @@ __global__ __launch_bounds__(512, 2) void k_bwd_mc1(Dims dm, Params P, Tape tp, 
         const float4 q0 = *reinterpret_cast<const float4*>(P.p[R_Y2_W] + 8 * e8), q1 = *reinterpret_cast<const float4*>(P.p[R_Y2_W] + 8 * e8 + 4);
         w2e[0] = q0.x; w2e[1] = q0.y; w2e[2] = q0.z; w2e[3] = q0.w; w2e[4] = q1.x; w2e[5] = q1.y; w2e[6] = q1.z; w2e[7] = q1.w;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { dCacc[j] = 0.f; Pacc[j] = 0.f; s_Cd[cls * LDC + 8 * e8 + j] = cd[j]; }
+        for (int j = 0; j < 8; ++j) s_Cd[cls * LDC + 8 * e8 + j] = cd[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cd2[q] = f32x2{cd[2 * q], cd[2 * q + 1]}; cdk2[q] = cd2[q] * BIG;
+            dC2[q] = f32x2{0.f, 0.f}; P2[q] = f32x2{0.f, 0.f};
+        }
     }
     // dA pass: sample i2 = tid / 32, columns 2 rp, 2 rp + 1
     const int i2 = tid >> 5, rp = tid & 31;
@@ -579,31 +591,33 @@ __global__ __launch_bounds__(512, 2) void k_bwd_mc1(Dims dm, Params P, Tape tp, 
         }
         __syncthreads();
         // ---- class side: sums over the tile's samples, accumulated in registers across the group's tiles
-#pragma unroll
+#pragma unroll 4
         for (int i = 0; i < TM; ++i) {
             const float4 a0 = *reinterpret_cast<const float4*>(s_A + i * LDA + 8 * e8);
             const float4 a1 = *reinterpret_cast<const float4*>(s_A + i * LDA + 8 * e8 + 4);
-            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const f32x2 av2[4] = {f32x2{a0.x, a0.y}, f32x2{a0.z, a0.w}, f32x2{a1.x, a1.y}, f32x2{a1.z, a1.w}};
             const float dyv = s_dy[i * LDY + cls];
+            const f32x2 dy2 = {dyv, dyv};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = av[j] + cd[j];
-                dCacc[j] += (x > 0.f) ? dyv : 0.f;
-                Pacc[j] = fmaf(dyv, fmaxf(x, 0.f), Pacc[j]);
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 ind = pk_fma_clamp(av2[q], BIG, cdk2[q]);
+                dC2[q] = __builtin_elementwise_fma(ind, dy2, dC2[q]);
+                P2[q] = __builtin_elementwise_fma(dy2, (av2[q] + cd2[q]) * ind, P2[q]);
             }
         }
         // ---- sample side: sums over the block's classes -> partial dA of the tile's samples
         {
-            const float a_a = s_A[i2 * LDA + 2 * rp], a_b = s_A[i2 * LDA + 2 * rp + 1];
-            float acc_a = 0.f, acc_b = 0.f, dsum = 0.f;
+            const f32x2 ak2 = f32x2{s_A[i2 * LDA + 2 * rp], s_A[i2 * LDA + 2 * rp + 1]} * BIG;
+            f32x2 acc2 = {0.f, 0.f};
+            float dsum = 0.f;
 #pragma unroll 16
             for (int c = 0; c < CAP; ++c) {
                 const float2 cv = *reinterpret_cast<const float2*>(s_Cd + c * LDC + 2 * rp);
                 const float dyv = s_dy[i2 * LDY + c];
-                acc_a += (a_a + cv.x > 0.f) ? dyv : 0.f;
-                acc_b += (a_b + cv.y > 0.f) ? dyv : 0.f;
+                acc2 = __builtin_elementwise_fma(pk_fma_clamp(f32x2{cv.x, cv.y}, BIG, ak2), f32x2{dyv, dyv}, acc2);
                 dsum += dyv;
             }
+            const float acc_a = acc2.x, acc_b = acc2.y;
             const int bi = b0 + i2;
             if (bi < B) {
                 *reinterpret_cast<float2*>(tp.mcdA + ((size_t)cb * B + bi) * R + 2 * rp) = make_float2(acc_a * w2a, acc_b * w2b);
@@ -614,11 +628,11 @@ __global__ __launch_bounds__(512, 2) void k_bwd_mc1(Dims dm, Params P, Tape tp, 
     // this group's partial dC | Py2 of the block's classes
     if (cls_ok) {
         float* o = tp.mcdC + ((size_t)grp * 2 * D + (c0 + cls)) * R + 8 * e8;
-        *reinterpret_cast<float4*>(o) = make_float4(dCacc[0] * w2e[0], dCacc[1] * w2e[1], dCacc[2] * w2e[2], dCacc[3] * w2e[3]);
-        *reinterpret_cast<float4*>(o + 4) = make_float4(dCacc[4] * w2e[4], dCacc[5] * w2e[5], dCacc[6] * w2e[6], dCacc[7] * w2e[7]);
+        *reinterpret_cast<float4*>(o) = make_float4(dC2[0].x * w2e[0], dC2[0].y * w2e[1], dC2[1].x * w2e[2], dC2[1].y * w2e[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(dC2[2].x * w2e[4], dC2[2].y * w2e[5], dC2[3].x * w2e[6], dC2[3].y * w2e[7]);
         float* q = o + (size_t)D * R;
-        *reinterpret_cast<float4*>(q) = make_float4(Pacc[0], Pacc[1], Pacc[2], Pacc[3]);
-        *reinterpret_cast<float4*>(q + 4) = make_float4(Pacc[4], Pacc[5], Pacc[6], Pacc[7]);
+        *reinterpret_cast<float4*>(q) = make_float4(P2[0].x, P2[0].y, P2[1].x, P2[1].y);
+        *reinterpret_cast<float4*>(q + 4) = make_float4(P2[2].x, P2[2].y, P2[3].x, P2[3].y);
     }
 }
 
